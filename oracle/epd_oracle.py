@@ -1,0 +1,442 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A plain numpy restatement of the gnn-manip rollout hot path:
+radius graph -> node/edge featurisation -> encode-process-decode GNN -> semi-implicit
+Euler integration -> rollout state update -> rigid-body (cup) trajectory.
+
+This module is the *checker*.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing under ``gnn_manip_amd/``
+imports it: the product path is the HIP library and fails loudly without it.
+
+Pinning (see DESIGN.md "Oracle"):
+  * every function except the two message-passing blocks is pinned against outputs of
+    the reference's own Python, imported by file path in the build container by
+    ``tests/golden/make_golden.py`` and committed as ``tests/golden/*.npz``;
+  * the arithmetic inside ``InteractionNetwork`` / ``GraphIndependent`` lives in the
+    third-party ``dblanm/torch-graphnet`` submodule, which is ABSENT from the reference
+    tree (empty ``deps/torch-graphnet``; version not recoverable).  For those two blocks
+    parity is UNPINNED: semantics follow BASELINE.json's north_star
+    (``e' = phi_e([h_i, h_j, e_ij])``, scatter-add at i, ``h' = phi_v([h_i, agg_i])``,
+    PyG source_to_target: j = edge_index[0], i = edge_index[1]).  The reference's
+    *wiring* around the blocks (epd_gnn.py) is pinned by fixture G7.
+
+All reference citations are relative to /root/reference.
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------------------
+# K1  radius graph  (gnn_manip/utils/utils.py:64-93)
+# --------------------------------------------------------------------------------------
+def _sq_dists_f64(q, p):
+    """d2[a,b] = sum_j ((double)q[a,j]-(double)p[b,j])^2 accumulated j = 0,1,2 in order.
+
+    Follows sklearn's EuclideanDistance64.rdist (metrics/_dist_metrics.pxd: sequential
+    ``d += tmp*tmp`` loop) on the float64-upcast data KDTree stores (utils.py:76).
+    """
+    q = np.asarray(q, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    d2 = np.zeros((q.shape[0], p.shape[0]), dtype=np.float64)
+    for j in range(q.shape[1]):
+        t = q[:, j:j + 1] - p[None, :, j]
+        d2 = d2 + t * t  # separate multiply and add: no FMA in numpy
+    return d2
+
+
+def get_connectivity(pos_nodes, conn_r, max_neighbours=20, chunk=1024):
+    """Reference ``get_connectivity`` (utils.py:64-93).
+
+    For every query node i (the reference calls it the *sender*): all j with
+    ``d2(i,j) <= conn_r*conn_r`` (float64; KDTree.query_radius leaf test), ordered by
+    ascending distance (sort_results=True, utils.py:78), first ``max_neighbours`` kept
+    (utils.py:80-85).  senders = repeat(i, len_i) (utils.py:87-88), receivers = concat of
+    the per-query lists (utils.py:90-91).
+
+    Ties in distance have no defined order in the reference (unstable quicksort over
+    tree traversal order); the oracle, like the HIP kernel, breaks ties on the smaller
+    index.  Fixtures assert tie-freeness.
+    Returns int64 arrays (senders, receivers).
+    """
+    pos = np.asarray(pos_nodes)
+    n = pos.shape[0]
+    r = float(conn_r)
+    r2 = r * r
+    use_cells = n > 4096
+    if use_cells:
+        return _get_connectivity_cells(pos, r, max_neighbours)
+    send, recv = [], []
+    for a in range(0, n, chunk):
+        d2 = _sq_dists_f64(pos[a:a + chunk], pos)
+        for row in range(d2.shape[0]):
+            idx = np.nonzero(d2[row] <= r2)[0]
+            order = np.lexsort((idx, d2[row, idx]))  # primary d2, secondary index
+            idx = idx[order][:max_neighbours]
+            send.append(np.full(idx.shape[0], a + row, dtype=np.int64))
+            recv.append(idx.astype(np.int64))
+    if not send:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    return np.concatenate(send), np.concatenate(recv)
+
+
+def _get_connectivity_cells(pos, r, max_neighbours):
+    """Same result as the brute-force path, candidates from a uniform cell list."""
+    n = pos.shape[0]
+    p64 = pos.astype(np.float64)
+    r2 = r * r
+    h = r * 1.001
+    lo = p64.min(axis=0)
+    cell = np.floor((p64 - lo) / h).astype(np.int64)
+    dims = cell.max(axis=0) + 1
+    key = (cell[:, 2] * dims[1] + cell[:, 1]) * dims[0] + cell[:, 0]
+    order = np.argsort(key, kind="stable")
+    skey = key[order]
+    ncell = int(dims[0] * dims[1] * dims[2])
+    start = np.searchsorted(skey, np.arange(ncell + 1))
+    send, recv = [], []
+    # group queries by cell so candidate sets are shared
+    ucells = np.unique(key)
+    res = [None] * n
+    for c in ucells:
+        cx = c % dims[0]
+        cy = (c // dims[0]) % dims[1]
+        cz = c // (dims[0] * dims[1])
+        cand = []
+        for dz in (-1, 0, 1):
+            z = cz + dz
+            if z < 0 or z >= dims[2]:
+                continue
+            for dy in (-1, 0, 1):
+                y = cy + dy
+                if y < 0 or y >= dims[1]:
+                    continue
+                x0 = max(cx - 1, 0)
+                x1 = min(cx + 1, dims[0] - 1)
+                c0 = (z * dims[1] + y) * dims[0] + x0
+                c1 = (z * dims[1] + y) * dims[0] + x1
+                cand.append(order[start[c0]:start[c1 + 1]])
+        cand = np.sort(np.concatenate(cand))
+        q = order[start[c]:start[c + 1]]
+        d2 = _sq_dists_f64(pos[q], pos[cand])
+        for row, qi in enumerate(q):
+            m = np.nonzero(d2[row] <= r2)[0]
+            o = np.lexsort((cand[m], d2[row, m]))
+            res[qi] = cand[m][o][:max_neighbours].astype(np.int64)
+    lens = np.array([len(x) for x in res], dtype=np.int64)
+    senders = np.repeat(np.arange(n, dtype=np.int64), lens)
+    receivers = np.concatenate(res) if n else np.zeros(0, np.int64)
+    return senders, receivers
+
+
+def connectivity_is_tie_free(pos_nodes, conn_r, max_neighbours=20):
+    """True when no query has two in-radius neighbours at equal sqrt-distance among its
+    first max_neighbours+1 (the reference sorts on sqrt(d2): _binary_tree.pxi query_radius)."""
+    pos = np.asarray(pos_nodes)
+    r2 = float(conn_r) * float(conn_r)
+    for a in range(0, pos.shape[0], 1024):
+        d2 = _sq_dists_f64(pos[a:a + 1024], pos)
+        for row in range(d2.shape[0]):
+            d = np.sort(np.sqrt(d2[row][d2[row] <= r2]))[:max_neighbours + 1]
+            if d.shape[0] > 1 and np.any(d[1:] == d[:-1]):
+                return False
+    return True
+
+
+# --------------------------------------------------------------------------------------
+# K2  edge features  (utils.py:43-61)
+# --------------------------------------------------------------------------------------
+def get_edges_displacement(last_pos, senders, receivers, conn_r):
+    """``[(p_s - p_r)/conn_r, ||.||_2]`` in float32 (utils.py:52-59)."""
+    last_pos = np.asarray(last_pos, dtype=F32)
+    ps = last_pos[np.asarray(senders)]
+    pr = last_pos[np.asarray(receivers)]
+    disp = (ps - pr) / F32(conn_r)
+    sq = disp * disp
+    acc = sq[:, 0]
+    for j in range(1, sq.shape[1]):
+        acc = acc + sq[:, j]
+    dist = np.sqrt(acc)[:, None]
+    return np.concatenate((disp, dist), axis=-1).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# K3  node features  (utils.py:27-40, collate_utils.py:195-232)
+# --------------------------------------------------------------------------------------
+def get_nodes_vel(pos_seq, velocity_mean, velocity_std):
+    """diff over time, normalise, [N, (k-1)*dim] time-major within node (utils.py:27-40)."""
+    pos_seq = np.asarray(pos_seq, dtype=F32)
+    vel = pos_seq[1:] - pos_seq[:-1]
+    vel = (vel - np.asarray(velocity_mean, F32)) / np.asarray(velocity_std, F32)
+    vel = np.transpose(vel, (1, 0, 2))
+    return np.ascontiguousarray(vel).reshape(vel.shape[0], -1)
+
+
+def compute_nodes(obs, stats, bounds, conn_r, cartesian_idx, material_idx, control_idx=None):
+    """GraphBoundedMultimaterial(Control).compute_nodes (collate_utils.py:195-208, 217-232)."""
+    obs = np.asarray(obs, dtype=F32)
+    pos_seq = obs[:, :, cartesian_idx]
+    last_pos = pos_seq[-1]
+    vel_attr = get_nodes_vel(pos_seq, stats["velocity_mean"], stats["velocity_std"])
+    lower = last_pos - np.asarray(bounds["lower_bounds"], F32)
+    upper = np.asarray(bounds["upper_bounds"], F32) - last_pos
+    b = np.concatenate((lower, upper), axis=1) / F32(conn_r)
+    b = np.clip(b, F32(-1), F32(1))
+    mat = obs[-1][:, material_idx]
+    parts = [vel_attr, b, mat]
+    if control_idx is not None:
+        ctrl = (obs[-1][:, control_idx] - np.asarray(stats["velocity_mean"], F32)) \
+            / np.asarray(stats["velocity_std"], F32)
+        parts.append(ctrl)
+    return np.concatenate(parts, axis=-1).astype(F32)
+
+
+def compute_acceleration(next_pos, pos_seq):
+    """utils.py:10-24."""
+    next_pos = np.asarray(next_pos, F32)
+    pos_seq = np.asarray(pos_seq, F32)
+    return next_pos - F32(2) * pos_seq[-1] + pos_seq[-2]
+
+
+def compute_target(obs, tgt, stats, cartesian_idx):
+    """GraphSimple.compute_target (collate_utils.py:150-159)."""
+    pos_seq = np.asarray(obs, F32)[:, :, cartesian_idx]
+    acc = compute_acceleration(tgt, pos_seq)
+    return (acc - np.asarray(stats["acceleration_mean"], F32)) / np.asarray(stats["acceleration_std"], F32)
+
+
+def process(obs, tgt, stats, bounds, conn_r, cartesian_idx, material_idx, control_idx=None,
+            max_neighbours=20):
+    """GraphAttributes._process_simple (collate_utils.py:29-40).
+
+    NB the reference does not forward max_neighbours here (always the default 20,
+    collate_utils.py:34); callers wanting reference behaviour pass 20.
+    """
+    obs = np.asarray(obs, F32)
+    last_pos = obs[-1][:, cartesian_idx]
+    nodes = compute_nodes(obs, stats, bounds, conn_r, cartesian_idx, material_idx, control_idx)
+    senders, receivers = get_connectivity(last_pos, conn_r, max_neighbours)
+    edge_attr = get_edges_displacement(last_pos, senders, receivers, conn_r)
+    nodes_tgt = compute_target(obs, tgt, stats, cartesian_idx) if tgt is not None else None
+    return nodes, edge_attr, senders, receivers, nodes_tgt
+
+
+def process_collate(batch, **kw):
+    """GraphAttributes.process_collate (collate_utils.py:68-87): per-graph offset N*i."""
+    nl, el, il, tl = [], [], [], []
+    for i, (obs, tgt) in enumerate(batch):
+        nodes, edge_attr, s, r, t = process(obs, tgt, **kw)
+        ei = np.stack((s, r)) + nodes.shape[0] * i
+        nl.append(nodes)
+        el.append(edge_attr)
+        il.append(ei)
+        tl.append(t)
+    tgt = np.concatenate(tl) if tl[0] is not None else None
+    return np.concatenate(nl), np.concatenate(el), np.concatenate(il, axis=1), tgt
+
+
+# --------------------------------------------------------------------------------------
+# K4-K9  encode-process-decode  (gnn_manip/models/epd_gnn.py)
+# --------------------------------------------------------------------------------------
+def layer_norm(x, weight, bias, eps=1e-5):
+    """torch.nn.LayerNorm over the last dim (epd_gnn.py:60-61,80-81), float32."""
+    x = np.asarray(x, F32)
+    mean = x.mean(axis=-1, keepdims=True, dtype=F32)
+    xc = x - mean
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=F32)
+    return (xc / np.sqrt(var + F32(eps))) * weight + bias
+
+
+def mlp(params, prefix, x, num_layers, norm):
+    """``_build_mlp`` (epd_gnn.py:72-84): Linear ReLU [Linear ReLU]*(L-1) Linear [LayerNorm].
+
+    Sequential indices: linears at 0,2,...,2L; LayerNorm at 2L+1.
+    """
+    h = np.asarray(x, F32)
+    for li in range(num_layers + 1):
+        w = params[f"{prefix}.{2 * li}.weight"]
+        b = params[f"{prefix}.{2 * li}.bias"]
+        h = h @ w.T + b
+        if li < num_layers:
+            h = np.maximum(h, F32(0))
+    if norm:
+        h = layer_norm(h, params[f"{prefix}.{2 * num_layers + 1}.weight"],
+                       params[f"{prefix}.{2 * num_layers + 1}.bias"])
+    return h.astype(F32)
+
+
+def graph_independent(params, prefix, x, edge_attr, num_layers):
+    """GraphIndependent block (call site epd_gnn.py:88): independent node / edge MLPs."""
+    return (mlp(params, f"{prefix}.phi_node", x, num_layers, True),
+            mlp(params, f"{prefix}.phi_edge", edge_attr, num_layers, True))
+
+
+def interaction_network(params, prefix, h, e, edge_index, num_layers):
+    """InteractionNetwork block (call site epd_gnn.py:101); semantics per north_star.
+
+    j = edge_index[0] (source), i = edge_index[1] (target / aggregation index).
+    e' = phi_e(cat[h_i, h_j, e]); agg_i = sum_{e->i} e'; h' = phi_v(cat[h, agg]).
+    No residual inside the block (added by the caller, epd_gnn.py:103-104).
+    """
+    j = np.asarray(edge_index[0])
+    i = np.asarray(edge_index[1])
+    e_in = np.concatenate((h[i], h[j], e), axis=-1)
+    e_new = mlp(params, f"{prefix}.phi_edge", e_in, num_layers, True)
+    agg = np.zeros_like(h)
+    np.add.at(agg, i, e_new)
+    h_in = np.concatenate((h, agg), axis=-1)
+    h_new = mlp(params, f"{prefix}.phi_node", h_in, num_layers, True)
+    return h_new, e_new
+
+
+def epd_forward(params, nodes, edge_attr, edge_index, num_layers=2, m_steps=10):
+    """EncProcDecGNN.forward (epd_gnn.py:86-105)."""
+    h, e = graph_independent(params, "encoder", nodes, edge_attr, num_layers)
+    for k in range(m_steps):
+        hn, en = interaction_network(params, f"processor.{k}", h, e, edge_index, num_layers)
+        h = hn + h  # epd_gnn.py:103
+        e = en + e  # epd_gnn.py:104
+    return mlp(params, "decoder", h, num_layers, False)
+
+
+def init_params(node_dim, edge_dim, out_dim, hidden, num_layers, m_steps, seed):
+    """Deterministic, platform-independent weights (numpy PCG64) in state_dict naming.
+
+    Distribution mimics torch's default Linear init (uniform +-1/sqrt(fan_in)); LayerNorm
+    weights are perturbed from (1, 0) so that affine parity is actually exercised.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p = {}
+
+    def lin(name, fin, fout):
+        bound = 1.0 / np.sqrt(fin)
+        p[f"{name}.weight"] = rng.uniform(-bound, bound, (fout, fin)).astype(F32)
+        p[f"{name}.bias"] = rng.uniform(-bound, bound, (fout,)).astype(F32)
+
+    def build(prefix, fin, fout, norm):
+        lin(f"{prefix}.0", fin, hidden)
+        for li in range(1, num_layers):
+            lin(f"{prefix}.{2 * li}", hidden, hidden)
+        lin(f"{prefix}.{2 * num_layers}", hidden, fout)
+        if norm:
+            p[f"{prefix}.{2 * num_layers + 1}.weight"] = (1.0 + 0.1 * rng.standard_normal(fout)).astype(F32)
+            p[f"{prefix}.{2 * num_layers + 1}.bias"] = (0.1 * rng.standard_normal(fout)).astype(F32)
+
+    build("encoder.phi_edge", edge_dim, hidden, True)
+    build("encoder.phi_node", node_dim, hidden, True)
+    for k in range(m_steps):
+        build(f"processor.{k}.phi_edge", 3 * hidden, hidden, True)
+        build(f"processor.{k}.phi_node", 2 * hidden, hidden, True)
+    build("decoder", hidden, out_dim, False)
+    return p
+
+
+# --------------------------------------------------------------------------------------
+# K10  integrator  (gnn_manip/utils/rollout_utils.py:145-158)
+# --------------------------------------------------------------------------------------
+def get_position_from_prediction(stats, cartesian_idx, pred_acc, obs_seq):
+    pred_acc = np.asarray(pred_acc, F32)
+    obs_seq = np.asarray(obs_seq, F32)
+    acc = pred_acc * np.asarray(stats["acceleration_std"], F32) + np.asarray(stats["acceleration_mean"], F32)
+    last_pos = obs_seq[-1][:, cartesian_idx]
+    last_vel = last_pos - obs_seq[-2][:, cartesian_idx]
+    vel = last_vel + acc
+    return (last_pos + vel).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# a12  rigid-body trajectory  (traj_utils.py:87-103,167-228; rollout_utils.py:161-205)
+# --------------------------------------------------------------------------------------
+def compute_particles_tmatrix(rotation, translation, ty_init, rigid_particles):
+    """traj_utils.py:167-194 == rollout_utils.py:178-205 (rotation about X, y/z swap)."""
+    rp = np.asarray(rigid_particles, F32)
+    c = F32(np.cos(rotation))
+    s = F32(np.sin(rotation))
+    T = np.array([[1, 0, 0, ty_init[0]],
+                  [0, c, -s, ty_init[1] + translation],
+                  [0, s, c, ty_init[2]],
+                  [0, 0, 0, 1]], dtype=F32)
+    init = np.ones((4, rp.shape[0]), dtype=F32)
+    init[0] = F32(ty_init[0]) - rp[:, 0]
+    init[1] = F32(ty_init[1]) - rp[:, 2]
+    init[2] = F32(ty_init[2]) - rp[:, 1]
+    tp = T @ init
+    out = np.zeros_like(rp)
+    out[:, 0] = tp[0]
+    out[:, 2] = tp[1]
+    out[:, 1] = tp[2]
+    return out
+
+
+def set_sample_traj(sample_traj, scale_rot, scale_ty):
+    """TrajectoryCMAsolver.set_sample_traj (traj_utils.py:199-204)."""
+    d = sample_traj[2:] - sample_traj[1:-1]
+    return np.stack((np.deg2rad(d[:, 0] / scale_rot), d[:, 1] / scale_ty)).T
+
+
+def interpolate_trajectory(x, n_points, rx_init, scale_rot, scale_ty, max_rot, max_ty):
+    """TrajectoryCMAsolver.interpolate_trajectory (traj_utils.py:206-228).
+
+    rx_init, max_rot in radians (already deg2rad'ed by the solver ctor, traj_utils.py:31,54).
+    """
+    prev_r, prev_t = rx_init, 0.0
+    rot, ty = [rx_init], [0.0]
+    for i in range(n_points):
+        inc_r = np.clip(np.deg2rad(scale_rot * np.rad2deg(x[i])), -max_rot, max_rot)
+        inc_t = np.clip(scale_ty * x[i + n_points], -max_ty, max_ty)
+        prev_r = prev_r + inc_r
+        prev_t = prev_t + inc_t
+        rot.append(prev_r)
+        ty.append(prev_t)
+    return rot, ty
+
+
+def rigid_body_trajectory(traj_rot, traj_ty, horizon, ty_init, rigid_particles):
+    """get_rigid_body_trajectory_from_diff body (traj_utils.py:97-99): [horizon, Nr, 3]."""
+    return np.stack([compute_particles_tmatrix(traj_rot[i], traj_ty[i], ty_init, rigid_particles)
+                     for i in range(horizon)])
+
+
+# --------------------------------------------------------------------------------------
+# a11  rollout loop  (rollout_utils.py:38-61 == traj_utils.py:123-152)
+# --------------------------------------------------------------------------------------
+def rollout(params, obs0, trajectory, horizon, stats, bounds, conn_r, cartesian_idx, material_idx,
+            control_idx, num_layers=2, m_steps=10, max_neighbours=20, record=False,
+            forward_fn=None):
+    """cma_objective's loop (traj_utils.py:119-152).  obs0: [k, N, D] float32.
+
+    Returns the final state [k, N, D] (and per-step last-frame records if asked).
+    ``forward_fn(nodes, edge_attr, edge_index)`` defaults to the oracle's epd_forward.
+    """
+    obs = np.array(obs0, dtype=F32, copy=True)
+    mat_col = material_idx[0]
+    rigid = obs[-1][:, mat_col] == 1
+    ci = list(cartesian_idx)
+    ui = list(control_idx)
+    recs = []
+    if forward_fn is None:
+        def forward_fn(n, ea, ei):
+            return epd_forward(params, n, ea, ei, num_layers, m_steps)
+    for i in range(horizon):
+        new_rigid = obs[-1][rigid].copy()
+        cur = obs[-1][rigid][:, ci]
+        if i >= trajectory.shape[0]:
+            new_rigid[:, ui] = cur  # traj_utils.py:130-131
+        else:
+            new_rigid[:, ui] = trajectory[i] - cur  # traj_utils.py:133
+        obs[-1][rigid] = new_rigid
+        if record:
+            recs.append(obs[-1].copy())
+        nodes, edge_attr, s, r, _ = process(obs, None, stats, bounds, conn_r, cartesian_idx,
+                                            material_idx, control_idx, max_neighbours)
+        pred = forward_fn(nodes, edge_attr, np.stack((s, r)))
+        next_pos = get_position_from_prediction(stats, cartesian_idx, pred, obs)
+        obs[:-1] = obs[1:].copy()
+        last = obs[-1]
+        last[:, ci] = next_pos
+        if i < trajectory.shape[0]:
+            new_rigid[:, ci] = trajectory[i]
+        last[rigid] = new_rigid
+    if record:
+        return obs, np.stack(recs)
+    return obs

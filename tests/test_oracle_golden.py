@@ -1,0 +1,154 @@
+"""The oracle against the reference's own outputs (fixtures from tests/golden/make_golden.py).
+
+CPU only.  Integer/index results must be bit-exact; float32 feature functions are compared
+with a tight tolerance (written next to each check) because numpy and torch may round a
+float32 division / norm differently in the last ulp.
+"""
+import numpy as np
+import pytest
+
+from oracle import epd_oracle as orc
+from conftest import STATS, BOUNDS, CART, MAT, CTRL, G1_CASES
+
+KW = dict(stats=STATS, bounds=BOUNDS, conn_r=0.015, cartesian_idx=CART, material_idx=MAT)
+
+
+@pytest.mark.parametrize("case", G1_CASES)
+def test_g1_connectivity_bit_exact(golden, case):
+    g = golden("g1_connectivity.npz")
+    pos = g[f"{case}.pos"]
+    r, cap = g[f"{case}.r_cap"]
+    s, rcv = orc.get_connectivity(pos, float(r), int(cap))
+    assert s.dtype == np.int64 and rcv.dtype == np.int64
+    assert np.array_equal(s, g[f"{case}.senders"])
+    assert np.array_equal(rcv, g[f"{case}.receivers"])
+    # self edge first for every query, cap respected
+    first = np.r_[True, s[1:] != s[:-1]]
+    assert np.array_equal(rcv[first], s[first])
+    assert np.bincount(s).max() <= int(cap)
+
+
+def test_g1_cell_list_path_matches_bruteforce(golden):
+    g = golden("g1_connectivity.npz")
+    pos = g["mean20_3000.pos"]
+    s, r = orc._get_connectivity_cells(pos, 0.015, 20)
+    assert np.array_equal(s, g["mean20_3000.senders"])
+    assert np.array_equal(r, g["mean20_3000.receivers"])
+
+
+@pytest.mark.parametrize("case", G1_CASES)
+def test_g2_edge_features(golden, case):
+    g = golden("g1_connectivity.npz")
+    r = float(g[f"{case}.r_cap"][0])
+    ea = orc.get_edges_displacement(g[f"{case}.pos"], g[f"{case}.senders"], g[f"{case}.receivers"], r)
+    np.testing.assert_allclose(ea, g[f"{case}.edge_attr"], rtol=2e-7, atol=1e-7)
+
+
+def test_g3_g4_node_features(golden):
+    g = golden("g4_features.npz")
+    obs = g["obs_a"]
+    vel = orc.get_nodes_vel(obs[:, :, CART], STATS["velocity_mean"], STATS["velocity_std"])
+    np.testing.assert_allclose(vel, g["vel_a"], rtol=2e-7, atol=1e-7)
+    n1 = orc.compute_nodes(obs, control_idx=CTRL, **KW)
+    assert n1.shape == (180, 25)
+    np.testing.assert_allclose(n1, g["nodes_ctrl_a"], rtol=2e-7, atol=1e-7)
+    n0 = orc.compute_nodes(obs[:, :, :5], control_idx=None, **KW)
+    assert n0.shape == (180, 22)
+    np.testing.assert_allclose(n0, g["nodes_noctrl_a"], rtol=2e-7, atol=1e-7)
+
+
+def test_g4_process_and_collate(golden):
+    g = golden("g4_features.npz")
+    nodes, ea, s, r, tgt = orc.process(g["obs_a"], g["tgt_a"], control_idx=CTRL, **KW)
+    assert np.array_equal(s, g["proc_senders"]) and np.array_equal(r, g["proc_receivers"])
+    np.testing.assert_allclose(nodes, g["proc_nodes"], rtol=2e-7, atol=1e-7)
+    np.testing.assert_allclose(ea, g["proc_edge_attr"], rtol=2e-7, atol=1e-7)
+    np.testing.assert_allclose(tgt, g["proc_tgt"], rtol=1e-5, atol=1e-5)
+    batch = [(g["obs_a"], g["tgt_a"]), (g["obs_b"], g["tgt_b"])]
+    nodes, ea, ei, tgt = orc.process_collate(batch, control_idx=CTRL, **KW)
+    assert np.array_equal(ei, g["coll_edge_index"])  # offset rule collate_utils.py:76
+    np.testing.assert_allclose(nodes, g["coll_nodes"], rtol=2e-7, atol=1e-7)
+    np.testing.assert_allclose(ea, g["coll_edge_attr"], rtol=2e-7, atol=1e-7)
+
+
+def test_g5_acceleration_and_integrator(golden):
+    g = golden("g4_features.npz")
+    acc = orc.compute_acceleration(g["tgt_a"], g["obs_a"][:, :, CART])
+    np.testing.assert_array_equal(acc, g["acc_a"])
+    nxt = orc.get_position_from_prediction(STATS, CART, g["pred_acc"], g["obs_a"])
+    np.testing.assert_array_equal(nxt, g["next_pos"])  # mul, add, sub, add: same roundings
+
+
+def test_g6_trajectory(golden):
+    g = golden("g6_trajectory.npz")
+    sample = None
+    scale_ty, scale_rot, rx_init, max_rot, max_ty = g["scale_ty_eff"]
+    x0 = g["x0"]
+    n = x0.shape[0] // 2
+    rot, ty = orc.interpolate_trajectory(x0, n, rx_init, scale_rot, scale_ty, max_rot, max_ty)
+    np.testing.assert_allclose(rot, g["traj_rot"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(ty, g["traj_ty"], rtol=0, atol=1e-15)
+    rot2, ty2 = orc.interpolate_trajectory(g["x_pert"], n, rx_init, scale_rot, scale_ty, max_rot, max_ty)
+    np.testing.assert_allclose(rot2, g["traj_rot_pert"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(ty2, g["traj_ty_pert"], rtol=0, atol=1e-15)
+    rp = g["obs_c"][-1, 36:, 2:5]
+    steps = g["rigid_traj_steps"]
+    for k, st in enumerate(steps):
+        out = orc.compute_particles_tmatrix(rot[st], ty[st], [0.5, 0.5, 0.4], rp)
+        np.testing.assert_allclose(out, g["rigid_traj"][k], rtol=0, atol=2e-7)
+    rb = orc.rigid_body_trajectory(rot, ty, 4, [0.5, 0.5, 0.4], rp)
+    np.testing.assert_allclose(rb, g["rigid_traj_rollout_utils"], rtol=0, atol=2e-7)
+
+
+def test_g6_set_sample_traj_against_fixture_inputs(golden):
+    # sample_traj.npy itself is reference data and is not copied; the scaled result is the vector.
+    g = golden("g6_trajectory.npz")
+    x0 = g["x0"]
+    n = x0.shape[0] // 2
+    assert n == 299  # 301-row sample trajectory -> 299 increments (traj_utils.py:200)
+    assert np.array_equal(g["sample_scaled"][:, 0], x0[:n])
+    assert np.array_equal(g["sample_scaled"][:, 1], x0[n:])
+    # reconstruct a sample trajectory consistent with the scaled increments and re-scale it
+    scale_ty, scale_rot = g["scale_ty_eff"][:2]
+    d = np.stack((np.rad2deg(g["sample_scaled"][:, 0]) * scale_rot, g["sample_scaled"][:, 1] * scale_ty)).T
+    traj = np.concatenate((np.zeros((2, 2)), np.cumsum(d, axis=0)))
+    again = orc.set_sample_traj(traj, scale_rot, scale_ty)
+    np.testing.assert_allclose(again, g["sample_scaled"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["h128", "h64_l3_m2"])
+def test_g7_epd_wiring(golden, tag):
+    g7 = golden("g7_epd_wiring.npz")
+    g4 = golden("g4_features.npz")
+    nd, ed, od, hid, nl, ms, seed = [int(v) for v in g7[f"{tag}.cfg"]]
+    params = orc.init_params(nd, ed, od, hid, nl, ms, seed)
+    assert sorted(params.keys()) == list(g7[f"{tag}.keys"])  # state_dict naming
+    nodes, ea, s, r, _ = orc.process(g4["obs_a"], None, control_idx=CTRL, **KW)
+    ei = np.stack((s, r))
+    h0, e0 = orc.graph_independent(params, "encoder", nodes, ea, nl)
+    np.testing.assert_allclose(h0, g7[f"{tag}.h0"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(e0[:64], g7[f"{tag}.e0_head"], rtol=1e-5, atol=2e-6)
+    h1, e1 = orc.interaction_network(params, "processor.0", h0, e0, ei, nl)
+    np.testing.assert_allclose(h1, g7[f"{tag}.h1"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(e1[:64], g7[f"{tag}.e1_head"], rtol=1e-5, atol=5e-6)
+    out = orc.epd_forward(params, nodes, ea, ei, nl, ms)
+    ref = g7[f"{tag}.out"]
+    # north_star tolerance: 1e-5 relative (to the output scale) in float32
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_g8_rollout_loop(golden):
+    g = golden("g8_rollout.npz")
+    nd, ed, od, hid, nl, ms, seed, horizon = [int(v) for v in g["cfg"]]
+    params = orc.init_params(nd, ed, od, hid, nl, ms, seed)
+    obs0 = g["obs0"]
+    rigid = obs0[-1, :, 1] == 1
+    rp = obs0[-1][rigid][:, CART]
+    traj = orc.rigid_body_trajectory(g["traj_rot"], g["traj_ty"], horizon, [0.5, 0.5, 0.4], rp)
+    final, recs = orc.rollout(params, obs0, traj, horizon, STATS, BOUNDS, 0.015, CART, MAT, CTRL,
+                              num_layers=nl, m_steps=ms, record=True)
+    end = final[-1][~rigid][:, CART]
+    # positions ~0.3-0.5, 7 steps of a random-weight model: 1e-5 relative to position scale
+    np.testing.assert_allclose(end, g["end_coffee"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(recs[:, ~rigid][:, :, CART], g["coffee_states"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(recs[:, rigid][:, :, CART], g["cup_states"], rtol=0, atol=5e-6)
