@@ -1,0 +1,7 @@
+"""gnn_manip_amd: MI355X-native (gfx950) rollout engine for gnn-manip's encode-process-decode
+particle simulator.  HIP kernels + C ABI in libgnnmanip_hip.so; this package is the host-side
+mirror of the reference's call surface (see DESIGN.md / INTEGRATION.md)."""
+from .epd_gnn import EncProcDecGNN, GraphIndependent, InteractionNetwork  # noqa: F401
+from .graph import (GraphBoundedMultimaterial, GraphBoundedMultimaterialControl, compute_acceleration,  # noqa: F401
+                    get_connectivity, get_edges_displacement)
+from .rollout import RolloutEngine, get_position_from_prediction  # noqa: F401

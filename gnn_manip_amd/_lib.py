@@ -1,0 +1,109 @@
+"""ctypes binding of libgnnmanip_hip.so (include/gnn_manip_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  Loading fails with a clear
+error if the shared object has not been built (``python -m gnn_manip_amd.build`` or
+``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnnmanip_hip.so")
+
+GM_OK = 0
+
+
+class GMError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgnnmanip_hip: {msg} (status {code})")
+        self.code = code
+
+
+class FeatureDesc(C.Structure):
+    _fields_ = [("conn_r", C.c_double), ("k_steps", C.c_int32), ("data_dim", C.c_int32),
+                ("cart_col", C.c_int32), ("material_col", C.c_int32), ("control_col", C.c_int32),
+                ("reserved", C.c_int32),
+                ("vel_mean", C.c_float * 3), ("vel_std", C.c_float * 3),
+                ("acc_mean", C.c_float * 3), ("acc_std", C.c_float * 3),
+                ("lower_bounds", C.c_float * 3), ("upper_bounds", C.c_float * 3)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("node_dim", C.c_int32), ("edge_dim", C.c_int32), ("out_dim", C.c_int32),
+                ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("m_steps", C.c_int32),
+                ("ln_eps", C.c_float)]
+
+
+_vp, _i64, _i32, _sz, _f32, _f64 = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float, C.c_double
+_FD, _MD = C.POINTER(FeatureDesc), C.POINTER(ModelDesc)
+
+# name -> (restype, argtypes); every symbol declared in include/gnn_manip_hip.h
+PROTOTYPES = {
+    "gm_last_error": (C.c_char_p, []),
+    "gm_abi_version": (_i32, []),
+    "gm_graph_workspace_bytes": (_sz, [_i64, _i32]),
+    "gm_radius_graph_build": (_i32, [_vp, _i64, _i64, _f64, _i32, _vp, _sz, _vp]),
+    "gm_radius_graph_num_edges": (_i32, [_vp, C.POINTER(_i64), _vp]),
+    "gm_radius_graph_edges": (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),
+    "gm_csr_workspace_bytes": (_sz, [_i64, _i64]),
+    "gm_csr_from_graph": (_i32, [_vp, _i64, _i32, _vp, _sz, _vp]),
+    "gm_csr_from_edge_index": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp]),
+    "gm_csr_num_edges": (_i32, [_vp, C.POINTER(_i64), _vp]),
+    "gm_edge_features": (_i32, [_vp, _i64, _vp, _vp, _i64, _f32, _vp, _vp]),
+    "gm_edge_features_csr": (_i32, [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp]),
+    "gm_node_features": (_i32, [_vp, _i64, _FD, _vp, _vp]),
+    "gm_integrate": (_i32, [_vp, _vp, _i64, _FD, _vp, _vp]),
+    "gm_rigid_rank": (_i32, [_vp, _i64, _FD, _vp, _vp, _vp]),
+    "gm_state_pre": (_i32, [_vp, _i64, _FD, _vp, _vp, _vp]),
+    "gm_state_post": (_i32, [_vp, _i64, _FD, _vp, _vp, _vp, _vp]),
+    "gm_rigid_transform": (_i32, [_vp, _i64, _vp, _i64, C.POINTER(_f32 * 3), _vp, _vp]),
+    "gm_model_num_tensors": (_i32, [_MD]),
+    "gm_model_create": (_i32, [_MD, C.POINTER(_vp), _i32, _i32, _vp, C.POINTER(_vp)]),
+    "gm_model_update": (_i32, [_vp, C.POINTER(_vp), _i32, _i32, _vp]),
+    "gm_model_destroy": (None, [_vp]),
+    "gm_forward_workspace_bytes": (_sz, [_MD, _i64, _i64]),
+    "gm_epd_forward": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "gm_graph_independent_forward": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "gm_interaction_network_forward": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "gm_rollout_workspace_bytes": (_sz, [_MD, _i64, _i32]),
+    "gm_rollout_step": (_i32, [_vp, _vp, _i64, _FD, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gm_rollout_status": (_i32, [_vp, _MD, _i64, _i32, C.POINTER(_i64), _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it was never built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension has not been built "
+                "(run `python -m gnn_manip_amd.build`). gnn_manip_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status):
+    if status != GM_OK:
+        msg = lib().gm_last_error()
+        raise GMError(status, msg.decode() if msg else "unknown error")
+
+
+def ptr(t):
+    """Device (or host) address of a contiguous torch tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libgnnmanip_hip needs contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,103 @@
+// Internal helpers shared by the HIP translation units of libgnnmanip_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/gnn_manip_hip.h"
+
+namespace gm {
+
+void set_error(const char* fmt, ...);
+
+#define GM_HIP_CHECK(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            gm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                          __LINE__);                                                        \
+            return GM_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+#define GM_REQUIRE(cond, code, ...)          \
+    do {                                     \
+        if (!(cond)) {                       \
+            gm::set_error(__VA_ARGS__);      \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+#define GM_LAUNCH_CHECK() GM_HIP_CHECK(hipGetLastError())
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Carves a caller-owned workspace into aligned arrays.
+struct Carver {
+    char* base;
+    size_t off;
+    explicit Carver(void* p) : base(static_cast<char*>(p)), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        off = align_up(off, 256);
+        T* r = reinterpret_cast<T*>(base + off);
+        off += count * sizeof(T);
+        return r;
+    }
+    size_t used() const { return align_up(off, 256); }
+};
+
+// ---- error flags written by device code into workspace headers
+enum : int { ERRF_NONFINITE_POS = 1, ERRF_BAD_EDGE_INDEX = 2, ERRF_CAPACITY = 4 };
+
+// ---- graph workspace (graph.hip) ---------------------------------------------------------
+struct GraphHeader {  // lives at the start of the graph workspace (device memory)
+    int n_edges;      // E of the last build
+    int error_flags;
+    int ncells;
+    int dims[3];
+    unsigned bbox_min[3];  // order-preserving uint encoding of float
+    unsigned bbox_max[3];
+    double origin[3];
+    double inv_h;
+};
+
+struct GraphWs {
+    GraphHeader* hdr;
+    int* cell_of;      // [N]
+    int* cell_start;   // [max_cells + 1]  counts, then exclusive offsets
+    int* cell_cursor;  // [max_cells]
+    float4* sorted;    // [N] (x, y, z, index bits), grouped by cell
+    int* cnt;          // [N + 1] neighbours kept per query (cnt[N] = 0)
+    int* out_ptr;      // [N + 1] exclusive scan of cnt; out_ptr[N] = E
+    int* nbr;          // [N * max_nb] neighbour lists, distance-sorted
+    int* scan_tmp;     // block sums for the scans
+    int max_cells;
+    size_t bytes;
+};
+int max_cells_for(int64_t n);
+GraphWs carve_graph(void* ws, int64_t n, int max_nb);
+
+// ---- destination-sorted edge structure (graph.hip) ----------------------------------------
+struct CsrHeader {
+    int n_edges;
+    int error_flags;
+    int pad[2];
+};
+struct CsrWs {
+    CsrHeader* hdr;
+    int* in_ptr;   // [N + 1] exclusive scan of in-degree
+    int* cursor;   // [N]
+    int* dst;      // [cap] aggregation node of sorted position p
+    int* src;      // [cap]
+    int* eid;      // [cap] original edge id (row in the caller's edge order)
+    int* scan_tmp;
+    size_t bytes;
+};
+CsrWs carve_csr(void* ws, int64_t n, int64_t cap);
+
+int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s);
+size_t scan_tmp_ints(int64_t n_max);
+
+}  // namespace gm

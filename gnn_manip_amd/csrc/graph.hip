@@ -1,0 +1,609 @@
+// Radius graph (uniform cell list, float64 distance test, per-query top-k by (d2, index)) and
+// the destination-sorted edge structure.  HBM-light integer work: coalesced streams, LDS-held
+// per-query candidate lists, no host synchronisation.
+//
+// Replaces get_connectivity, gnn_manip/utils/utils.py:64-93 (sklearn KDTree.query_radius:
+// float64 d2 = sum_j (x_j - y_j)^2 accumulated j = 0..2, kept when d2 <= r*r, ordered by
+// ascending distance, first max_neighbours kept).
+#include <stdarg.h>
+#include "common.h"
+
+namespace gm {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of int32, n known on the host or read from device memory
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+size_t scan_tmp_ints(int64_t n_max) { return (size_t)cdiv(n_max, SCAN_TILE) + 1; }
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one int per thread (blockDim.x == SCAN_BLOCK); returns exclusive
+// prefix, *total = block sum.  sm: >= 4 ints of LDS.
+__device__ __forceinline__ int block_excl_scan(int v, int* sm, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = wave_incl_scan(v, lane);
+    if (lane == 63) sm[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+        int s = sm[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const int* __restrict__ in, int64_t n_host,
+                                                                  const int* __restrict__ n_dev,
+                                                                  int* __restrict__ tmp) {
+    __shared__ int sm[4];
+    const int64_t n = n_dev ? (int64_t)(*n_dev) : n_host;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    if (base >= n) return;
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        int64_t i = base + (int64_t)threadIdx.x * SCAN_ITEMS + k;
+        if (i < n) v += in[i];
+    }
+    int tot;
+    block_excl_scan(v, sm, &tot);
+    if (threadIdx.x == 0) tmp[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_top_kernel(int64_t n_host, const int* __restrict__ n_dev,
+                                                               int* __restrict__ tmp) {
+    __shared__ int sm[4];
+    const int64_t n = n_dev ? (int64_t)(*n_dev) : n_host;
+    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    int carry = 0;
+    for (int64_t b0 = 0; b0 < nb; b0 += SCAN_BLOCK) {
+        int64_t i = b0 + threadIdx.x;
+        int v = i < nb ? tmp[i] : 0;
+        int tot;
+        int ex = block_excl_scan(v, sm, &tot);
+        if (i < nb) tmp[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const int* in, int64_t n_host,
+                                                                 const int* __restrict__ n_dev,
+                                                                 const int* __restrict__ tmp, int* out) {
+    __shared__ int sm[4];
+    const int64_t n = n_dev ? (int64_t)(*n_dev) : n_host;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    if (base >= n) return;
+    int item[SCAN_ITEMS];
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        int64_t i = base + (int64_t)threadIdx.x * SCAN_ITEMS + k;
+        item[k] = i < n ? in[i] : 0;
+        v += item[k];
+    }
+    int tot;
+    int ex = block_excl_scan(v, sm, &tot) + tmp[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        int64_t i = base + (int64_t)threadIdx.x * SCAN_ITEMS + k;
+        if (i < n) out[i] = ex;
+        ex += item[k];
+    }
+}
+
+// out may alias in.  Scans n items (n = *n_dev when n_dev != nullptr, bounded by n_max).
+int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s) {
+    if (n_max <= 0) return GM_OK;
+    const int nb = (int)cdiv(n_max, SCAN_TILE);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n_max, n_dev, tmp);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, n_max, n_dev, tmp);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n_max, n_dev, tmp, out);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------
+int max_cells_for(int64_t n) {
+    int64_t c = 2 * n;
+    if (c < 32768) c = 32768;
+    if (c > (1 << 22)) c = (1 << 22);
+    return (int)c;
+}
+
+GraphWs carve_graph(void* ws, int64_t n, int max_nb) {
+    GraphWs g;
+    Carver c(ws);
+    g.max_cells = max_cells_for(n);
+    g.hdr = c.take<GraphHeader>(1);
+    g.cell_of = c.take<int>(n);
+    g.cell_start = c.take<int>((size_t)g.max_cells + 1);
+    g.cell_cursor = c.take<int>(g.max_cells);
+    g.sorted = c.take<float4>(n);
+    g.cnt = c.take<int>(n + 1);
+    g.out_ptr = c.take<int>(n + 1);
+    g.nbr = c.take<int>((size_t)n * max_nb);
+    size_t st = scan_tmp_ints((int64_t)g.max_cells + 1);
+    size_t st2 = scan_tmp_ints(n + 1);
+    g.scan_tmp = c.take<int>(st > st2 ? st : st2);
+    g.bytes = c.used();
+    return g;
+}
+
+CsrWs carve_csr(void* ws, int64_t n, int64_t cap) {
+    CsrWs w;
+    Carver c(ws);
+    w.hdr = c.take<CsrHeader>(1);
+    w.in_ptr = c.take<int>(n + 1);
+    w.cursor = c.take<int>(n + 1);
+    w.dst = c.take<int>(cap);
+    w.src = c.take<int>(cap);
+    w.eid = c.take<int>(cap);
+    w.scan_tmp = c.take<int>(scan_tmp_ints(n + 1));
+    w.bytes = c.used();
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// cell list
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ void graph_init_kernel(GraphHeader* hdr) {
+    if (threadIdx.x == 0) {
+        hdr->n_edges = 0;
+        hdr->error_flags = 0;
+        hdr->ncells = 1;
+        for (int a = 0; a < 3; ++a) {
+            hdr->bbox_min[a] = 0xffffffffu;
+            hdr->bbox_max[a] = 0u;
+            hdr->dims[a] = 1;
+            hdr->origin[a] = 0.0;
+        }
+        hdr->inv_h = 1.0;
+    }
+}
+
+__global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pos, int64_t stride, int64_t n,
+                                                    GraphHeader* hdr) {
+    unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = pos[i * stride + a];
+            if (!isfinite(v)) { bad = true; continue; }
+            unsigned o = f2ord(v);
+            mn[a] = min(mn[a], o);
+            mx[a] = max(mx[a], o);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[a] = min(mn[a], (unsigned)__shfl_xor((int)mn[a], d, 64));
+            mx[a] = max(mx[a], (unsigned)__shfl_xor((int)mx[a], d, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&hdr->bbox_min[a], mn[a]);
+            atomicMax(&hdr->bbox_max[a], mx[a]);
+        }
+    }
+    if (bad) atomicOr(&hdr->error_flags, ERRF_NONFINITE_POS);
+}
+
+// One thread: grid origin, cell edge h >= r*(1+2^-10) (so |x_i-x_j| <= r implies cell coordinates
+// differ by at most 1 on every axis despite rounding), enlarged until the grid fits max_cells.
+__global__ void grid_params_kernel(GraphHeader* hdr, double r, int max_cells, int64_t n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double lo[3], ext[3];
+    for (int a = 0; a < 3; ++a) {
+        double mn = n > 0 && hdr->bbox_min[a] <= hdr->bbox_max[a] ? (double)ord2f(hdr->bbox_min[a]) : 0.0;
+        double mx = n > 0 && hdr->bbox_min[a] <= hdr->bbox_max[a] ? (double)ord2f(hdr->bbox_max[a]) : 0.0;
+        lo[a] = mn;
+        ext[a] = mx - mn;
+    }
+    double h = r * (1.0 + 1.0 / 1024.0);
+    if (!(h > 0.0)) h = 1.0;
+    int d[3];
+    for (int it = 0; it < 256; ++it) {
+        double prod = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            double c = floor(ext[a] / h) + 1.0;
+            if (c > 2.0e9) c = 2.0e9;
+            d[a] = (int)c;
+            prod *= c;
+        }
+        if (prod <= (double)max_cells) break;
+        h *= 1.2599210498948732;  // doubles the cell volume
+    }
+    for (int a = 0; a < 3; ++a) {
+        hdr->dims[a] = d[a];
+        hdr->origin[a] = lo[a];
+    }
+    hdr->inv_h = 1.0 / h;
+    hdr->ncells = d[0] * d[1] * d[2];
+}
+
+__device__ __forceinline__ int cell_coord(float v, double origin, double inv_h, int dim) {
+    double c = floor(((double)v - origin) * inv_h);
+    int ci = (c > 0.0) ? (c < (double)(dim - 1) ? (int)c : dim - 1) : 0;
+    return ci;
+}
+
+__global__ void __launch_bounds__(256) cell_assign_kernel(const float* __restrict__ pos, int64_t stride, int64_t n,
+                                                           const GraphHeader* __restrict__ hdr,
+                                                           int* __restrict__ cell_of, int* __restrict__ cell_count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int dx = hdr->dims[0], dy = hdr->dims[1], dz = hdr->dims[2];
+    float x = pos[i * stride], y = pos[i * stride + 1], z = pos[i * stride + 2];
+    if (!isfinite(x)) x = 0.f;
+    if (!isfinite(y)) y = 0.f;
+    if (!isfinite(z)) z = 0.f;
+    int cx = cell_coord(x, hdr->origin[0], hdr->inv_h, dx);
+    int cy = cell_coord(y, hdr->origin[1], hdr->inv_h, dy);
+    int cz = cell_coord(z, hdr->origin[2], hdr->inv_h, dz);
+    int c = (cz * dy + cy) * dx + cx;
+    cell_of[i] = c;
+    atomicAdd(&cell_count[c], 1);
+}
+
+__global__ void __launch_bounds__(256) cell_fill_kernel(const float* __restrict__ pos, int64_t stride, int64_t n,
+                                                         const int* __restrict__ cell_of,
+                                                         const int* __restrict__ cell_start,
+                                                         int* __restrict__ cell_cursor, float4* __restrict__ sorted) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = cell_of[i];
+    int p = cell_start[c] + atomicAdd(&cell_cursor[c], 1);
+    sorted[p] = make_float4(pos[i * stride], pos[i * stride + 1], pos[i * stride + 2], __int_as_float((int)i));
+}
+
+// ------------------------------------------------------------------------------------------
+// neighbour search: thread t owns the query in sorted slot t; candidate lists live in LDS as
+// [slot][thread] (conflict-free), kept sorted by (d2, index).
+// ------------------------------------------------------------------------------------------
+template <int BS>
+__global__ void __launch_bounds__(BS) neighbor_kernel(const float4* __restrict__ sorted,
+                                                       const int* __restrict__ cell_start,
+                                                       const GraphHeader* __restrict__ hdr, int64_t n, double r2,
+                                                       int K, int* __restrict__ cnt, int* __restrict__ nbr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* kd = reinterpret_cast<double*>(smem);                   // [K][BS]
+    int* ki = reinterpret_cast<int*>(smem + (size_t)K * BS * 8);    // [K][BS]
+    const int t = threadIdx.x;
+    const int64_t slot = (int64_t)blockIdx.x * BS + t;
+    if (slot >= n) return;
+    const float4 q = sorted[slot];
+    const int qi = __float_as_int(q.w);
+    const int dx = hdr->dims[0], dy = hdr->dims[1], dz = hdr->dims[2];
+    const double inv_h = hdr->inv_h;
+    const int cx = cell_coord(q.x, hdr->origin[0], inv_h, dx);
+    const int cy = cell_coord(q.y, hdr->origin[1], inv_h, dy);
+    const int cz = cell_coord(q.z, hdr->origin[2], inv_h, dz);
+    const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
+    int kept = 0;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, dx - 1);
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, dz - 1); ++z) {
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, dy - 1); ++y) {
+            const int row = (z * dy + y) * dx;
+            const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
+            for (int c = b; c < e; ++c) {
+                const float4 p = sorted[c];
+                // float64, accumulated x -> y -> z (utils.py:76-78 via sklearn rdist); every
+                // product of float32-origin differences is exact in float64.
+                double d = qx - (double)p.x;
+                double d2 = __dmul_rn(d, d);
+                d = qy - (double)p.y;
+                d2 = __dadd_rn(d2, __dmul_rn(d, d));
+                d = qz - (double)p.z;
+                d2 = __dadd_rn(d2, __dmul_rn(d, d));
+                if (!(d2 <= r2)) continue;
+                const int j = __float_as_int(p.w);
+                int pos;
+                if (kept < K) {
+                    pos = kept++;
+                } else {
+                    const double ld = kd[(K - 1) * BS + t];
+                    const int lj = ki[(K - 1) * BS + t];
+                    if (!(d2 < ld || (d2 == ld && j < lj))) continue;
+                    pos = K - 1;
+                }
+                while (pos > 0) {
+                    const double pd = kd[(pos - 1) * BS + t];
+                    const int pj = ki[(pos - 1) * BS + t];
+                    if (!(d2 < pd || (d2 == pd && j < pj))) break;
+                    kd[pos * BS + t] = pd;
+                    ki[pos * BS + t] = pj;
+                    --pos;
+                }
+                kd[pos * BS + t] = d2;
+                ki[pos * BS + t] = j;
+            }
+        }
+    }
+    cnt[qi] = kept;
+    for (int s = 0; s < kept; ++s) nbr[(int64_t)qi * K + s] = ki[s * BS + t];
+}
+
+__global__ void set_total_kernel(GraphHeader* hdr, const int* __restrict__ out_ptr, int64_t n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) hdr->n_edges = out_ptr[n];
+}
+
+__global__ void __launch_bounds__(256) emit_edges_kernel(const int* __restrict__ cnt, const int* __restrict__ out_ptr,
+                                                          const int* __restrict__ nbr, int64_t n, int K,
+                                                          int64_t capacity, int64_t* __restrict__ senders,
+                                                          int64_t* __restrict__ receivers) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n * K) return;
+    int64_t i = id / K;
+    int s = (int)(id - i * K);
+    if (s >= cnt[i]) return;
+    int64_t e = (int64_t)out_ptr[i] + s;
+    if (e >= capacity) return;
+    senders[e] = i;
+    receivers[e] = nbr[id];
+}
+
+// ------------------------------------------------------------------------------------------
+// destination-sorted structure
+// ------------------------------------------------------------------------------------------
+__global__ void csr_init_kernel(CsrHeader* hdr) {
+    if (threadIdx.x == 0) {
+        hdr->n_edges = 0;
+        hdr->error_flags = 0;
+    }
+}
+
+// mode 0: slots of the radius graph (source = query i, destination = neighbour)
+__global__ void __launch_bounds__(256) indeg_graph_kernel(const int* __restrict__ cnt, const int* __restrict__ nbr,
+                                                           int64_t n, int K, int* __restrict__ indeg) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n * K) return;
+    int64_t i = id / K;
+    if ((int)(id - i * K) >= cnt[i]) return;
+    atomicAdd(&indeg[nbr[id]], 1);
+}
+
+__global__ void __launch_bounds__(256) fill_graph_kernel(const int* __restrict__ cnt, const int* __restrict__ out_ptr,
+                                                          const int* __restrict__ nbr, int64_t n, int K,
+                                                          const int* __restrict__ in_ptr, int* __restrict__ cursor,
+                                                          int64_t cap, int* __restrict__ dst, int* __restrict__ src,
+                                                          int* __restrict__ eid, CsrHeader* hdr) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n * K) return;
+    int64_t i = id / K;
+    int s = (int)(id - i * K);
+    if (s >= cnt[i]) return;
+    int d = nbr[id];
+    int p = in_ptr[d] + atomicAdd(&cursor[d], 1);
+    if (p >= cap) { atomicOr(&hdr->error_flags, ERRF_CAPACITY); return; }
+    dst[p] = d;
+    src[p] = (int)i;
+    eid[p] = out_ptr[i] + s;
+}
+
+// mode 1: caller-supplied edge_index [2, E] (int64)
+__global__ void __launch_bounds__(256) indeg_ei_kernel(const int64_t* __restrict__ ei, int64_t n, int64_t e,
+                                                        int* __restrict__ indeg, CsrHeader* hdr) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= e) return;
+    int64_t s = ei[id], d = ei[e + id];
+    if (s < 0 || s >= n || d < 0 || d >= n) { atomicOr(&hdr->error_flags, ERRF_BAD_EDGE_INDEX); return; }
+    atomicAdd(&indeg[d], 1);
+}
+
+__global__ void __launch_bounds__(256) fill_ei_kernel(const int64_t* __restrict__ ei, int64_t n, int64_t e,
+                                                       const int* __restrict__ in_ptr, int* __restrict__ cursor,
+                                                       int* __restrict__ dst, int* __restrict__ src,
+                                                       int* __restrict__ eid) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= e) return;
+    int64_t s = ei[id], d = ei[e + id];
+    if (s < 0 || s >= n || d < 0 || d >= n) return;
+    int p = in_ptr[d] + atomicAdd(&cursor[d], 1);
+    dst[p] = (int)d;
+    src[p] = (int)s;
+    eid[p] = (int)id;
+}
+
+// Make the order inside each destination segment deterministic: ascending original edge id.
+__global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict__ in_ptr, int64_t n,
+                                                            int* __restrict__ src, int* __restrict__ eid,
+                                                            CsrHeader* hdr) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) hdr->n_edges = in_ptr[n];
+    if (i >= n) return;
+    const int b = in_ptr[i], e = in_ptr[i + 1];
+    for (int a = b + 1; a < e; ++a) {
+        const int ke = eid[a], ks = src[a];
+        int p = a;
+        while (p > b && eid[p - 1] > ke) {
+            eid[p] = eid[p - 1];
+            src[p] = src[p - 1];
+            --p;
+        }
+        eid[p] = ke;
+        src[p] = ks;
+    }
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+extern "C" {
+
+const char* gm_last_error(void) { return gm::last_error(); }
+int gm_abi_version(void) { return 1; }
+
+size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours) {
+    if (n_nodes < 0 || max_neighbours < 1) return 0;
+    return carve_graph(nullptr, n_nodes, max_neighbours).bytes;
+}
+
+int gm_radius_graph_build(const float* pos, int64_t pos_stride, int64_t n, double conn_r, int K, void* ws,
+                          size_t ws_bytes, void* stream) {
+    GM_REQUIRE(n >= 0 && n < (int64_t)1 << 30, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: n_nodes=%lld out of range", (long long)n);
+    GM_REQUIRE(K >= 1 && K <= 160, GM_ERR_UNSUPPORTED, "gm_radius_graph_build: max_neighbours=%d unsupported (1..160)", K);
+    GM_REQUIRE(n * (int64_t)K < (int64_t)1 << 31, GM_ERR_UNSUPPORTED, "gm_radius_graph_build: n*max_neighbours overflows int32");
+    GM_REQUIRE(conn_r > 0.0 && conn_r == conn_r, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: conn_r must be > 0");
+    GM_REQUIRE(pos_stride >= 3, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: pos_stride < 3");
+    GM_REQUIRE(ws != nullptr && (pos != nullptr || n == 0), GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: null pointer");
+    GraphWs g = carve_graph(ws, n, K);
+    GM_REQUIRE(ws_bytes >= g.bytes, GM_ERR_WORKSPACE, "gm_radius_graph_build: workspace %zu < %zu", ws_bytes, g.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(graph_init_kernel, dim3(1), dim3(64), 0, s, g.hdr);
+    GM_HIP_CHECK(hipMemsetAsync(g.cell_start, 0, ((size_t)g.max_cells + 1) * sizeof(int), s));
+    GM_HIP_CHECK(hipMemsetAsync(g.cell_cursor, 0, (size_t)g.max_cells * sizeof(int), s));
+    GM_HIP_CHECK(hipMemsetAsync(g.cnt, 0, (size_t)(n + 1) * sizeof(int), s));
+    if (n > 0) {
+        int nb = (int)cdiv(n, 256);
+        hipLaunchKernelGGL(bbox_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, pos, pos_stride, n, g.hdr);
+        hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, s, g.hdr, conn_r, g.max_cells, n);
+        hipLaunchKernelGGL(cell_assign_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.hdr, g.cell_of, g.cell_start);
+        int rc = exclusive_scan_i32(g.cell_start, g.cell_start, (int64_t)g.max_cells + 1, nullptr, g.scan_tmp, s);
+        if (rc != GM_OK) return rc;
+        hipLaunchKernelGGL(cell_fill_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.cell_of, g.cell_start,
+                           g.cell_cursor, g.sorted);
+        const double r2 = conn_r * conn_r;  // KDTree compares rdist with r*r in float64
+        if (K <= 64) {
+            constexpr int BS = 128;
+            size_t lds = (size_t)K * BS * 12;
+            hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
+                               g.hdr, n, r2, K, g.cnt, g.nbr);
+        } else {
+            constexpr int BS = 64;
+            size_t lds = (size_t)K * BS * 12;
+            hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
+                               g.hdr, n, r2, K, g.cnt, g.nbr);
+        }
+        GM_LAUNCH_CHECK();
+    }
+    int rc = exclusive_scan_i32(g.cnt, g.out_ptr, n + 1, nullptr, g.scan_tmp, s);
+    if (rc != GM_OK) return rc;
+    hipLaunchKernelGGL(set_total_kernel, dim3(1), dim3(64), 0, s, g.hdr, g.out_ptr, n);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int gm_radius_graph_num_edges(const void* ws, int64_t* n_edges_host, void* stream) {
+    GM_REQUIRE(ws && n_edges_host, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_num_edges: null pointer");
+    GraphHeader h;
+    GM_HIP_CHECK(hipMemcpyAsync(&h, ws, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    *n_edges_host = h.n_edges;
+    GM_REQUIRE(!(h.error_flags & ERRF_NONFINITE_POS), GM_ERR_DATA, "radius graph: non-finite position in input");
+    return GM_OK;
+}
+
+int gm_radius_graph_edges(const void* ws, int64_t n, int K, int64_t* senders, int64_t* receivers, int64_t capacity,
+                          void* stream) {
+    GM_REQUIRE(ws && (capacity == 0 || (senders && receivers)), GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_edges: null pointer");
+    if (n == 0 || capacity == 0) return GM_OK;
+    GraphWs g = carve_graph(const_cast<void*>(ws), n, K);
+    hipLaunchKernelGGL(emit_edges_kernel, dim3((unsigned)cdiv(n * K, 256)), dim3(256), 0, (hipStream_t)stream, g.cnt,
+                       g.out_ptr, g.nbr, n, K, capacity, senders, receivers);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+size_t gm_csr_workspace_bytes(int64_t n_nodes, int64_t edge_capacity) {
+    if (n_nodes < 0 || edge_capacity < 0) return 0;
+    return carve_csr(nullptr, n_nodes, edge_capacity).bytes;
+}
+
+int gm_csr_from_graph(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, void* stream) {
+    GM_REQUIRE(graph_ws && csr_ws, GM_ERR_INVALID_ARGUMENT, "gm_csr_from_graph: null pointer");
+    const int64_t cap = n * K;
+    GraphWs g = carve_graph(const_cast<void*>(graph_ws), n, K);
+    CsrWs c = carve_csr(csr_ws, n, cap);
+    GM_REQUIRE(csr_ws_bytes >= c.bytes, GM_ERR_WORKSPACE, "gm_csr_from_graph: workspace %zu < %zu", csr_ws_bytes, c.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(csr_init_kernel, dim3(1), dim3(64), 0, s, c.hdr);
+    GM_HIP_CHECK(hipMemsetAsync(c.in_ptr, 0, (size_t)(n + 1) * sizeof(int), s));
+    GM_HIP_CHECK(hipMemsetAsync(c.cursor, 0, (size_t)(n + 1) * sizeof(int), s));
+    if (n > 0) {
+        unsigned nb = (unsigned)cdiv(cap, 256);
+        hipLaunchKernelGGL(indeg_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.nbr, n, K, c.in_ptr);
+        int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s);
+        if (rc != GM_OK) return rc;
+        hipLaunchKernelGGL(fill_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.out_ptr, g.nbr, n, K, c.in_ptr,
+                           c.cursor, cap, c.dst, c.src, c.eid, c.hdr);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr);
+        GM_LAUNCH_CHECK();
+    }
+    return GM_OK;
+}
+
+int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws, size_t csr_ws_bytes, void* stream) {
+    GM_REQUIRE(csr_ws && (ei || e == 0), GM_ERR_INVALID_ARGUMENT, "gm_csr_from_edge_index: null pointer");
+    GM_REQUIRE(n >= 0 && e >= 0 && e < ((int64_t)1 << 31) && n < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT,
+               "gm_csr_from_edge_index: sizes out of range");
+    CsrWs c = carve_csr(csr_ws, n, e);
+    GM_REQUIRE(csr_ws_bytes >= c.bytes, GM_ERR_WORKSPACE, "gm_csr_from_edge_index: workspace %zu < %zu", csr_ws_bytes, c.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(csr_init_kernel, dim3(1), dim3(64), 0, s, c.hdr);
+    GM_HIP_CHECK(hipMemsetAsync(c.in_ptr, 0, (size_t)(n + 1) * sizeof(int), s));
+    GM_HIP_CHECK(hipMemsetAsync(c.cursor, 0, (size_t)(n + 1) * sizeof(int), s));
+    if (e > 0) {
+        unsigned nb = (unsigned)cdiv(e, 256);
+        hipLaunchKernelGGL(indeg_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, c.in_ptr, c.hdr);
+        int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s);
+        if (rc != GM_OK) return rc;
+        hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, c.in_ptr, c.cursor, c.dst, c.src, c.eid);
+    }
+    if (n > 0)
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream) {
+    GM_REQUIRE(csr_ws && n_edges_host, GM_ERR_INVALID_ARGUMENT, "gm_csr_num_edges: null pointer");
+    CsrHeader h;
+    GM_HIP_CHECK(hipMemcpyAsync(&h, csr_ws, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    *n_edges_host = h.n_edges;
+    GM_REQUIRE(!(h.error_flags & ERRF_BAD_EDGE_INDEX), GM_ERR_DATA, "edge_index entry out of range [0, n_nodes)");
+    GM_REQUIRE(!(h.error_flags & ERRF_CAPACITY), GM_ERR_DATA, "edge capacity exceeded");
+    return GM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// Argument blocks and launchers of the fused MLP kernels (mlp.hip), used by model.hip.
+#pragma once
+#include "common.h"
+
+namespace gm {
+
+struct EdgeArgs {
+    const CsrHeader* hdr;  // device-side edge count (rollout path) or nullptr
+    int n_edges_host;
+    const int* dst;        // [E] aggregation node per sorted position (processor only)
+    const int* src;        // [E]
+    const int* eid;        // [E] row of e_in / e_out for sorted position p, or nullptr: row = p
+    const float* P;        // [N][2H]  P_i (+b1) | P_j
+    const float* e_in;     // processor: [E][H]; encoder: raw edge_attr [E][k1]
+    float* e_out;          // [E][H]
+    float* agg;            // [N][H] pre-zeroed, or nullptr
+    const float* wstream;  // packed weights, stage 0
+    const float* bias;     // processor: biases of layers 2..; encoder: biases of layers 1..
+    const float* ln_g;
+    const float* ln_b;
+    float eps;
+    int residual;          // e_out = e' + e_in
+    int k1;                // encoder: edge_dim
+};
+
+struct NodeArgs {
+    int n_nodes;
+    const float* x_in;     // mode 0: raw node features [N][k1]; mode 1/2: h [N][H]
+    int k1;
+    const float* agg;      // mode 1: [N][H]
+    float* h_out;          // [N][H] (may alias x_in)
+    int residual;
+    const float* wstream;
+    const float* bias;     // [NL+1][H]
+    const float* ln_g;
+    const float* ln_b;
+    float eps;
+    int tail;              // 0 none, 1 projection, 2 decoder
+    const float* proj_bias;  // [H] layer-1 bias of the next edge MLP
+    float* P_out;            // [N][2H]
+    const float* dec_bias;   // [NL][H] then [32] (out bias zero-padded)
+    float* dec_out;          // [N][out_dim]
+    int out_dim;
+};
+
+int layer_stages(int k, int out);
+int pack_linear(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s);
+int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
+int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
+constexpr int kStageFloats = 4096;
+
+}  // namespace gm

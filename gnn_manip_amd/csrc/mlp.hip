@@ -1,0 +1,533 @@
+// Fused encode / process / decode kernels for gfx950 (CDNA4), exact-fp32 MFMA.
+//
+// Formulation.  Every Linear runs TRANSPOSED on v_mfma_f32_32x32x2_f32:
+//     D[j][n] = sum_k W[j][k] * X[n][k]          (A operand = weights, B operand = activations)
+// so the graph element n (edge or node) sits on the MFMA lane (n = lane & 31) and the feature
+// index on the accumulator registers.  With hi = lane >> 5, register r of 32-feature block jb
+// holds feature
+//     f(jb, r, hi) = 32*jb + 8*(r >> 2) + 4*hi + (r & 3)
+// which is exactly the k-index lane (n, hi) must supply as B operand in k-step r of k-block jb of
+// the NEXT layer.  A layer's accumulators therefore feed the next layer directly (bias + ReLU in
+// registers, no LDS round trip, no shuffles): a whole 3-Linear MLP + LayerNorm + residual runs out
+// of one wave's registers, 32 graph elements x H features per wave.
+//
+// Weights are pre-packed (pack_linear_kernel) into the operand image: 1 KiB "pieces"
+//     piece(kq, jb)[lane = (i, hi)][t] = W[32*jb + i][8*kq + 4*hi + t]
+// ordered [kq][jb], 16 pieces per 16 KiB stage.  A stage is copied global(L2) -> LDS linearly by
+// LDS-DMA (global_load_lds_dwordx4) into a 2-deep ring, one workgroup barrier per stage, the DMA
+// of stage s+1 in flight under the 64 MFMAs of stage s.  A wave reads one conflict-free
+// ds_read_b128 per piece = the A operands of 4 MFMAs.
+//
+// Edge kernel (processor): layer 1 is factorised, W1 = [W_i | W_j | W_e]:
+//     z = P_i[dst] + P_j[src] + W_e e      with  P = h [W_i | W_j]^T (+ b1) computed per NODE
+// (the node kernel's tail), so the gathered node terms enter as the INITIAL ACCUMULATOR and the
+// edge MLP issues 3 instead of 5 HxH products per edge.  Edges are destination-sorted; after
+// LayerNorm the tile is staged through LDS once, serving both the segmented reduction
+// (scatter-add without atomics except for segments that cross a tile boundary) and whole-row
+// coalesced stores of e + e'.
+//
+// Reference semantics: EncProcDecGNN.forward / _process / _build_mlp,
+// gnn_manip/models/epd_gnn.py:72-105; block semantics per BASELINE.json north_star.
+#include "common.h"
+#include "mlp.h"
+
+namespace gm {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int PIECE_FLOATS = 256;                  // 1 KiB
+constexpr int STAGE_PIECES = 16;
+constexpr int STAGE_FLOATS = PIECE_FLOATS * STAGE_PIECES;  // 16 KiB
+constexpr int TILE = 128;                          // graph elements per workgroup tile
+constexpr int THREADS = 256;
+constexpr int TS = 68;                             // LDS row stride (floats) of the 64-feature staging tile
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_linear_kernel(const float* __restrict__ W, int out_rows, int ld, int col0,
+                                                           int kvalid, int nkq, int njb, int stages,
+                                                           float* __restrict__ dst) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)stages * STAGE_FLOATS;
+    if (idx >= total) return;
+    const int p = (int)(idx / PIECE_FLOATS);
+    const int within = (int)(idx % PIECE_FLOATS);
+    const int lane = within >> 2, t = within & 3;
+    const int i = lane & 31, hi = lane >> 5;
+    float v = 0.f;
+    if (p < nkq * njb) {
+        const int kq = p / njb, jb = p % njb;
+        const int row = 32 * jb + i, col = 8 * kq + 4 * hi + t;
+        if (row < out_rows && col < kvalid) v = W[(int64_t)row * ld + col0 + col];
+    }
+    dst[idx] = v;
+}
+
+int layer_stages(int k, int out) {
+    const int nkq = (k + 7) / 8, njb = (out + 31) / 32;
+    return (nkq * njb + STAGE_PIECES - 1) / STAGE_PIECES;
+}
+
+int pack_linear(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s) {
+    const int nkq = (kvalid + 7) / 8, njb = (out_rows + 31) / 32;
+    const int stages = layer_stages(kvalid, out_rows);
+    const int64_t total = (int64_t)stages * STAGE_FLOATS;
+    hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, W, out_rows, ld, col0,
+                       kvalid, nkq, njb, stages, dst);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device building blocks
+// ------------------------------------------------------------------------------------------
+struct WStream {
+    const float* base;  // stage 0 of this kernel's packed stream (global)
+    float* ring;        // LDS, 2 * STAGE_FLOATS
+    int total;          // stages per tile
+    int cur;            // next stage to consume (index within the tile sequence)
+    int parity;         // ring buffer holding stage `cur`
+    int lane, wave;
+};
+
+__device__ __forceinline__ void issue_stage(const WStream& ws, int stage, int buf) {
+#pragma unroll
+    for (int c = 0; c < STAGE_PIECES / 4; ++c) {
+        const int piece = c * 4 + ws.wave;  // one wave-instruction = one contiguous 1 KiB piece
+        const float* g = ws.base + (size_t)stage * STAGE_FLOATS + piece * PIECE_FLOATS + ws.lane * 4;
+        float* l = ws.ring + buf * STAGE_FLOATS + piece * PIECE_FLOATS;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+}
+
+// One Linear: acc[jb] += W(jb-block rows) . act.   NKQ = K/8 input octets, NJB = OUT/32 blocks.
+// `more` = another stage will be consumed after this layer's last one (this tile or the next).
+template <int NKQ, int NJB, int NKB>
+__device__ __forceinline__ void run_layer(floatx16 (&acc)[NJB], const floatx16 (&act)[NKB], WStream& ws, bool more_tiles) {
+    constexpr int NP = NKQ * NJB;
+    constexpr int NST = (NP + STAGE_PIECES - 1) / STAGE_PIECES;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // stage `cur` has landed for every wave; the other buffer is free
+        int nxt = ws.cur + 1;
+        const bool wrap = nxt == ws.total;
+        if (wrap) nxt = 0;
+        {
+            // launder the stage index: otherwise every stage's DMA addresses are precomputed outside
+            // the tile loop and spilled
+            int st = nxt;
+            asm volatile("" : "+s"(st));
+            if (!wrap || more_tiles) issue_stage(ws, st, ws.parity ^ 1);
+        }
+        const float* buf = ws.ring + ws.parity * STAGE_FLOATS + ws.lane * 4;
+#pragma unroll
+        for (int slot = 0; slot < STAGE_PIECES; ++slot) {
+            const int p = s * STAGE_PIECES + slot;
+            if (p < NP) {
+                const int kq = p / NJB, jb = p % NJB;
+                const floatx4 a = *reinterpret_cast<const floatx4*>(buf + slot * PIECE_FLOATS);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], act[kq >> 2][(kq & 3) * 4 + t], acc[jb], 0, 0, 0);
+            }
+        }
+        ws.cur = nxt;
+        ws.parity ^= 1;
+    }
+}
+
+// registers <-> feature vectors.  v[kb][4g + t] <-> row[32 kb + 8 g + 4 hi + t]
+template <int NKB>
+__device__ __forceinline__ void load_feat(floatx16 (&v)[NKB], const float* __restrict__ row, int hi) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 x = *reinterpret_cast<const floatx4*>(row + 32 * kb + 8 * g + 4 * hi);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[kb][4 * g + t] = x[t];
+        }
+}
+// v += row, one 32-feature block at a time (bounds the registers held by in-flight loads)
+template <int NKB>
+__device__ __forceinline__ void add_feat(floatx16 (&v)[NKB], const float* __restrict__ row, int hi) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 x = *reinterpret_cast<const floatx4*>(row + 32 * kb + 8 * g + 4 * hi);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[kb][4 * g + t] += x[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// guarded scalar loads for a raw input row of k (< 32*NKB) floats
+template <int NKB>
+__device__ __forceinline__ void load_feat_guard(floatx16 (&v)[NKB], const float* __restrict__ row, int hi, int k) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3);
+            v[kb][r] = f < k ? row[f] : 0.f;
+        }
+}
+template <int NKB>
+__device__ __forceinline__ void store_feat(const floatx16 (&v)[NKB], float* __restrict__ row, int hi) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            floatx4 x;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = v[kb][4 * g + t];
+            *reinterpret_cast<floatx4*>(row + 32 * kb + 8 * g + 4 * hi) = x;
+        }
+}
+template <int NKB>
+__device__ __forceinline__ void relu_to(floatx16 (&dst)[NKB], const floatx16 (&src)[NKB]) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[kb][r] = fmaxf(src[kb][r], 0.f);
+}
+
+// LayerNorm over the H = 32*NJB features of each lane pair (n, hi=0/1); two-pass, float32.
+template <int NJB>
+__device__ __forceinline__ void layer_norm_regs(floatx16 (&acc)[NJB], const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float eps, int hi) {
+    constexpr float INV_H = 1.0f / (32 * NJB);
+    float s = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[jb][r];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * INV_H;
+    float q = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc[jb][r] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * INV_H + eps);
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 gm = *reinterpret_cast<const floatx4*>(gamma + 32 * jb + 8 * g + 4 * hi);
+            const floatx4 bt = *reinterpret_cast<const floatx4*>(beta + 32 * jb + 8 * g + 4 * hi);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[jb][4 * g + t] = (acc[jb][4 * g + t] - mean) * rstd * gm[t] + bt[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// hidden layers 2..NL and the output layer of an MLP whose layer 1 has just been accumulated
+template <int H, int NL>
+__device__ __forceinline__ void mlp_tail_layers(floatx16 (&acc)[H / 32], floatx16 (&act)[H / 32], const float* __restrict__ bias,
+                                                WStream& ws, bool more_tiles, int hi) {
+#pragma unroll
+    for (int l = 1; l <= NL; ++l) {
+        relu_to(act, acc);
+        load_feat(acc, bias + (l - 1) * H, hi);
+        run_layer<H / 8, H / 32, H / 32>(acc, act, ws, more_tiles);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// EDGE kernel
+// ------------------------------------------------------------------------------------------
+template <int H, int NL, bool ENC>
+__global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArgs A) {
+    constexpr int NJB = H / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ring = reinterpret_cast<float*>(smem);
+    float* T = ring + 2 * STAGE_FLOATS;
+    int* sdst = reinterpret_cast<int*>(T + TILE * TS);  // [TILE + 2] (+2 pad)
+    float* headv = reinterpret_cast<float*>(sdst + TILE + 4);
+    float* tailv = headv + 4 * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hi = lane >> 5;
+    const int E = A.hdr ? A.hdr->n_edges : A.n_edges_host;
+    const int ntiles = (E + TILE - 1) / TILE;
+
+    WStream ws;
+    ws.base = A.wstream;
+    ws.ring = ring;
+    ws.total = ENC ? (1 + NL * (H / 8) * NJB / STAGE_PIECES) : ((NL + 1) * (H / 8) * NJB / STAGE_PIECES);
+    ws.cur = 0;
+    ws.parity = 0;
+    ws.lane = lane;
+    ws.wave = wave;
+    if ((int)blockIdx.x < ntiles) issue_stage(ws, 0, 0);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
+        const int p0 = tile * TILE;
+        const int p = p0 + wave * 32 + n;
+        const int pc = p < E ? p : E - 1;
+        const int er = A.eid ? A.eid[pc] : pc;
+        if (!ENC && tid < TILE + 2) {
+            const int pp = p0 - 1 + tid;
+            sdst[tid] = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+        }
+        floatx16 acc[NJB], act[NJB];
+        if (ENC) {
+            load_feat_guard(act, A.e_in + (int64_t)er * A.k1, hi, A.k1);
+            load_feat(acc, A.bias, hi);
+            // layer 1: K = edge_dim padded to 8 -> one k-octet (edge_dim <= 8 checked on the host)
+            run_layer<1, NJB, NJB>(acc, act, ws, more_tiles);
+            mlp_tail_layers<H, NL>(acc, act, A.bias + H, ws, more_tiles, hi);
+        } else {
+            const int d = A.dst[pc], sr = A.src[pc];
+            load_feat(acc, A.P + (int64_t)d * (2 * H), hi);        // P_i[dst] (+ b1)
+            add_feat(acc, A.P + (int64_t)sr * (2 * H) + H, hi);    // P_j[src]
+            load_feat(act, A.e_in + (int64_t)er * H, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more_tiles);  // + W_e e
+            mlp_tail_layers<H, NL>(acc, act, A.bias, ws, more_tiles, hi);
+        }
+        layer_norm_regs(acc, A.ln_g, A.ln_b, A.eps, hi);
+
+        // ---- epilogue: 64 features at a time through the LDS staging tile
+#pragma unroll
+        for (int fh = 0; fh < H / 64; ++fh) {
+#pragma unroll
+            for (int jb2 = 0; jb2 < 2; ++jb2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 x;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) x[t] = acc[2 * fh + jb2][4 * g + t];
+                    *reinterpret_cast<floatx4*>(T + (wave * 32 + n) * TS + 32 * jb2 + 8 * g + 4 * hi) = x;
+                }
+            __syncthreads();
+            if (!ENC && A.agg) {
+                // segmented sum over destination-sorted rows: wave q walks rows 32q..32q+31, lane = column
+                const int r0 = 32 * wave;
+                float run = 0.f;
+                bool first = sdst[r0 + 1] >= 0 && sdst[r0] == sdst[r0 + 1];
+#pragma unroll 1
+                for (int r = 0; r < 32; ++r) {
+                    const int row = r0 + r;
+                    const int d = sdst[row + 1], dn = sdst[row + 2];
+                    if (d >= 0) run += T[row * TS + lane];
+                    if (dn != d && d >= 0) {
+                        if (first) headv[wave * 64 + lane] = run;
+                        else A.agg[(int64_t)d * H + 64 * fh + lane] = run;
+                        run = 0.f;
+                        first = false;
+                    }
+                }
+                {
+                    const int dl = sdst[r0 + 32];
+                    if (dl >= 0 && sdst[r0 + 33] == dl) tailv[wave * 64 + lane] = run;
+                }
+                __syncthreads();
+                if (wave == 0) {  // stitch segments that cross quarter / tile boundaries
+                    float carry = 0.f;
+                    bool ext = false;
+#pragma unroll 1
+                    for (int q = 0; q < 4; ++q) {
+                        const int q0 = 32 * q;
+                        const int df = sdst[q0 + 1];
+                        const bool cont_in = df >= 0 && sdst[q0] == df;
+                        const bool through = cont_in && sdst[q0 + 32] == df && sdst[q0 + 33] == df;
+                        if (cont_in) {
+                            if (q == 0) { carry = 0.f; ext = true; }
+                            if (through) {
+                                carry += tailv[q * 64 + lane];
+                            } else {
+                                const float tot = carry + headv[q * 64 + lane];
+                                float* dstp = A.agg + (int64_t)df * H + 64 * fh + lane;
+                                if (ext) atomicAdd(dstp, tot); else *dstp = tot;
+                                carry = 0.f;
+                                ext = false;
+                            }
+                        }
+                        if (!through) {
+                            const int dl = sdst[q0 + 32];
+                            if (dl >= 0 && sdst[q0 + 33] == dl) { carry = tailv[q * 64 + lane]; ext = false; }
+                        }
+                    }
+                    const int dl = sdst[TILE];
+                    if (dl >= 0 && sdst[TILE + 1] == dl)  // open at the tile end: the rest is in the next tile
+                        atomicAdd(A.agg + (int64_t)dl * H + 64 * fh + lane, carry);
+                }
+            }
+            // coalesced row stores: e_out = e' (+ e_in)
+#pragma unroll 1
+            for (int pass = 0; pass < TILE / 16; ++pass) {
+                const int row = pass * 16 + (tid >> 4);
+                const int c4 = (tid & 15) * 4;
+                const int pr = p0 + row;
+                if (pr < E) {
+                    floatx4 v = *reinterpret_cast<const floatx4*>(T + row * TS + c4);
+                    const int64_t orow = A.eid ? A.eid[pr] : pr;
+                    if (!ENC && A.residual) {
+                        const floatx4 o = *reinterpret_cast<const floatx4*>(A.e_in + orow * H + 64 * fh + c4);
+                        v += o;
+                    }
+                    *reinterpret_cast<floatx4*>(A.e_out + orow * H + 64 * fh + c4) = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// NODE kernel.  MODE 0: encoder MLP on raw node features; 1: processor phi_v on [h | agg];
+// 2: projection only (block API).  Tail (runtime, uniform): 0 none, 1 projection P = h'[W_i|W_j]^T
+// for the next edge step, 2 decoder.
+// ------------------------------------------------------------------------------------------
+template <int H, int NL, int MODE>
+__global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) node_kernel(NodeArgs A) {
+    constexpr int NJB = H / 32;
+    constexpr int SL = (H / 8) * NJB / STAGE_PIECES;  // stages of one HxH layer
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ring = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hi = lane >> 5;
+    const int N = A.n_nodes;
+    const int ntiles = (N + TILE - 1) / TILE;
+
+    WStream ws;
+    ws.base = A.wstream;
+    ws.ring = ring;
+    const int mlp_stages = MODE == 0 ? (1 + NL * SL) : (MODE == 1 ? (NL + 2) * SL : 0);
+    const int tail_stages = A.tail == 1 ? 2 * SL : (A.tail == 2 ? NL * SL + 1 : 0);
+    ws.total = mlp_stages + tail_stages;
+    ws.cur = 0;
+    ws.parity = 0;
+    ws.lane = lane;
+    ws.wave = wave;
+    if ((int)blockIdx.x < ntiles) issue_stage(ws, 0, 0);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
+        const int p = tile * TILE + wave * 32 + n;
+        const bool valid = p < N;
+        const int64_t pc = valid ? p : N - 1;
+        floatx16 acc[NJB], act[NJB];
+        if (MODE == 0) {
+            load_feat_guard(act, A.x_in + pc * A.k1, hi, A.k1);
+            load_feat(acc, A.bias, hi);
+            run_layer<4, NJB, NJB>(acc, act, ws, more_tiles);  // K = node_dim padded to 32
+            mlp_tail_layers<H, NL>(acc, act, A.bias + H, ws, more_tiles, hi);
+            layer_norm_regs(acc, A.ln_g, A.ln_b, A.eps, hi);
+        } else if (MODE == 1) {
+            load_feat(act, A.x_in + pc * H, hi);
+            load_feat(acc, A.bias, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more_tiles);  // W_h h
+            load_feat(act, A.agg + pc * H, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more_tiles);  // + W_agg agg
+            mlp_tail_layers<H, NL>(acc, act, A.bias + H, ws, more_tiles, hi);
+            layer_norm_regs(acc, A.ln_g, A.ln_b, A.eps, hi);
+            if (A.residual) add_feat(acc, A.x_in + pc * H, hi);  // h <- h' + h (epd_gnn.py:103)
+        } else {
+            load_feat(acc, A.x_in + pc * H, hi);
+        }
+        if (MODE != 2 && valid) store_feat(acc, A.h_out + pc * H, hi);
+
+        if (A.tail == 1) {
+            // P_i = h' W_i^T + b1_edge ; P_j = h' W_j^T   (layer-1 factorisation of the next edge MLP)
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
+            load_feat(acc, A.proj_bias, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more_tiles);
+            if (valid) store_feat(acc, A.P_out + pc * (2 * H), hi);
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jb][r] = 0.f;
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more_tiles);
+            if (valid) store_feat(acc, A.P_out + pc * (2 * H) + H, hi);
+        } else if (A.tail == 2) {
+            // decoder (epd_gnn.py:49,96): Linear ReLU [Linear ReLU]x(NL-1) Linear(H -> out_dim), no LayerNorm
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
+            load_feat(acc, A.dec_bias, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more_tiles);
+#pragma unroll
+            for (int l = 1; l < NL; ++l) {
+                relu_to(act, acc);
+                load_feat(acc, A.dec_bias + l * H, hi);
+                run_layer<H / 8, NJB, NJB>(acc, act, ws, more_tiles);
+            }
+            relu_to(act, acc);
+            floatx16 o[1];
+            load_feat(o, A.dec_bias + NL * H, hi);  // out bias, zero-padded to 32
+            run_layer<H / 8, 1, NJB>(o, act, ws, more_tiles);
+            if (valid && hi == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < A.out_dim) A.dec_out[pc * A.out_dim + c] = o[0][c];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+size_t edge_lds_bytes() { return (size_t)(2 * STAGE_FLOATS + TILE * TS + (TILE + 4) + 2 * 4 * 64) * 4; }
+size_t node_lds_bytes() { return (size_t)(2 * STAGE_FLOATS) * 4; }
+
+static int grid_for(int64_t tiles) {
+    if (tiles < 1) tiles = 1;
+    return (int)(tiles < 2048 ? tiles : 2048);
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return GM_OK;
+}
+
+int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s) {
+    if (edge_capacity <= 0) return GM_OK;
+    GM_REQUIRE(H == 128 && NL == 2, GM_ERR_UNSUPPORTED, "edge kernel: hidden_size=%d num_layers=%d not instantiated (128, 2)", H, NL);
+    const int grid = grid_for(cdiv(edge_capacity, TILE));
+    const size_t lds = edge_lds_bytes();
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = set_lds(edge_kernel<128, 2, true>, lds);
+        if (rc != GM_OK) return rc;
+        rc = set_lds(edge_kernel<128, 2, false>, lds);
+        if (rc != GM_OK) return rc;
+        attr_done = true;
+    }
+    if (enc) hipLaunchKernelGGL((edge_kernel<128, 2, true>), dim3(grid), dim3(THREADS), lds, s, a);
+    else hipLaunchKernelGGL((edge_kernel<128, 2, false>), dim3(grid), dim3(THREADS), lds, s, a);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
+    if (a.n_nodes <= 0) return GM_OK;
+    GM_REQUIRE(H == 128 && NL == 2, GM_ERR_UNSUPPORTED, "node kernel: hidden_size=%d num_layers=%d not instantiated (128, 2)", H, NL);
+    const int grid = grid_for(cdiv(a.n_nodes, TILE));
+    const size_t lds = node_lds_bytes();
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((node_kernel<128, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        case 1: hipLaunchKernelGGL((node_kernel<128, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        default: hipLaunchKernelGGL((node_kernel<128, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a); break;
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+}  // namespace gm

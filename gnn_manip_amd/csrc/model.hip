@@ -1,0 +1,430 @@
+// Model handle (packed weight image), forward orchestration and the device-resident rollout step.
+// Host-side C++ only: every kernel lives in graph.hip / features.hip / mlp.hip.
+#include <vector>
+#include "common.h"
+#include "mlp.h"
+
+using namespace gm;
+
+struct gm_model {
+    gm_model_desc d;
+    int H, NL, M;
+    float* packed = nullptr;  // operand image of every Linear, stage-aligned streams
+    float* vec = nullptr;     // per-MLP contiguous [bias_0..bias_NL, ln_gamma, ln_beta]
+    size_t packed_floats = 0, vec_floats = 0;
+    // stream offsets (floats) into packed
+    size_t s_enc_edge, s_enc_node;
+    std::vector<size_t> s_edge, s_node;
+    // vec offsets (floats): start of MLP block
+    size_t v_enc_edge, v_enc_node, v_dec;
+    std::vector<size_t> v_edge, v_node;
+    int S_HH, S_e0, S_n0, S_out;
+};
+
+namespace {
+
+int tensors_per_normed_mlp(int NL) { return 2 * (NL + 1) + 2; }
+
+int check_desc(const gm_model_desc* d, const char* who) {
+    GM_REQUIRE(d != nullptr, GM_ERR_INVALID_ARGUMENT, "%s: null model descriptor", who);
+    // the reference's two ctor asserts (epd_gnn.py:26-27)
+    GM_REQUIRE(d->num_layers >= 2, GM_ERR_INVALID_ARGUMENT, "The number of layers num_layers must be at least 2");
+    GM_REQUIRE(d->m_steps >= 1, GM_ERR_INVALID_ARGUMENT, "The number of m_steps message pasting steps must be at least 1");
+    GM_REQUIRE(d->hidden_size == 128, GM_ERR_UNSUPPORTED, "%s: hidden_size=%d: kernels are instantiated for 128", who, d->hidden_size);
+    GM_REQUIRE(d->num_layers == 2, GM_ERR_UNSUPPORTED, "%s: num_layers=%d: kernels are instantiated for 2", who, d->num_layers);
+    GM_REQUIRE(d->edge_dim >= 1 && d->edge_dim <= 8, GM_ERR_UNSUPPORTED, "%s: edge_dim=%d unsupported (1..8)", who, d->edge_dim);
+    GM_REQUIRE(d->node_dim >= 1 && d->node_dim <= 32, GM_ERR_UNSUPPORTED, "%s: node_dim=%d unsupported (1..32)", who, d->node_dim);
+    GM_REQUIRE(d->out_dim >= 1 && d->out_dim <= 4, GM_ERR_UNSUPPORTED, "%s: out_dim=%d unsupported (1..4)", who, d->out_dim);
+    GM_REQUIRE(d->ln_eps > 0.f, GM_ERR_INVALID_ARGUMENT, "%s: ln_eps must be > 0", who);
+    return GM_OK;
+}
+
+struct FwdWs {
+    float *h, *P, *agg, *e;
+    size_t bytes;
+};
+FwdWs carve_fwd(void* ws, int H, int64_t n, int64_t cap) {
+    FwdWs f;
+    Carver c(ws);
+    f.h = c.take<float>((size_t)n * H);
+    f.P = c.take<float>((size_t)n * 2 * H);
+    f.agg = c.take<float>((size_t)n * H);
+    f.e = c.take<float>((size_t)cap * H);
+    f.bytes = c.used();
+    return f;
+}
+
+int copy_vec(float* dst, const float* src, size_t count, bool on_device, hipStream_t s) {
+    GM_HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    return GM_OK;
+}
+
+// (re)build packed + vec from the caller's tensors
+int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hipStream_t s) {
+    const int H = m->H, NL = m->NL, M = m->M;
+    const int PM = tensors_per_normed_mlp(NL);
+    GM_REQUIRE(nt == gm_model_num_tensors(&m->d), GM_ERR_INVALID_ARGUMENT, "model: expected %d tensors, got %d",
+               gm_model_num_tensors(&m->d), nt);
+    for (int i = 0; i < nt; ++i) GM_REQUIRE(T[i] != nullptr, GM_ERR_INVALID_ARGUMENT, "model: tensor %d is null", i);
+    // device staging for host weights
+    float* stage = nullptr;
+    size_t stage_floats = (size_t)H * 3 * H;
+    if (!on_device) GM_HIP_CHECK(hipMalloc(&stage, stage_floats * sizeof(float)));
+    int rc = GM_OK;
+    auto weight = [&](int ti, size_t count) -> const float* {
+        if (on_device) return T[ti];
+        if (hipMemcpyAsync(stage, T[ti], count * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) rc = GM_ERR_HIP;
+        return stage;
+    };
+    auto pack = [&](int ti, int out_rows, int ld, int col0, int k, size_t& off) {
+        if (rc != GM_OK) return;
+        const float* W = weight(ti, (size_t)out_rows * ld);
+        if (rc != GM_OK) return;
+        rc = pack_linear(W, out_rows, ld, col0, k, m->packed + off, s);
+        off += (size_t)layer_stages(k, out_rows) * kStageFloats;
+        // staging buffer is reused: serialise host copies behind the pack kernel
+        if (!on_device && rc == GM_OK && hipStreamSynchronize(s) != hipSuccess) rc = GM_ERR_HIP;
+    };
+    auto vecs = [&](int base, bool normed, size_t voff) {  // biases (+ LN) of the MLP whose first tensor is `base`
+        for (int l = 0; l <= NL && rc == GM_OK; ++l) {
+            const bool dec_out = !normed && l == NL;
+            if (dec_out) {
+                if (hipMemsetAsync(m->vec + voff + (size_t)NL * H, 0, 32 * sizeof(float), s) != hipSuccess) rc = GM_ERR_HIP;
+                if (rc == GM_OK) rc = copy_vec(m->vec + voff + (size_t)NL * H, T[base + 2 * l + 1], m->d.out_dim, on_device, s);
+            } else {
+                rc = copy_vec(m->vec + voff + (size_t)l * H, T[base + 2 * l + 1], H, on_device, s);
+            }
+        }
+        if (normed && rc == GM_OK) rc = copy_vec(m->vec + voff + (size_t)(NL + 1) * H, T[base + 2 * (NL + 1)], H, on_device, s);
+        if (normed && rc == GM_OK) rc = copy_vec(m->vec + voff + (size_t)(NL + 2) * H, T[base + 2 * (NL + 1) + 1], H, on_device, s);
+    };
+    auto hidden = [&](int base, size_t& off) {  // Linear 1..NL of an MLP (HxH)
+        for (int l = 1; l <= NL; ++l) pack(base + 2 * l, H, H, 0, H, off);
+    };
+    const int b_enc_edge = 0, b_enc_node = PM, b_dec = (2 + 2 * M) * PM;
+    auto b_edge = [&](int k) { return (2 + 2 * k) * PM; };
+    auto b_node = [&](int k) { return (3 + 2 * k) * PM; };
+
+    size_t off = m->s_enc_edge;
+    pack(b_enc_edge, H, m->d.edge_dim, 0, m->d.edge_dim, off);
+    hidden(b_enc_edge, off);
+    off = m->s_enc_node;
+    pack(b_enc_node, H, m->d.node_dim, 0, m->d.node_dim, off);
+    hidden(b_enc_node, off);
+    pack(b_edge(0), H, 3 * H, 0, H, off);  // W_i of processor 0
+    pack(b_edge(0), H, 3 * H, H, H, off);  // W_j
+    for (int k = 0; k < M; ++k) {
+        off = m->s_edge[k];
+        pack(b_edge(k), H, 3 * H, 2 * H, H, off);  // W_e
+        hidden(b_edge(k), off);
+        off = m->s_node[k];
+        pack(b_node(k), H, 2 * H, 0, H, off);  // W_h
+        pack(b_node(k), H, 2 * H, H, H, off);  // W_agg
+        hidden(b_node(k), off);
+        if (k + 1 < M) {
+            pack(b_edge(k + 1), H, 3 * H, 0, H, off);
+            pack(b_edge(k + 1), H, 3 * H, H, H, off);
+        } else {
+            for (int l = 0; l < NL; ++l) pack(b_dec + 2 * l, H, H, 0, H, off);
+            pack(b_dec + 2 * NL, m->d.out_dim, H, 0, H, off);
+        }
+    }
+    vecs(b_enc_edge, true, m->v_enc_edge);
+    vecs(b_enc_node, true, m->v_enc_node);
+    for (int k = 0; k < M; ++k) {
+        vecs(b_edge(k), true, m->v_edge[k]);
+        vecs(b_node(k), true, m->v_node[k]);
+    }
+    vecs(b_dec, false, m->v_dec);
+    if (stage) {
+        hipStreamSynchronize(s);
+        hipFree(stage);
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gm_model_num_tensors(const gm_model_desc* d) {
+    if (!d) return 0;
+    return (2 + 2 * d->m_steps) * tensors_per_normed_mlp(d->num_layers) + 2 * (d->num_layers + 1);
+}
+
+int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int n_tensors, int on_device, void* stream,
+                    gm_model** out) {
+    GM_REQUIRE(out && tensors, GM_ERR_INVALID_ARGUMENT, "gm_model_create: null pointer");
+    int rc = check_desc(desc, "gm_model_create");
+    if (rc != GM_OK) return rc;
+    gm_model* m = new gm_model();
+    m->d = *desc;
+    const int H = m->H = desc->hidden_size, NL = m->NL = desc->num_layers, M = m->M = desc->m_steps;
+    m->S_HH = layer_stages(H, H);
+    m->S_e0 = layer_stages(desc->edge_dim, H);
+    m->S_n0 = layer_stages(desc->node_dim, H);
+    m->S_out = layer_stages(H, desc->out_dim);
+    size_t st = 0;
+    m->s_enc_edge = st * kStageFloats; st += m->S_e0 + NL * m->S_HH;
+    m->s_enc_node = st * kStageFloats; st += m->S_n0 + NL * m->S_HH + 2 * m->S_HH;
+    m->s_edge.resize(M);
+    m->s_node.resize(M);
+    for (int k = 0; k < M; ++k) {
+        m->s_edge[k] = st * kStageFloats; st += (NL + 1) * m->S_HH;
+        m->s_node[k] = st * kStageFloats; st += (NL + 2) * m->S_HH + (k + 1 < M ? 2 * m->S_HH : NL * m->S_HH + m->S_out);
+    }
+    m->packed_floats = st * kStageFloats;
+    size_t v = 0;
+    const size_t VM = (size_t)(NL + 3) * H;
+    m->v_enc_edge = v; v += VM;
+    m->v_enc_node = v; v += VM;
+    m->v_edge.resize(M);
+    m->v_node.resize(M);
+    for (int k = 0; k < M; ++k) {
+        m->v_edge[k] = v; v += VM;
+        m->v_node[k] = v; v += VM;
+    }
+    m->v_dec = v; v += (size_t)NL * H + 32;
+    m->vec_floats = v;
+    if (hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess ||
+        hipMalloc(&m->vec, m->vec_floats * sizeof(float)) != hipSuccess) {
+        gm::set_error("gm_model_create: hipMalloc failed");
+        gm_model_destroy(m);
+        return GM_ERR_HIP;
+    }
+    rc = load_weights(m, tensors, n_tensors, on_device != 0, (hipStream_t)stream);
+    if (rc != GM_OK) {
+        gm_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return GM_OK;
+}
+
+int gm_model_update(gm_model* m, const float* const* tensors, int n_tensors, int on_device, void* stream) {
+    GM_REQUIRE(m && tensors, GM_ERR_INVALID_ARGUMENT, "gm_model_update: null pointer");
+    return load_weights(m, tensors, n_tensors, on_device != 0, (hipStream_t)stream);
+}
+
+void gm_model_destroy(gm_model* m) {
+    if (!m) return;
+    if (m->packed) hipFree(m->packed);
+    if (m->vec) hipFree(m->vec);
+    delete m;
+}
+
+size_t gm_forward_workspace_bytes(const gm_model_desc* desc, int64_t n, int64_t cap) {
+    if (!desc || n < 0 || cap < 0) return 0;
+    return carve_fwd(nullptr, desc->hidden_size, n, cap).bytes;
+}
+
+}  // extern "C"
+
+namespace {
+
+EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid, const CsrHeader* hdr, int e_host, float* e_out) {
+    EdgeArgs a{};
+    a.hdr = hdr; a.n_edges_host = e_host; a.eid = eid;
+    a.e_in = edge_attr; a.e_out = e_out; a.k1 = m->d.edge_dim;
+    a.wstream = m->packed + m->s_enc_edge;
+    const float* v = m->vec + m->v_enc_edge;
+    a.bias = v; a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
+    return a;
+}
+EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, const CsrHeader* hdr, int e_host, const int* eid,
+                        const float* P, const float* e_in, float* e_out, float* agg, int residual) {
+    EdgeArgs a{};
+    a.hdr = hdr; a.n_edges_host = e_host; a.dst = c.dst; a.src = c.src; a.eid = eid;
+    a.P = P; a.e_in = e_in; a.e_out = e_out; a.agg = agg; a.residual = residual;
+    a.wstream = m->packed + m->s_edge[k];
+    const float* v = m->vec + m->v_edge[k];
+    a.bias = v + m->H;  // layer-1 bias lives in P_i
+    a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
+    return a;
+}
+void set_tail(const gm_model* m, NodeArgs& a, int next_edge_step /* -1: none, M: decoder */, float* P, float* out) {
+    if (next_edge_step < 0) { a.tail = 0; return; }
+    if (next_edge_step < m->M) {
+        a.tail = 1;
+        a.proj_bias = m->vec + m->v_edge[next_edge_step];
+        a.P_out = P;
+    } else {
+        a.tail = 2;
+        a.dec_bias = m->vec + m->v_dec;
+        a.dec_out = out;
+        a.out_dim = m->d.out_dim;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, int attr_is_csr_order,
+                   const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream) {
+    GM_REQUIRE(m && csr_ws && fwd_ws, GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: null pointer");
+    GM_REQUIRE(n >= 0 && cap >= 0 && n < ((int64_t)1 << 31) && cap < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: sizes out of range");
+    if (n == 0) return GM_OK;
+    GM_REQUIRE(nodes && out && (edge_attr || cap == 0), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: null tensor");
+    const int H = m->H, NL = m->NL, M = m->M;
+    FwdWs f = carve_fwd(fwd_ws, H, n, cap);
+    GM_REQUIRE(fwd_ws_bytes >= f.bytes, GM_ERR_WORKSPACE, "gm_epd_forward: workspace %zu < %zu", fwd_ws_bytes, f.bytes);
+    CsrWs c = carve_csr(const_cast<void*>(csr_ws), n, cap);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_edge(H, NL, true, enc_edge_args(m, edge_attr, attr_is_csr_order ? nullptr : c.eid, c.hdr, 0, f.e), cap, s);
+    if (rc != GM_OK) return rc;
+    NodeArgs na{};
+    na.n_nodes = (int)n; na.x_in = nodes; na.k1 = m->d.node_dim; na.h_out = f.h;
+    na.wstream = m->packed + m->s_enc_node;
+    const float* v = m->vec + m->v_enc_node;
+    na.bias = v; na.ln_g = v + (size_t)(NL + 1) * H; na.ln_b = v + (size_t)(NL + 2) * H; na.eps = m->d.ln_eps;
+    set_tail(m, na, 0, f.P, out);
+    rc = launch_node(H, NL, 0, na, s);
+    if (rc != GM_OK) return rc;
+    for (int k = 0; k < M; ++k) {
+        GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
+        rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, 1), cap, s);
+        if (rc != GM_OK) return rc;
+        NodeArgs a{};
+        a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.h_out = f.h; a.residual = 1;
+        a.wstream = m->packed + m->s_node[k];
+        const float* vn = m->vec + m->v_node[k];
+        a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
+        set_tail(m, a, k + 1, f.P, out);
+        rc = launch_node(H, NL, 1, a, s);
+        if (rc != GM_OK) return rc;
+    }
+    return GM_OK;
+}
+
+int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n, const float* edge_attr, int64_t e,
+                                 float* h_out, float* e_out, void* stream) {
+    GM_REQUIRE(m, GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_forward: null model");
+    GM_REQUIRE(n >= 0 && e >= 0 && n < ((int64_t)1 << 31) && e < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "sizes out of range");
+    GM_REQUIRE((n == 0 || (x && h_out)) && (e == 0 || (edge_attr && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_forward: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_edge(m->H, m->NL, true, enc_edge_args(m, edge_attr, nullptr, nullptr, (int)e, e_out), e, s);
+    if (rc != GM_OK) return rc;
+    NodeArgs na{};
+    na.n_nodes = (int)n; na.x_in = x; na.k1 = m->d.node_dim; na.h_out = h_out;
+    na.wstream = m->packed + m->s_enc_node;
+    const float* v = m->vec + m->v_enc_node;
+    na.bias = v; na.ln_g = v + (size_t)(m->NL + 1) * m->H; na.ln_b = v + (size_t)(m->NL + 2) * m->H; na.eps = m->d.ln_eps;
+    na.tail = 0;
+    return launch_node(m->H, m->NL, 0, na, s);
+}
+
+int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int64_t n, const float* e,
+                                   const void* csr_ws, int64_t cap, float* h_out, float* e_out, void* fwd_ws,
+                                   size_t fwd_ws_bytes, void* stream) {
+    GM_REQUIRE(m && csr_ws && fwd_ws, GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward: null pointer");
+    GM_REQUIRE(k >= 0 && k < m->M, GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward: block %d out of range", k);
+    GM_REQUIRE(n >= 0 && cap >= 0 && n < ((int64_t)1 << 31) && cap < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "sizes out of range");
+    if (n == 0) return GM_OK;
+    GM_REQUIRE(h && h_out && (cap == 0 || (e && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward: null tensor");
+    const int H = m->H, NL = m->NL;
+    FwdWs f = carve_fwd(fwd_ws, H, n, 0);  // only P and agg are used
+    GM_REQUIRE(fwd_ws_bytes >= f.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_forward: workspace %zu < %zu", fwd_ws_bytes, f.bytes);
+    CsrWs c = carve_csr(const_cast<void*>(csr_ws), n, cap);
+    hipStream_t s = (hipStream_t)stream;
+    // projection P = h [W_i | W_j]^T (+ b1): the tail section of the preceding node stream
+    NodeArgs pa{};
+    pa.n_nodes = (int)n; pa.x_in = h;
+    pa.wstream = k == 0 ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
+                        : m->packed + m->s_node[k - 1] + (size_t)((NL + 2) * m->S_HH) * kStageFloats;
+    set_tail(m, pa, k, f.P, nullptr);
+    int rc = launch_node(H, NL, 2, pa, s);
+    if (rc != GM_OK) return rc;
+    GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
+    rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, c.hdr, 0, c.eid, f.P, e, e_out, f.agg, 0), cap, s);
+    if (rc != GM_OK) return rc;
+    NodeArgs a{};
+    a.n_nodes = (int)n; a.x_in = h; a.agg = f.agg; a.h_out = h_out; a.residual = 0;
+    a.wstream = m->packed + m->s_node[k];
+    const float* vn = m->vec + m->v_node[k];
+    a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
+    a.tail = 0;
+    return launch_node(H, NL, 1, a, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// rollout step
+// ------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+struct RolloutWs {
+    void *graph, *csr, *fwd;
+    float *x, *edge_attr, *pred, *next_pos;
+    size_t graph_bytes, csr_bytes, fwd_bytes, bytes;
+};
+RolloutWs carve_rollout(void* ws, const gm_model_desc* d, int64_t n, int K) {
+    RolloutWs r;
+    const int64_t cap = n * K;
+    r.graph_bytes = gm_graph_workspace_bytes(n, K);
+    r.csr_bytes = gm_csr_workspace_bytes(n, cap);
+    r.fwd_bytes = gm_forward_workspace_bytes(d, n, cap);
+    Carver c(ws);
+    r.graph = c.take<char>(r.graph_bytes);
+    r.csr = c.take<char>(r.csr_bytes);
+    r.fwd = c.take<char>(r.fwd_bytes);
+    r.x = c.take<float>((size_t)n * 32);
+    r.edge_attr = c.take<float>((size_t)cap * 4);
+    r.pred = c.take<float>((size_t)n * 4);
+    r.next_pos = c.take<float>((size_t)n * 3);
+    r.bytes = c.used();
+    return r;
+}
+}  // namespace
+
+extern "C" {
+
+size_t gm_rollout_workspace_bytes(const gm_model_desc* desc, int64_t n, int K) {
+    if (!desc || n < 0 || K < 1) return 0;
+    return carve_rollout(nullptr, desc, n, K).bytes;
+}
+
+int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_desc* fd, int K, const int32_t* rigid_rank,
+                    const float* rigid_target, float* pred_acc_out, void* ws, size_t ws_bytes, void* stream) {
+    GM_REQUIRE(m && obs && fd && ws, GM_ERR_INVALID_ARGUMENT, "gm_rollout_step: null pointer");
+    const int F = 3 * (fd->k_steps - 1) + 7 + (fd->control_col >= 0 ? 3 : 0);
+    GM_REQUIRE(m->d.node_dim == F, GM_ERR_INVALID_ARGUMENT, "gm_rollout_step: model node_dim=%d but features give %d", m->d.node_dim, F);
+    GM_REQUIRE(m->d.edge_dim == 4 && m->d.out_dim == 3, GM_ERR_INVALID_ARGUMENT, "gm_rollout_step: needs edge_dim=4, out_dim=3 (3-D scene)");
+    GM_REQUIRE(n < ((int64_t)1 << 31) / (K > 0 ? K : 1), GM_ERR_UNSUPPORTED, "gm_rollout_step: n*max_neighbours overflows int32");
+    RolloutWs r = carve_rollout(ws, &m->d, n, K);
+    GM_REQUIRE(ws_bytes >= r.bytes, GM_ERR_WORKSPACE, "gm_rollout_step: workspace %zu < %zu", ws_bytes, r.bytes);
+    if (n == 0) return GM_OK;
+    const int64_t cap = n * K;
+    int rc;
+    if (rigid_rank && fd->control_col >= 0) {
+        rc = gm_state_pre(obs, n, fd, rigid_rank, rigid_target, stream);
+        if (rc != GM_OK) return rc;
+    }
+    rc = gm_node_features(obs, n, fd, r.x, stream);
+    if (rc != GM_OK) return rc;
+    const float* last_pos = obs + (size_t)(fd->k_steps - 1) * n * fd->data_dim + fd->cart_col;
+    rc = gm_radius_graph_build(last_pos, fd->data_dim, n, fd->conn_r, K, r.graph, r.graph_bytes, stream);
+    if (rc != GM_OK) return rc;
+    rc = gm_csr_from_graph(r.graph, n, K, r.csr, r.csr_bytes, stream);
+    if (rc != GM_OK) return rc;
+    rc = gm_edge_features_csr(last_pos, fd->data_dim, r.csr, n, cap, (float)fd->conn_r, r.edge_attr, stream);
+    if (rc != GM_OK) return rc;
+    rc = gm_epd_forward(m, r.x, n, r.edge_attr, 1, r.csr, cap, r.pred, r.fwd, r.fwd_bytes, stream);
+    if (rc != GM_OK) return rc;
+    rc = gm_integrate(r.pred, obs, n, fd, r.next_pos, stream);
+    if (rc != GM_OK) return rc;
+    if (pred_acc_out)
+        GM_HIP_CHECK(hipMemcpyAsync(pred_acc_out, r.pred, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return gm_state_post(obs, n, fd, r.next_pos, rigid_rank, rigid_target, stream);
+}
+
+int gm_rollout_status(const void* ws, const gm_model_desc* desc, int64_t n, int K, int64_t* n_edges_host, void* stream) {
+    GM_REQUIRE(ws && desc && n_edges_host, GM_ERR_INVALID_ARGUMENT, "gm_rollout_status: null pointer");
+    RolloutWs r = carve_rollout(const_cast<void*>(ws), desc, n, K);
+    int rc = gm_radius_graph_num_edges(r.graph, n_edges_host, stream);
+    if (rc != GM_OK) return rc;
+    int64_t e2 = 0;
+    return gm_csr_num_edges(r.csr, &e2, stream);
+}
+
+}  // extern "C"

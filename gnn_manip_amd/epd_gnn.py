@@ -1,0 +1,273 @@
+"""Encode-process-decode GNN on the MI355X: drop-in for the reference's
+``gnn_manip/models/epd_gnn.py`` (``EncProcDecGNN``) and for the two ``torch_graphnet`` blocks it
+is built from (``GraphIndependent``, ``InteractionNetwork``; call sites epd_gnn.py:30-33,42-45,88,101).
+
+The modules own ordinary ``nn.Sequential`` MLPs, so ``state_dict()`` / ``load_state_dict()``
+round-trip vanilla checkpoints (keys ``encoder.phi_edge.0.weight`` ...).  ``forward`` never runs
+those Sequentials: it hands the parameters to libgnnmanip_hip.so, which keeps a packed MFMA
+operand image of them (re-packed when a parameter changes) and runs the fused HIP kernels.
+
+Block semantics (the torch_graphnet source is absent from the reference tree; fixed by
+BASELINE.json north_star): j = edge_index[0] (source), i = edge_index[1] (target);
+e' = phi_e(cat[h_i, h_j, e]); agg_i = sum_{e -> i} e'; h' = phi_v(cat[h, agg]); no residual inside
+the block.  Forward only (inference / planning); autograd is not implemented yet.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ._lib import ModelDesc, check, current_stream, lib, ptr
+from .graph import _need_cuda, _ws
+
+
+def _mlp_params(seq):
+    """Parameters of a reference-style MLP in state_dict order."""
+    return [p for _, p in seq.named_parameters()]
+
+
+def _mlp_dims(seq):
+    lin = [m for m in seq if isinstance(m, nn.Linear)]
+    norm = [m for m in seq if isinstance(m, nn.LayerNorm)]
+    return lin, norm
+
+
+class _Handle:
+    """Owns a gm_model built from a list of parameter tensors; re-packs when they change."""
+
+    def __init__(self):
+        self.h = None
+        self.key = None
+        self.desc = None
+
+    def get(self, desc_tuple, params, device):
+        key = (desc_tuple, str(device), tuple((p.data_ptr(), p._version) for p in params))
+        if self.h is not None and key == self.key:
+            return self.h
+        L = lib()
+        tensors = [p.detach().to(device=device, dtype=torch.float32).contiguous() for p in params]
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        d = ModelDesc(*desc_tuple)
+        if self.h is not None and self.key[0] == desc_tuple and self.key[1] == str(device):
+            check(L.gm_model_update(self.h, arr, len(tensors), 1, current_stream()))
+        else:
+            self.close()
+            out = C.c_void_p()
+            check(L.gm_model_create(C.byref(d), arr, len(tensors), 1, current_stream(), C.byref(out)))
+            self.h = out
+        torch.cuda.current_stream().synchronize()  # the temporaries above may be freed now
+        self.key = key
+        self.desc = d
+        return self.h
+
+    def close(self):
+        if self.h is not None:
+            lib().gm_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _no_grad_guard(params, who):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        raise NotImplementedError(
+            f"{who}: the HIP path is forward-only (no autograd yet, SURVEY.md section 8f-1); call it under "
+            "torch.no_grad() as the reference's rollout / planner do (rollout_utils.py:39, traj_utils.py:124)")
+
+
+class DstCsr:
+    """Destination-sorted edge structure of an edge_index [2, E] (int64) on the device."""
+
+    def __init__(self, edge_index, n_nodes):
+        _need_cuda(edge_index, "edge_index")
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must be int64 [2, E]")
+        ei = edge_index.contiguous()
+        self.n = int(n_nodes)
+        self.e = int(ei.shape[1])
+        L = lib()
+        self.ws = _ws(L.gm_csr_workspace_bytes(self.n, self.e), ei.device)
+        check(L.gm_csr_from_edge_index(ptr(ei), self.n, self.e, ptr(self.ws), self.ws.numel(), current_stream()))
+
+    def validate(self):
+        e = C.c_int64(0)
+        check(lib().gm_csr_num_edges(ptr(self.ws), C.byref(e), current_stream()))
+        return int(e.value)
+
+
+def _zeros_mlp(fin, hidden, fout, num_layers, norm, device):
+    t = [torch.zeros(hidden, fin, device=device), torch.zeros(hidden, device=device)]
+    for _ in range(num_layers - 1):
+        t += [torch.zeros(hidden, hidden, device=device), torch.zeros(hidden, device=device)]
+    t += [torch.zeros(fout, hidden, device=device), torch.zeros(fout, device=device)]
+    if norm:
+        t += [torch.ones(fout, device=device), torch.zeros(fout, device=device)]
+    return t
+
+
+class GraphIndependent(nn.Module):
+    """``torch_graphnet.GraphIndependent(phi_edge=, phi_node=)``: (x, e, idx) -> (phi_node(x), phi_edge(e), None)."""
+
+    def __init__(self, phi_edge, phi_node):
+        super().__init__()
+        self.phi_edge = phi_edge
+        self.phi_node = phi_node
+        self._handle = _Handle()
+        self._pad = {}
+
+    def _standalone(self, device):
+        # a standalone block runs through a one-step model handle whose other MLPs are zero placeholders
+        le, ne = _mlp_dims(self.phi_edge)
+        ln, nn_ = _mlp_dims(self.phi_node)
+        hidden, nl = le[-1].out_features, len(le) - 1
+        eps = ne[0].eps if ne else 1e-5
+        desc = (ln[0].in_features, le[0].in_features, 1, hidden, nl, 1, float(eps))
+        if str(device) not in self._pad:
+            self._pad[str(device)] = (_zeros_mlp(3 * hidden, hidden, hidden, nl, True, device)
+                                      + _zeros_mlp(2 * hidden, hidden, hidden, nl, True, device)
+                                      + _zeros_mlp(hidden, hidden, 1, nl, False, device))
+        params = _mlp_params(self.phi_edge) + _mlp_params(self.phi_node) + self._pad[str(device)]
+        return desc, params
+
+    def forward(self, x, edge_attr, edge_index=None):
+        _need_cuda(x, "x")
+        _no_grad_guard(list(self.parameters()), "GraphIndependent")
+        desc, params = self._standalone(x.device)
+        h = self._handle.get(desc, params, x.device)
+        x = x.contiguous().float()
+        edge_attr = edge_attr.contiguous().float()
+        hidden = desc[3]
+        h_out = torch.empty((x.shape[0], hidden), dtype=torch.float32, device=x.device)
+        e_out = torch.empty((edge_attr.shape[0], hidden), dtype=torch.float32, device=x.device)
+        check(lib().gm_graph_independent_forward(h, ptr(x), x.shape[0], ptr(edge_attr), edge_attr.shape[0],
+                                                 ptr(h_out), ptr(e_out), current_stream()))
+        return h_out, e_out, None
+
+
+class InteractionNetwork(nn.Module):
+    """``torch_graphnet.InteractionNetwork(phi_edge=, phi_node=)``: (h, e, idx) -> (h', e', None)."""
+
+    def __init__(self, phi_edge, phi_node):
+        super().__init__()
+        self.phi_edge = phi_edge
+        self.phi_node = phi_node
+        self._handle = _Handle()
+        self._pad = {}
+
+    def _standalone(self, device):
+        le, ne = _mlp_dims(self.phi_edge)
+        hidden, nl = le[-1].out_features, len(le) - 1
+        if le[0].in_features != 3 * hidden:
+            raise ValueError("InteractionNetwork.phi_edge must take 3*hidden inputs ([h_i, h_j, e])")
+        eps = ne[0].eps if ne else 1e-5
+        desc = (1, 1, 1, hidden, nl, 1, float(eps))
+        if str(device) not in self._pad:
+            self._pad[str(device)] = (_zeros_mlp(1, hidden, hidden, nl, True, device) + _zeros_mlp(1, hidden, hidden, nl, True, device),
+                                      _zeros_mlp(hidden, hidden, 1, nl, False, device))
+        pre, post = self._pad[str(device)]
+        params = pre + _mlp_params(self.phi_edge) + _mlp_params(self.phi_node) + post
+        return desc, params
+
+    def forward(self, x, edge_attr, edge_index):
+        _need_cuda(x, "x")
+        _no_grad_guard(list(self.parameters()), "InteractionNetwork")
+        desc, params = self._standalone(x.device)
+        h = self._handle.get(desc, params, x.device)
+        return _run_block(h, desc, 0, x, edge_attr, edge_index)
+
+
+def _run_block(handle, desc, k, x, edge_attr, edge_index, csr=None):
+    x = x.contiguous().float()
+    edge_attr = edge_attr.contiguous().float()
+    n, e = x.shape[0], edge_attr.shape[0]
+    if csr is None:
+        csr = DstCsr(edge_index, n)
+    L = lib()
+    d = ModelDesc(*desc)
+    fwd = _ws(L.gm_forward_workspace_bytes(C.byref(d), n, 0), x.device)
+    h_out = torch.empty_like(x)
+    e_out = torch.empty_like(edge_attr)
+    check(L.gm_interaction_network_forward(handle, k, ptr(x), n, ptr(edge_attr), ptr(csr.ws), e, ptr(h_out),
+                                           ptr(e_out), ptr(fwd), fwd.numel(), current_stream()))
+    return h_out, e_out, None
+
+
+class EncProcDecGNN(nn.Module):
+    """Drop-in for the reference ``EncProcDecGNN`` (gnn_manip/models/epd_gnn.py:11-105)."""
+
+    def __init__(self, node_dim, edge_dim, out_dim, hidden_size, num_layers, m_steps, norm_type='LayerNorm'):
+        super().__init__()
+        assert (num_layers >= 2), "The number of layers num_layers must be at least 2"
+        assert (m_steps >= 1), "The number of m_steps message pasting steps must be at least 1"
+        if norm_type != 'LayerNorm':
+            # the reference's BatchNorm2d / InstanceNorm2d branches (epd_gnn.py:53-58) cannot run on its 2-D inputs
+            raise NotImplementedError("only norm_type='LayerNorm' is supported")
+        self.dims = (node_dim, edge_dim, out_dim, hidden_size, num_layers, m_steps)
+        self.encoder = GraphIndependent(phi_edge=self._build_mlp(edge_dim, hidden_size, hidden_size, num_layers, norm=True),
+                                        phi_node=self._build_mlp(node_dim, hidden_size, hidden_size, num_layers, norm=True))
+        self.processor = nn.ModuleList([
+            InteractionNetwork(phi_edge=self._build_mlp(3 * hidden_size, hidden_size, hidden_size, num_layers, norm=True),
+                               phi_node=self._build_mlp(2 * hidden_size, hidden_size, hidden_size, num_layers, norm=True))
+            for _ in range(m_steps)])
+        self.decoder = self._build_mlp(hidden_size, hidden_size, out_dim, num_layers, norm=False)
+        self._handle = _Handle()
+
+    @staticmethod
+    def _build_mlp(input_dim, hidden_size, output_dim, num_layers, norm=False):
+        modules = [nn.Linear(input_dim, hidden_size), nn.ReLU()]
+        for _ in range(num_layers - 1):
+            modules.append(nn.Linear(hidden_size, hidden_size))
+            modules.append(nn.ReLU())
+        modules.append(nn.Linear(hidden_size, output_dim))
+        if norm:
+            modules.append(nn.LayerNorm(output_dim))
+        return nn.Sequential(*modules)
+
+    def print_structure(self):
+        print("Encoder ")
+        print(self.encoder)
+        print("Processor")
+        for module in self.processor:
+            print(module)
+        print("Decoder ")
+        print(self.decoder)
+
+    # -- device handle
+    def model_desc(self):
+        eps = self.encoder.phi_edge[-1].eps
+        return tuple(int(v) for v in self.dims) + (float(eps),)
+
+    def device_handle(self, device):
+        """gm_model* for the current parameters on `device` (packed once, re-packed on change)."""
+        return self._handle.get(self.model_desc(), list(self.parameters()), device)
+
+    def forward(self, nodes, edge_attr, edge_index):
+        """epd_gnn.py:86-98: encoder -> m_steps x (InteractionNetwork + residuals) -> decoder, fused."""
+        _need_cuda(nodes, "nodes")
+        _no_grad_guard(list(self.parameters()), "EncProcDecGNN.forward")
+        nodes = nodes.contiguous().float()
+        edge_attr = edge_attr.contiguous().float()
+        n, e = int(nodes.shape[0]), int(edge_attr.shape[0])
+        if nodes.shape[1] != self.dims[0] or edge_attr.shape[1] != self.dims[1]:
+            raise ValueError("nodes / edge_attr feature widths do not match the model")
+        if edge_index.shape[1] != e:
+            raise ValueError("edge_index and edge_attr disagree on the number of edges")
+        h = self.device_handle(nodes.device)
+        csr = DstCsr(edge_index, n)
+        L = lib()
+        d = ModelDesc(*self.model_desc())
+        fwd = _ws(L.gm_forward_workspace_bytes(C.byref(d), n, e), nodes.device)
+        out = torch.empty((n, self.dims[2]), dtype=torch.float32, device=nodes.device)
+        check(L.gm_epd_forward(h, ptr(nodes), n, ptr(edge_attr), 0, ptr(csr.ws), e, ptr(out), ptr(fwd),
+                               fwd.numel(), current_stream()))
+        csr.validate()  # raises on an out-of-range edge_index entry
+        return out
+
+    # the reference's per-step helper, kept for API parity (epd_gnn.py:100-105)
+    def _process(self, in_module, prev_latent_node, prev_latent_edge, edge_index):
+        latent_node_k, latent_edge_k, _ = in_module(prev_latent_node, prev_latent_edge, edge_index)
+        return latent_node_k + prev_latent_node, latent_edge_k + prev_latent_edge

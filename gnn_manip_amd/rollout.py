@@ -1,0 +1,102 @@
+"""Device-resident rollout: host-side mirror of the reference's rollout loop
+(``compute_rollout`` gnn_manip/utils/rollout_utils.py:14-67 == ``cma_objective``'s loop
+gnn_manip/utils/traj_utils.py:119-152) and of ``get_position_from_prediction``
+(rollout_utils.py:145-158).
+
+One step = state_pre -> node features -> radius graph -> destination sort -> edge features ->
+encode/process/decode -> Euler integration -> state_post, all enqueued on the current HIP stream
+by ``gm_rollout_step`` with no host synchronisation and no PCIe traffic.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import ModelDesc, check, current_stream, lib, ptr
+from .graph import _need_cuda, _ws, make_feature_desc
+
+
+def get_position_from_prediction(stats, cartesian_idx, pred_acc, obs_seq, _desc=None):
+    """Reference ``get_position_from_prediction`` (rollout_utils.py:145-158) on the device."""
+    _need_cuda(pred_acc, "pred_acc")
+    obs = obs_seq.contiguous().float()
+    pred = pred_acc.contiguous().float()
+    k, n, dd = obs.shape
+    if _desc is None:
+        one = [1.0, 1.0, 1.0]
+        full = dict(velocity_mean=[0.0] * 3, velocity_std=one)
+        full.update(stats)
+        _desc = make_feature_desc(1.0, full, dict(lower_bounds=[0.0] * 3, upper_bounds=one), cartesian_idx,
+                                  [0], None, k, dd)
+    out = torch.empty((n, 3), dtype=torch.float32, device=obs.device)
+    check(lib().gm_integrate(ptr(pred), ptr(obs), n, C.byref(_desc), ptr(out), current_stream()))
+    return out
+
+
+class RolloutEngine:
+    """Runs rollouts of an ``EncProcDecGNN`` for scenes of ``n_nodes`` particles.
+
+    graph_attr: a ``GraphBoundedMultimaterial(Control)`` (gnn_manip_amd.graph) carrying conn_r,
+    stats, bounds and the column indices, exactly like ``dataset.graph_attr`` in the reference.
+    """
+
+    def __init__(self, model, graph_attr, n_nodes, k_steps=6, data_dim=None, max_neighbours=20, device="cuda:0"):
+        self.model = model
+        self.graph_attr = graph_attr
+        self.n = int(n_nodes)
+        self.k = int(k_steps)
+        self.device = torch.device(device)
+        self.max_neighbours = int(max_neighbours)
+        if data_dim is None:
+            data_dim = (graph_attr.control_idx[-1] + 1) if graph_attr.control_idx is not None else graph_attr.cartesian_idx[-1] + 1
+        self.data_dim = int(data_dim)
+        self.fdesc = make_feature_desc(graph_attr.conn_r, graph_attr.stats, graph_attr.bounds, graph_attr.cartesian_idx,
+                                       graph_attr.material_idx, graph_attr.control_idx, self.k, self.data_dim)
+        self.mdesc = ModelDesc(*model.model_desc())
+        L = lib()
+        self.ws = _ws(L.gm_rollout_workspace_bytes(C.byref(self.mdesc), self.n, self.max_neighbours), self.device)
+        self.rigid_rank = None
+        self.n_rigid = 0
+
+    def set_scene(self, obs):
+        """Classify rigid rows (material == 1, rollout_utils.py:20) once per scene."""
+        _need_cuda(obs, "obs")
+        assert obs.shape == (self.k, self.n, self.data_dim) and obs.dtype == torch.float32 and obs.is_contiguous()
+        self.rigid_rank = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(lib().gm_rigid_rank(ptr(obs), self.n, C.byref(self.fdesc), ptr(self.rigid_rank), ptr(cnt), current_stream()))
+        self.n_rigid = int(cnt.item())
+        return self.n_rigid
+
+    def step(self, obs, rigid_target=None, pred_out=None, use_rigid=True):
+        """One rollout step in place on ``obs`` [k, N, D]; rigid_target: [N_rigid, 3] scripted pose or None."""
+        handle = self.model.device_handle(self.device)
+        rr = self.rigid_rank if use_rigid else None
+        check(lib().gm_rollout_step(handle, ptr(obs), self.n, C.byref(self.fdesc), self.max_neighbours, ptr(rr),
+                                    ptr(rigid_target), ptr(pred_out), ptr(self.ws), self.ws.numel(), current_stream()))
+
+    def status(self):
+        """Synchronises; raises on a device-side data error; returns the last step's edge count."""
+        e = C.c_int64(0)
+        check(lib().gm_rollout_status(ptr(self.ws), C.byref(self.mdesc), self.n, self.max_neighbours, C.byref(e), current_stream()))
+        return int(e.value)
+
+    def rollout(self, obs0, trajectory=None, horizon=None, record=False):
+        """cma_objective's loop (traj_utils.py:119-152).  trajectory: [T, N_rigid, 3] device tensor of scripted
+        rigid poses (or None: no rigid overwrite).  Returns the final state (and the recorded last frames)."""
+        obs = obs0.clone().contiguous()
+        if self.rigid_rank is None:
+            self.set_scene(obs)
+        steps = horizon if horizon is not None else (trajectory.shape[0] if trajectory is not None else 0)
+        recs = []
+        for i in range(steps):
+            tgt = trajectory[i] if (trajectory is not None and i < trajectory.shape[0]) else None
+            if record:
+                # the reference records the last frame after the control overwrite, before the prediction
+                from ._lib import lib as _l
+                check(_l().gm_state_pre(ptr(obs), self.n, C.byref(self.fdesc), ptr(self.rigid_rank), ptr(tgt), current_stream()))
+                recs.append(obs[-1].clone())
+            self.step(obs, tgt)
+        self.status()
+        if record:
+            return obs, torch.stack(recs)
+        return obs

@@ -1,0 +1,194 @@
+/*
+ * gnn_manip_hip.h -- C ABI of libgnnmanip_hip.so: the MI355X (gfx950) rollout engine for
+ * gnn-manip's encode-process-decode particle simulator.
+ *
+ * The reference (dblanm/gnn-manip) is pure Python and has no FFI of its own; its boundary is
+ * the duck-typed call surface listed in SURVEY.md section 8b.  Every entry point below names
+ * the reference function it replaces (paths relative to the reference checkout).  The Python
+ * host layer in gnn_manip_amd/ binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is DEVICE memory unless the name ends
+ *     in _host; the caller (PyTorch) owns every buffer and every workspace;
+ *   - nothing is allocated per call; gm_model_create() allocates the packed weight image once;
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns without
+ *     synchronising, unless documented otherwise;
+ *   - return value: GM_OK (0) or a negative gm_status; gm_last_error() returns a thread-local
+ *     message for the last failure.  Nothing throws or aborts across this boundary.
+ */
+#ifndef GNN_MANIP_HIP_H
+#define GNN_MANIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gm_status {
+    GM_OK = 0,
+    GM_ERR_INVALID_ARGUMENT = -1,
+    GM_ERR_UNSUPPORTED = -2,   /* e.g. hidden size the kernels are not instantiated for */
+    GM_ERR_HIP = -3,           /* a HIP runtime call failed */
+    GM_ERR_WORKSPACE = -4,     /* workspace too small */
+    GM_ERR_DATA = -5           /* device-side data error (non-finite position, bad index) */
+} gm_status;
+
+typedef struct gm_model gm_model; /* opaque */
+
+const char* gm_last_error(void);
+int gm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Radius graph.   Replaces get_connectivity(pos_nodes, conn_r, max_neighbours)
+ *                 gnn_manip/utils/utils.py:64-93  (sklearn KDTree.query_radius semantics:
+ *                 float64 squared distance, d2 <= r*r, ascending distance, first max_nb kept,
+ *                 ties broken on the smaller index).
+ * ------------------------------------------------------------------------------------------ */
+size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours);
+
+/* Build per-query neighbour lists into the workspace.  pos points at x of node 0; node i is at
+ * pos + i*pos_stride (floats), so the xyz columns of a [N, D] state row can be passed directly. */
+int gm_radius_graph_build(const float* pos, int64_t pos_stride, int64_t n_nodes, double conn_r,
+                          int max_neighbours, void* graph_ws, size_t graph_ws_bytes, void* stream);
+
+/* Synchronises `stream`; returns E and the device error flags of the last build. */
+int gm_radius_graph_num_edges(const void* graph_ws, int64_t* n_edges_host, void* stream);
+
+/* Emit the reference-ordered edge list: grouped by sender (= query node) ascending, distance
+ * ascending inside a group.  senders/receivers: int64[capacity], capacity >= E. */
+int gm_radius_graph_edges(const void* graph_ws, int64_t n_nodes, int max_neighbours,
+                          int64_t* senders, int64_t* receivers, int64_t capacity, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Destination-sorted edge structure (the engine's internal edge order).
+ * Aggregation index i = edge_index[1], source j = edge_index[0] (PyG source_to_target, see
+ * DESIGN.md).  Edges are grouped by i; inside a group ascending original edge id (stable).
+ * ------------------------------------------------------------------------------------------ */
+size_t gm_csr_workspace_bytes(int64_t n_nodes, int64_t edge_capacity);
+int gm_csr_from_graph(const void* graph_ws, int64_t n_nodes, int max_neighbours,
+                      void* csr_ws, size_t csr_ws_bytes, void* stream);
+int gm_csr_from_edge_index(const int64_t* edge_index /* [2,E] row-major */, int64_t n_nodes,
+                           int64_t n_edges, void* csr_ws, size_t csr_ws_bytes, void* stream);
+/* Synchronises; copies E and error flags to the host. */
+int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Features.
+ * gm_edge_features      replaces get_edges_displacement   gnn_manip/utils/utils.py:43-61
+ *                       out[e] = [(p[s]-p[r])/conn_r, ||.||], reference edge order.
+ * gm_edge_features_csr  same values in the destination-sorted order of a csr workspace.
+ * gm_node_features      replaces GraphBoundedMultimaterial(Control).compute_nodes
+ *                       gnn_manip/utils/collate_utils.py:195-208,217-232 (+ get_nodes_vel,
+ *                       utils.py:27-40).  obs: [k, N, D] float32 row-major.
+ * ------------------------------------------------------------------------------------------ */
+int gm_edge_features(const float* pos, int64_t pos_stride, const int64_t* senders,
+                     const int64_t* receivers, int64_t n_edges, float conn_r, float* out /*[E,4]*/,
+                     void* stream);
+int gm_edge_features_csr(const float* pos, int64_t pos_stride, const void* csr_ws, int64_t n_nodes,
+                         int64_t edge_capacity, float conn_r, float* out /*[cap,4]*/, void* stream);
+
+typedef struct gm_feature_desc {
+    double conn_r;          /* connectivity radius as the Python float the reference passes: the radius
+                               test runs in float64 on it, float32 feature divisions on (float)conn_r */
+    int32_t k_steps;        /* frames in the window (6) */
+    int32_t data_dim;       /* D: columns per particle row (8 with control, 5 without) */
+    int32_t cart_col;       /* first of the 3 contiguous position columns (2) */
+    int32_t material_col;   /* (1) */
+    int32_t control_col;    /* first of the 3 contiguous control columns (5), or -1: no control */
+    int32_t reserved;
+    float vel_mean[3], vel_std[3];
+    float acc_mean[3], acc_std[3];
+    float lower_bounds[3], upper_bounds[3];
+} gm_feature_desc;
+
+int gm_node_features(const float* obs, int64_t n_nodes, const gm_feature_desc* desc,
+                     float* out /* [N, 3*(k-1)+6+1(+3)] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Integrator + rollout state update.
+ * gm_integrate     replaces get_position_from_prediction  gnn_manip/utils/rollout_utils.py:145-158
+ * gm_state_pre     replaces rollout_utils.py:40-47 == traj_utils.py:126-134: control columns of the
+ *                  rigid rows (material == 1) of the last frame <- rigid_target - current xyz.
+ * gm_state_post    replaces rollout_utils.py:53-61 == traj_utils.py:146-152: window shift, write
+ *                  p_{t+1}, overwrite rigid rows' xyz with the scripted pose.
+ * rigid_target: [N_rigid,3] poses in rigid-row order; rigid_rank: int32[N] = rank of row among
+ * rigid rows (or -1), built once per scene by gm_rigid_rank.
+ * gm_rigid_transform replaces compute_particles_tmatrix    gnn_manip/utils/traj_utils.py:167-194
+ * ------------------------------------------------------------------------------------------ */
+int gm_integrate(const float* pred_acc /*[N,3]*/, const float* obs, int64_t n_nodes,
+                 const gm_feature_desc* desc, float* next_pos /*[N,3]*/, void* stream);
+int gm_rigid_rank(const float* obs, int64_t n_nodes, const gm_feature_desc* desc, int32_t* rigid_rank,
+                  int32_t* n_rigid_dev, void* stream);
+int gm_state_pre(float* obs, int64_t n_nodes, const gm_feature_desc* desc, const int32_t* rigid_rank,
+                 const float* rigid_target /* or NULL: control <- current xyz (traj_utils.py:131) */,
+                 void* stream);
+int gm_state_post(float* obs, int64_t n_nodes, const gm_feature_desc* desc, const float* next_pos,
+                  const int32_t* rigid_rank, const float* rigid_target /* or NULL */, void* stream);
+int gm_rigid_transform(const float* rigid_init /*[Nr,3]*/, int64_t n_rigid, const float* rot_cs_ty
+                       /* [T,3] host-computed (cos, sin, ty_init[1]+translation) float32 */,
+                       int64_t n_steps, const float ty_init[3], float* out /*[T,Nr,3]*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Model.  Replaces EncProcDecGNN.__init__/_build_mlp + load_state_dict
+ *         gnn_manip/models/epd_gnn.py:13-49,72-84 ; rollout_utils.py:137-139.
+ * tensors_host_or_dev: the model's parameters in state_dict order (encoder.phi_edge.*,
+ * encoder.phi_node.*, processor.k.phi_edge.*, processor.k.phi_node.*, decoder.*; inside an MLP:
+ * Linear weight [out,in] row-major, bias, ..., LayerNorm weight, bias).  They are copied and
+ * repacked into the MFMA operand image; the caller's tensors are not referenced afterwards.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gm_model_desc {
+    int32_t node_dim, edge_dim, out_dim;
+    int32_t hidden_size;   /* 128 (256: see DESIGN.md) */
+    int32_t num_layers;    /* >= 2: hidden layers per MLP (epd_gnn.py:26) */
+    int32_t m_steps;       /* >= 1 */
+    float ln_eps;          /* 1e-5 */
+} gm_model_desc;
+
+int gm_model_num_tensors(const gm_model_desc* desc);
+int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int n_tensors,
+                    int tensors_on_device, void* stream, gm_model** out);
+int gm_model_update(gm_model* m, const float* const* tensors, int n_tensors, int tensors_on_device,
+                    void* stream);
+void gm_model_destroy(gm_model* m);
+
+size_t gm_forward_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t edge_capacity);
+
+/* EncProcDecGNN.forward(nodes, edge_attr, edge_index)   epd_gnn.py:86-105.
+ * edge_attr is in the CALLER's edge order; the csr workspace (built from the same edge_index or
+ * from the radius graph) carries the permutation.  edge_attr_is_csr_order != 0 says edge_attr is
+ * already destination-sorted (rollout path). */
+int gm_epd_forward(const gm_model* m, const float* nodes /*[N,node_dim]*/, int64_t n_nodes,
+                   const float* edge_attr /*[E,edge_dim]*/, int edge_attr_is_csr_order,
+                   const void* csr_ws, int64_t edge_capacity, float* out /*[N,out_dim]*/,
+                   void* fwd_ws, size_t fwd_ws_bytes, void* stream);
+
+/* torch_graphnet.GraphIndependent call site epd_gnn.py:88 -- (phi_node(x), phi_edge(e)).
+ * torch_graphnet.InteractionNetwork call site epd_gnn.py:101 -- (h', e'), no residual.
+ * `block` = -1: encoder; 0..m_steps-1: processor block.  Outputs in the caller's edge order. */
+int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n_nodes, const float* edge_attr,
+                                 int64_t n_edges, float* h_out, float* e_out, void* stream);
+int gm_interaction_network_forward(const gm_model* m, int block, const float* h, int64_t n_nodes,
+                                   const float* e, const void* csr_ws, int64_t edge_capacity,
+                                   float* h_out, float* e_out, void* fwd_ws, size_t fwd_ws_bytes,
+                                   void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One device-resident rollout step = compute_rollout's loop body, rollout_utils.py:38-61 ==
+ * cma_objective's, traj_utils.py:123-152:  state_pre -> node features -> radius graph -> csr ->
+ * edge features -> forward -> integrate -> state_post.  No host synchronisation.
+ * ------------------------------------------------------------------------------------------ */
+size_t gm_rollout_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int max_neighbours);
+int gm_rollout_step(const gm_model* m, float* obs /*[k,N,D] in/out*/, int64_t n_nodes,
+                    const gm_feature_desc* fdesc, int max_neighbours, const int32_t* rigid_rank,
+                    const float* rigid_target /*[Nr,3] or NULL*/, float* pred_acc_out /*[N,3] or NULL*/,
+                    void* rollout_ws, size_t rollout_ws_bytes, void* stream);
+/* Error flags / edge count of the last step (synchronises). */
+int gm_rollout_status(const void* rollout_ws, const gm_model_desc* desc, int64_t n_nodes,
+                      int max_neighbours, int64_t* n_edges_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNN_MANIP_HIP_H */

@@ -1,0 +1,301 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden fixtures and the CPU oracle.
+
+Integer / index results are compared bit-exactly.  Float32 tolerances are written at each check:
+the north_star bar is 1e-5 relative on the predicted accelerations.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import BOUNDS, CART, CTRL, G1_CASES, MAT, STATS
+from oracle import epd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(stats=STATS, bounds=BOUNDS, conn_r=0.015, cartesian_idx=CART, material_idx=MAT)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _model(params, dims, dev):
+    from gnn_manip_amd import EncProcDecGNN
+    m = EncProcDecGNN(*dims)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return m.to(dev)
+
+
+def _ga():
+    from gnn_manip_amd import GraphBoundedMultimaterialControl
+    return GraphBoundedMultimaterialControl(0.015, STATS, CART, MAT, CTRL, BOUNDS)
+
+
+# ------------------------------------------------------------------ K1 radius graph
+@pytest.mark.parametrize("case", G1_CASES)
+def test_radius_graph_golden_bit_exact(golden, dev, case):
+    from gnn_manip_amd import get_connectivity
+    g = golden("g1_connectivity.npz")
+    r, cap = g[f"{case}.r_cap"]
+    s, rcv = get_connectivity(_t(g[f"{case}.pos"], dev), float(r), int(cap))
+    assert s.dtype == torch.int64 and rcv.dtype == torch.int64
+    assert np.array_equal(s.cpu().numpy(), g[f"{case}.senders"])
+    assert np.array_equal(rcv.cpu().numpy(), g[f"{case}.receivers"])
+
+
+@pytest.mark.parametrize("n,side,seed", [(20000, 0.22, 5), (7000, 0.5, 6), (1, 0.1, 7), (3, 0.001, 8)])
+def test_radius_graph_vs_oracle(dev, n, side, seed):
+    from gnn_manip_amd import get_connectivity
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pos = (0.2 + side * rng.random((n, 3))).astype(np.float32)
+    s, r = get_connectivity(_t(pos, dev), 0.015, 20)
+    so, ro = orc.get_connectivity(pos, 0.015, 20)
+    assert np.array_equal(s.cpu().numpy(), so)
+    assert np.array_equal(r.cpu().numpy(), ro)
+
+
+def test_radius_graph_strided_view_and_idempotence(dev, golden):
+    from gnn_manip_amd import get_connectivity
+    g = golden("g4_features.npz")
+    obs = _t(g["obs_a"], dev)
+    view = obs[-1][:, 2:5]  # stride 8
+    s1, r1 = get_connectivity(view, 0.015)
+    s2, r2 = get_connectivity(view.contiguous(), 0.015)
+    assert torch.equal(s1, s2) and torch.equal(r1, r2)
+    assert np.array_equal(s1.cpu().numpy(), g["proc_senders"])
+    assert np.array_equal(r1.cpu().numpy(), g["proc_receivers"])
+
+
+def test_radius_graph_rejects_nonfinite(dev):
+    from gnn_manip_amd import get_connectivity
+    from gnn_manip_amd._lib import GMError
+    pos = torch.rand(100, 3, device=dev)
+    pos[5, 1] = float("nan")
+    with pytest.raises(GMError):
+        get_connectivity(pos, 0.015)
+
+
+# ------------------------------------------------------------------ K2 / K3 / K10
+@pytest.mark.parametrize("case", G1_CASES)
+def test_edge_features_golden(golden, dev, case):
+    from gnn_manip_amd import get_edges_displacement
+    g = golden("g1_connectivity.npz")
+    r = float(g[f"{case}.r_cap"][0])
+    ea = get_edges_displacement(_t(g[f"{case}.pos"], dev), _t(g[f"{case}.senders"].astype(np.int64), dev),
+                                _t(g[f"{case}.receivers"].astype(np.int64), dev), r)
+    np.testing.assert_allclose(ea.cpu().numpy(), g[f"{case}.edge_attr"], rtol=2e-7, atol=1e-7)
+
+
+def test_node_features_process_collate_golden(golden, dev):
+    from gnn_manip_amd import GraphBoundedMultimaterial
+    g = golden("g4_features.npz")
+    ga = _ga()
+    n1 = ga.compute_nodes(_t(g["obs_a"], dev))
+    np.testing.assert_allclose(n1.cpu().numpy(), g["nodes_ctrl_a"], rtol=2e-7, atol=1e-7)
+    gn = GraphBoundedMultimaterial(0.015, STATS, CART, MAT, BOUNDS)
+    n0 = gn.compute_nodes(_t(g["obs_a"][:, :, :5], dev))
+    np.testing.assert_allclose(n0.cpu().numpy(), g["nodes_noctrl_a"], rtol=2e-7, atol=1e-7)
+    nodes, ea, s, r, tgt = ga.process(_t(g["obs_a"], dev), _t(g["tgt_a"], dev))
+    assert np.array_equal(s.cpu().numpy(), g["proc_senders"]) and np.array_equal(r.cpu().numpy(), g["proc_receivers"])
+    np.testing.assert_allclose(nodes.cpu().numpy(), g["proc_nodes"], rtol=2e-7, atol=1e-7)
+    np.testing.assert_allclose(ea.cpu().numpy(), g["proc_edge_attr"], rtol=2e-7, atol=1e-7)
+    np.testing.assert_allclose(tgt.cpu().numpy(), g["proc_tgt"], rtol=1e-5, atol=1e-5)
+    batch = [(_t(g["obs_a"], dev), _t(g["tgt_a"], dev)), (_t(g["obs_b"], dev), _t(g["tgt_b"], dev))]
+    nodes, ea, ei, tgt = ga.process_collate(batch)
+    assert np.array_equal(ei.cpu().numpy(), g["coll_edge_index"])
+    np.testing.assert_allclose(nodes.cpu().numpy(), g["coll_nodes"], rtol=2e-7, atol=1e-7)
+    np.testing.assert_allclose(ea.cpu().numpy(), g["coll_edge_attr"], rtol=2e-7, atol=1e-7)
+
+
+def test_integrator_golden_bit_exact(golden, dev):
+    from gnn_manip_amd import get_position_from_prediction
+    g = golden("g4_features.npz")
+    nxt = get_position_from_prediction(STATS, CART, _t(g["pred_acc"], dev), _t(g["obs_a"], dev))
+    np.testing.assert_array_equal(nxt.cpu().numpy(), g["next_pos"])
+
+
+def test_rigid_transform_golden(golden, dev):
+    from gnn_manip_amd.planner import get_rigid_body_trajectory
+    g = golden("g6_trajectory.npz")
+    rp = _t(g["obs_c"][-1, 36:, 2:5], dev)
+    out = get_rigid_body_trajectory(g["traj_rot"], g["traj_ty"], 300, [0.5, 0.5, 0.4], rp).cpu().numpy()
+    np.testing.assert_allclose(out[g["rigid_traj_steps"]], g["rigid_traj"], rtol=0, atol=2e-7)
+
+
+# ------------------------------------------------------------------ destination-sorted structure
+def test_dst_csr_is_stable_sort_by_destination(dev):
+    import ctypes as C
+    from gnn_manip_amd.epd_gnn import DstCsr
+    rng = np.random.Generator(np.random.PCG64(3))
+    n, e = 500, 7000
+    ei = rng.integers(0, n, size=(2, e)).astype(np.int64)
+    ei[1, :50] = 7  # a long segment
+    csr = DstCsr(_t(ei, dev), n)
+    assert csr.validate() == e
+    raw = csr.ws.cpu().numpy()
+    # parse the workspace the same way the library carves it (256-byte aligned arrays)
+    def take(off, count):
+        off = (off + 255) // 256 * 256
+        return np.frombuffer(raw[off:off + 4 * count].tobytes(), dtype=np.int32), off + 4 * count
+    off = 16
+    in_ptr, off = take(off, n + 1)
+    _, off = take(off, n + 1)
+    dst, off = take(off, e)
+    src, off = take(off, e)
+    eid, off = take(off, e)
+    order = np.argsort(ei[1], kind="stable")
+    assert np.array_equal(eid, order)
+    assert np.array_equal(dst, ei[1][order]) and np.array_equal(src, ei[0][order])
+    assert np.array_equal(in_ptr, np.r_[0, np.cumsum(np.bincount(ei[1], minlength=n))])
+
+
+def test_bad_edge_index_raises(dev):
+    from gnn_manip_amd._lib import GMError
+    from gnn_manip_amd.epd_gnn import DstCsr
+    ei = torch.tensor([[0, 1, 2], [1, 2, 9]], dtype=torch.int64, device=dev)
+    with pytest.raises(GMError):
+        DstCsr(ei, 3).validate()
+
+
+# ------------------------------------------------------------------ K4-K9 model
+def _scene_graph(golden):
+    g4 = golden("g4_features.npz")
+    nodes, ea, s, r, _ = orc.process(g4["obs_a"], None, control_idx=CTRL, **KW)
+    return nodes, ea, np.stack((s, r))
+
+
+def test_graph_independent_block_vs_golden(golden, dev):
+    g7 = golden("g7_epd_wiring.npz")
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 41)
+    m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    nodes, ea, ei = _scene_graph(golden)
+    with torch.no_grad():
+        h0, e0, _ = m.encoder(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+    np.testing.assert_allclose(h0.cpu().numpy(), g7["h128.h0"], rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(e0.cpu().numpy()[:64], g7["h128.e0_head"], rtol=1e-5, atol=3e-6)
+    ho, eo = orc.graph_independent(params, "encoder", nodes, ea, 2)
+    np.testing.assert_allclose(e0.cpu().numpy(), eo, rtol=1e-5, atol=3e-6)
+
+
+def test_interaction_network_block_vs_golden(golden, dev):
+    g7 = golden("g7_epd_wiring.npz")
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 41)
+    m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    nodes, ea, ei = _scene_graph(golden)
+    h0, e0 = orc.graph_independent(params, "encoder", nodes, ea, 2)
+    with torch.no_grad():
+        h1, e1, _ = m.processor[0](_t(h0, dev), _t(e0, dev), _t(ei, dev))
+    h1o, e1o = orc.interaction_network(params, "processor.0", h0, e0, ei, 2)
+    np.testing.assert_allclose(e1.cpu().numpy(), e1o, rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), h1o, rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), g7["h128.h1"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(e1.cpu().numpy()[:64], g7["h128.e1_head"], rtol=1e-5, atol=5e-6)
+
+
+def test_epd_forward_golden(golden, dev):
+    g7 = golden("g7_epd_wiring.npz")
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 41)
+    m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    nodes, ea, ei = _scene_graph(golden)
+    with torch.no_grad():
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    ref = g7["h128.out"]
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()  # north_star: 1e-5 relative fp32
+
+
+@pytest.mark.parametrize("n,side,seed", [(3000, 0.11, 61), (130, 0.3, 62), (1, 0.1, 63)])
+def test_epd_forward_vs_oracle(dev, n, side, seed):
+    """Bigger / ragged graphs: several tiles, segments crossing tile and wave boundaries, isolated nodes."""
+    from gnn_manip_amd import scene
+    obs = scene.make_scene(n, seed=seed, side=side)
+    params = orc.init_params(25, 4, 3, 128, 2, 10, seed)
+    m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    ei = np.stack((s, r))
+    with torch.no_grad():
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    ref = orc.epd_forward(params, nodes, ea, ei, 2, 10)
+    assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
+
+
+def test_epd_forward_permutation_of_edges_is_immaterial(dev):
+    """Property: the result does not depend on the caller's edge order (destination sort + eid indirection),
+    and a hub node with in-degree > 128 (a segment spanning whole tiles) aggregates correctly."""
+    rng = np.random.Generator(np.random.PCG64(71))
+    n, e = 400, 6000
+    ei = rng.integers(0, n, size=(2, e)).astype(np.int64)
+    ei[1, :700] = 11
+    nodes = rng.standard_normal((n, 25)).astype(np.float32)
+    ea = rng.standard_normal((e, 4)).astype(np.float32)
+    params = orc.init_params(25, 4, 3, 128, 2, 3, 72)
+    m = _model(params, (25, 4, 3, 128, 2, 3), dev)
+    with torch.no_grad():
+        out1 = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+        perm = rng.permutation(e)
+        out2 = m.forward(_t(nodes, dev), _t(ea[perm], dev), _t(ei[:, perm], dev)).cpu().numpy()
+    ref = orc.epd_forward(params, nodes, ea, ei, 2, 3)
+    scale = np.abs(ref).max()
+    assert np.abs(out1 - ref).max() <= 2e-5 * scale
+    assert np.abs(out1 - out2).max() <= 2e-5 * scale
+
+
+def test_weight_update_repacks(dev, golden):
+    params = orc.init_params(25, 4, 3, 128, 2, 2, 81)
+    m = _model(params, (25, 4, 3, 128, 2, 2), dev)
+    nodes, ea, ei = _scene_graph(golden)
+    with torch.no_grad():
+        a = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+        m.decoder[4].bias.add_(1.0)
+        b = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    np.testing.assert_allclose(b - a, 1.0, atol=1e-5)
+
+
+def test_forward_needs_no_grad(dev, golden):
+    params = orc.init_params(25, 4, 3, 128, 2, 2, 81)
+    m = _model(params, (25, 4, 3, 128, 2, 2), dev)
+    nodes, ea, ei = _scene_graph(golden)
+    with pytest.raises(NotImplementedError):
+        m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+
+
+# ------------------------------------------------------------------ rollout
+def test_rollout_golden_g8(golden, dev):
+    from gnn_manip_amd import RolloutEngine
+    from gnn_manip_amd.planner import get_rigid_body_trajectory
+    g = golden("g8_rollout.npz")
+    nd, ed, od, hid, nl, ms, seed, horizon = [int(v) for v in g["cfg"]]
+    params = orc.init_params(nd, ed, od, hid, nl, ms, seed)
+    m = _model(params, (nd, ed, od, hid, nl, ms), dev)
+    obs0 = g["obs0"]
+    rigid = obs0[-1, :, 1] == 1
+    traj = get_rigid_body_trajectory(g["traj_rot"], g["traj_ty"], horizon, [0.5, 0.5, 0.4], _t(obs0[-1][rigid][:, 2:5], dev))
+    eng = RolloutEngine(m, _ga(), obs0.shape[1], device=dev)
+    with torch.no_grad():
+        final, recs = eng.rollout(_t(obs0, dev), traj, horizon=horizon, record=True)
+    final, recs = final.cpu().numpy(), recs.cpu().numpy()
+    np.testing.assert_allclose(final[-1][~rigid][:, 2:5], g["end_coffee"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(recs[:, ~rigid][:, :, 2:5], g["coffee_states"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(recs[:, rigid][:, :, 2:5], g["cup_states"], rtol=0, atol=5e-6)
+
+
+def test_rollout_vs_oracle_whole_state(dev):
+    from gnn_manip_amd import RolloutEngine, scene
+    n, steps = 2500, 3
+    obs = scene.make_scene(n, seed=91, side=0.1)
+    traj = scene.rigid_drift_trajectory(obs, steps - 1)  # last step has no scripted pose (traj_utils.py:130-131)
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 92)
+    m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    eng = RolloutEngine(m, _ga(), n, device=dev)
+    with torch.no_grad():
+        final = eng.rollout(_t(obs, dev), _t(traj, dev), horizon=steps).cpu().numpy()
+    ref = orc.rollout(params, obs, traj, steps, STATS, BOUNDS, 0.015, CART, MAT, CTRL)
+    np.testing.assert_allclose(final[:, :, 2:5], ref[:, :, 2:5], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(final[:, :, 5:8], ref[:, :, 5:8], rtol=0, atol=5e-6)
+    np.testing.assert_array_equal(final[:, :, :2], ref[:, :, :2])
+    assert eng.status() > 0
