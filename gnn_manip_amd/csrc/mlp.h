@@ -9,7 +9,8 @@ struct EdgeArgs {
     int n_edges_host;
     const int* dst;        // [E] aggregation node per sorted position (processor only)
     const int* src;        // [E]
-    const int* eid;        // [E] row of e_in / e_out for sorted position p, or nullptr: row = p
+    const int* eid;        // [E] row of e_in for sorted position p, or nullptr: row = p
+    const int* eid_out;    // [E] row of e_out (and of the residual read), or nullptr: row = p
     const float* P;        // [N][2H]  P_i (+b1) | P_j
     const float* e_in;     // processor: [E][H]; encoder: raw edge_attr [E][k1]
     float* e_out;          // [E][H]

@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArg
                 const int pr = p0 + row;
                 if (pr < E) {
                     floatx4 v = *reinterpret_cast<const floatx4*>(T + row * TS + c4);
-                    const int64_t orow = A.eid ? A.eid[pr] : pr;
+                    const int64_t orow = A.eid_out ? A.eid_out[pr] : pr;
                     if (!ENC && A.residual) {
                         const floatx4 o = *reinterpret_cast<const floatx4*>(A.e_in + orow * H + 64 * fh + c4);
                         v += o;

@@ -234,7 +234,7 @@ EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid
 EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, const CsrHeader* hdr, int e_host, const int* eid,
                         const float* P, const float* e_in, float* e_out, float* agg, int residual) {
     EdgeArgs a{};
-    a.hdr = hdr; a.n_edges_host = e_host; a.dst = c.dst; a.src = c.src; a.eid = eid;
+    a.hdr = hdr; a.n_edges_host = e_host; a.dst = c.dst; a.src = c.src; a.eid = eid; a.eid_out = eid;
     a.P = P; a.e_in = e_in; a.e_out = e_out; a.agg = agg; a.residual = residual;
     a.wstream = m->packed + m->s_edge[k];
     const float* v = m->vec + m->v_edge[k];
