@@ -97,6 +97,16 @@ struct CsrWs {
 };
 CsrWs carve_csr(void* ws, int64_t n, int64_t cap);
 
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
+enum ProfKind : int { PROF_EDGE = 0, PROF_NODE = 1, PROF_GRAPH = 2, PROF_ENC = 3, PROF_KINDS = 4 };
+struct ProfScope {
+    int idx;
+    int kind;
+    hipStream_t s;
+    ProfScope(int kind, hipStream_t s);
+    ~ProfScope();
+};
+
 int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s);
 size_t scan_tmp_ints(int64_t n_max);
 

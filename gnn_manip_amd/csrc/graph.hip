@@ -20,6 +20,35 @@ void set_error(const char* fmt, ...) {
 const char* last_error() { return g_err; }
 
 // ------------------------------------------------------------------------------------------
+// profiling hooks
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr int PROF_MAX = 4096;
+struct ProfState {
+    bool on = false;
+    int count[PROF_KINDS] = {0, 0, 0, 0};
+    hipEvent_t* start[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t* stop[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
+} g_prof;
+}  // namespace
+
+ProfScope::ProfScope(int k, hipStream_t st) : idx(-1), kind(k), s(st) {
+    if (!g_prof.on || g_prof.count[k] >= PROF_MAX) return;
+    if (!g_prof.start[k]) {
+        g_prof.start[k] = new hipEvent_t[PROF_MAX];
+        g_prof.stop[k] = new hipEvent_t[PROF_MAX];
+        for (int i = 0; i < PROF_MAX; ++i) {
+            if (hipEventCreate(&g_prof.start[k][i]) != hipSuccess || hipEventCreate(&g_prof.stop[k][i]) != hipSuccess) return;
+        }
+    }
+    idx = g_prof.count[k]++;
+    (void)hipEventRecord(g_prof.start[k][idx], s);
+}
+ProfScope::~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_prof.stop[kind][idx], s);
+}
+
+// ------------------------------------------------------------------------------------------
 // exclusive scan of int32, n known on the host or read from device memory
 // ------------------------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 256;
@@ -471,6 +500,25 @@ using namespace gm;
 extern "C" {
 
 const char* gm_last_error(void) { return gm::last_error(); }
+
+int gm_profile_enable(int on) {
+    g_prof.on = on != 0;
+    if (on) for (int k = 0; k < PROF_KINDS; ++k) g_prof.count[k] = 0;
+    return GM_OK;
+}
+
+int gm_profile_query(int kind, int64_t* launches, double* total_ms) {
+    GM_REQUIRE(kind >= 0 && kind < PROF_KINDS && launches && total_ms, GM_ERR_INVALID_ARGUMENT, "gm_profile_query: bad argument");
+    *launches = g_prof.count[kind];
+    *total_ms = 0.0;
+    for (int i = 0; i < g_prof.count[kind]; ++i) {
+        GM_HIP_CHECK(hipEventSynchronize(g_prof.stop[kind][i]));
+        float ms = 0.f;
+        GM_HIP_CHECK(hipEventElapsedTime(&ms, g_prof.start[kind][i], g_prof.stop[kind][i]));
+        *total_ms += ms;
+    }
+    return GM_OK;
+}
 int gm_abi_version(void) { return 1; }
 
 size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours) {
@@ -489,6 +537,7 @@ int gm_radius_graph_build(const float* pos, int64_t pos_stride, int64_t n, doubl
     GraphWs g = carve_graph(ws, n, K);
     GM_REQUIRE(ws_bytes >= g.bytes, GM_ERR_WORKSPACE, "gm_radius_graph_build: workspace %zu < %zu", ws_bytes, g.bytes);
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_GRAPH, s);
     hipLaunchKernelGGL(graph_init_kernel, dim3(1), dim3(64), 0, s, g.hdr);
     GM_HIP_CHECK(hipMemsetAsync(g.cell_start, 0, ((size_t)g.max_cells + 1) * sizeof(int), s));
     GM_HIP_CHECK(hipMemsetAsync(g.cell_cursor, 0, (size_t)g.max_cells * sizeof(int), s));

@@ -122,6 +122,9 @@ __device__ __forceinline__ void run_layer(floatx16 (&acc)[NJB], const floatx16 (
             int st = nxt;
             asm volatile("" : "+s"(st));
             if (!wrap || more_tiles) issue_stage(ws, st, ws.parity ^ 1);
+            // keep the DMA issue HERE, right behind the barrier: the scheduler otherwise sinks it below
+            // the stage's MFMAs, next to the wait that needs it, and the copy no longer overlaps them
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float* buf = ws.ring + ws.parity * STAGE_FLOATS + ws.lane * 4;
 #pragma unroll
@@ -365,20 +368,28 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArg
                         atomicAdd(A.agg + (int64_t)dl * H + 64 * fh + lane, carry);
                 }
             }
-            // coalesced row stores: e_out = e' (+ e_in)
-#pragma unroll 1
-            for (int pass = 0; pass < TILE / 16; ++pass) {
-                const int row = pass * 16 + (tid >> 4);
+            // coalesced row stores: e_out = e' (+ e_in); all residual loads in flight before the first add
+            {
                 const int c4 = (tid & 15) * 4;
-                const int pr = p0 + row;
-                if (pr < E) {
+                int64_t orow[TILE / 16];
+                floatx4 o[TILE / 16];
+#pragma unroll
+                for (int pass = 0; pass < TILE / 16; ++pass) {
+                    const int pr = p0 + pass * 16 + (tid >> 4);
+                    const int prc = pr < E ? pr : E - 1;
+                    orow[pass] = A.eid_out ? A.eid_out[prc] : prc;
+                }
+                if (!ENC && A.residual) {
+#pragma unroll
+                    for (int pass = 0; pass < TILE / 16; ++pass)
+                        o[pass] = *reinterpret_cast<const floatx4*>(A.e_in + orow[pass] * H + 64 * fh + c4);
+                }
+#pragma unroll
+                for (int pass = 0; pass < TILE / 16; ++pass) {
+                    const int row = pass * 16 + (tid >> 4);
                     floatx4 v = *reinterpret_cast<const floatx4*>(T + row * TS + c4);
-                    const int64_t orow = A.eid_out ? A.eid_out[pr] : pr;
-                    if (!ENC && A.residual) {
-                        const floatx4 o = *reinterpret_cast<const floatx4*>(A.e_in + orow * H + 64 * fh + c4);
-                        v += o;
-                    }
-                    *reinterpret_cast<floatx4*>(A.e_out + orow * H + 64 * fh + c4) = v;
+                    if (!ENC && A.residual) v += o[pass];
+                    if (p0 + row < E) *reinterpret_cast<floatx4*>(A.e_out + orow[pass] * H + 64 * fh + c4) = v;
                 }
             }
             __syncthreads();
@@ -510,8 +521,11 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacit
         if (rc != GM_OK) return rc;
         attr_done = true;
     }
-    if (enc) hipLaunchKernelGGL((edge_kernel<128, 2, true>), dim3(grid), dim3(THREADS), lds, s, a);
-    else hipLaunchKernelGGL((edge_kernel<128, 2, false>), dim3(grid), dim3(THREADS), lds, s, a);
+    {
+        ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
+        if (enc) hipLaunchKernelGGL((edge_kernel<128, 2, true>), dim3(grid), dim3(THREADS), lds, s, a);
+        else hipLaunchKernelGGL((edge_kernel<128, 2, false>), dim3(grid), dim3(THREADS), lds, s, a);
+    }
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -521,10 +535,13 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
     GM_REQUIRE(H == 128 && NL == 2, GM_ERR_UNSUPPORTED, "node kernel: hidden_size=%d num_layers=%d not instantiated (128, 2)", H, NL);
     const int grid = grid_for(cdiv(a.n_nodes, TILE));
     const size_t lds = node_lds_bytes();
-    switch (mode) {
-        case 0: hipLaunchKernelGGL((node_kernel<128, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a); break;
-        case 1: hipLaunchKernelGGL((node_kernel<128, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a); break;
-        default: hipLaunchKernelGGL((node_kernel<128, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a); break;
+    {
+        ProfScope prof(mode == 1 ? PROF_NODE : PROF_ENC, s);
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((node_kernel<128, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a); break;
+            case 1: hipLaunchKernelGGL((node_kernel<128, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a); break;
+            default: hipLaunchKernelGGL((node_kernel<128, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        }
     }
     GM_LAUNCH_CHECK();
     return GM_OK;

@@ -27,7 +27,7 @@ def make_scene(n, seed=0, k=6, rigid_frac=0.1, side=None, lo=0.3, vel_scale=5e-4
     v = vel_scale * rng.standard_normal((n, 3))
     obs = np.zeros((k, n, 8), dtype=np.float32)
     for t in range(k):
-        obs[t, :, 2:5] = (p0 + t * v + 1e-5 * rng.standard_normal((n, 3))).astype(np.float32)
+        obs[t, :, 2:5] = (p0 + t * v + 0.02 * vel_scale * rng.standard_normal((n, 3))).astype(np.float32)
     obs[:, :, 0] = np.arange(n, dtype=np.float32)
     n_rigid = int(round(n * rigid_frac))
     if n_rigid:

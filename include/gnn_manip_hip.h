@@ -188,6 +188,16 @@ int gm_rollout_step(const gm_model* m, float* obs /*[k,N,D] in/out*/, int64_t n_
 int gm_rollout_status(const void* rollout_ws, const gm_model_desc* desc, int64_t n_nodes,
                       int max_neighbours, int64_t* n_edges_host, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (no reference counterpart; the reference only wraps model.forward in
+ * time.time(), examples/optimise_traj.py:99-103).  When enabled, the library brackets its dominant
+ * kernel launches with HIP events on the launch stream.  kind: 0 processor edge kernel,
+ * 1 processor node kernel, 2 radius-graph build (all its kernels), 3 encoder kernels.
+ * gm_profile_query synchronises on the recorded events.
+ * ------------------------------------------------------------------------------------------ */
+int gm_profile_enable(int on);
+int gm_profile_query(int kind, int64_t* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif
