@@ -22,6 +22,8 @@ struct EdgeArgs {
     float eps;
     int residual;          // e_out = e' + e_in
     int k1;                // encoder: edge_dim
+    int debug;             // timing ablations (GM_DEBUG_SKIP), 0 in production
+    unsigned long long* stamps;  // diagnostic build only: per-tile s_memrealtime stamps, or nullptr
 };
 
 struct NodeArgs {
@@ -49,5 +51,6 @@ int pack_linear(const float* W, int out_rows, int ld, int col0, int kvalid, floa
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
 constexpr int kStageFloats = 4096;
+void set_stamp_buffer(unsigned long long* p);
 
 }  // namespace gm

@@ -28,6 +28,7 @@
 //
 // Reference semantics: EncProcDecGNN.forward / _process / _build_mlp,
 // gnn_manip/models/epd_gnn.py:72-105; block semantics per BASELINE.json north_star.
+#include <stdlib.h>
 #include "common.h"
 #include "mlp.h"
 
@@ -103,6 +104,11 @@ __device__ __forceinline__ void issue_stage(const WStream& ws, int stage, int bu
     }
 }
 
+// Workgroup barrier that orders LDS traffic only (does not drain global stores / loads in flight).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // One Linear: acc[jb] += W(jb-block rows) . act.   NKQ = K/8 input octets, NJB = OUT/32 blocks.
 // `more` = another stage will be consumed after this layer's last one (this tile or the next).
 template <int NKQ, int NJB, int NKB>
@@ -127,16 +133,37 @@ __device__ __forceinline__ void run_layer(floatx16 (&acc)[NJB], const floatx16 (
             __builtin_amdgcn_sched_barrier(0);
         }
         const float* buf = ws.ring + ws.parity * STAGE_FLOATS + ws.lane * 4;
+        // A operands are fetched one group of pieces ahead of the MFMAs that consume them, so the LDS
+        // latency sits under the matrix pipe instead of in front of it.
+        constexpr int GP = NJB >= 2 ? 2 : 1;  // pieces per group
+        constexpr int NG = STAGE_PIECES / GP;
+        floatx4 a_cur[GP], a_nxt[GP];
 #pragma unroll
-        for (int slot = 0; slot < STAGE_PIECES; ++slot) {
-            const int p = s * STAGE_PIECES + slot;
-            if (p < NP) {
-                const int kq = p / NJB, jb = p % NJB;
-                const floatx4 a = *reinterpret_cast<const floatx4*>(buf + slot * PIECE_FLOATS);
+        for (int q = 0; q < GP; ++q)
+            if (s * STAGE_PIECES + q < NP) a_cur[q] = *reinterpret_cast<const floatx4*>(buf + q * PIECE_FLOATS);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], act[kq >> 2][(kq & 3) * 4 + t], acc[jb], 0, 0, 0);
+        for (int gidx = 0; gidx < NG; ++gidx) {
+            if (gidx + 1 < NG) {
+#pragma unroll
+                for (int q = 0; q < GP; ++q) {
+                    const int slot = (gidx + 1) * GP + q;
+                    if (s * STAGE_PIECES + slot < NP) a_nxt[q] = *reinterpret_cast<const floatx4*>(buf + slot * PIECE_FLOATS);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < GP; ++q) {
+                    const int p = s * STAGE_PIECES + gidx * GP + q;
+                    if (p < NP) {
+                        const int kq = p / NJB, jb = p % NJB;
+                        acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][t], act[kq >> 2][(kq & 3) * 4 + t], acc[jb], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < GP; ++q) a_cur[q] = a_nxt[q];
         }
         ws.cur = nxt;
         ws.parity ^= 1;
@@ -224,6 +251,9 @@ __device__ __forceinline__ void layer_norm_regs(floatx16 (&acc)[NJB], const floa
     const float rstd = 1.0f / sqrtf(q * INV_H + eps);
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb) {
+        // compiler-level memory barrier: keeps the gamma / beta loads of block jb from being hoisted
+        // above block jb-1 (all 128 values in flight at once cost 128 VGPRs and spill the accumulators)
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const floatx4 gm = *reinterpret_cast<const floatx4*>(gamma + 32 * jb + 8 * g + 4 * hi);
@@ -234,6 +264,15 @@ __device__ __forceinline__ void layer_norm_regs(floatx16 (&acc)[NJB], const floa
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+
+// Two workgroups share a CU (two waves per SIMD).  The matrix pipe is the shared resource; everything
+// else a tile does (index / gather issue, LayerNorm, LDS staging, segmented reduction, stores) is a
+// latency-bound chain of few instructions.  Those phases run at raised priority so that they are never
+// starved by the partner workgroup's MFMA stream (measured: at equal or lower priority a workgroup's
+// epilogue stretches from ~12 us to ~27 us while its partner is in its MFMA phase); the MFMA phases
+// run at priority 0 and take whatever issue slots are left, which is all the pipe needs.
+__device__ __forceinline__ void prio_latency_phase() { __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void prio_mfma_phase() { __builtin_amdgcn_s_setprio(0); }
 
 // hidden layers 2..NL and the output layer of an MLP whose layer 1 has just been accumulated
 template <int H, int NL>
@@ -250,19 +289,30 @@ __device__ __forceinline__ void mlp_tail_layers(floatx16 (&acc)[H / 32], floatx1
 // ------------------------------------------------------------------------------------------
 // EDGE kernel
 // ------------------------------------------------------------------------------------------
-template <int H, int NL, bool ENC>
+// Diagnostic stamps (tools/stamps.py): 100 MHz s_memrealtime per tile phase, written to a buffer that no
+// other code reads.  Never enabled in a timed run.
+#define GM_STAMP(k)                                                                          \
+    do {                                                                                     \
+        if (A.stamps && tid == 0) A.stamps[(size_t)tile * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
+// MODE 0: encoder phi_e on raw edge attributes; 1: processor phi_e with the residual e <- e' + e
+// (fused forward); 2: processor phi_e without residual (InteractionNetwork block API).
+template <int H, int NL, int MODE>
 __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArgs A) {
+    constexpr bool ENC = MODE == 0;
+    constexpr bool with_resid = MODE == 1;
     constexpr int NJB = H / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ring = reinterpret_cast<float*>(smem);
     float* T = ring + 2 * STAGE_FLOATS;
-    int* sdst = reinterpret_cast<int*>(T + TILE * TS);  // [TILE + 2] (+2 pad)
-    float* headv = reinterpret_cast<float*>(sdst + TILE + 4);
-    float* tailv = headv + 4 * 64;
+    int* sdst = reinterpret_cast<int*>(T + TILE * TS);                 // 2 x [TILE + 2] (+2 pad): per tile parity
+    float* headv = reinterpret_cast<float*>(sdst + 2 * (TILE + 4));   // 2 x (head[4][64], tail[4][64]): per chunk parity
+    int tpar = 0;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 31, hi = lane >> 5;
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6, n0 = lane0 & 31;
     const int E = A.hdr ? A.hdr->n_edges : A.n_edges_host;
+
     const int ntiles = (E + TILE - 1) / TILE;
 
     WStream ws;
@@ -271,40 +321,111 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArg
     ws.total = ENC ? (1 + NL * (H / 8) * NJB / STAGE_PIECES) : ((NL + 1) * (H / 8) * NJB / STAGE_PIECES);
     ws.cur = 0;
     ws.parity = 0;
-    ws.lane = lane;
-    ws.wave = wave;
+    ws.lane = lane0;
+    ws.wave = wave0;
     if ((int)blockIdx.x < ntiles) issue_stage(ws, 0, 0);
+    {   // experiment: start the workgroup in the odd hardware slot late, to de-phase the two workgroups of a CU
+        const int delay = (A.debug >> 8) & 0xff;
+        const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        if (delay && (wave_slot & 1))
+            for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
+    // Per-tile indices are fetched one tile ahead (registers), so that a tile's gathers do not wait
+    // behind an index load.
+    struct TileIdx { int er, d, sr, dq, sd; };
+    auto fetch_idx = [&](int tile) {
+        TileIdx ix;
+        const int p0 = tile * TILE;
+        const int p = p0 + wave0 * 32 + n0;
+        const int pc = p < E ? p : E - 1;
+        ix.er = A.eid ? A.eid[pc] : pc;
+        ix.d = ix.sr = 0;
+        ix.dq = ix.sd = -1;
+        if (!ENC) {
+            ix.d = A.dst[pc];
+            ix.sr = A.src[pc];
+            if (tid0 < TILE + 2) {
+                const int pp = p0 - 1 + tid0;
+                ix.sd = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+            }
+            if (lane0 < 34) {  // lane l: destination of row (32*wave - 1 + l) of the tile; -2 before edge 0, -1 past E
+                const int pp = p0 + 32 * wave0 - 1 + lane0;
+                ix.dq = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+            }
+        }
+        return ix;
+    };
+    TileIdx nx = {0, 0, 0, -1, -1};
+    if ((int)blockIdx.x < ntiles) nx = fetch_idx(blockIdx.x);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const bool more_tiles = tile + (int)gridDim.x < ntiles;
         const int p0 = tile * TILE;
-        const int p = p0 + wave * 32 + n;
-        const int pc = p < E ? p : E - 1;
-        const int er = A.eid ? A.eid[pc] : pc;
-        if (!ENC && tid < TILE + 2) {
-            const int pp = p0 - 1 + tid;
-            sdst[tid] = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+        const TileIdx ix = nx;
+        if (!(A.debug & 16)) prio_latency_phase();
+        // Per-tile copies of the thread coordinates, laundered so that the prologue / epilogue address
+        // arithmetic is recomputed per tile instead of being hoisted out of the loop and spilled (a spill
+        // reload is a full memory round trip).  The weight stream keeps the un-laundered lane0 / wave0.
+        int tid_t = tid0;
+        asm volatile("" : "+v"(tid_t));
+        const int tid = tid_t, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
+        GM_STAMP(0);
+        if (A.stamps && tid == 0) {
+            A.stamps[(size_t)tile * 8 + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32) |
+                                             __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_ID, XCC_ID
+            A.stamps[(size_t)tile * 8 + 7] = blockIdx.x;
         }
+        int* sd = sdst + tpar * (TILE + 4);
+        if (!ENC && tid < TILE + 2) sd[tid] = ix.sd;  // ordered before its readers by the stage barriers
+        const int dq = ix.dq;
         floatx16 acc[NJB], act[NJB];
         if (ENC) {
-            load_feat_guard(act, A.e_in + (int64_t)er * A.k1, hi, A.k1);
+            load_feat_guard(act, A.e_in + (int64_t)ix.er * A.k1, hi, A.k1);
             load_feat(acc, A.bias, hi);
+            if (more_tiles) nx = fetch_idx(tile + gridDim.x);
+            prio_mfma_phase();
             // layer 1: K = edge_dim padded to 8 -> one k-octet (edge_dim <= 8 checked on the host)
             run_layer<1, NJB, NJB>(acc, act, ws, more_tiles);
             mlp_tail_layers<H, NL>(acc, act, A.bias + H, ws, more_tiles, hi);
         } else {
-            const int d = A.dst[pc], sr = A.src[pc];
-            load_feat(acc, A.P + (int64_t)d * (2 * H), hi);        // P_i[dst] (+ b1)
-            add_feat(acc, A.P + (int64_t)sr * (2 * H) + H, hi);    // P_j[src]
-            load_feat(act, A.e_in + (int64_t)er * H, hi);
-            run_layer<H / 8, NJB, NJB>(acc, act, ws, more_tiles);  // + W_e e
-            mlp_tail_layers<H, NL>(acc, act, A.bias, ws, more_tiles, hi);
+            if (A.debug & 8) {  // ablation: no gathers
+                load_feat(acc, A.bias, hi);
+                load_feat(act, A.bias, hi);
+            } else {
+                load_feat(acc, A.P + (int64_t)ix.d * (2 * H), hi);        // P_i[dst] (+ b1)
+                add_feat(acc, A.P + (int64_t)ix.sr * (2 * H) + H, hi);    // P_j[src]
+                load_feat(act, A.e_in + (int64_t)ix.er * H, hi);
+            }
+            if (more_tiles) nx = fetch_idx(tile + gridDim.x);
+            prio_mfma_phase();
+            if (!(A.debug & 1)) {
+                run_layer<H / 8, NJB, NJB>(acc, act, ws, more_tiles);  // + W_e e
+                GM_STAMP(1);
+                mlp_tail_layers<H, NL>(acc, act, A.bias, ws, more_tiles, hi);
+            }
+            GM_STAMP(2);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(A.debug & 16)) prio_latency_phase();
         layer_norm_regs(acc, A.ln_g, A.ln_b, A.eps, hi);
+        GM_STAMP(3);
+        if (A.debug & 2) {  // ablation: no epilogue (keep the result alive)
+            if (acc[0][0] == 123.456f) A.e_out[p0] = acc[1][1] + acc[2][2] + acc[3][3];
+            continue;
+        }
 
-        // ---- epilogue: 64 features at a time through the LDS staging tile
+        // ---- epilogue: 64 features at a time through the LDS tile, which serves the segmented reduction
+        // (scatter-add) and whole-row coalesced stores of e_out = e' (+ e_in).  Barriers here order LDS
+        // traffic only (lgkmcnt): a __syncthreads() would also drain every global store in flight.
+        constexpr int NCH = H / 64;
+        constexpr int NPASS = TILE / 16;
+        const bool do_agg = !ENC && !(A.debug & 4);
+        const int c4 = (tid & 15) * 4;
 #pragma unroll
-        for (int fh = 0; fh < H / 64; ++fh) {
+        for (int fh = 0; fh < NCH; ++fh) {
+            float* hv = headv + (fh & 1) * 512;  // head / tail partials double-buffered across chunks
+            float* tl = hv + 256;
 #pragma unroll
             for (int jb2 = 0; jb2 < 2; ++jb2)
 #pragma unroll
@@ -314,44 +435,50 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArg
                     for (int t = 0; t < 4; ++t) x[t] = acc[2 * fh + jb2][4 * g + t];
                     *reinterpret_cast<floatx4*>(T + (wave * 32 + n) * TS + 32 * jb2 + 8 * g + 4 * hi) = x;
                 }
-            __syncthreads();
-            if (!ENC && A.agg) {
-                // segmented sum over destination-sorted rows: wave q walks rows 32q..32q+31, lane = column
+            lds_barrier();
+            if (do_agg) {
+                // segmented sum over destination-sorted rows: wave q owns rows 32q..32q+31, lane = column.
+                // Row destinations come from a lane-held register through v_readlane (scalar, so every
+                // branch is a scalar branch); the 32 tile values are fetched with independent LDS reads.
                 const int r0 = 32 * wave;
+                float tv[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) tv[r] = T[(r0 + r) * TS + lane];
                 float run = 0.f;
-                bool first = sdst[r0 + 1] >= 0 && sdst[r0] == sdst[r0 + 1];
-#pragma unroll 1
+                int d = __builtin_amdgcn_readlane(dq, 1);
+                bool first = d >= 0 && __builtin_amdgcn_readlane(dq, 0) == d;
+#pragma unroll
                 for (int r = 0; r < 32; ++r) {
-                    const int row = r0 + r;
-                    const int d = sdst[row + 1], dn = sdst[row + 2];
-                    if (d >= 0) run += T[row * TS + lane];
+                    const int dn = __builtin_amdgcn_readlane(dq, r + 2);
+                    if (d >= 0) run += tv[r];
                     if (dn != d && d >= 0) {
-                        if (first) headv[wave * 64 + lane] = run;
+                        if (first) hv[wave * 64 + lane] = run;
                         else A.agg[(int64_t)d * H + 64 * fh + lane] = run;
                         run = 0.f;
                         first = false;
                     }
+                    d = dn;
                 }
                 {
-                    const int dl = sdst[r0 + 32];
-                    if (dl >= 0 && sdst[r0 + 33] == dl) tailv[wave * 64 + lane] = run;
+                    const int dl = __builtin_amdgcn_readlane(dq, 32);
+                    if (dl >= 0 && __builtin_amdgcn_readlane(dq, 33) == dl) tl[wave * 64 + lane] = run;
                 }
-                __syncthreads();
+                lds_barrier();  // T is free again; head / tail partials are visible
                 if (wave == 0) {  // stitch segments that cross quarter / tile boundaries
                     float carry = 0.f;
                     bool ext = false;
 #pragma unroll 1
                     for (int q = 0; q < 4; ++q) {
                         const int q0 = 32 * q;
-                        const int df = sdst[q0 + 1];
-                        const bool cont_in = df >= 0 && sdst[q0] == df;
-                        const bool through = cont_in && sdst[q0 + 32] == df && sdst[q0 + 33] == df;
+                        const int df = sd[q0 + 1];
+                        const bool cont_in = df >= 0 && sd[q0] == df;
+                        const bool through = cont_in && sd[q0 + 32] == df && sd[q0 + 33] == df;
                         if (cont_in) {
                             if (q == 0) { carry = 0.f; ext = true; }
                             if (through) {
-                                carry += tailv[q * 64 + lane];
+                                carry += tl[q * 64 + lane];
                             } else {
-                                const float tot = carry + headv[q * 64 + lane];
+                                const float tot = carry + hv[q * 64 + lane];
                                 float* dstp = A.agg + (int64_t)df * H + 64 * fh + lane;
                                 if (ext) atomicAdd(dstp, tot); else *dstp = tot;
                                 carry = 0.f;
@@ -359,41 +486,42 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArg
                             }
                         }
                         if (!through) {
-                            const int dl = sdst[q0 + 32];
-                            if (dl >= 0 && sdst[q0 + 33] == dl) { carry = tailv[q * 64 + lane]; ext = false; }
+                            const int dl = sd[q0 + 32];
+                            if (dl >= 0 && sd[q0 + 33] == dl) { carry = tl[q * 64 + lane]; ext = false; }
                         }
                     }
-                    const int dl = sdst[TILE];
-                    if (dl >= 0 && sdst[TILE + 1] == dl)  // open at the tile end: the rest is in the next tile
+                    const int dl = sd[TILE];
+                    if (dl >= 0 && sd[TILE + 1] == dl)  // open at the tile end: the rest is in the next tile
                         atomicAdd(A.agg + (int64_t)dl * H + 64 * fh + lane, carry);
                 }
             }
-            // coalesced row stores: e_out = e' (+ e_in); all residual loads in flight before the first add
+            // coalesced row stores: e_out = e' (+ e_in); the residual loads of all passes are in flight together
             {
-                const int c4 = (tid & 15) * 4;
-                int64_t orow[TILE / 16];
-                floatx4 o[TILE / 16];
+                int orow[NPASS];
+                floatx4 o[NPASS];
 #pragma unroll
-                for (int pass = 0; pass < TILE / 16; ++pass) {
+                for (int pass = 0; pass < NPASS; ++pass) {
                     const int pr = p0 + pass * 16 + (tid >> 4);
                     const int prc = pr < E ? pr : E - 1;
                     orow[pass] = A.eid_out ? A.eid_out[prc] : prc;
                 }
-                if (!ENC && A.residual) {
+                if (with_resid) {
 #pragma unroll
-                    for (int pass = 0; pass < TILE / 16; ++pass)
-                        o[pass] = *reinterpret_cast<const floatx4*>(A.e_in + orow[pass] * H + 64 * fh + c4);
+                    for (int pass = 0; pass < NPASS; ++pass)
+                        o[pass] = *reinterpret_cast<const floatx4*>(A.e_in + (int64_t)orow[pass] * H + 64 * fh + c4);
                 }
 #pragma unroll
-                for (int pass = 0; pass < TILE / 16; ++pass) {
+                for (int pass = 0; pass < NPASS; ++pass) {
                     const int row = pass * 16 + (tid >> 4);
                     floatx4 v = *reinterpret_cast<const floatx4*>(T + row * TS + c4);
-                    if (!ENC && A.residual) v += o[pass];
-                    if (p0 + row < E) *reinterpret_cast<floatx4*>(A.e_out + orow[pass] * H + 64 * fh + c4) = v;
+                    if (with_resid) v += o[pass];
+                    if (p0 + row < E) *reinterpret_cast<floatx4*>(A.e_out + (int64_t)orow[pass] * H + 64 * fh + c4) = v;
                 }
             }
-            __syncthreads();
+            lds_barrier();  // T may be overwritten by the next chunk / tile
+            GM_STAMP(4 + fh);
         }
+        tpar ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -494,7 +622,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) node_kernel(NodeArg
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-size_t edge_lds_bytes() { return (size_t)(2 * STAGE_FLOATS + TILE * TS + (TILE + 4) + 2 * 4 * 64) * 4; }
+size_t edge_lds_bytes() { return (size_t)(2 * STAGE_FLOATS + TILE * TS + 2 * (TILE + 4) + 2 * 2 * 4 * 64) * 4; }
 size_t node_lds_bytes() { return (size_t)(2 * STAGE_FLOATS) * 4; }
 
 static int grid_for(int64_t tiles) {
@@ -508,23 +636,32 @@ static int set_lds(K kernel, size_t bytes) {
     return GM_OK;
 }
 
-int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s) {
+static unsigned long long* g_stamps = nullptr;
+void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
+
+int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capacity, hipStream_t s) {
     if (edge_capacity <= 0) return GM_OK;
+    static const int dbg = getenv("GM_DEBUG_SKIP") ? atoi(getenv("GM_DEBUG_SKIP")) : 0;
+    static const int extra_lds = getenv("GM_DEBUG_LDS") ? atoi(getenv("GM_DEBUG_LDS")) : 0;
+    EdgeArgs a = a_in;
+    a.debug = enc ? 0 : dbg;
+    a.stamps = enc ? nullptr : g_stamps;
     GM_REQUIRE(H == 128 && NL == 2, GM_ERR_UNSUPPORTED, "edge kernel: hidden_size=%d num_layers=%d not instantiated (128, 2)", H, NL);
     const int grid = grid_for(cdiv(edge_capacity, TILE));
-    const size_t lds = edge_lds_bytes();
+    const size_t lds = edge_lds_bytes() + (size_t)extra_lds;
     static bool attr_done = false;
     if (!attr_done) {
-        int rc = set_lds(edge_kernel<128, 2, true>, lds);
-        if (rc != GM_OK) return rc;
-        rc = set_lds(edge_kernel<128, 2, false>, lds);
+        int rc = set_lds(edge_kernel<128, 2, 0>, lds);
+        if (rc == GM_OK) rc = set_lds(edge_kernel<128, 2, 1>, lds);
+        if (rc == GM_OK) rc = set_lds(edge_kernel<128, 2, 2>, lds);
         if (rc != GM_OK) return rc;
         attr_done = true;
     }
     {
         ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
-        if (enc) hipLaunchKernelGGL((edge_kernel<128, 2, true>), dim3(grid), dim3(THREADS), lds, s, a);
-        else hipLaunchKernelGGL((edge_kernel<128, 2, false>), dim3(grid), dim3(THREADS), lds, s, a);
+        if (enc) hipLaunchKernelGGL((edge_kernel<128, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a);
+        else if (a.residual) hipLaunchKernelGGL((edge_kernel<128, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a);
+        else hipLaunchKernelGGL((edge_kernel<128, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;

@@ -379,6 +379,13 @@ RolloutWs carve_rollout(void* ws, const gm_model_desc* d, int64_t n, int K) {
 
 extern "C" {
 
+// diagnostics (tools/stamps.py): device buffer [tiles][8] u64 receiving per-tile phase stamps of the
+// processor edge kernel; nullptr disables.  Not used by any timed path.
+int gm_debug_set_stamp_buffer(void* device_buffer) {
+    gm::set_stamp_buffer(static_cast<unsigned long long*>(device_buffer));
+    return GM_OK;
+}
+
 size_t gm_rollout_workspace_bytes(const gm_model_desc* desc, int64_t n, int K) {
     if (!desc || n < 0 || K < 1) return 0;
     return carve_rollout(nullptr, desc, n, K).bytes;

@@ -196,6 +196,7 @@ int gm_rollout_status(const void* rollout_ws, const gm_model_desc* desc, int64_t
  * gm_profile_query synchronises on the recorded events.
  * ------------------------------------------------------------------------------------------ */
 int gm_profile_enable(int on);
+int gm_debug_set_stamp_buffer(void* device_buffer /* u64 [tiles][8] or NULL */);
 int gm_profile_query(int kind, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus
