@@ -325,6 +325,91 @@ __global__ void __launch_bounds__(256) cell_fill_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// neighbour search, fast path: 8 lanes per query.  The lanes scan the 27-cell candidate ranges
+// together, append in-radius candidates (d2, index) to the query's list in LDS through a ballot
+// prefix, then rank the list (rank = number of smaller (d2, index) keys: no dependent chains, the
+// order (d2, index) is total so the result is order-independent) and emit the first K.  Queries
+// with more than NB_CAP in-radius candidates are marked (cnt = -1) for the general kernel below.
+// ------------------------------------------------------------------------------------------
+constexpr int NB_CAP = 96;
+constexpr int NB_STRIDE = NB_CAP + 1;  // doubles per list: odd stride keeps the 8 groups of a wave on distinct banks
+constexpr int NB_QPB = 32;             // queries per 256-thread block
+
+__global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __restrict__ sorted,
+                                                             const int* __restrict__ cell_start,
+                                                             const GraphHeader* __restrict__ hdr, int64_t n, double r2,
+                                                             int K, int* __restrict__ cnt, int* __restrict__ nbr) {
+    __shared__ double sd2[NB_QPB * NB_STRIDE];
+    __shared__ int sj[NB_QPB * NB_STRIDE];
+    const int tid = threadIdx.x, sub = tid & 7, ql = tid >> 3, lane = tid & 63;
+    const int grp_shift = (lane >> 3) * 8;  // position of this group's 8 bits in the wave ballot
+    const int64_t slot = (int64_t)blockIdx.x * NB_QPB + ql;
+    const bool active = slot < n;
+    const float4 q = sorted[active ? slot : 0];
+    const int qi = __float_as_int(q.w);
+    const int dx = hdr->dims[0], dy = hdr->dims[1], dz = hdr->dims[2];
+    const double inv_h = hdr->inv_h;
+    const int cx = cell_coord(q.x, hdr->origin[0], inv_h, dx);
+    const int cy = cell_coord(q.y, hdr->origin[1], inv_h, dy);
+    const int cz = cell_coord(q.z, hdr->origin[2], inv_h, dz);
+    const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
+    double* ld = sd2 + ql * NB_STRIDE;
+    int* lj = sj + ql * NB_STRIDE;
+    int count = 0;  // group-uniform
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, dx - 1);
+    if (active) {
+        for (int z = max(cz - 1, 0); z <= min(cz + 1, dz - 1); ++z) {
+            for (int y = max(cy - 1, 0); y <= min(cy + 1, dy - 1); ++y) {
+                const int row = (z * dy + y) * dx;
+                const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
+                for (int c0 = b; c0 < e; c0 += 8) {
+                    const int c = c0 + sub;
+                    bool in = false;
+                    double d2 = 0.0;
+                    int j = 0;
+                    if (c < e) {
+                        const float4 p = sorted[c];
+                        double d = qx - (double)p.x;
+                        d2 = __dmul_rn(d, d);
+                        d = qy - (double)p.y;
+                        d2 = __dadd_rn(d2, __dmul_rn(d, d));
+                        d = qz - (double)p.z;
+                        d2 = __dadd_rn(d2, __dmul_rn(d, d));
+                        in = d2 <= r2;
+                        j = __float_as_int(p.w);
+                    }
+                    const unsigned m = (unsigned)(__ballot(in) >> grp_shift) & 0xffu;
+                    const int pos = count + __popc(m & ((1u << sub) - 1u));
+                    if (in && pos < NB_CAP) {
+                        ld[pos] = d2;
+                        lj[pos] = j;
+                    }
+                    count += __popc(m);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    if (count > NB_CAP) {
+        if (sub == 0) cnt[qi] = -1;  // general kernel takes this query
+        return;
+    }
+    for (int a = sub; a < count; a += 8) {
+        const double da = ld[a];
+        const int ja = lj[a];
+        int rank = 0;
+        for (int f = 0; f < count; ++f) {
+            const double df = ld[f];
+            const int jf = lj[f];
+            rank += (df < da || (df == da && jf < ja)) ? 1 : 0;
+        }
+        if (rank < K) nbr[(int64_t)qi * K + rank] = ja;
+    }
+    if (sub == 0) cnt[qi] = count < K ? count : K;
+}
+
+// ------------------------------------------------------------------------------------------
 // neighbour search: thread t owns the query in sorted slot t; candidate lists live in LDS as
 // [slot][thread] (conflict-free), kept sorted by (d2, index).
 // ------------------------------------------------------------------------------------------
@@ -341,6 +426,7 @@ __global__ void __launch_bounds__(BS) neighbor_kernel(const float4* __restrict__
     if (slot >= n) return;
     const float4 q = sorted[slot];
     const int qi = __float_as_int(q.w);
+    if (cnt[qi] != -1) return;  // done by neighbor_fast_kernel
     const int dx = hdr->dims[0], dy = hdr->dims[1], dz = hdr->dims[2];
     const double inv_h = hdr->inv_h;
     const int cx = cell_coord(q.x, hdr->origin[0], inv_h, dx);
@@ -473,23 +559,52 @@ __global__ void __launch_bounds__(256) fill_ei_kernel(const int64_t* __restrict_
 }
 
 // Make the order inside each destination segment deterministic: ascending original edge id.
+// 8 lanes per segment: the segment is staged in LDS, every element is ranked against the others
+// (ids are unique) and written back in place.  Segments longer than SEG_CAP (in-degree > 96) are
+// sorted by one lane with an insertion sort in global memory.
+constexpr int SEG_CAP = 96;
+constexpr int SEG_STRIDE = SEG_CAP + 1;
 __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict__ in_ptr, int64_t n,
                                                             int* __restrict__ src, int* __restrict__ eid,
                                                             CsrHeader* hdr) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) hdr->n_edges = in_ptr[n];
-    if (i >= n) return;
-    const int b = in_ptr[i], e = in_ptr[i + 1];
-    for (int a = b + 1; a < e; ++a) {
-        const int ke = eid[a], ks = src[a];
-        int p = a;
-        while (p > b && eid[p - 1] > ke) {
-            eid[p] = eid[p - 1];
-            src[p] = src[p - 1];
-            --p;
+    __shared__ int se[32 * SEG_STRIDE];
+    __shared__ int ss[32 * SEG_STRIDE];
+    const int tid = threadIdx.x, sub = tid & 7, sl = tid >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 32 + sl;
+    if (i == 0 && sub == 0) hdr->n_edges = in_ptr[n];
+    const bool active = i < n;
+    const int b = active ? in_ptr[i] : 0, e = active ? in_ptr[i + 1] : 0;
+    const int len = e - b;
+    int* le = se + sl * SEG_STRIDE;
+    int* ls = ss + sl * SEG_STRIDE;
+    const bool small = len <= SEG_CAP;
+    if (small)
+        for (int a = sub; a < len; a += 8) {
+            le[a] = eid[b + a];
+            ls[a] = src[b + a];
         }
-        eid[p] = ke;
-        src[p] = ks;
+    __syncthreads();
+    if (!active) return;
+    if (small) {
+        for (int a = sub; a < len; a += 8) {
+            const int ka = le[a];
+            int rank = 0;
+            for (int f = 0; f < len; ++f) rank += le[f] < ka ? 1 : 0;
+            eid[b + rank] = ka;
+            src[b + rank] = ls[a];
+        }
+    } else if (sub == 0) {
+        for (int a = b + 1; a < e; ++a) {
+            const int ke = eid[a], ks = src[a];
+            int p = a;
+            while (p > b && eid[p - 1] > ke) {
+                eid[p] = eid[p - 1];
+                src[p] = src[p - 1];
+                --p;
+            }
+            eid[p] = ke;
+            src[p] = ks;
+        }
     }
 }
 
@@ -552,6 +667,8 @@ int gm_radius_graph_build(const float* pos, int64_t pos_stride, int64_t n, doubl
         hipLaunchKernelGGL(cell_fill_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.cell_of, g.cell_start,
                            g.cell_cursor, g.sorted);
         const double r2 = conn_r * conn_r;  // KDTree compares rdist with r*r in float64
+        hipLaunchKernelGGL(neighbor_fast_kernel, dim3((unsigned)cdiv(n, NB_QPB)), dim3(256), 0, s, g.sorted, g.cell_start,
+                           g.hdr, n, r2, K, g.cnt, g.nbr);
         if (K <= 64) {
             constexpr int BS = 128;
             size_t lds = (size_t)K * BS * 12;
@@ -615,7 +732,7 @@ int gm_csr_from_graph(const void* graph_ws, int64_t n, int K, void* csr_ws, size
         if (rc != GM_OK) return rc;
         hipLaunchKernelGGL(fill_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.out_ptr, g.nbr, n, K, c.in_ptr,
                            c.cursor, cap, c.dst, c.src, c.eid, c.hdr);
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr);
         GM_LAUNCH_CHECK();
     }
     return GM_OK;
@@ -639,7 +756,7 @@ int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws
         hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, c.in_ptr, c.cursor, c.dst, c.src, c.eid);
     }
     if (n > 0)
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -31,6 +31,7 @@ struct NodeArgs {
     const float* x_in;     // mode 0: raw node features [N][k1]; mode 1/2: h [N][H]
     int k1;
     const float* agg;      // mode 1: [N][H]
+    float* agg_clear;      // mode 1: same buffer, zeroed row by row after it is read (next step's scatter-add target), or nullptr
     float* h_out;          // [N][H] (may alias x_in)
     int residual;
     const float* wstream;

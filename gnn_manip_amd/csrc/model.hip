@@ -281,12 +281,13 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     set_tail(m, na, 0, f.P, out);
     rc = launch_node(H, NL, 0, na, s);
     if (rc != GM_OK) return rc;
+    // agg is zeroed once; afterwards every node kernel clears the rows it has consumed
+    GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
     for (int k = 0; k < M; ++k) {
-        GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
         rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, 1), cap, s);
         if (rc != GM_OK) return rc;
         NodeArgs a{};
-        a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.h_out = f.h; a.residual = 1;
+        a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.agg_clear = k + 1 < M ? f.agg : nullptr; a.h_out = f.h; a.residual = 1;
         a.wstream = m->packed + m->s_node[k];
         const float* vn = m->vec + m->v_node[k];
         a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
