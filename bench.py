@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rollout-throughput bench for the MI355X rollout engine (contract: see DESIGN.md "Measurement").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|target]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|target|c4]
 
 A "step" is one full rollout step of the hot path (state update -> node features -> radius graph
 -> destination sort -> edge features -> encode / 10x process / decode -> Euler integration) on a
@@ -32,6 +32,8 @@ WORKLOADS = {
                n=50000, hidden=128),
     "target": dict(name="north_star target: N=100k dense synthetic scene, conn_r=0.015, hidden=128, 10 MP steps",
                    n=100000, hidden=128),
+    "c4": dict(name="C4: N=100k dense synthetic scene, hidden=256, 10 MP steps (MFMA-bound MLP run)",
+               n=100000, hidden=256),
 }
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 HBM_PEAK_GBS = 8000.0
@@ -154,7 +156,7 @@ def main():
         # layer-1 factorisation, not MFMA speed (SURVEY.md 8d "utilisation uses F_issued").
         achieved = issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         out = {
-            "metric": "rollout steps/sec (N particles, 10 MP steps, hidden=128)",
+            "metric": f"rollout steps/sec (N particles, 10 MP steps, hidden={hidden})",
             "value": world * args.steps / el,
             "unit": "rollout steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +167,7 @@ def main():
                     "pile stays dense over the rollout)",
             "config": {"workload": wl["name"], "n_particles": n, "edges_last_step": edges, "k_steps": 6,
                        "candidates_per_gpu": 1, "parallelism": f"candidate-parallel x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "edge_kernel<128,2,1> (processor phi_e + scatter-add)",
+            "roofline": {"bound": "mfma", "kernel": f"edge_kernel<{hidden},2,1> (processor phi_e + scatter-add)",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": k_ms, "launches_timed": int(launches.value),

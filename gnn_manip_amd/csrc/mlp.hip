@@ -819,8 +819,10 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) node_kernel(NodeArg
     WStream ws;
     ws.base = A.wstream;
     ws.ring = ring;
-    const int mlp_stages = MODE == 0 ? (1 + NL * SL) : (MODE == 1 ? (NL + 2) * SL : 0);
-    const int tail_stages = A.tail == 1 ? 2 * SL : (A.tail == 2 ? NL * SL + 1 : 0);
+    constexpr int S_IN = (4 * NJB + STAGE_PIECES - 1) / STAGE_PIECES;       // encoder layer 1: K padded to 32
+    constexpr int S_OUT = (H / 8 + STAGE_PIECES - 1) / STAGE_PIECES;        // decoder output layer: one 32-row block
+    const int mlp_stages = MODE == 0 ? (S_IN + NL * SL) : (MODE == 1 ? (NL + 2) * SL : 0);
+    const int tail_stages = A.tail == 1 ? 2 * SL : (A.tail == 2 ? NL * SL + S_OUT : 0);
     ws.total = mlp_stages + tail_stages;
     ws.cur = 0;
     ws.parity = 0;
@@ -920,6 +922,23 @@ static int set_lds(K kernel, size_t bytes) {
 static unsigned long long* g_stamps = nullptr;
 void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 
+template <int H>
+static int launch_edge_h(bool enc, const EdgeArgs& a, int grid, size_t lds, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = set_lds(edge_kernel<H, 2, 0>, lds);
+        if (rc == GM_OK) rc = set_lds(edge_kernel<H, 2, 1>, lds);
+        if (rc == GM_OK) rc = set_lds(edge_kernel<H, 2, 2>, lds);
+        if (rc != GM_OK) return rc;
+        attr_done = true;
+    }
+    ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
+    if (enc) hipLaunchKernelGGL((edge_kernel<H, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a);
+    else if (a.residual) hipLaunchKernelGGL((edge_kernel<H, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a);
+    else hipLaunchKernelGGL((edge_kernel<H, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a);
+    return GM_OK;
+}
+
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capacity, hipStream_t s) {
     if (edge_capacity <= 0) return GM_OK;
     static const int dbg = getenv("GM_DEBUG_SKIP") ? atoi(getenv("GM_DEBUG_SKIP")) : 0;
@@ -927,16 +946,15 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     EdgeArgs a = a_in;
     a.debug = enc ? 0 : dbg;
     a.stamps = enc ? nullptr : g_stamps;
-    GM_REQUIRE(H == 128 && NL == 2, GM_ERR_UNSUPPORTED, "edge kernel: hidden_size=%d num_layers=%d not instantiated (128, 2)", H, NL);
+    GM_REQUIRE((H == 128 || H == 256) && NL == 2, GM_ERR_UNSUPPORTED,
+               "edge kernel: hidden_size=%d num_layers=%d not instantiated (128 or 256, 2)", H, NL);
     const int grid = grid_for(cdiv(edge_capacity, TILE));
     const size_t lds = edge_lds_bytes() + (size_t)extra_lds;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int rc = set_lds(edge_kernel<128, 2, 0>, lds);
-        if (rc == GM_OK) rc = set_lds(edge_kernel<128, 2, 1>, lds);
-        if (rc == GM_OK) rc = set_lds(edge_kernel<128, 2, 2>, lds);
+    if (H == 256) {
+        int rc = launch_edge_h<256>(enc, a, grid, lds, s);
         if (rc != GM_OK) return rc;
-        attr_done = true;
+        GM_LAUNCH_CHECK();
+        return GM_OK;
     }
     // The role-alternating 8-wave form is experimental (GM_EDGE_KERNEL=alt): correct, but its P-role
     // sub-steps still gate the M group's stage barriers (register spills around the epilogue), so the
@@ -961,10 +979,8 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         else if (a.residual) hipLaunchKernelGGL((edge_kernel_alt<128, 2, 1>), dim3(g2), dim3(2 * THREADS), lds, s, a);
         else hipLaunchKernelGGL((edge_kernel_alt<128, 2, 2>), dim3(g2), dim3(2 * THREADS), lds, s, a);
     } else {
-        ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
-        if (enc) hipLaunchKernelGGL((edge_kernel<128, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a);
-        else if (a.residual) hipLaunchKernelGGL((edge_kernel<128, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a);
-        else hipLaunchKernelGGL((edge_kernel<128, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a);
+        int rc = launch_edge_h<128>(enc, a, grid, lds, s);
+        if (rc != GM_OK) return rc;
     }
     GM_LAUNCH_CHECK();
     return GM_OK;
@@ -972,15 +988,24 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
 
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
     if (a.n_nodes <= 0) return GM_OK;
-    GM_REQUIRE(H == 128 && NL == 2, GM_ERR_UNSUPPORTED, "node kernel: hidden_size=%d num_layers=%d not instantiated (128, 2)", H, NL);
+    GM_REQUIRE((H == 128 || H == 256) && NL == 2, GM_ERR_UNSUPPORTED,
+               "node kernel: hidden_size=%d num_layers=%d not instantiated (128 or 256, 2)", H, NL);
     const int grid = grid_for(cdiv(a.n_nodes, TILE));
     const size_t lds = node_lds_bytes();
     {
         ProfScope prof(mode == 1 ? PROF_NODE : PROF_ENC, s);
-        switch (mode) {
-            case 0: hipLaunchKernelGGL((node_kernel<128, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a); break;
-            case 1: hipLaunchKernelGGL((node_kernel<128, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a); break;
-            default: hipLaunchKernelGGL((node_kernel<128, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        if (H == 128) {
+            switch (mode) {
+                case 0: hipLaunchKernelGGL((node_kernel<128, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a); break;
+                case 1: hipLaunchKernelGGL((node_kernel<128, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a); break;
+                default: hipLaunchKernelGGL((node_kernel<128, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a); break;
+            }
+        } else {
+            switch (mode) {
+                case 0: hipLaunchKernelGGL((node_kernel<256, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a); break;
+                case 1: hipLaunchKernelGGL((node_kernel<256, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a); break;
+                default: hipLaunchKernelGGL((node_kernel<256, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a); break;
+            }
         }
     }
     GM_LAUNCH_CHECK();

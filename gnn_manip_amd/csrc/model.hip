@@ -30,7 +30,8 @@ int check_desc(const gm_model_desc* d, const char* who) {
     // the reference's two ctor asserts (epd_gnn.py:26-27)
     GM_REQUIRE(d->num_layers >= 2, GM_ERR_INVALID_ARGUMENT, "The number of layers num_layers must be at least 2");
     GM_REQUIRE(d->m_steps >= 1, GM_ERR_INVALID_ARGUMENT, "The number of m_steps message pasting steps must be at least 1");
-    GM_REQUIRE(d->hidden_size == 128, GM_ERR_UNSUPPORTED, "%s: hidden_size=%d: kernels are instantiated for 128", who, d->hidden_size);
+    GM_REQUIRE(d->hidden_size == 128 || d->hidden_size == 256, GM_ERR_UNSUPPORTED,
+               "%s: hidden_size=%d: kernels are instantiated for 128 and 256", who, d->hidden_size);
     GM_REQUIRE(d->num_layers == 2, GM_ERR_UNSUPPORTED, "%s: num_layers=%d: kernels are instantiated for 2", who, d->num_layers);
     GM_REQUIRE(d->edge_dim >= 1 && d->edge_dim <= 8, GM_ERR_UNSUPPORTED, "%s: edge_dim=%d unsupported (1..8)", who, d->edge_dim);
     GM_REQUIRE(d->node_dim >= 1 && d->node_dim <= 32, GM_ERR_UNSUPPORTED, "%s: node_dim=%d unsupported (1..32)", who, d->node_dim);

@@ -224,6 +224,38 @@ def test_epd_forward_vs_oracle(dev, n, side, seed):
     assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
 
 
+@pytest.mark.parametrize("n,side,seed", [(700, 0.075, 65), (129, 0.2, 66)])
+def test_epd_forward_hidden_256_vs_oracle(dev, n, side, seed):
+    """BASELINE config C4 geometry (hidden=256): one-wave-per-SIMD instantiation of the same kernels."""
+    from gnn_manip_amd import scene
+    obs = scene.make_scene(n, seed=seed, side=side)
+    params = orc.init_params(25, 4, 3, 256, 2, 10, seed)
+    m = _model(params, (25, 4, 3, 256, 2, 10), dev)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    ei = np.stack((s, r))
+    with torch.no_grad():
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+        h0, e0, _ = m.encoder(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+        h1, e1, _ = m.processor[0](h0, e0, _t(ei, dev))
+    ho, eo = orc.graph_independent(params, "encoder", nodes, ea, 2)
+    np.testing.assert_allclose(h0.cpu().numpy(), ho, rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(e0.cpu().numpy(), eo, rtol=1e-5, atol=3e-6)
+    h1o, e1o = orc.interaction_network(params, "processor.0", ho, eo, ei, 2)
+    np.testing.assert_allclose(e1.cpu().numpy(), e1o, rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), h1o, rtol=1e-5, atol=5e-6)
+    ref = orc.epd_forward(params, nodes, ea, ei, 2, 10)
+    assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
+
+
+def test_unsupported_sizes_fail_loudly(dev):
+    from gnn_manip_amd import EncProcDecGNN
+    from gnn_manip_amd._lib import GMError
+    m = EncProcDecGNN(25, 4, 3, 64, 2, 2).to(dev)
+    with pytest.raises(GMError), torch.no_grad():
+        m.forward(torch.zeros(4, 25, device=dev), torch.zeros(4, 4, device=dev),
+                  torch.zeros(2, 4, dtype=torch.long, device=dev))
+
+
 def test_epd_forward_permutation_of_edges_is_immaterial(dev):
     """Property: the result does not depend on the caller's edge order (destination sort + eid indirection),
     and a hub node with in-degree > 128 (a segment spanning whole tiles) aggregates correctly."""
