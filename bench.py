@@ -174,6 +174,15 @@ def main():
                          "issued_flops_per_launch": issued, "alg_flops_per_launch": alg,
                          "alg_tflops": alg / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0},
         }
+        # HBM traffic of the same kernel from rocprofv3 PMC passes (collected separately, committed under profiles/)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if args.workload in tr:
+                out["roofline"]["traffic"] = tr[args.workload]["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per guide)"
+        except (OSError, ValueError, KeyError):
+            pass
+        out["roofline"]["alg_bytes_per_launch"] = edges * hidden * 4 * 2 + n * hidden * 4 * 3 + edges * 12
         per_step = {"node_kernel": (1, 10), "graph_build": (2, 1), "encoder_kernels": (3, 2)}
         br = {"edge_kernel_ms_per_step": k_ms * 10}
         for name, (kind, calls) in per_step.items():

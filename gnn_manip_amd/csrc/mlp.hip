@@ -903,10 +903,279 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) node_kernel(NodeArg
 }
 
 // ------------------------------------------------------------------------------------------
+// NODE kernel, wide form for small graphs.  The form above gives one wave 32 nodes x all H features:
+// 6 layer-units = 1536 dependent-chain MFMAs per wave, ~41 us however few nodes there are, and at
+// N = 5k only 40 workgroups exist for 256 CUs.  Here a 4-wave workgroup owns 32 nodes and wave w
+// computes feature block jb = w of every layer (64 instead of 256 MFMAs per layer); between layers the
+// four blocks are exchanged through LDS ([32 nodes][H] tile) and every wave re-reads the full vector as
+// its next B operand.  Same packed weight stream (every wave reads its jb piece of each k-octet),
+// 4-deep ring so that a whole layer is in flight.  Used when it gives more workgroups than CUs can
+// otherwise be offered (launch_node).
+// ------------------------------------------------------------------------------------------
+constexpr int WTILE = 32;
+constexpr int WRING = 4;
+constexpr int XS = 132;  // LDS row stride of the exchange tile
+
+template <int H>
+struct WideCtx {
+    const float* base;   // packed stream, stage 0
+    float* ring;         // WRING stages
+    int total;           // stages per tile
+    int cur;             // next stage to consume (within the tile sequence)
+    int slot;            // ring slot of `cur`
+    int issued;          // stages issued ahead of `cur` (<= WRING - 1)
+    int lane, wave;
+    bool more_tiles;
+};
+
+template <int H>
+__device__ __forceinline__ void wide_issue(const WideCtx<H>& c, int stage, int slot) {
+#pragma unroll
+    for (int q = 0; q < STAGE_PIECES / 4; ++q) {
+        const int piece = q * 4 + c.wave;
+        const float* g = c.base + (size_t)stage * STAGE_FLOATS + piece * PIECE_FLOATS + c.lane * 4;
+        float* l = c.ring + slot * STAGE_FLOATS + piece * PIECE_FLOATS;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+}
+
+// One Linear for this wave's 32-feature block.  NKQ input octets; NJB_L = output blocks of the LAYER
+// (4 for an HxH layer: wave w takes block w; 1 for the decoder output: wave 0 only).
+// DRAIN: other vector-memory operations may be in flight -> wait for everything at the first stage;
+// otherwise a counted wait leaves the younger DMA stages in flight.
+template <int H, int NKQ, int NJB_L, bool DRAIN>
+__device__ __forceinline__ void wide_layer(floatx16& acc, const floatx16 (&act)[H / 32], WideCtx<H>& c) {
+    constexpr int NP = NKQ * NJB_L;
+    constexpr int NST = (NP + STAGE_PIECES - 1) / STAGE_PIECES;
+    constexpr int KQ_PER_STAGE = STAGE_PIECES / NJB_L;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        // stage `cur` landed?  younger stages (4 DMA instructions each) may stay in flight
+        if (DRAIN && s == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (c.issued >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (c.issued == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        lds_barrier();  // stage `cur` visible to every wave; the slot consumed before it is free
+        const float* buf = c.ring + c.slot * STAGE_FLOATS + c.lane * 4;
+        const bool mine = NJB_L > 1 || c.wave == 0;
+        floatx4 a[KQ_PER_STAGE > 4 ? 4 : KQ_PER_STAGE];
+        // advance the stream state, then top the ring up (`issued` = stages requested and not yet consumed)
+        c.issued--;
+        c.cur++;
+        if (c.cur == c.total) c.cur = 0;
+        c.slot = (c.slot + 1) % WRING;
+        {
+            int st = c.cur + c.issued;
+            const bool wrap = st >= c.total;
+            if (wrap) st -= c.total;
+            // stages past the end of the sequence (and everything requested right after the sequence wrapped)
+            // belong to the workgroup's next tile: request them only if there is one
+            const bool next_tile_stage = wrap || c.cur == 0;
+            if (!next_tile_stage || c.more_tiles) {
+                int ss = st;
+                asm volatile("" : "+s"(ss));
+                wide_issue(c, ss, (c.slot + c.issued) % WRING);
+                c.issued++;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mine) {
+            if (NJB_L > 1) {
+#pragma unroll
+                for (int kl = 0; kl < KQ_PER_STAGE; ++kl) {
+                    const int kq = s * KQ_PER_STAGE + kl;
+                    if (kq < NKQ) a[kl] = *reinterpret_cast<const floatx4*>(buf + (kl * NJB_L + c.wave) * PIECE_FLOATS);
+                }
+#pragma unroll
+                for (int kl = 0; kl < KQ_PER_STAGE; ++kl) {
+                    const int kq = s * KQ_PER_STAGE + kl;
+                    if (kq < NKQ) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kl][t], act[kq >> 2][(kq & 3) * 4 + t], acc, 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kl = 0; kl < KQ_PER_STAGE; ++kl) {
+                    const int kq = s * KQ_PER_STAGE + kl;
+                    if (kq < NKQ) {
+                        const floatx4 av = *reinterpret_cast<const floatx4*>(buf + kl * PIECE_FLOATS);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], act[kq >> 2][(kq & 3) * 4 + t], acc, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// this wave's 16 registers <-> features 32*wave + 8g + 4hi + t of a row
+__device__ __forceinline__ void load_q(floatx16& v, const float* __restrict__ row, int hi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const floatx4 x = *reinterpret_cast<const floatx4*>(row + 8 * g + 4 * hi);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[4 * g + t] = x[t];
+    }
+}
+__device__ __forceinline__ void store_q(const floatx16& v, float* __restrict__ row, int hi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        floatx4 x;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = v[4 * g + t];
+        *reinterpret_cast<floatx4*>(row + 8 * g + 4 * hi) = x;
+    }
+}
+
+// exchange: every wave publishes its block (optionally through ReLU), then reads the full vector
+template <int H, bool RELU>
+__device__ __forceinline__ void wide_exchange(const floatx16& acc, floatx16 (&act)[H / 32], float* X, int n, int hi, int wave) {
+    floatx16 v = acc;
+    if (RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    store_q(v, X + n * XS + 32 * wave, hi);
+    lds_barrier();
+    load_feat(act, X + n * XS, hi);
+    // the tile is rewritten only after the next layer's stage barriers (all reads above are waited by then)
+}
+
+template <int H, int NL, int MODE>
+__global__ void __launch_bounds__(THREADS, 2) node_kernel_wide(NodeArgs A) {
+    constexpr int NJB = H / 32;
+    static_assert(NJB == 4, "wide node kernel: one feature block per wave of a 4-wave workgroup");
+    constexpr int SL = (H / 8) * NJB / STAGE_PIECES;
+    constexpr int S_IN = (4 * NJB + STAGE_PIECES - 1) / STAGE_PIECES;
+    constexpr int S_OUT = (H / 8 + STAGE_PIECES - 1) / STAGE_PIECES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ring = reinterpret_cast<float*>(smem);
+    float* X = ring + WRING * STAGE_FLOATS;
+    float* vecs = X + WTILE * XS;  // [NL+1 biases | gamma | beta | proj_bias | dec biases NL x H + 32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
+    const int N = A.n_nodes;
+    const int ntiles = (N + WTILE - 1) / WTILE;
+
+    float* lbias = vecs;
+    float* lgamma = lbias + (NL + 1) * H;
+    float* lbeta = lgamma + H;
+    float* lproj = lbeta + H;
+    float* ldec = lproj + H;
+    if (MODE != 2) {
+        for (int i = tid; i < (NL + 1) * H; i += THREADS) lbias[i] = A.bias[i];
+        for (int i = tid; i < H; i += THREADS) { lgamma[i] = A.ln_g[i]; lbeta[i] = A.ln_b[i]; }
+    }
+    if (A.tail == 1) for (int i = tid; i < H; i += THREADS) lproj[i] = A.proj_bias[i];
+    if (A.tail == 2) for (int i = tid; i < NL * H + 32; i += THREADS) ldec[i] = A.dec_bias[i];
+
+    WideCtx<H> c;
+    c.base = A.wstream;
+    c.ring = ring;
+    const int mlp_stages = MODE == 0 ? (S_IN + NL * SL) : (MODE == 1 ? (NL + 2) * SL : 0);
+    const int tail_stages = A.tail == 1 ? 2 * SL : (A.tail == 2 ? NL * SL + S_OUT : 0);
+    c.total = mlp_stages + tail_stages;
+    c.cur = 0;
+    c.slot = 0;
+    c.issued = 0;
+    c.lane = lane;
+    c.wave = wave;
+    c.more_tiles = true;
+    if ((int)blockIdx.x < ntiles) {
+        for (int st = 0; st < WRING - 1 && st < c.total; ++st) {
+            wide_issue(c, st, st);
+            c.issued++;
+        }
+    }
+    // `issued` counts stages requested but not yet consumed, including `cur` itself
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        c.more_tiles = tile + (int)gridDim.x < ntiles;
+        const int p = tile * WTILE + n;
+        const bool valid = p < N;
+        const int64_t pc = valid ? p : N - 1;
+        floatx16 act[NJB];
+        floatx16 acc;
+        if (MODE == 0) {
+            load_feat_guard(act, A.x_in + pc * A.k1, hi, A.k1);
+            load_q(acc, lbias + 32 * wave, hi);
+            wide_layer<H, 4, NJB, true>(acc, act, c);
+        } else if (MODE == 1) {
+            load_feat(act, A.x_in + pc * H, hi);
+            load_q(acc, lbias + 32 * wave, hi);
+            wide_layer<H, H / 8, NJB, true>(acc, act, c);
+            load_feat(act, A.agg + pc * H, hi);
+            if (A.agg_clear && valid) {  // each wave clears its own block of the row
+                floatx16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                store_q(z, A.agg_clear + pc * H + 32 * wave, hi);
+            }
+            wide_layer<H, H / 8, NJB, true>(acc, act, c);
+        }
+        if (MODE != 2) {
+#pragma unroll
+            for (int l = 1; l <= NL; ++l) {
+                wide_exchange<H, true>(acc, act, X, n, hi, wave);
+                load_q(acc, lbias + l * H + 32 * wave, hi);
+                wide_layer<H, H / 8, NJB, false>(acc, act, c);
+            }
+            wide_exchange<H, false>(acc, act, X, n, hi, wave);   // act = full pre-LayerNorm vector (in every wave)
+            layer_norm_regs(act, lgamma, lbeta, A.eps, hi);
+            if (MODE == 1 && A.residual) add_feat(act, A.x_in + pc * H, hi);
+            if (valid) {  // each wave stores its own block of h'
+                float* row = A.h_out + pc * H + 32 * wave;
+                if (wave == 0) store_q(act[0], row, hi);
+                else if (wave == 1) store_q(act[1], row, hi);
+                else if (wave == 2) store_q(act[2], row, hi);
+                else store_q(act[3], row, hi);
+            }
+        } else {
+            load_feat(act, A.x_in + pc * H, hi);
+        }
+        if (A.tail == 1) {
+            load_q(acc, lproj + 32 * wave, hi);
+            wide_layer<H, H / 8, NJB, true>(acc, act, c);
+            if (valid) store_q(acc, A.P_out + pc * (2 * H) + 32 * wave, hi);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            wide_layer<H, H / 8, NJB, true>(acc, act, c);
+            if (valid) store_q(acc, A.P_out + pc * (2 * H) + H + 32 * wave, hi);
+        } else if (A.tail == 2) {
+            load_q(acc, ldec + 32 * wave, hi);
+            wide_layer<H, H / 8, NJB, true>(acc, act, c);
+#pragma unroll
+            for (int l = 1; l < NL; ++l) {
+                wide_exchange<H, true>(acc, act, X, n, hi, wave);
+                load_q(acc, ldec + l * H + 32 * wave, hi);
+                wide_layer<H, H / 8, NJB, false>(acc, act, c);
+            }
+            wide_exchange<H, true>(acc, act, X, n, hi, wave);
+            load_q(acc, ldec + NL * H, hi);  // out bias, zero-padded to 32 (only wave 0's result is used)
+            wide_layer<H, H / 8, 1, false>(acc, act, c);
+            if (valid && hi == 0 && wave == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < A.out_dim) A.dec_out[pc * A.out_dim + q] = acc[q];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 size_t edge_lds_bytes() { return (size_t)(2 * STAGE_FLOATS + TILE * TS + 2 * (TILE + 4) + 2 * 2 * 4 * 64 + 8 * 128) * 4; }
 size_t node_lds_bytes() { return (size_t)(2 * STAGE_FLOATS) * 4; }
+size_t node_wide_lds_bytes() { return (size_t)(WRING * STAGE_FLOATS + WTILE * XS + 12 * 128 + 64) * 4; }
 
 static int grid_for(int64_t tiles) {
     if (tiles < 1) tiles = 1;
@@ -992,7 +1261,26 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
                "node kernel: hidden_size=%d num_layers=%d not instantiated (128 or 256, 2)", H, NL);
     const int grid = grid_for(cdiv(a.n_nodes, TILE));
     const size_t lds = node_lds_bytes();
-    {
+    static const int wide_env = getenv("GM_NODE_WIDE") ? atoi(getenv("GM_NODE_WIDE")) : -1;
+    const bool wide = H == 128 && (wide_env == 1 || (wide_env != 0 && cdiv(a.n_nodes, TILE) <= 64));
+    if (wide) {
+        const size_t wl = node_wide_lds_bytes();
+        static bool attr_done = false;
+        if (!attr_done) {
+            int rc = set_lds(node_kernel_wide<128, 2, 0>, wl);
+            if (rc == GM_OK) rc = set_lds(node_kernel_wide<128, 2, 1>, wl);
+            if (rc == GM_OK) rc = set_lds(node_kernel_wide<128, 2, 2>, wl);
+            if (rc != GM_OK) return rc;
+            attr_done = true;
+        }
+        const int wg = grid_for(cdiv(a.n_nodes, WTILE));
+        ProfScope prof(mode == 1 ? PROF_NODE : PROF_ENC, s);
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((node_kernel_wide<128, 2, 0>), dim3(wg), dim3(THREADS), wl, s, a); break;
+            case 1: hipLaunchKernelGGL((node_kernel_wide<128, 2, 1>), dim3(wg), dim3(THREADS), wl, s, a); break;
+            default: hipLaunchKernelGGL((node_kernel_wide<128, 2, 2>), dim3(wg), dim3(THREADS), wl, s, a); break;
+        }
+    } else {
         ProfScope prof(mode == 1 ? PROF_NODE : PROF_ENC, s);
         if (H == 128) {
             switch (mode) {
