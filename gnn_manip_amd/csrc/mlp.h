@@ -15,7 +15,8 @@ struct EdgeArgs {
     const float* e_in;     // processor: [E][H]; encoder: raw edge_attr [E][k1]
     float* e_out;          // [E][H]
     float* agg;            // [N][H] pre-zeroed, or nullptr
-    const float* wstream;  // packed weights, stage 0
+    const float* wstream;  // packed weights (32x32x2 operand image), stage 0
+    const float* wstream16;  // same layers in the 16x16x4 operand image, or nullptr
     const float* bias;     // processor: biases of layers 2..; encoder: biases of layers 1..
     const float* ln_g;
     const float* ln_b;
@@ -48,6 +49,8 @@ struct NodeArgs {
 };
 
 int layer_stages(int k, int out);
+int layer_stages16(int k, int out);
+int pack_linear16(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s);
 int pack_linear(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s);
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);

@@ -67,6 +67,41 @@ __global__ void __launch_bounds__(256) pack_linear_kernel(const float* __restric
     dst[idx] = v;
 }
 
+// 16x16x4 operand image: piece(kq, jb)[lane = (i = lane & 15, g = lane >> 4)][r] = W[16 jb + i][16 kq + 4 g + r]
+__global__ void __launch_bounds__(256) pack_linear16_kernel(const float* __restrict__ W, int out_rows, int ld, int col0,
+                                                             int kvalid, int nkq, int njb, int stages,
+                                                             float* __restrict__ dst) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)stages * STAGE_FLOATS;
+    if (idx >= total) return;
+    const int p = (int)(idx / PIECE_FLOATS);
+    const int within = (int)(idx % PIECE_FLOATS);
+    const int lane = within >> 2, r = within & 3;
+    const int i = lane & 15, g = lane >> 4;
+    float v = 0.f;
+    if (p < nkq * njb) {
+        const int kq = p / njb, jb = p % njb;
+        const int row = 16 * jb + i, col = 16 * kq + 4 * g + r;
+        if (row < out_rows && col < kvalid) v = W[(int64_t)row * ld + col0 + col];
+    }
+    dst[idx] = v;
+}
+
+int layer_stages16(int k, int out) {
+    const int nkq = (k + 15) / 16, njb = (out + 15) / 16;
+    return (nkq * njb + STAGE_PIECES - 1) / STAGE_PIECES;
+}
+
+int pack_linear16(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s) {
+    const int nkq = (kvalid + 15) / 16, njb = (out_rows + 15) / 16;
+    const int stages = layer_stages16(kvalid, out_rows);
+    const int64_t total = (int64_t)stages * STAGE_FLOATS;
+    hipLaunchKernelGGL(pack_linear16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, W, out_rows, ld, col0,
+                       kvalid, nkq, njb, stages, dst);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
 int layer_stages(int k, int out) {
     const int nkq = (k + 7) / 8, njb = (out + 31) / 32;
     return (nkq * njb + STAGE_PIECES - 1) / STAGE_PIECES;
@@ -294,11 +329,11 @@ __device__ __forceinline__ void mlp_tail_layers(floatx16 (&acc)[H / 32], floatx1
 // other code reads.  Never enabled in a timed run.
 #define GM_STAMP_T(tile_, k)                                                                      \
     do {                                                                                          \
-        if (A.stamps && gt0 == 0) A.stamps[(size_t)(tile_) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (A.stamps && gt0 == 0) A.stamps[(size_t)(tile_) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #define GM_STAMP(k)                                                                          \
     do {                                                                                     \
-        if (A.stamps && tid == 0) A.stamps[(size_t)tile * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (A.stamps && tid == 0) A.stamps[(size_t)tile * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 // MODE 0: encoder phi_e on raw edge attributes; 1: processor phi_e with the residual e <- e' + e
@@ -377,9 +412,9 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArg
         const int tid = tid_t, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
         GM_STAMP(0);
         if (A.stamps && tid == 0) {
-            A.stamps[(size_t)tile * 8 + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32) |
+            A.stamps[(size_t)tile * 16 + 14] = ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32) |
                                              __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_ID, XCC_ID
-            A.stamps[(size_t)tile * 8 + 7] = blockIdx.x;
+            A.stamps[(size_t)tile * 16 + 15] = blockIdx.x;
         }
         int* sd = sdst + tpar * (TILE + 4);
         if (!ENC && tid < TILE + 2) sd[tid] = ix.sd;  // ordered before its readers by the stage barriers
@@ -658,9 +693,9 @@ __global__ void __launch_bounds__(2 * THREADS, 2) edge_kernel_alt(EdgeArgs A) {
                 const int hi = lane0 >> 5;
                 GM_STAMP_T(tile, 0);
                 if (A.stamps && gt0 == 0) {
-                    A.stamps[(size_t)tile * 8 + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32) |
+                    A.stamps[(size_t)tile * 16 + 14] = ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32) |
                                                      __builtin_amdgcn_s_getreg((3 << 11) | 20);
-                    A.stamps[(size_t)tile * 8 + 7] = blockIdx.x;
+                    A.stamps[(size_t)tile * 16 + 15] = blockIdx.x;
                 }
                 if (ENC) {
                     load_feat(acc, lbias, hi);
@@ -796,6 +831,382 @@ __global__ void __launch_bounds__(2 * THREADS, 2) edge_kernel_alt(EdgeArgs A) {
             // this group did not consume the ring: keep its view of the stream in step with the M group
             ws.parity ^= (TOTAL & 1);
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// EDGE kernel on v_mfma_f32_16x16x4_f32 (the form production launches for H = 128).
+//
+// Why a second formulation: the 32x32x2 form above holds 32 edges x 128 features per wave (64 + 64
+// registers of state), which leaves no room to prefetch, and the measured cost of that is large --
+// the two workgroups of a CU run in phase, so their gather / epilogue phases (bound by the CU's own
+// ~24 GB/s memory path) serialise with their MFMA phases instead of hiding under them
+// (tools/stamps.py).  16x16x4 runs at the same FLOP rate with HALF the state per wave (16 edges:
+// 32 + 32 registers), and the same register-chaining trick holds:
+//     D block jb, lane (n = lane & 15, g = lane >> 4), register r  <->  feature 16 jb + 4 g + r
+// is exactly the k this lane must supply as B operand in step r of k-block jb of the next layer.
+// The freed registers hold (a) the tile's input rows e for the residual (no re-read), and (b) the
+// NEXT tile's gathered operands, requested two loads per weight stage so that every wait in the MFMA
+// phase finds its loads one stage old: the memory phase runs under the matrix pipe.
+// ------------------------------------------------------------------------------------------
+constexpr int T16 = 64;   // edges per workgroup tile (4 waves x 16)
+constexpr int TS16 = 132; // LDS row stride (floats) of the H-wide staging tile
+constexpr int NB16 = 8;   // 16-feature blocks in H = 128
+
+template <int NB>
+__device__ __forceinline__ void load_feat16(floatx4 (&v)[NB], const float* __restrict__ row, int g) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) v[kb] = *reinterpret_cast<const floatx4*>(row + 16 * kb + 4 * g);
+}
+
+// one weight stage (16 pieces) of an H x H layer: pieces [kq = 2 st + (0,1)][jb = 0..7]
+template <int NKQ, int NJB>
+__device__ __forceinline__ void stage16(floatx4 (&acc)[NJB], const floatx4 (&act)[NB16], const float* buf, int st) {
+    constexpr int KQ_PER_STAGE = STAGE_PIECES / NJB;  // 2 for an H x H layer
+    constexpr int NG = STAGE_PIECES / 2;              // groups of 2 pieces (two independent accumulators)
+    floatx4 a_cur[2], a_nxt[2];
+    a_cur[0] = *reinterpret_cast<const floatx4*>(buf);
+    a_cur[1] = *reinterpret_cast<const floatx4*>(buf + PIECE_FLOATS);
+#pragma unroll
+    for (int gidx = 0; gidx < NG; ++gidx) {
+        if (gidx + 1 < NG) {
+            a_nxt[0] = *reinterpret_cast<const floatx4*>(buf + (2 * gidx + 2) * PIECE_FLOATS);
+            a_nxt[1] = *reinterpret_cast<const floatx4*>(buf + (2 * gidx + 3) * PIECE_FLOATS);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int p = 2 * gidx + q;
+                const int kq = st * KQ_PER_STAGE + p / NJB, jb = p % NJB;
+                if (kq < NKQ) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[q][r], act[kq][r], acc[jb], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur[0] = a_nxt[0];
+        a_cur[1] = a_nxt[1];
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void layer_norm16(floatx4 (&acc)[NB], const float* lgamma, const float* lbeta, float eps, int g) {
+    constexpr float INV_H = 1.0f / (16 * NB);
+    float s = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[jb][r];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * INV_H;
+    float q = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = acc[jb][r] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * INV_H + eps);
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+        const floatx4 gm = *reinterpret_cast<const floatx4*>(lgamma + 16 * jb + 4 * g);
+        const floatx4 bt = *reinterpret_cast<const floatx4*>(lbeta + 16 * jb + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jb][r] = (acc[jb][r] - mean) * rstd * gm[r] + bt[r];
+    }
+}
+
+template <int NL, int MODE>
+__global__ void __launch_bounds__(THREADS, 2) edge_kernel16(EdgeArgs A) {
+    constexpr int H = 128;
+    constexpr bool ENC = MODE == 0;
+    constexpr bool with_resid = MODE == 1;
+    constexpr int NB = NB16;
+    constexpr int SL = 4;                                   // stages of an H x H layer (64 pieces)
+    constexpr int TOTAL = ENC ? 1 + NL * SL : (NL + 1) * SL;
+    constexpr int NBIAS = ENC ? NL + 1 : NL;
+    constexpr int NCH = H / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ring = reinterpret_cast<float*>(smem);
+    float* T = ring + 2 * STAGE_FLOATS;                                // [T16][TS16]
+    int* sdst = reinterpret_cast<int*>(T + T16 * TS16);                // 2 x [T16 + 4]: per tile parity
+    float* headv = reinterpret_cast<float*>(sdst + 2 * (T16 + 4));    // 2 tile parities x 2 halves x (head[4][64] | tail[4][64])
+    float* vecs = headv + 2 * 1024;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int E = A.hdr ? A.hdr->n_edges : A.n_edges_host;
+    const int ntiles = (E + T16 - 1) / T16;
+    if ((int)blockIdx.x >= ntiles) return;
+
+    WStream ws;
+    ws.base = A.wstream;
+    ws.ring = ring;
+    ws.total = TOTAL;
+    ws.cur = 0;
+    ws.parity = 0;
+    ws.lane = lane;
+    ws.wave = wave;
+    issue_stage(ws, 0, 0);
+    for (int i = tid; i < NBIAS * H; i += THREADS) vecs[i] = A.bias[i];
+    for (int i = tid; i < H; i += THREADS) {
+        vecs[NBIAS * H + i] = A.ln_g[i];
+        vecs[(NBIAS + 1) * H + i] = A.ln_b[i];
+    }
+    const float* lbias = vecs;
+    const float* lgamma = vecs + NBIAS * H;
+    const float* lbeta = lgamma + H;
+
+    struct TileIdx { int er, d, sr, dq, sd; };
+    auto fetch_idx = [&](int tile) {
+        TileIdx ix;
+        const int p0 = tile * T16;
+        const int p = p0 + wave * 16 + n;
+        const int pc = p < E ? p : E - 1;
+        ix.er = A.eid ? A.eid[pc] : pc;
+        ix.d = ix.sr = 0;
+        ix.dq = ix.sd = -1;
+        if (!ENC) {
+            ix.d = A.dst[pc];
+            ix.sr = A.src[pc];
+            if (tid < T16 + 2) {
+                const int pp = p0 - 1 + tid;
+                ix.sd = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+            }
+            if (lane < 18) {  // lane l: destination of row (16*wave - 1 + l) of the tile; -2 before edge 0, -1 past E
+                const int pp = p0 + 16 * wave - 1 + lane;
+                ix.dq = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+            }
+        }
+        return ix;
+    };
+
+    floatx4 acc[NB], act[NB], ekeep[NB], nacc[NB], nact[NB];
+    // ---- first tile: operands requested directly
+    TileIdx ix = fetch_idx(blockIdx.x);
+    if (ENC) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * kb + 4 * g + r;
+                nact[kb][r] = f < A.k1 ? A.e_in[(int64_t)ix.er * A.k1 + f] : 0.f;
+            }
+    } else {
+        load_feat16(nact, A.e_in + (int64_t)ix.er * H, g);
+        load_feat16(nacc, A.P + (int64_t)ix.d * (2 * H), g);
+        floatx4 pj[NB];
+        load_feat16(pj, A.P + (int64_t)ix.sr * (2 * H) + H, g);
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) nacc[kb] += pj[kb];
+    }
+    TileIdx nx = ix;
+    if ((int)(blockIdx.x + gridDim.x) < ntiles) nx = fetch_idx(blockIdx.x + gridDim.x);
+    __syncthreads();  // vecs visible
+    int tpar = 0;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
+        const int p0 = tile * T16;
+        // operands of this tile arrive from the prefetch registers; its indices from `ix`
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            act[kb] = nact[kb];
+            if (with_resid) ekeep[kb] = nact[kb];
+        }
+        if (ENC) {
+            load_feat16(acc, lbias, g);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) acc[kb] = nacc[kb];
+        }
+        int* sd = sdst + tpar * (T16 + 4);
+        if (!ENC && tid < T16 + 2) sd[tid] = ix.sd;  // ordered before its readers by the stage barriers
+        const int dq = ix.dq;
+        const int er_cur = ix.er;
+        const TileIdx jx = nx;                        // indices of the NEXT tile (loaded one tile ago)
+        if (more_tiles && tile + 2 * (int)gridDim.x < ntiles) nx = fetch_idx(tile + 2 * gridDim.x);
+        floatx4 pj0, pj1;                             // rotating temporaries for the P_j rows of the next tile
+        GM_STAMP(0);
+        if (A.stamps && tid == 0) {
+            A.stamps[(size_t)tile * 16 + 14] = ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32) |
+                                             __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            A.stamps[(size_t)tile * 16 + 15] = blockIdx.x;
+        }
+        prio_mfma_phase();
+        // ---- the MLP: TOTAL weight stages; stage s also requests loads 2s, 2s+1 of the next tile
+#pragma unroll
+        for (int s = 0; s < TOTAL; ++s) {
+            constexpr int L1S = ENC ? 1 : SL;                       // stages of layer 1
+            const int layer = s < L1S ? 0 : 1 + (s - L1S) / SL;     // compile-time after unrolling
+            const int st_in_layer = s < L1S ? s : (s - L1S) % SL;
+            if (s >= L1S && st_in_layer == 0) {                     // layer boundary: ReLU -> B operand, bias -> accumulator
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) act[kb][r] = fmaxf(acc[kb][r], 0.f);
+                load_feat16(acc, lbias + (ENC ? layer : layer - 1) * H, g);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            {
+                int nxt = ws.cur + 1;
+                const bool wrap = nxt == ws.total;
+                if (wrap) nxt = 0;
+                int stl = nxt;
+                asm volatile("" : "+s"(stl));
+                if (!wrap || more_tiles) issue_stage(ws, stl, ws.parity ^ 1);
+            }
+            // drip-fed prefetch of the next tile's operands (previous stage's loads have landed: the wait above)
+            if (!ENC && more_tiles) {
+                if (s < 4) {
+                    nact[2 * s] = *reinterpret_cast<const floatx4*>(A.e_in + (int64_t)jx.er * H + 16 * (2 * s) + 4 * g);
+                    nact[2 * s + 1] = *reinterpret_cast<const floatx4*>(A.e_in + (int64_t)jx.er * H + 16 * (2 * s + 1) + 4 * g);
+                } else if (s < 8) {
+                    const int kb = 2 * (s - 4);
+                    nacc[kb] = *reinterpret_cast<const floatx4*>(A.P + (int64_t)jx.d * (2 * H) + 16 * kb + 4 * g);
+                    nacc[kb + 1] = *reinterpret_cast<const floatx4*>(A.P + (int64_t)jx.d * (2 * H) + 16 * (kb + 1) + 4 * g);
+                } else if (s < 12) {
+                    const int kb = 2 * (s - 8);
+                    if (s > 8) {
+                        nacc[kb - 2] += pj0;
+                        nacc[kb - 1] += pj1;
+                    }
+                    pj0 = *reinterpret_cast<const floatx4*>(A.P + (int64_t)jx.sr * (2 * H) + H + 16 * kb + 4 * g);
+                    pj1 = *reinterpret_cast<const floatx4*>(A.P + (int64_t)jx.sr * (2 * H) + H + 16 * (kb + 1) + 4 * g);
+                }
+            }
+            if (ENC && more_tiles && s == 0) {
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 16 * kb + 4 * g + r;
+                        nact[kb][r] = f < A.k1 ? A.e_in[(int64_t)jx.er * A.k1 + f] : 0.f;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* buf = ws.ring + ws.parity * STAGE_FLOATS + lane * 4;
+            if (ENC && s == 0) stage16<1, NB>(acc, act, buf, 0);
+            else stage16<H / 16, NB>(acc, act, buf, st_in_layer);
+            ws.cur = ws.cur + 1 == ws.total ? 0 : ws.cur + 1;
+            ws.parity ^= 1;
+            if (s == L1S - 1) GM_STAMP(1);
+        }
+        GM_STAMP(2);
+        __builtin_amdgcn_sched_barrier(0);
+        prio_latency_phase();
+        layer_norm16(acc, lgamma, lbeta, A.eps, g);
+        GM_STAMP(3);
+
+        // ---- e_out = e' (+ e) straight from the registers: 64 contiguous bytes per row and instruction
+        const int p = p0 + wave * 16 + n;
+        const bool valid = p < E;
+        const int64_t out_row = !valid ? 0 : (!A.eid_out ? (int64_t)p : (A.eid_out == A.eid ? (int64_t)er_cur : (int64_t)A.eid_out[p]));
+        if (valid) {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+                floatx4 x = acc[kb];
+                if (with_resid) x += ekeep[kb];
+                *reinterpret_cast<floatx4*>(A.e_out + out_row * H + 16 * kb + 4 * g) = x;
+            }
+        }
+        GM_STAMP(4);
+        // ---- scatter-add.  e' (all H features of the 64 rows) is staged in LDS once; wave q sums the
+        // destination segments inside its rows 16q..16q+15 (lane = column, two passes of 64 columns);
+        // segments that cross a wave's rows or the tile are stitched from the per-wave head / tail
+        // partials by wave 0 (columns 0..63) and wave 1 (columns 64..127) with scalar control flow.
+        // Two LDS-only barriers per tile; the stitch is off the other waves' critical path.
+        if (!ENC) {
+            float* part = headv + tpar * 1024;  // [2 halves][head 4x64 | tail 4x64], double-buffered per tile
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+                *reinterpret_cast<floatx4*>(T + (wave * 16 + n) * TS16 + 16 * kb + 4 * g) = acc[kb];
+            lds_barrier();
+            GM_STAMP(5);
+            {   // one pass: lane owns columns 2*lane, 2*lane+1 (the scalar segment logic runs once per row)
+                typedef float floatx2 __attribute__((ext_vector_type(2)));
+                float* hv = part;         // head[4][128]
+                float* tl = part + 512;   // tail[4][128]
+                const int r0 = 16 * wave;
+                floatx2 tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tv[r] = *reinterpret_cast<const floatx2*>(T + (r0 + r) * TS16 + 2 * lane);
+                floatx2 run = {0.f, 0.f};
+                int d = __builtin_amdgcn_readlane(dq, 1);
+                bool first = d >= 0 && __builtin_amdgcn_readlane(dq, 0) == d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dn = __builtin_amdgcn_readlane(dq, r + 2);
+                    if (d >= 0) run += tv[r];
+                    if (dn != d && d >= 0) {
+                        if (first) *reinterpret_cast<floatx2*>(hv + wave * 128 + 2 * lane) = run;
+                        else *reinterpret_cast<floatx2*>(A.agg + (int64_t)d * H + 2 * lane) = run;
+                        run = floatx2{0.f, 0.f};
+                        first = false;
+                    }
+                    d = dn;
+                }
+                const int dl = __builtin_amdgcn_readlane(dq, 16);
+                if (dl >= 0 && __builtin_amdgcn_readlane(dq, 17) == dl) *reinterpret_cast<floatx2*>(tl + wave * 128 + 2 * lane) = run;
+            }
+            lds_barrier();  // partials visible; staging tile free for the next tile
+            GM_STAMP(6);
+            if (wave < NCH) {
+                const int fh = wave;
+                const float* hv = part + 64 * fh;        // head[q][128], this wave's 64 columns
+                const float* tl = part + 512 + 64 * fh;
+                // boundary destinations of the four 16-row quarters, fetched once and read back as scalars:
+                // lane 4q + j holds sd[16q + {0, 1, 16, 17}[j]]  (row 16q-1, 16q, 16q+15, 16q+16 of the tile)
+                const int bl = lane & 15;
+                const int bv = sd[16 * (bl >> 2) + ((bl & 3) < 2 ? (bl & 3) : 14 + (bl & 3))];
+                float hq[4], tq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    hq[q] = hv[q * 128 + lane];
+                    tq[q] = tl[q * 128 + lane];
+                }
+                float carry = 0.f;
+                bool ext = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int dprev = __builtin_amdgcn_readlane(bv, 4 * q);
+                    const int df = __builtin_amdgcn_readlane(bv, 4 * q + 1);
+                    const int dlast = __builtin_amdgcn_readlane(bv, 4 * q + 2);
+                    const int dnext = __builtin_amdgcn_readlane(bv, 4 * q + 3);
+                    const bool cont_in = df >= 0 && dprev == df;
+                    const bool through = cont_in && dlast == df && dnext == df;
+                    if (cont_in) {
+                        if (q == 0) { carry = 0.f; ext = true; }
+                        if (through) {
+                            carry += tq[q];
+                        } else {
+                            const float tot = carry + hq[q];
+                            float* dstp = A.agg + (int64_t)df * H + 64 * fh + lane;
+                            if (ext) atomicAdd(dstp, tot); else *dstp = tot;
+                            carry = 0.f;
+                            ext = false;
+                        }
+                    }
+                    if (!through && dlast >= 0 && dnext == dlast) { carry = tq[q]; ext = false; }
+                    if (q == 3 && dlast >= 0 && dnext == dlast)  // open at the tile end: the rest is in the next tile
+                        atomicAdd(A.agg + (int64_t)dlast * H + 64 * fh + lane, carry);
+                }
+            }
+        }
+        GM_STAMP(7);
+        GM_STAMP(8); GM_STAMP(9); GM_STAMP(10); GM_STAMP(11);
+        // last P_j pair of the next tile
+        if (!ENC && more_tiles) {
+            nacc[NB - 2] += pj0;
+            nacc[NB - 1] += pj1;
+        }
+        ix = jx;
+        tpar ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1174,6 +1585,7 @@ __global__ void __launch_bounds__(THREADS, 2) node_kernel_wide(NodeArgs A) {
 // launchers
 // ------------------------------------------------------------------------------------------
 size_t edge_lds_bytes() { return (size_t)(2 * STAGE_FLOATS + TILE * TS + 2 * (TILE + 4) + 2 * 2 * 4 * 64 + 8 * 128) * 4; }
+size_t edge16_lds_bytes() { return (size_t)(2 * STAGE_FLOATS + T16 * TS16 + 2 * (T16 + 4) + 2 * 1024 + 6 * 128) * 4; }
 size_t node_lds_bytes() { return (size_t)(2 * STAGE_FLOATS) * 4; }
 size_t node_wide_lds_bytes() { return (size_t)(WRING * STAGE_FLOATS + WTILE * XS + 12 * 128 + 64) * 4; }
 
@@ -1222,6 +1634,28 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     if (H == 256) {
         int rc = launch_edge_h<256>(enc, a, grid, lds, s);
         if (rc != GM_OK) return rc;
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
+    static const bool use16 = !(getenv("GM_EDGE_KERNEL") && strcmp(getenv("GM_EDGE_KERNEL"), "16"));
+    if (H == 128 && use16 && a.wstream16) {
+        const size_t l16 = edge16_lds_bytes();
+        static bool done16 = false;
+        if (!done16) {
+            int rc = set_lds(edge_kernel16<2, 0>, l16);
+            if (rc == GM_OK) rc = set_lds(edge_kernel16<2, 1>, l16);
+            if (rc == GM_OK) rc = set_lds(edge_kernel16<2, 2>, l16);
+            if (rc != GM_OK) return rc;
+            done16 = true;
+        }
+        a.wstream = a.wstream16;
+        const int g16 = grid_for(cdiv(edge_capacity, T16));
+        {
+            ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
+            if (enc) hipLaunchKernelGGL((edge_kernel16<2, 0>), dim3(g16), dim3(THREADS), l16, s, a);
+            else if (a.residual) hipLaunchKernelGGL((edge_kernel16<2, 1>), dim3(g16), dim3(THREADS), l16, s, a);
+            else hipLaunchKernelGGL((edge_kernel16<2, 2>), dim3(g16), dim3(THREADS), l16, s, a);
+        }
         GM_LAUNCH_CHECK();
         return GM_OK;
     }

@@ -10,6 +10,9 @@ struct gm_model {
     gm_model_desc d;
     int H, NL, M;
     float* packed = nullptr;  // operand image of every Linear, stage-aligned streams
+    float* packed16 = nullptr;  // 16x16x4 operand image of the edge MLPs (hidden 128)
+    size_t packed16_floats = 0, s16_enc_edge = 0;
+    std::vector<size_t> s16_edge;
     float* vec = nullptr;     // per-MLP contiguous [bias_0..bias_NL, ln_gamma, ln_beta]
     size_t packed_floats = 0, vec_floats = 0;
     // stream offsets (floats) into packed
@@ -130,6 +133,24 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
             pack(b_dec + 2 * NL, m->d.out_dim, H, 0, H, off);
         }
     }
+    if (m->packed16) {  // 16x16x4 image of the edge MLPs
+        auto pack16 = [&](int ti, int out_rows, int ld, int col0, int k, size_t& o16) {
+            if (rc != GM_OK) return;
+            const float* W = weight(ti, (size_t)out_rows * ld);
+            if (rc != GM_OK) return;
+            rc = pack_linear16(W, out_rows, ld, col0, k, m->packed16 + o16, s);
+            o16 += (size_t)layer_stages16(k, out_rows) * kStageFloats;
+            if (!on_device && rc == GM_OK && hipStreamSynchronize(s) != hipSuccess) rc = GM_ERR_HIP;
+        };
+        size_t o16 = m->s16_enc_edge;
+        pack16(b_enc_edge, H, m->d.edge_dim, 0, m->d.edge_dim, o16);
+        for (int l = 1; l <= NL; ++l) pack16(b_enc_edge + 2 * l, H, H, 0, H, o16);
+        for (int k = 0; k < M; ++k) {
+            o16 = m->s16_edge[k];
+            pack16(b_edge(k), H, 3 * H, 2 * H, H, o16);
+            for (int l = 1; l <= NL; ++l) pack16(b_edge(k) + 2 * l, H, H, 0, H, o16);
+        }
+    }
     vecs(b_enc_edge, true, m->v_enc_edge);
     vecs(b_enc_node, true, m->v_enc_node);
     for (int k = 0; k < M; ++k) {
@@ -187,6 +208,22 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
     }
     m->v_dec = v; v += (size_t)NL * H + 32;
     m->vec_floats = v;
+    if (H == 128 && desc->edge_dim <= 16) {
+        size_t st16 = 0;
+        m->s16_enc_edge = 0;
+        st16 += layer_stages16(desc->edge_dim, H) + NL * layer_stages16(H, H);
+        m->s16_edge.resize(M);
+        for (int k = 0; k < M; ++k) {
+            m->s16_edge[k] = st16 * kStageFloats;
+            st16 += (NL + 1) * layer_stages16(H, H);
+        }
+        m->packed16_floats = st16 * kStageFloats;
+        if (hipMalloc(&m->packed16, m->packed16_floats * sizeof(float)) != hipSuccess) {
+            gm::set_error("gm_model_create: hipMalloc failed");
+            gm_model_destroy(m);
+            return GM_ERR_HIP;
+        }
+    }
     if (hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess ||
         hipMalloc(&m->vec, m->vec_floats * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
@@ -210,6 +247,7 @@ int gm_model_update(gm_model* m, const float* const* tensors, int n_tensors, int
 void gm_model_destroy(gm_model* m) {
     if (!m) return;
     if (m->packed) hipFree(m->packed);
+    if (m->packed16) hipFree(m->packed16);
     if (m->vec) hipFree(m->vec);
     delete m;
 }
@@ -228,6 +266,7 @@ EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid
     a.hdr = hdr; a.n_edges_host = e_host; a.eid = eid;
     a.e_in = edge_attr; a.e_out = e_out; a.k1 = m->d.edge_dim;
     a.wstream = m->packed + m->s_enc_edge;
+    a.wstream16 = m->packed16 ? m->packed16 + m->s16_enc_edge : nullptr;
     const float* v = m->vec + m->v_enc_edge;
     a.bias = v; a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
     return a;
@@ -238,6 +277,7 @@ EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, const CsrHeade
     a.hdr = hdr; a.n_edges_host = e_host; a.dst = c.dst; a.src = c.src; a.eid = eid; a.eid_out = eid;
     a.P = P; a.e_in = e_in; a.e_out = e_out; a.agg = agg; a.residual = residual;
     a.wstream = m->packed + m->s_edge[k];
+    a.wstream16 = m->packed16 ? m->packed16 + m->s16_edge[k] : nullptr;
     const float* v = m->vec + m->v_edge[k];
     a.bias = v + m->H;  // layer-1 bias lives in P_i
     a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;

@@ -19,8 +19,9 @@ ga = GraphBoundedMultimaterialControl(scene.CONN_R, stats, scene.CART, scene.MAT
 eng = RolloutEngine(model, ga, n, device=dev)
 eng.set_scene(obs)
 L = _lib.lib()
-tiles = (n * 20 + 127) // 128
-buf = torch.zeros((tiles, 8), dtype=torch.int64, device=dev)
+TILE = int(os.environ.get('GM_STAMP_TILE', '64'))
+tiles = (n * 20 + TILE - 1) // TILE
+buf = torch.zeros((tiles, 16), dtype=torch.int64, device=dev)
 with torch.no_grad():
     for _ in range(3):
         eng.step(obs, None)
@@ -31,24 +32,25 @@ with torch.no_grad():
     L.gm_debug_set_stamp_buffer(None)
 e = eng.status()
 s = buf.cpu().numpy()
-nt = (e + 127) // 128
+nt = (e + TILE - 1) // TILE
 s = s[:nt]
 t0 = s[:, 0].min()
-ph = (s[:, 1:6] - s[:, 0:5]) / 100.0  # microseconds
-names = ["gather+layer1", "layers 2-3", "layernorm", "epilogue chunk0", "epilogue chunk1"]
-print(f"tiles {nt}; kernel span {(s[:, 5].max() - t0) / 100.0:.1f} us")
+names = ["layer1", "layers 2-3", "layernorm", "e_out stores", "c0 stage+barrier", "c0 segsum+barrier", "c0 stitch",
+         "c1 stage+barrier", "c1 segsum+barrier", "c1 stitch", "tile end"]
+ph = (s[:, 1:12] - s[:, 0:11]) / 100.0  # microseconds
+print(f"tiles {nt}; kernel span {(s[:, 11].max() - t0) / 100.0:.1f} us")
 for k, nm in enumerate(names):
     print(f"  {nm:18s} mean {ph[:, k].mean():7.2f} us   p10 {np.percentile(ph[:, k], 10):7.2f}  p90 {np.percentile(ph[:, k], 90):7.2f}")
-print(f"  tile total         mean {((s[:, 5] - s[:, 0]) / 100.0).mean():7.2f} us")
+print(f"  tile total         mean {((s[:, 11] - s[:, 0]) / 100.0).mean():7.2f} us")
 # co-residency: group tiles by (xcc, hw_id cu/se/sh bits), look at overlap of MFMA phases
-hw = (s[:, 6] >> 32) & 0xffff
-xcc = s[:, 6] & 0xf
+hw = (s[:, 14] >> 32) & 0xffff
+xcc = s[:, 14] & 0xf
 cu = (xcc << 16) | (hw & 0xff00)  # se_id, sh_id, cu_id bits
 slot = hw & 0xf
 print("wave slots seen:", np.unique(slot, return_counts=True))
 key = cu[0]
 sel = np.nonzero(cu == key)[0]
 sel = sel[np.argsort(s[sel, 0])][:12]
-print("timeline on one CU (us from kernel start): tile, block, slot, start, l1_end, l3_end, ln_end, c0_end, c1_end")
+print("timeline on one CU (us from kernel start): tile, block, slot, stamps 0..11")
 for i in sel:
-    print(i, s[i, 7], slot[i], np.round((s[i, 0:6] - t0) / 100.0, 1))
+    print(i, s[i, 15], slot[i], np.round((s[i, 0:12] - t0) / 100.0, 1))
