@@ -167,7 +167,7 @@ def main():
                     "pile stays dense over the rollout)",
             "config": {"workload": wl["name"], "n_particles": n, "edges_last_step": edges, "k_steps": 6,
                        "candidates_per_gpu": 1, "parallelism": f"candidate-parallel x{world}"},
-            "roofline": {"bound": "mfma", "kernel": f"edge_kernel<{hidden},2,1> (processor phi_e + scatter-add)",
+            "roofline": {"bound": "mfma", "kernel": ("edge_kernel16<2,1>" if hidden == 128 else f"edge_kernel<{hidden},2,1>") + " (processor phi_e + scatter-add)",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": k_ms, "launches_timed": int(launches.value),
