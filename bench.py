@@ -84,12 +84,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
-    dev = torch.device(f"cuda:{local_rank}")
+    # GM_BENCH_REHEARSE=1: all ranks on cuda:0 with gloo (multi-rank rehearsal on a one-GPU box; RCCL
+    # refuses two ranks per device).  Never set by the driver.
+    rehearse = os.environ.get("GM_BENCH_REHEARSE") == "1"
+    dev = torch.device("cuda:0" if rehearse else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if rehearse else dev  # where collective payloads live
 
     from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, RolloutEngine, _lib, scene
 
@@ -129,11 +136,14 @@ def main():
         L.gm_profile_enable(1)
         t0 = time.perf_counter()
         if dist:  # per-generation exchange of the candidate-parallel planner: scripted poses out ...
-            dist.broadcast(traj[args.warmup], src=0)
+            first = traj[args.warmup].to(cdev)
+            dist.broadcast(first, src=0)
+            traj[args.warmup].copy_(first)
         for i in range(args.steps):
             eng.step(obs, traj[args.warmup + i])
         result = obs[-1, :, 2:5].mean(dim=0)
         if dist:  # ... per-candidate results back
+            result = result.to(cdev)
             gathered = [torch.empty_like(result) for _ in range(world)]
             dist.all_gather(gathered, result)
         barrier()
@@ -141,7 +151,7 @@ def main():
     L.gm_profile_enable(0)
     edges = eng.status()  # edge count of the last timed step
     if dist:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 

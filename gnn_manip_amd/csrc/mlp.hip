@@ -327,10 +327,6 @@ __device__ __forceinline__ void mlp_tail_layers(floatx16 (&acc)[H / 32], floatx1
 // ------------------------------------------------------------------------------------------
 // Diagnostic stamps (tools/stamps.py): 100 MHz s_memrealtime per tile phase, written to a buffer that no
 // other code reads.  Never enabled in a timed run.
-#define GM_STAMP_T(tile_, k)                                                                      \
-    do {                                                                                          \
-        if (A.stamps && gt0 == 0) A.stamps[(size_t)(tile_) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
 #define GM_STAMP(k)                                                                          \
     do {                                                                                     \
         if (A.stamps && tid == 0) A.stamps[(size_t)tile * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
@@ -364,13 +360,6 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArg
     ws.lane = lane0;
     ws.wave = wave0;
     if ((int)blockIdx.x < ntiles) issue_stage(ws, 0, 0);
-    {   // experiment: start the workgroup in the odd hardware slot late, to de-phase the two workgroups of a CU
-        const int delay = (A.debug >> 8) & 0xff;
-        const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-        if (delay && (wave_slot & 1))
-            for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-
     // Per-tile indices are fetched one tile ahead (registers), so that a tile's gathers do not wait
     // behind an index load.
     struct TileIdx { int er, d, sr, dq, sd; };
@@ -562,275 +551,6 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArg
             GM_STAMP(4 + fh);
         }
         tpar ^= 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// ------------------------------------------------------------------------------------------
-// EDGE kernel, role-alternating form (the one the launcher uses).
-//
-// Measured on the kernel above (tools/stamps.py, N=100k): two independent 4-wave workgroups per CU run
-// IN PHASE -- both in their MFMA phase (each at half speed), then both in their memory-bound gather /
-// epilogue phase with the matrix pipe idle -- and neither priorities nor a start offset keep them apart.
-// Here ONE 8-wave workgroup per CU holds two 4-wave groups that alternate roles by construction:
-//
-//     interval k   :  group (k & 1)     M role: the three Linear layers of its tile (12 weight stages)
-//                     group (k & 1) ^ 1 P role: LayerNorm, LDS staging, segmented reduction and stores of
-//                                               the tile it finished in interval k-1, then the gathers of
-//                                               the tile it will compute in interval k+1
-//
-// Both roles execute exactly `TOTAL` workgroup barriers per interval (the weight ring needs one per
-// stage anyway), so the P group's sub-steps are paced by the M group's stages and its memory latency
-// sits under the other group's MFMAs.  One LDS staging tile serves both groups (only one is in P).
-// ------------------------------------------------------------------------------------------
-template <int H, int NL, int MODE>
-__global__ void __launch_bounds__(2 * THREADS, 2) edge_kernel_alt(EdgeArgs A) {
-    constexpr bool ENC = MODE == 0;
-    constexpr bool with_resid = MODE == 1;
-    constexpr int NJB = H / 32;
-    constexpr int SL = (H / 8) * NJB / STAGE_PIECES;
-    constexpr int TOTAL = ENC ? 1 + NL * SL : (NL + 1) * SL;
-    constexpr int NCH = H / 64;
-    constexpr int NBIAS = ENC ? NL + 1 : NL;  // bias rows this kernel needs (processor layer-1 bias lives in P_i)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ring = reinterpret_cast<float*>(smem);
-    float* T = ring + 2 * STAGE_FLOATS;
-    int* sdst = reinterpret_cast<int*>(T + TILE * TS);                 // [2 groups][TILE + 4]
-    float* headv = reinterpret_cast<float*>(sdst + 2 * (TILE + 4));   // [2 chunk parities][head 4x64 | tail 4x64]
-    float* vecs = headv + 2 * 512;                                     // [NBIAS + 2][H]: biases, LayerNorm gamma, beta
-
-    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
-    const int grp = wave0 >> 2, w4 = wave0 & 3, n0 = lane0 & 31;
-    const int gt0 = tid0 & (THREADS - 1);  // thread index inside the group
-    const int E = A.hdr ? A.hdr->n_edges : A.n_edges_host;
-    const int ntiles = (E + TILE - 1) / TILE;
-    const int tstride = 2 * gridDim.x;
-    const int first_tile = 2 * blockIdx.x + grp;
-    const int wg_first = 2 * blockIdx.x;
-    const int n_it = wg_first < ntiles ? (ntiles - wg_first + tstride - 1) / tstride : 0;  // tiles of group 0
-    if (n_it == 0) return;
-    const int n_intervals = 2 * n_it + 1;
-
-    WStream ws;
-    ws.base = A.wstream;
-    ws.ring = ring;
-    ws.total = TOTAL;
-    ws.cur = 0;
-    ws.parity = 0;
-    ws.lane = lane0;
-    ws.wave = w4;
-    if (grp == 0) issue_stage(ws, 0, 0);
-    // per-kernel vectors into LDS: no global load is left inside the MFMA role
-    for (int i = tid0; i < NBIAS * H; i += 2 * THREADS) vecs[i] = A.bias[i];
-    for (int i = tid0; i < H; i += 2 * THREADS) {
-        vecs[NBIAS * H + i] = A.ln_g[i];
-        vecs[(NBIAS + 1) * H + i] = A.ln_b[i];
-    }
-    const float* lbias = vecs;
-    const float* lgamma = vecs + NBIAS * H;
-    const float* lbeta = lgamma + H;
-
-    struct TileIdx { int er, d, sr, dq, sd; };
-    auto fetch_idx = [&](int tile) {
-        TileIdx ix;
-        const int p0 = tile * TILE;
-        const int p = p0 + w4 * 32 + n0;
-        const int pc = p < E ? p : E - 1;
-        ix.er = A.eid ? A.eid[pc] : pc;
-        ix.d = ix.sr = 0;
-        ix.dq = ix.sd = -1;
-        if (!ENC) {
-            ix.d = A.dst[pc];
-            ix.sr = A.src[pc];
-            if (gt0 < TILE + 2) {
-                const int pp = p0 - 1 + gt0;
-                ix.sd = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
-            }
-            if (lane0 < 34) {
-                const int pp = p0 + 32 * w4 - 1 + lane0;
-                ix.dq = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
-            }
-        }
-        return ix;
-    };
-    floatx16 acc[NJB], act[NJB];
-    int* sd = sdst + grp * (TILE + 4);
-    int cur_dq = -1;
-
-    // gathers of a tile: accumulator <- P_i[dst] + P_j[src] (+ b1), B operand <- e rows
-    auto gather = [&](const TileIdx& ix, int hi) {
-        if (ENC) {
-            load_feat_guard(act, A.e_in + (int64_t)ix.er * A.k1, hi, A.k1);
-        } else {
-            load_feat(acc, A.P + (int64_t)ix.d * (2 * H), hi);
-            add_feat(acc, A.P + (int64_t)ix.sr * (2 * H) + H, hi);
-            load_feat(act, A.e_in + (int64_t)ix.er * H, hi);
-            if (gt0 < TILE + 2) sd[gt0] = ix.sd;
-            cur_dq = ix.dq;
-        }
-    };
-
-    // ---- prologue: both groups request their first tile
-    TileIdx nx = {0, 0, 0, -1, -1};
-    if (first_tile < ntiles) {
-        nx = fetch_idx(first_tile);
-        gather(nx, lane0 >> 5);
-        if (first_tile + tstride < ntiles) nx = fetch_idx(first_tile + tstride);
-    }
-    __syncthreads();  // vecs visible
-
-    for (int k = 0; k < n_intervals; ++k) {
-        const bool m_role = (k & 1) == grp;
-        if (m_role) {
-            const int it = (k - grp) >> 1;
-            const int tile = first_tile + it * tstride;
-            const bool has = it < n_it && tile < ntiles;
-            // does the M group of the next interval have a tile?  (decides the wrap-around prefetch)
-            const int it_n = (k + 1 - (grp ^ 1)) >> 1;
-            const bool next_has = it_n < n_it && (2 * (int)blockIdx.x + (grp ^ 1) + it_n * tstride) < ntiles;
-            prio_mfma_phase();
-            if (has) {
-                const int hi = lane0 >> 5;
-                GM_STAMP_T(tile, 0);
-                if (A.stamps && gt0 == 0) {
-                    A.stamps[(size_t)tile * 16 + 14] = ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 32) |
-                                                     __builtin_amdgcn_s_getreg((3 << 11) | 20);
-                    A.stamps[(size_t)tile * 16 + 15] = blockIdx.x;
-                }
-                if (ENC) {
-                    load_feat(acc, lbias, hi);
-                    run_layer<1, NJB, NJB>(acc, act, ws, next_has);
-                    mlp_tail_layers<H, NL>(acc, act, lbias + H, ws, next_has, hi);
-                } else {
-                    run_layer<H / 8, NJB, NJB>(acc, act, ws, next_has);
-                    GM_STAMP_T(tile, 1);
-                    mlp_tail_layers<H, NL>(acc, act, lbias, ws, next_has, hi);
-                }
-                GM_STAMP_T(tile, 2);
-            } else {
-#pragma unroll 1
-                for (int b = 0; b < TOTAL; ++b) lds_barrier();
-            }
-        } else {
-            // ---- P role: finish the tile computed in interval k-1, request the tile of interval k+1
-            const int it_p = (k - 1 - grp) >> 1;
-            const int tile = first_tile + it_p * tstride;
-            const bool has_prev = k >= 1 && it_p >= 0 && it_p < n_it && tile < ntiles;
-            const int it_n = it_p + 1;
-            const int tile_n = first_tile + it_n * tstride;
-            const bool has_next = it_n >= 1 && it_n < n_it && tile_n < ntiles;  // tile 0 was requested in the prologue
-            int tid_t = gt0;
-            asm volatile("" : "+v"(tid_t));
-            const int tid = tid_t, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
-            const int p0 = tile * TILE;
-            const int p = p0 + wave * 32 + n;
-            const bool valid = has_prev && p < E;
-            const int64_t out_row = valid ? (A.eid_out ? (int64_t)A.eid_out[p] : (int64_t)p) : 0;
-            int nbar = 0;
-            prio_latency_phase();
-            lds_barrier(); ++nbar;   // ---- slot 0: residual rows requested, LayerNorm, first half staged
-            if (has_prev) {
-                if (with_resid) load_feat(act, A.e_in + out_row * H, hi);  // B-operand registers are free in this role
-                layer_norm_regs(acc, lgamma, lbeta, A.eps, hi);
-                GM_STAMP_T(tile, 3);
-            }
-            if (!ENC) {
-#pragma unroll
-                for (int fh = 0; fh < NCH; ++fh) {
-                    float* hv = headv + (fh & 1) * 512;
-                    float* tl = hv + 256;
-                    // stage e' (64 features) for the segmented reduction; the tile was last read two barriers ago
-                    if (has_prev) {
-#pragma unroll
-                        for (int jb2 = 0; jb2 < 2; ++jb2)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                floatx4 x;
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) x[t] = acc[2 * fh + jb2][4 * g + t];
-                                *reinterpret_cast<floatx4*>(T + (wave * 32 + n) * TS + 32 * jb2 + 8 * g + 4 * hi) = x;
-                            }
-                    }
-                    lds_barrier(); ++nbar;   // ---- staged rows visible: segmented sum, wave q owns rows 32q..32q+31
-                    if (has_prev) {
-                        const int r0 = 32 * wave;
-                        float tv[32];
-#pragma unroll
-                        for (int r = 0; r < 32; ++r) tv[r] = T[(r0 + r) * TS + lane];
-                        float run = 0.f;
-                        int d = __builtin_amdgcn_readlane(cur_dq, 1);
-                        bool first = d >= 0 && __builtin_amdgcn_readlane(cur_dq, 0) == d;
-#pragma unroll
-                        for (int r = 0; r < 32; ++r) {
-                            const int dn = __builtin_amdgcn_readlane(cur_dq, r + 2);
-                            if (d >= 0) run += tv[r];
-                            if (dn != d && d >= 0) {
-                                if (first) hv[wave * 64 + lane] = run;
-                                else A.agg[(int64_t)d * H + 64 * fh + lane] = run;
-                                run = 0.f;
-                                first = false;
-                            }
-                            d = dn;
-                        }
-                        const int dl = __builtin_amdgcn_readlane(cur_dq, 32);
-                        if (dl >= 0 && __builtin_amdgcn_readlane(cur_dq, 33) == dl) tl[wave * 64 + lane] = run;
-                    }
-                    lds_barrier(); ++nbar;   // ---- head / tail partials visible; staging tile free again
-                    if (has_prev && wave == 0) {  // stitch segments that cross quarter / tile boundaries
-                        float carry = 0.f;
-                        bool ext = false;
-#pragma unroll 1
-                        for (int q = 0; q < 4; ++q) {
-                            const int q0 = 32 * q;
-                            const int df = sd[q0 + 1];
-                            const bool cont_in = df >= 0 && sd[q0] == df;
-                            const bool through = cont_in && sd[q0 + 32] == df && sd[q0 + 33] == df;
-                            if (cont_in) {
-                                if (q == 0) { carry = 0.f; ext = true; }
-                                if (through) {
-                                    carry += tl[q * 64 + lane];
-                                } else {
-                                    const float tot = carry + hv[q * 64 + lane];
-                                    float* dstp = A.agg + (int64_t)df * H + 64 * fh + lane;
-                                    if (ext) atomicAdd(dstp, tot); else *dstp = tot;
-                                    carry = 0.f;
-                                    ext = false;
-                                }
-                            }
-                            if (!through) {
-                                const int dl = sd[q0 + 32];
-                                if (dl >= 0 && sd[q0 + 33] == dl) { carry = tl[q * 64 + lane]; ext = false; }
-                            }
-                        }
-                        const int dl = sd[TILE];
-                        if (dl >= 0 && sd[TILE + 1] == dl) atomicAdd(A.agg + (int64_t)dl * H + 64 * fh + lane, carry);
-                    }
-                }
-            }
-            // ---- e_out = e' (+ e_in), stored from the registers (16-byte pieces; the two half-lanes of a row
-            // are adjacent and the four pieces of a 128-byte line come from consecutive instructions)
-            if (valid) {
-#pragma unroll
-                for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        floatx4 x;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) x[t] = acc[jb][4 * g + t] + (with_resid ? act[jb][4 * g + t] : 0.f);
-                        *reinterpret_cast<floatx4*>(A.e_out + out_row * H + 32 * jb + 8 * g + 4 * hi) = x;
-                    }
-                GM_STAMP_T(tile, 4);
-                GM_STAMP_T(tile, 5);
-            }
-            lds_barrier(); ++nbar;   // ---- partials consumed (sd may be rewritten); request the next tile
-            if (has_next) {
-                gather(nx, hi);
-                if (tile_n + tstride < ntiles) nx = fetch_idx(tile_n + tstride);
-            }
-            for (; nbar < TOTAL; ++nbar) lds_barrier();
-            // this group did not consume the ring: keep its view of the stream in step with the M group
-            ws.parity ^= (TOTAL & 1);
-        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1659,29 +1379,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         GM_LAUNCH_CHECK();
         return GM_OK;
     }
-    // The role-alternating 8-wave form is experimental (GM_EDGE_KERNEL=alt): correct, but its P-role
-    // sub-steps still gate the M group's stage barriers (register spills around the epilogue), so the
-    // two-workgroups-per-CU form below is what production launches.
-    static const bool alt = getenv("GM_EDGE_KERNEL") && !strcmp(getenv("GM_EDGE_KERNEL"), "alt");
-    if (alt) {
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
-            else n_cu = prop.multiProcessorCount;
-            int rc = set_lds(edge_kernel_alt<128, 2, 0>, lds);
-            if (rc == GM_OK) rc = set_lds(edge_kernel_alt<128, 2, 1>, lds);
-            if (rc == GM_OK) rc = set_lds(edge_kernel_alt<128, 2, 2>, lds);
-            if (rc != GM_OK) return rc;
-        }
-        const int64_t pairs = cdiv(cdiv(edge_capacity, TILE), 2);
-        const int g2 = (int)(pairs < n_cu ? pairs : n_cu);  // one 8-wave workgroup per CU, persistent
-        ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
-        if (enc) hipLaunchKernelGGL((edge_kernel_alt<128, 2, 0>), dim3(g2), dim3(2 * THREADS), lds, s, a);
-        else if (a.residual) hipLaunchKernelGGL((edge_kernel_alt<128, 2, 1>), dim3(g2), dim3(2 * THREADS), lds, s, a);
-        else hipLaunchKernelGGL((edge_kernel_alt<128, 2, 2>), dim3(g2), dim3(2 * THREADS), lds, s, a);
-    } else {
+    {
         int rc = launch_edge_h<128>(enc, a, grid, lds, s);
         if (rc != GM_OK) return rc;
     }
