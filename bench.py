@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--candidates", type=int, default=1,
+                    help="candidate rollouts batched per GPU (block-diagonal); value counts candidates x steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -117,9 +119,14 @@ def main():
         model.decoder[-1].bias.mul_(1e-5)
     model = model.to(dev)
     ga = GraphBoundedMultimaterialControl(scene.CONN_R, stats, scene.CART, scene.MAT, scene.CTRL, scene.BOUNDS)
-    eng = RolloutEngine(model, ga, n, device=dev)
+    nb = args.candidates
+    eng = RolloutEngine(model, ga, n, device=dev, candidates=nb)
     obs = torch.from_numpy(obs_np).to(dev)
     traj = torch.from_numpy(traj_np).to(dev)
+    if nb > 1:  # the same scene under nb scripted trajectories, stored back to back
+        obs = obs.unsqueeze(1).repeat(1, nb, 1, 1).reshape(obs.shape[0], nb * n, obs.shape[2]).contiguous()
+        traj = traj.unsqueeze(1).repeat(1, nb, 1, 1)
+        traj = (traj + 1e-7 * torch.arange(nb, device=dev).view(1, nb, 1, 1)).reshape(total, -1, 3).contiguous()
     eng.set_scene(obs)
     L = _lib.lib()
 
@@ -167,7 +174,7 @@ def main():
         achieved = issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         out = {
             "metric": f"rollout steps/sec (N particles, 10 MP steps, hidden={hidden})",
-            "value": world * args.steps / el,
+            "value": world * nb * args.steps / el,
             "unit": "rollout steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
@@ -176,7 +183,7 @@ def main():
             "data": "synthetic (seeded dense scene; random-init weights, decoder output layer scaled 1e-5 so the "
                     "pile stays dense over the rollout)",
             "config": {"workload": wl["name"], "n_particles": n, "edges_last_step": edges, "k_steps": 6,
-                       "candidates_per_gpu": 1, "parallelism": f"candidate-parallel x{world}"},
+                       "candidates_per_gpu": nb, "parallelism": f"candidate-parallel x{world}"},
             "roofline": {"bound": "mfma", "kernel": ("edge_kernel16<2,1>" if hidden == 128 else f"edge_kernel<{hidden},2,1>") + " (processor phi_e + scatter-add)",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,

@@ -22,7 +22,7 @@ class GMError(RuntimeError):
 class FeatureDesc(C.Structure):
     _fields_ = [("conn_r", C.c_double), ("k_steps", C.c_int32), ("data_dim", C.c_int32),
                 ("cart_col", C.c_int32), ("material_col", C.c_int32), ("control_col", C.c_int32),
-                ("reserved", C.c_int32),
+                ("nodes_per_graph", C.c_int32),
                 ("vel_mean", C.c_float * 3), ("vel_std", C.c_float * 3),
                 ("acc_mean", C.c_float * 3), ("acc_std", C.c_float * 3),
                 ("lower_bounds", C.c_float * 3), ("upper_bounds", C.c_float * 3)]
@@ -43,6 +43,7 @@ PROTOTYPES = {
     "gm_abi_version": (_i32, []),
     "gm_graph_workspace_bytes": (_sz, [_i64, _i32]),
     "gm_radius_graph_build": (_i32, [_vp, _i64, _i64, _f64, _i32, _vp, _sz, _vp]),
+    "gm_radius_graph_build_batched": (_i32, [_vp, _i64, _i64, _i64, _f64, _i32, _vp, _sz, _vp]),
     "gm_radius_graph_num_edges": (_i32, [_vp, C.POINTER(_i64), _vp]),
     "gm_radius_graph_edges": (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),
     "gm_csr_workspace_bytes": (_sz, [_i64, _i64]),

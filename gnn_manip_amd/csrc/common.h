@@ -61,6 +61,8 @@ struct GraphHeader {  // lives at the start of the graph workspace (device memor
     unsigned bbox_max[3];
     double origin[3];
     double inv_h;
+    int n_per_graph;   // nodes per graph of a batch of equal-sized graphs (= n for a single graph)
+    int ncells_local;  // cells of one graph's grid; graph b owns cells [b*ncells_local, (b+1)*ncells_local)
 };
 
 struct GraphWs {

@@ -221,6 +221,8 @@ __global__ void graph_init_kernel(GraphHeader* hdr) {
             hdr->origin[a] = 0.0;
         }
         hdr->inv_h = 1.0;
+        hdr->n_per_graph = 1;
+        hdr->ncells_local = 1;
     }
 }
 
@@ -258,8 +260,12 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pos
 
 // One thread: grid origin, cell edge h >= r*(1+2^-10) (so |x_i-x_j| <= r implies cell coordinates
 // differ by at most 1 on every axis despite rounding), enlarged until the grid fits max_cells.
-__global__ void grid_params_kernel(GraphHeader* hdr, double r, int max_cells, int64_t n) {
+__global__ void grid_params_kernel(GraphHeader* hdr, double r, int max_cells, int64_t n, int64_t n_per) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // a batch of equal-sized graphs shares one grid geometry; every graph gets its own block of cells, so
+    // no edge can cross graphs (the batch offset rule of collate_utils.py:76)
+    const int64_t n_graphs = n_per > 0 && n > 0 ? (n + n_per - 1) / n_per : 1;
+    max_cells = (int)(max_cells / n_graphs) > 0 ? (int)(max_cells / n_graphs) : 1;
     double lo[3], ext[3];
     for (int a = 0; a < 3; ++a) {
         double mn = n > 0 && hdr->bbox_min[a] <= hdr->bbox_max[a] ? (double)ord2f(hdr->bbox_min[a]) : 0.0;
@@ -286,7 +292,9 @@ __global__ void grid_params_kernel(GraphHeader* hdr, double r, int max_cells, in
         hdr->origin[a] = lo[a];
     }
     hdr->inv_h = 1.0 / h;
-    hdr->ncells = d[0] * d[1] * d[2];
+    hdr->ncells_local = d[0] * d[1] * d[2];
+    hdr->ncells = hdr->ncells_local * (int)n_graphs;
+    hdr->n_per_graph = (int)(n_per > 0 ? n_per : (n > 0 ? n : 1));
 }
 
 __device__ __forceinline__ int cell_coord(float v, double origin, double inv_h, int dim) {
@@ -308,7 +316,7 @@ __global__ void __launch_bounds__(256) cell_assign_kernel(const float* __restric
     int cx = cell_coord(x, hdr->origin[0], hdr->inv_h, dx);
     int cy = cell_coord(y, hdr->origin[1], hdr->inv_h, dy);
     int cz = cell_coord(z, hdr->origin[2], hdr->inv_h, dz);
-    int c = (cz * dy + cy) * dx + cx;
+    int c = (int)(i / hdr->n_per_graph) * hdr->ncells_local + (cz * dy + cy) * dx + cx;
     cell_of[i] = c;
     atomicAdd(&cell_count[c], 1);
 }
@@ -353,6 +361,7 @@ __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __rest
     const int cy = cell_coord(q.y, hdr->origin[1], inv_h, dy);
     const int cz = cell_coord(q.z, hdr->origin[2], inv_h, dz);
     const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
+    const int cbase = (qi / hdr->n_per_graph) * hdr->ncells_local;  // this graph's block of cells
     double* ld = sd2 + ql * NB_STRIDE;
     int* lj = sj + ql * NB_STRIDE;
     int count = 0;  // group-uniform
@@ -360,7 +369,7 @@ __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __rest
     if (active) {
         for (int z = max(cz - 1, 0); z <= min(cz + 1, dz - 1); ++z) {
             for (int y = max(cy - 1, 0); y <= min(cy + 1, dy - 1); ++y) {
-                const int row = (z * dy + y) * dx;
+                const int row = cbase + (z * dy + y) * dx;
                 const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
                 for (int c0 = b; c0 < e; c0 += 8) {
                     const int c = c0 + sub;
@@ -427,6 +436,7 @@ __global__ void __launch_bounds__(BS) neighbor_kernel(const float4* __restrict__
     const float4 q = sorted[slot];
     const int qi = __float_as_int(q.w);
     if (cnt[qi] != -1) return;  // done by neighbor_fast_kernel
+    const int cbase = (qi / hdr->n_per_graph) * hdr->ncells_local;
     const int dx = hdr->dims[0], dy = hdr->dims[1], dz = hdr->dims[2];
     const double inv_h = hdr->inv_h;
     const int cx = cell_coord(q.x, hdr->origin[0], inv_h, dx);
@@ -437,7 +447,7 @@ __global__ void __launch_bounds__(BS) neighbor_kernel(const float4* __restrict__
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, dx - 1);
     for (int z = max(cz - 1, 0); z <= min(cz + 1, dz - 1); ++z) {
         for (int y = max(cy - 1, 0); y <= min(cy + 1, dy - 1); ++y) {
-            const int row = (z * dy + y) * dx;
+            const int row = cbase + (z * dy + y) * dx;
             const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
             for (int c = b; c < e; ++c) {
                 const float4 p = sorted[c];
@@ -643,6 +653,13 @@ size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours) {
 
 int gm_radius_graph_build(const float* pos, int64_t pos_stride, int64_t n, double conn_r, int K, void* ws,
                           size_t ws_bytes, void* stream) {
+    return gm_radius_graph_build_batched(pos, pos_stride, n, n, conn_r, K, ws, ws_bytes, stream);
+}
+
+int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    GM_REQUIRE(n_per >= 0 && (n_per == 0 || n % n_per == 0 || n_per >= n), GM_ERR_INVALID_ARGUMENT,
+               "gm_radius_graph_build_batched: n_nodes=%lld is not a multiple of nodes_per_graph=%lld", (long long)n, (long long)n_per);
     GM_REQUIRE(n >= 0 && n < (int64_t)1 << 30, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: n_nodes=%lld out of range", (long long)n);
     GM_REQUIRE(K >= 1 && K <= 160, GM_ERR_UNSUPPORTED, "gm_radius_graph_build: max_neighbours=%d unsupported (1..160)", K);
     GM_REQUIRE(n * (int64_t)K < (int64_t)1 << 31, GM_ERR_UNSUPPORTED, "gm_radius_graph_build: n*max_neighbours overflows int32");
@@ -660,7 +677,7 @@ int gm_radius_graph_build(const float* pos, int64_t pos_stride, int64_t n, doubl
     if (n > 0) {
         int nb = (int)cdiv(n, 256);
         hipLaunchKernelGGL(bbox_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, pos, pos_stride, n, g.hdr);
-        hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, s, g.hdr, conn_r, g.max_cells, n);
+        hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, s, g.hdr, conn_r, g.max_cells, n, n_per);
         hipLaunchKernelGGL(cell_assign_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.hdr, g.cell_of, g.cell_start);
         int rc = exclusive_scan_i32(g.cell_start, g.cell_start, (int64_t)g.max_cells + 1, nullptr, g.scan_tmp, s);
         if (rc != GM_OK) return rc;

@@ -452,7 +452,8 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
     rc = gm_node_features(obs, n, fd, r.x, stream);
     if (rc != GM_OK) return rc;
     const float* last_pos = obs + (size_t)(fd->k_steps - 1) * n * fd->data_dim + fd->cart_col;
-    rc = gm_radius_graph_build(last_pos, fd->data_dim, n, fd->conn_r, K, r.graph, r.graph_bytes, stream);
+    rc = gm_radius_graph_build_batched(last_pos, fd->data_dim, n, fd->nodes_per_graph > 0 ? fd->nodes_per_graph : n, fd->conn_r, K,
+                                       r.graph, r.graph_bytes, stream);
     if (rc != GM_OK) return rc;
     rc = gm_csr_from_graph(r.graph, n, K, r.csr, r.csr_bytes, stream);
     if (rc != GM_OK) return rc;

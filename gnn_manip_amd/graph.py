@@ -35,7 +35,7 @@ def _pos_view(pos):
 class RadiusGraph:
     """Device-resident result of one radius-graph build (neighbour lists in a workspace)."""
 
-    def __init__(self, pos_nodes, conn_r, max_neighbours=20):
+    def __init__(self, pos_nodes, conn_r, max_neighbours=20, nodes_per_graph=None):
         _need_cuda(pos_nodes, "pos_nodes")
         pos, stride = _pos_view(pos_nodes)
         self._keep = pos
@@ -44,8 +44,9 @@ class RadiusGraph:
         self.device = pos.device
         L = lib()
         self.ws = _ws(L.gm_graph_workspace_bytes(self.n, self.max_neighbours), self.device)
-        check(L.gm_radius_graph_build(C.c_void_p(pos.data_ptr()), stride, self.n, float(conn_r),
-                                      self.max_neighbours, ptr(self.ws), self.ws.numel(), current_stream()))
+        per = self.n if nodes_per_graph is None else int(nodes_per_graph)
+        check(L.gm_radius_graph_build_batched(C.c_void_p(pos.data_ptr()), stride, self.n, per, float(conn_r),
+                                              self.max_neighbours, ptr(self.ws), self.ws.numel(), current_stream()))
 
     def num_edges(self):
         e = C.c_int64(0)
@@ -61,12 +62,14 @@ class RadiusGraph:
         return senders, receivers
 
 
-def get_connectivity(pos_nodes, conn_r, max_neighbours=20):
+def get_connectivity(pos_nodes, conn_r, max_neighbours=20, nodes_per_graph=None):
     """Reference ``get_connectivity`` (gnn_manip/utils/utils.py:64-93).
 
     Returns (senders, receivers) int64: senders = query node repeated, receivers = its in-radius
-    neighbours by ascending distance, at most ``max_neighbours`` (self edge first)."""
-    return RadiusGraph(pos_nodes, conn_r, max_neighbours).edges()
+    neighbours by ascending distance, at most ``max_neighbours`` (self edge first).
+    ``nodes_per_graph``: the positions are a batch of equal-sized graphs stored back to back; edges never
+    cross graphs and indices carry the batch offset (collate_utils.py:76)."""
+    return RadiusGraph(pos_nodes, conn_r, max_neighbours, nodes_per_graph).edges()
 
 
 def get_edges_displacement(last_pos, senders, receivers, conn_r):
@@ -103,7 +106,7 @@ def make_feature_desc(conn_r, stats, bounds, cartesian_idx, material_idx, contro
     d.cart_col = _contiguous_cols(cartesian_idx, "cartesian_idx")
     d.material_col = int(material_idx[0] if isinstance(material_idx, (list, tuple)) else material_idx)
     d.control_col = -1 if control_idx is None else _contiguous_cols(control_idx, "control_idx")
-    d.reserved = 0
+    d.nodes_per_graph = 0
 
     def put(dst, src):
         vals = [float(v) for v in (src.tolist() if hasattr(src, "tolist") else src)]

@@ -39,10 +39,16 @@ class RolloutEngine:
     stats, bounds and the column indices, exactly like ``dataset.graph_attr`` in the reference.
     """
 
-    def __init__(self, model, graph_attr, n_nodes, k_steps=6, data_dim=None, max_neighbours=20, device="cuda:0"):
+    def __init__(self, model, graph_attr, n_nodes, k_steps=6, data_dim=None, max_neighbours=20, device="cuda:0",
+                 candidates=1):
+        """candidates > 1: the engine steps that many equal-sized scenes at once, stored back to back along the
+        node axis ([k, candidates*n_nodes, D]); the radius graph never links two scenes (block-diagonal batch,
+        the offset rule of collate_utils.py:76), everything else is per node / per edge."""
         self.model = model
         self.graph_attr = graph_attr
-        self.n = int(n_nodes)
+        self.candidates = int(candidates)
+        self.n_per = int(n_nodes)
+        self.n = int(n_nodes) * self.candidates
         self.k = int(k_steps)
         self.device = torch.device(device)
         self.max_neighbours = int(max_neighbours)
@@ -51,6 +57,7 @@ class RolloutEngine:
         self.data_dim = int(data_dim)
         self.fdesc = make_feature_desc(graph_attr.conn_r, graph_attr.stats, graph_attr.bounds, graph_attr.cartesian_idx,
                                        graph_attr.material_idx, graph_attr.control_idx, self.k, self.data_dim)
+        self.fdesc.nodes_per_graph = self.n_per if self.candidates > 1 else 0
         self.mdesc = ModelDesc(*model.model_desc())
         L = lib()
         self.ws = _ws(L.gm_rollout_workspace_bytes(C.byref(self.mdesc), self.n, self.max_neighbours), self.device)
@@ -79,6 +86,22 @@ class RolloutEngine:
         e = C.c_int64(0)
         check(lib().gm_rollout_status(ptr(self.ws), C.byref(self.mdesc), self.n, self.max_neighbours, C.byref(e), current_stream()))
         return int(e.value)
+
+    def rollout_candidates(self, obs0, trajectories, horizon=None):
+        """Roll `candidates` copies of one initial state [k, N, D] under per-candidate scripted rigid poses
+        `trajectories` [B, T, N_rigid, 3] (the CMA-ES population of traj_utils.py:247-259, evaluated together
+        instead of serially).  Returns the final states [B, k, N, D]."""
+        b, k, n = self.candidates, self.k, self.n_per
+        assert trajectories.shape[0] == b
+        obs = obs0.unsqueeze(1).repeat(1, b, 1, 1).reshape(k, b * n, self.data_dim).contiguous()
+        self.set_scene(obs)
+        steps = horizon if horizon is not None else trajectories.shape[1]
+        traj_t = trajectories.permute(1, 0, 2, 3).contiguous()  # [T, B, Nr, 3]: one step's poses are contiguous
+        for i in range(steps):
+            tgt = traj_t[i].reshape(-1, 3) if i < traj_t.shape[0] else None
+            self.step(obs, tgt)
+        self.status()
+        return obs.reshape(k, b, n, self.data_dim).permute(1, 0, 2, 3).contiguous()
 
     def rollout(self, obs0, trajectory=None, horizon=None, record=False):
         """cma_objective's loop (traj_utils.py:119-152).  trajectory: [T, N_rigid, 3] device tensor of scripted

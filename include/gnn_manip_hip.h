@@ -53,6 +53,11 @@ size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours);
 int gm_radius_graph_build(const float* pos, int64_t pos_stride, int64_t n_nodes, double conn_r,
                           int max_neighbours, void* graph_ws, size_t graph_ws_bytes, void* stream);
 
+/* Same for a batch of equal-sized graphs stored back to back (node i belongs to graph i / nodes_per_graph):
+ * no edge crosses graphs -- the batch of collate_utils.py:68-87 (edge indices offset by N*i, :76). */
+int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t n_nodes, int64_t nodes_per_graph,
+                                  double conn_r, int max_neighbours, void* graph_ws, size_t graph_ws_bytes, void* stream);
+
 /* Synchronises `stream`; returns E and the device error flags of the last build. */
 int gm_radius_graph_num_edges(const void* graph_ws, int64_t* n_edges_host, void* stream);
 
@@ -97,7 +102,7 @@ typedef struct gm_feature_desc {
     int32_t cart_col;       /* first of the 3 contiguous position columns (2) */
     int32_t material_col;   /* (1) */
     int32_t control_col;    /* first of the 3 contiguous control columns (5), or -1: no control */
-    int32_t reserved;
+    int32_t nodes_per_graph; /* rollout of a batch of equal-sized scenes stored back to back (candidates); 0: one scene */
     float vel_mean[3], vel_std[3];
     float acc_mean[3], acc_std[3];
     float lower_bounds[3], upper_bounds[3];

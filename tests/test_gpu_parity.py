@@ -331,3 +331,41 @@ def test_rollout_vs_oracle_whole_state(dev):
     np.testing.assert_allclose(final[:, :, 5:8], ref[:, :, 5:8], rtol=0, atol=5e-6)
     np.testing.assert_array_equal(final[:, :, :2], ref[:, :, :2])
     assert eng.status() > 0
+
+
+# ------------------------------------------------------------------ batches of scenes (candidates)
+def test_batched_radius_graph_is_block_diagonal(dev, golden):
+    """collate_utils.py:68-87: a batch is the graphs side by side, indices offset by N*i -- no cross edges."""
+    from gnn_manip_amd import get_connectivity
+    g = golden("g4_features.npz")
+    pa = g["obs_a"][-1, :, 2:5]
+    rng = np.random.Generator(np.random.PCG64(5))
+    pb = (pa + 1e-3 * rng.standard_normal(pa.shape)).astype(np.float32)   # overlapping in space, different graph
+    pc = (pa[::-1] + np.float32(0.2)).copy()
+    n = pa.shape[0]
+    s, r = get_connectivity(_t(np.concatenate((pa, pb, pc)), dev), 0.015, 20, nodes_per_graph=n)
+    ss, rr = [], []
+    for i, p in enumerate((pa, pb, pc)):
+        so, ro = orc.get_connectivity(p, 0.015, 20)
+        ss.append(so + n * i)
+        rr.append(ro + n * i)
+    assert np.array_equal(s.cpu().numpy(), np.concatenate(ss))
+    assert np.array_equal(r.cpu().numpy(), np.concatenate(rr))
+
+
+def test_candidate_batched_rollout_matches_independent_rollouts(dev):
+    from gnn_manip_amd import RolloutEngine, scene
+    n, steps, b = 700, 3, 3
+    obs = scene.make_scene(n, seed=95, side=0.075)
+    trajs = np.stack([scene.rigid_drift_trajectory(obs, steps, seed=100 + c, step_size=3e-4) for c in range(b)])
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 96)
+    m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    with torch.no_grad():
+        eng_b = RolloutEngine(m, _ga(), n, device=dev, candidates=b)
+        out = eng_b.rollout_candidates(_t(obs, dev), _t(trajs, dev)).cpu().numpy()
+        eng_1 = RolloutEngine(m, _ga(), n, device=dev)
+        for c in range(b):
+            one = eng_1.rollout(_t(obs, dev), _t(trajs[c], dev), horizon=steps).cpu().numpy()
+            np.testing.assert_allclose(out[c][:, :, 2:8], one[:, :, 2:8], rtol=0, atol=2e-6)
+    ref = orc.rollout(params, obs, trajs[1], steps, STATS, BOUNDS, 0.015, CART, MAT, CTRL)
+    np.testing.assert_allclose(out[1][:, :, 2:5], ref[:, :, 2:5], rtol=0, atol=5e-6)
