@@ -140,7 +140,7 @@ def main():
             eng.step(obs, traj[i])
         eng.status()
         barrier()
-        L.gm_profile_enable(1)
+        L.gm_profile_enable(1)  # HIP events around the dominant kernel only (kind 0: processor edge kernel)
         t0 = time.perf_counter()
         if dist:  # per-generation exchange of the candidate-parallel planner: scripted poses out ...
             first = traj[args.warmup].to(cdev)
@@ -157,6 +157,13 @@ def main():
         el = time.perf_counter() - t0
     L.gm_profile_enable(0)
     edges = eng.status()  # edge count of the last timed step
+    # breakdown of the other kernels: a few extra, untimed steps with their events on
+    L.gm_profile_enable(14)
+    with torch.no_grad():
+        for i in range(min(10, args.steps)):
+            eng.step(obs, traj[args.warmup + i])
+    torch.cuda.synchronize()
+    L.gm_profile_enable(0)
     if dist:
         t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

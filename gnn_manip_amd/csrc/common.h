@@ -63,6 +63,7 @@ struct GraphHeader {  // lives at the start of the graph workspace (device memor
     double inv_h;
     int n_per_graph;   // nodes per graph of a batch of equal-sized graphs (= n for a single graph)
     int ncells_local;  // cells of one graph's grid; graph b owns cells [b*ncells_local, (b+1)*ncells_local)
+    int ticket;        // blocks of the bounding-box kernel that have finished (the last one derives the grid)
 };
 
 struct GraphWs {
@@ -109,7 +110,16 @@ struct ProfScope {
     ~ProfScope();
 };
 
-int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s);
+// fused kernels of the rollout step (features.hip)
+int rollout_pre_features(float* obs, int64_t n, const gm_feature_desc* d, const int* rank, const float* target, float* out,
+                         hipStream_t s);
+int rollout_integrate_post(float* obs, int64_t n, const gm_feature_desc* d, const float* pred, const int* rank,
+                           const float* target, float* pred_out, hipStream_t s);
+// destination sort of the radius graph with the edge features computed in the same pass (graph.hip)
+int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, const float* pos,
+                                 int64_t pos_stride, float conn_r, float* edge_attr, hipStream_t s);
+
+int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s, int* total_out);
 size_t scan_tmp_ints(int64_t n_max);
 
 }  // namespace gm

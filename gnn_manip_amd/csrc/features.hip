@@ -114,6 +114,85 @@ __global__ void __launch_bounds__(256) integrate_kernel(const float* __restrict_
     }
 }
 
+// rollout step, fused: state_pre + node features (one thread owns row i of every frame)
+__global__ void __launch_bounds__(256) pre_features_kernel(float* __restrict__ obs, int64_t n, FeatParams P,
+                                                            const int* __restrict__ rank, const float* __restrict__ target,
+                                                            float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t fs = n * P.D;
+    float* row = obs + i * P.D;
+    float* last = row + (int64_t)(P.k - 1) * fs;
+    if (rank && P.ctrl >= 0) {
+        const int rk = rank[i];
+        if (rk >= 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float cur = last[P.cart + a];
+                last[P.ctrl + a] = target ? __fsub_rn(target[(int64_t)rk * 3 + a], cur) : cur;
+            }
+        }
+    }
+    const int F = 3 * (P.k - 1) + 7 + (P.ctrl >= 0 ? 3 : 0);
+    float* o = out + i * F;
+    float prev[3], cur[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) prev[a] = row[P.cart + a];
+    for (int t = 1; t < P.k; ++t) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            cur[a] = row[t * fs + P.cart + a];
+            o[(t - 1) * 3 + a] = __fdiv_rn(__fsub_rn(__fsub_rn(cur[a], prev[a]), P.vm[a]), P.vs[a]);
+            prev[a] = cur[a];
+        }
+    }
+    float* b = o + 3 * (P.k - 1);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = __fdiv_rn(__fsub_rn(cur[a], P.lo[a]), P.r);
+        float u = __fdiv_rn(__fsub_rn(P.hi[a], cur[a]), P.r);
+        b[a] = fminf(fmaxf(l, -1.f), 1.f);
+        b[3 + a] = fminf(fmaxf(u, -1.f), 1.f);
+    }
+    b[6] = last[P.mat];
+    if (P.ctrl >= 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) b[7 + a] = __fdiv_rn(__fsub_rn(last[P.ctrl + a], P.vm[a]), P.vs[a]);
+    }
+}
+
+// rollout step, fused: integrator + window shift + write-back (+ optional copy of the prediction)
+__global__ void __launch_bounds__(256) integrate_post_kernel(float* __restrict__ obs, int64_t n, FeatParams P,
+                                                              const float* __restrict__ pred, const int* __restrict__ rank,
+                                                              const float* __restrict__ target, float* __restrict__ pred_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t fs = n * P.D;
+    float* row = obs + i * P.D;
+    const float* l1 = row + (int64_t)(P.k - 1) * fs + P.cart;
+    const float* l2 = row + (int64_t)(P.k - 2) * fs + P.cart;
+    float nxt[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float pa = pred[i * 3 + a];
+        if (pred_out) pred_out[i * 3 + a] = pa;
+        const float acc = __fadd_rn(__fmul_rn(pa, P.as[a]), P.am[a]);
+        const float lv = __fsub_rn(l1[a], l2[a]);
+        nxt[a] = __fadd_rn(l1[a], __fadd_rn(lv, acc));
+    }
+    for (int t = 0; t + 1 < P.k; ++t)
+        for (int d = 0; d < P.D; ++d) row[t * fs + d] = row[(t + 1) * fs + d];
+    float* last = row + (int64_t)(P.k - 1) * fs;
+    const int rk = rank ? rank[i] : -1;
+    if (rk < 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) last[P.cart + a] = nxt[a];
+    } else if (target) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) last[P.cart + a] = target[(int64_t)rk * 3 + a];
+    }
+}
+
 // rank of each rigid row (material == 1) among the rigid rows; one block, running carry
 __global__ void __launch_bounds__(1024) rigid_rank_kernel(const float* __restrict__ obs, int64_t n, FeatParams P,
                                                            int* __restrict__ rank, int* __restrict__ n_rigid) {
@@ -197,6 +276,26 @@ __global__ void __launch_bounds__(256) rigid_transform_kernel(const float* __res
     out[id * 3 + 0] = p0;
     out[id * 3 + 2] = p1;
     out[id * 3 + 1] = p2;
+}
+
+int rollout_pre_features(float* obs, int64_t n, const gm_feature_desc* d, const int* rank, const float* target, float* out,
+                         hipStream_t s) {
+    FeatParams P;
+    int rc = to_params(d, &P, "gm_rollout_step");
+    if (rc != GM_OK) return rc;
+    hipLaunchKernelGGL(pre_features_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, obs, n, P, rank, target, out);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int rollout_integrate_post(float* obs, int64_t n, const gm_feature_desc* d, const float* pred, const int* rank,
+                           const float* target, float* pred_out, hipStream_t s) {
+    FeatParams P;
+    int rc = to_params(d, &P, "gm_rollout_step");
+    if (rc != GM_OK) return rc;
+    hipLaunchKernelGGL(integrate_post_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, obs, n, P, pred, rank, target, pred_out);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
 }
 
 }  // namespace gm

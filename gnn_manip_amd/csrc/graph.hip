@@ -25,7 +25,7 @@ const char* last_error() { return g_err; }
 namespace {
 constexpr int PROF_MAX = 4096;
 struct ProfState {
-    bool on = false;
+    int mask = 0;  // bit k: record kind k
     int count[PROF_KINDS] = {0, 0, 0, 0};
     hipEvent_t* start[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t* stop[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
@@ -33,7 +33,7 @@ struct ProfState {
 }  // namespace
 
 ProfScope::ProfScope(int k, hipStream_t st) : idx(-1), kind(k), s(st) {
-    if (!g_prof.on || g_prof.count[k] >= PROF_MAX) return;
+    if (!((g_prof.mask >> k) & 1) || g_prof.count[k] >= PROF_MAX) return;
     if (!g_prof.start[k]) {
         g_prof.start[k] = new hipEvent_t[PROF_MAX];
         g_prof.stop[k] = new hipEvent_t[PROF_MAX];
@@ -144,13 +144,65 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const int* in, i
     }
 }
 
-// out may alias in.  Scans n items (n = *n_dev when n_dev != nullptr, bounded by n_max).
-int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s) {
+// small arrays: one 1024-thread block walks the array in chunks with a running carry (one launch instead
+// of three; at N = 5k every scan of the graph build is this small)
+constexpr int SCAN1_THREADS = 1024;
+constexpr int64_t SCAN1_MAX = 1 << 17;
+__global__ void __launch_bounds__(SCAN1_THREADS) scan_single_kernel(const int* in, int64_t n, int* out, int* total_out) {
+    __shared__ int wsum[SCAN1_THREADS / 64];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t b = 0; b < n; b += SCAN1_THREADS * SCAN_ITEMS) {
+        int item[SCAN_ITEMS];
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            const int64_t i = b + (int64_t)threadIdx.x * SCAN_ITEMS + k;
+            item[k] = i < n ? in[i] : 0;
+            v += item[k];
+        }
+        const int incl = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = carry_s;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        int ex = base + incl - v;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            const int64_t i = b + (int64_t)threadIdx.x * SCAN_ITEMS + k;
+            if (i < n) out[i] = ex;
+            ex += item[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == SCAN1_THREADS - 1) carry_s = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
+__global__ void scan_total_kernel(const int* __restrict__ out, int64_t n, int* total_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *total_out = out[n - 1];
+}
+
+// out may alias in.  Scans n items (n = *n_dev when n_dev != nullptr, bounded by n_max).  total_out (optional)
+// receives the sum; callers that ask for it append a zero item, so the sum is also the last output.
+int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s, int* total_out) {
     if (n_max <= 0) return GM_OK;
+    if (!n_dev && n_max <= SCAN1_MAX) {
+        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN1_THREADS), 0, s, in, n_max, out, total_out);
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
     const int nb = (int)cdiv(n_max, SCAN_TILE);
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n_max, n_dev, tmp);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, n_max, n_dev, tmp);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n_max, n_dev, tmp, out);
+    if (total_out) {
+        GM_REQUIRE(!n_dev, GM_ERR_INVALID_ARGUMENT, "exclusive_scan_i32: total_out needs a host-side length");
+        hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, s, out, n_max, total_out);
+    }
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -209,6 +261,31 @@ __device__ __forceinline__ float ord2f(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+// one launch: header reset + the three zero-fills of a graph build
+__global__ void __launch_bounds__(256) graph_clear_kernel(GraphHeader* hdr, int* __restrict__ cell_start, int64_t n_cs,
+                                                           int* __restrict__ cell_cursor, int64_t n_cc,
+                                                           int* __restrict__ cnt, int64_t n_cnt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cs; i += stride) cell_start[i] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cc; i += stride) cell_cursor[i] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cnt; i += stride) cnt[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr->n_edges = 0;
+        hdr->error_flags = 0;
+        hdr->ncells = 1;
+        for (int a = 0; a < 3; ++a) {
+            hdr->bbox_min[a] = 0xffffffffu;
+            hdr->bbox_max[a] = 0u;
+            hdr->dims[a] = 1;
+            hdr->origin[a] = 0.0;
+        }
+        hdr->inv_h = 1.0;
+        hdr->n_per_graph = 1;
+        hdr->ncells_local = 1;
+        hdr->ticket = 0;
+    }
+}
+
 __global__ void graph_init_kernel(GraphHeader* hdr) {
     if (threadIdx.x == 0) {
         hdr->n_edges = 0;
@@ -226,8 +303,11 @@ __global__ void graph_init_kernel(GraphHeader* hdr) {
     }
 }
 
+__device__ void grid_params(GraphHeader* hdr, double r, int max_cells, int64_t n, int64_t n_per);
+
+// bounding box; the block that finishes last derives the grid from it (no separate launch)
 __global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pos, int64_t stride, int64_t n,
-                                                    GraphHeader* hdr) {
+                                                    GraphHeader* hdr, double r, int max_cells, int64_t n_per) {
     unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
     bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -256,12 +336,29 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pos
         }
     }
     if (bad) atomicOr(&hdr->error_flags, ERRF_NONFINITE_POS);
+    // last block done -> grid parameters.  Every block's atomics are ordered before its ticket by the
+    // release fence; the last arriver acquires before reading the box.
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        last = atomicAdd(&hdr->ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // read the box through device-scope atomics (the values were produced by atomics in L2)
+        for (int a = 0; a < 3; ++a) {
+            hdr->bbox_min[a] = atomicMin(&hdr->bbox_min[a], 0xffffffffu);
+            hdr->bbox_max[a] = atomicMax(&hdr->bbox_max[a], 0u);
+        }
+        grid_params(hdr, r, max_cells, n, n_per);
+    }
 }
 
 // One thread: grid origin, cell edge h >= r*(1+2^-10) (so |x_i-x_j| <= r implies cell coordinates
 // differ by at most 1 on every axis despite rounding), enlarged until the grid fits max_cells.
-__global__ void grid_params_kernel(GraphHeader* hdr, double r, int max_cells, int64_t n, int64_t n_per) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void grid_params(GraphHeader* hdr, double r, int max_cells, int64_t n, int64_t n_per) {
     // a batch of equal-sized graphs shares one grid geometry; every graph gets its own block of cells, so
     // no edge can cross graphs (the batch offset rule of collate_utils.py:76)
     const int64_t n_graphs = n_per > 0 && n > 0 ? (n + n_per - 1) / n_per : 1;
@@ -509,8 +606,14 @@ __global__ void __launch_bounds__(256) emit_edges_kernel(const int* __restrict__
 // ------------------------------------------------------------------------------------------
 // destination-sorted structure
 // ------------------------------------------------------------------------------------------
-__global__ void csr_init_kernel(CsrHeader* hdr) {
-    if (threadIdx.x == 0) {
+__global__ void __launch_bounds__(256) csr_clear_kernel(CsrHeader* hdr, int* __restrict__ in_ptr, int* __restrict__ cursor,
+                                                         int64_t n1) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) {
+        in_ptr[i] = 0;
+        cursor[i] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr->n_edges = 0;
         hdr->error_flags = 0;
     }
@@ -576,7 +679,8 @@ constexpr int SEG_CAP = 96;
 constexpr int SEG_STRIDE = SEG_CAP + 1;
 __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict__ in_ptr, int64_t n,
                                                             int* __restrict__ src, int* __restrict__ eid,
-                                                            CsrHeader* hdr) {
+                                                            CsrHeader* hdr, const float* __restrict__ pos,
+                                                            int64_t pos_stride, float conn_r, float* __restrict__ edge_attr) {
     __shared__ int se[32 * SEG_STRIDE];
     __shared__ int ss[32 * SEG_STRIDE];
     const int tid = threadIdx.x, sub = tid & 7, sl = tid >> 3;
@@ -602,6 +706,16 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
             for (int f = 0; f < len; ++f) rank += le[f] < ka ? 1 : 0;
             eid[b + rank] = ka;
             src[b + rank] = ls[a];
+            if (edge_attr) {  // [(p_s - p_r)/r, |.|] of the edge now at sorted position b + rank (utils.py:43-61)
+                float d[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    d[c] = __fdiv_rn(__fsub_rn(pos[(int64_t)ls[a] * pos_stride + c], pos[i * pos_stride + c]), conn_r);
+                float q = __fmul_rn(d[0], d[0]);
+                q = __fadd_rn(q, __fmul_rn(d[1], d[1]));
+                q = __fadd_rn(q, __fmul_rn(d[2], d[2]));
+                *reinterpret_cast<float4*>(edge_attr + (int64_t)(b + rank) * 4) = make_float4(d[0], d[1], d[2], __fsqrt_rn(q));
+            }
         }
     } else if (sub == 0) {
         for (int a = b + 1; a < e; ++a) {
@@ -615,6 +729,16 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
             eid[p] = ke;
             src[p] = ks;
         }
+        if (edge_attr)
+            for (int a = b; a < e; ++a) {
+                float d[3];
+                for (int c = 0; c < 3; ++c)
+                    d[c] = __fdiv_rn(__fsub_rn(pos[(int64_t)src[a] * pos_stride + c], pos[i * pos_stride + c]), conn_r);
+                float q = __fmul_rn(d[0], d[0]);
+                q = __fadd_rn(q, __fmul_rn(d[1], d[1]));
+                q = __fadd_rn(q, __fmul_rn(d[2], d[2]));
+                *reinterpret_cast<float4*>(edge_attr + (int64_t)a * 4) = make_float4(d[0], d[1], d[2], __fsqrt_rn(q));
+            }
     }
 }
 
@@ -626,9 +750,10 @@ extern "C" {
 
 const char* gm_last_error(void) { return gm::last_error(); }
 
-int gm_profile_enable(int on) {
-    g_prof.on = on != 0;
-    if (on) for (int k = 0; k < PROF_KINDS; ++k) g_prof.count[k] = 0;
+int gm_profile_enable(int kind_mask) {
+    for (int k = 0; k < PROF_KINDS; ++k)
+        if (((kind_mask & ~g_prof.mask) >> k) & 1) g_prof.count[k] = 0;  // newly enabled kinds start from zero
+    g_prof.mask = kind_mask;
     return GM_OK;
 }
 
@@ -670,16 +795,18 @@ int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t 
     GM_REQUIRE(ws_bytes >= g.bytes, GM_ERR_WORKSPACE, "gm_radius_graph_build: workspace %zu < %zu", ws_bytes, g.bytes);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GRAPH, s);
-    hipLaunchKernelGGL(graph_init_kernel, dim3(1), dim3(64), 0, s, g.hdr);
-    GM_HIP_CHECK(hipMemsetAsync(g.cell_start, 0, ((size_t)g.max_cells + 1) * sizeof(int), s));
-    GM_HIP_CHECK(hipMemsetAsync(g.cell_cursor, 0, (size_t)g.max_cells * sizeof(int), s));
-    GM_HIP_CHECK(hipMemsetAsync(g.cnt, 0, (size_t)(n + 1) * sizeof(int), s));
+    {
+        const int64_t work = (int64_t)g.max_cells + 1;
+        int cb = (int)cdiv(work, 256);
+        hipLaunchKernelGGL(graph_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, g.hdr, g.cell_start,
+                           (int64_t)g.max_cells + 1, g.cell_cursor, (int64_t)g.max_cells, g.cnt, n + 1);
+    }
     if (n > 0) {
         int nb = (int)cdiv(n, 256);
-        hipLaunchKernelGGL(bbox_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, pos, pos_stride, n, g.hdr);
-        hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, s, g.hdr, conn_r, g.max_cells, n, n_per);
+        hipLaunchKernelGGL(bbox_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, pos, pos_stride, n, g.hdr, conn_r,
+                           g.max_cells, n_per);
         hipLaunchKernelGGL(cell_assign_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.hdr, g.cell_of, g.cell_start);
-        int rc = exclusive_scan_i32(g.cell_start, g.cell_start, (int64_t)g.max_cells + 1, nullptr, g.scan_tmp, s);
+        int rc = exclusive_scan_i32(g.cell_start, g.cell_start, (int64_t)g.max_cells + 1, nullptr, g.scan_tmp, s, nullptr);
         if (rc != GM_OK) return rc;
         hipLaunchKernelGGL(cell_fill_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.cell_of, g.cell_start,
                            g.cell_cursor, g.sorted);
@@ -699,9 +826,8 @@ int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t 
         }
         GM_LAUNCH_CHECK();
     }
-    int rc = exclusive_scan_i32(g.cnt, g.out_ptr, n + 1, nullptr, g.scan_tmp, s);
+    int rc = exclusive_scan_i32(g.cnt, g.out_ptr, n + 1, nullptr, g.scan_tmp, s, &g.hdr->n_edges);
     if (rc != GM_OK) return rc;
-    hipLaunchKernelGGL(set_total_kernel, dim3(1), dim3(64), 0, s, g.hdr, g.out_ptr, n);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -733,27 +859,39 @@ size_t gm_csr_workspace_bytes(int64_t n_nodes, int64_t edge_capacity) {
 }
 
 int gm_csr_from_graph(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, void* stream) {
+    return gm::csr_from_graph_with_features(graph_ws, n, K, csr_ws, csr_ws_bytes, nullptr, 3, 1.f, nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace gm {
+int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, const float* pos,
+                                 int64_t pos_stride, float conn_r, float* edge_attr, hipStream_t stream) {
     GM_REQUIRE(graph_ws && csr_ws, GM_ERR_INVALID_ARGUMENT, "gm_csr_from_graph: null pointer");
     const int64_t cap = n * K;
     GraphWs g = carve_graph(const_cast<void*>(graph_ws), n, K);
     CsrWs c = carve_csr(csr_ws, n, cap);
     GM_REQUIRE(csr_ws_bytes >= c.bytes, GM_ERR_WORKSPACE, "gm_csr_from_graph: workspace %zu < %zu", csr_ws_bytes, c.bytes);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(csr_init_kernel, dim3(1), dim3(64), 0, s, c.hdr);
-    GM_HIP_CHECK(hipMemsetAsync(c.in_ptr, 0, (size_t)(n + 1) * sizeof(int), s));
-    GM_HIP_CHECK(hipMemsetAsync(c.cursor, 0, (size_t)(n + 1) * sizeof(int), s));
+    {
+        int cb = (int)cdiv(n + 1, 256);
+        hipLaunchKernelGGL(csr_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, c.hdr, c.in_ptr, c.cursor, n + 1);
+    }
     if (n > 0) {
         unsigned nb = (unsigned)cdiv(cap, 256);
         hipLaunchKernelGGL(indeg_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.nbr, n, K, c.in_ptr);
-        int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s);
+        int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s, nullptr);
         if (rc != GM_OK) return rc;
         hipLaunchKernelGGL(fill_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.out_ptr, g.nbr, n, K, c.in_ptr,
                            c.cursor, cap, c.dst, c.src, c.eid, c.hdr);
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, pos, pos_stride, conn_r, edge_attr);
         GM_LAUNCH_CHECK();
     }
     return GM_OK;
 }
+}  // namespace gm
+
+extern "C" {
 
 int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws, size_t csr_ws_bytes, void* stream) {
     GM_REQUIRE(csr_ws && (ei || e == 0), GM_ERR_INVALID_ARGUMENT, "gm_csr_from_edge_index: null pointer");
@@ -762,18 +900,19 @@ int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws
     CsrWs c = carve_csr(csr_ws, n, e);
     GM_REQUIRE(csr_ws_bytes >= c.bytes, GM_ERR_WORKSPACE, "gm_csr_from_edge_index: workspace %zu < %zu", csr_ws_bytes, c.bytes);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(csr_init_kernel, dim3(1), dim3(64), 0, s, c.hdr);
-    GM_HIP_CHECK(hipMemsetAsync(c.in_ptr, 0, (size_t)(n + 1) * sizeof(int), s));
-    GM_HIP_CHECK(hipMemsetAsync(c.cursor, 0, (size_t)(n + 1) * sizeof(int), s));
+    {
+        int cb = (int)cdiv(n + 1, 256);
+        hipLaunchKernelGGL(csr_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, c.hdr, c.in_ptr, c.cursor, n + 1);
+    }
     if (e > 0) {
         unsigned nb = (unsigned)cdiv(e, 256);
         hipLaunchKernelGGL(indeg_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, c.in_ptr, c.hdr);
-        int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s);
+        int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s, nullptr);
         if (rc != GM_OK) return rc;
         hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, c.in_ptr, c.cursor, c.dst, c.src, c.eid);
     }
     if (n > 0)
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

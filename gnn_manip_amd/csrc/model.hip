@@ -445,27 +445,22 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
     if (n == 0) return GM_OK;
     const int64_t cap = n * K;
     int rc;
-    if (rigid_rank && fd->control_col >= 0) {
-        rc = gm_state_pre(obs, n, fd, rigid_rank, rigid_target, stream);
-        if (rc != GM_OK) return rc;
-    }
-    rc = gm_node_features(obs, n, fd, r.x, stream);
+    hipStream_t hs = (hipStream_t)stream;
+    // state_pre + node features in one launch
+    rc = gm::rollout_pre_features(obs, n, fd, rigid_rank, rigid_target, r.x, hs);
     if (rc != GM_OK) return rc;
     const float* last_pos = obs + (size_t)(fd->k_steps - 1) * n * fd->data_dim + fd->cart_col;
     rc = gm_radius_graph_build_batched(last_pos, fd->data_dim, n, fd->nodes_per_graph > 0 ? fd->nodes_per_graph : n, fd->conn_r, K,
                                        r.graph, r.graph_bytes, stream);
     if (rc != GM_OK) return rc;
-    rc = gm_csr_from_graph(r.graph, n, K, r.csr, r.csr_bytes, stream);
-    if (rc != GM_OK) return rc;
-    rc = gm_edge_features_csr(last_pos, fd->data_dim, r.csr, n, cap, (float)fd->conn_r, r.edge_attr, stream);
+    // destination sort; the edge features are written by the same pass that fixes each segment's order
+    rc = gm::csr_from_graph_with_features(r.graph, n, K, r.csr, r.csr_bytes, last_pos, fd->data_dim, (float)fd->conn_r,
+                                          r.edge_attr, hs);
     if (rc != GM_OK) return rc;
     rc = gm_epd_forward(m, r.x, n, r.edge_attr, 1, r.csr, cap, r.pred, r.fwd, r.fwd_bytes, stream);
     if (rc != GM_OK) return rc;
-    rc = gm_integrate(r.pred, obs, n, fd, r.next_pos, stream);
-    if (rc != GM_OK) return rc;
-    if (pred_acc_out)
-        GM_HIP_CHECK(hipMemcpyAsync(pred_acc_out, r.pred, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return gm_state_post(obs, n, fd, r.next_pos, rigid_rank, rigid_target, stream);
+    // integrator + window shift + write-back (+ copy of the prediction) in one launch
+    return gm::rollout_integrate_post(obs, n, fd, r.pred, rigid_rank, rigid_target, pred_acc_out, hs);
 }
 
 int gm_rollout_status(const void* ws, const gm_model_desc* desc, int64_t n, int K, int64_t* n_edges_host, void* stream) {
