@@ -201,7 +201,7 @@ def main():
         # HBM traffic of the same kernel from rocprofv3 PMC passes (collected separately, committed under profiles/)
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if args.workload in tr:
+            if args.workload in tr and args.candidates == 1:  # only for the profiled configuration
                 out["roofline"]["traffic"] = tr[args.workload]["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per guide)"
         except (OSError, ValueError, KeyError):
