@@ -52,6 +52,7 @@ int layer_stages(int k, int out);
 int layer_stages16(int k, int out);
 int pack_linear16(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s);
 int pack_linear(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s);
+int pack_linear_t(const float* W, int w_rows, int ld, int col0, int ksub, float* dst, hipStream_t s);
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
 constexpr int kStageFloats = 4096;

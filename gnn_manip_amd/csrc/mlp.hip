@@ -33,23 +33,16 @@
 #include "common.h"
 #include "mlp.h"
 
+#include "mlp_dev.h"
+
 namespace gm {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-constexpr int PIECE_FLOATS = 256;                  // 1 KiB
-constexpr int STAGE_PIECES = 16;
-constexpr int STAGE_FLOATS = PIECE_FLOATS * STAGE_PIECES;  // 16 KiB
-constexpr int TILE = 128;                          // graph elements per workgroup tile
-constexpr int THREADS = 256;
-constexpr int TS = 68;                             // LDS row stride (floats) of the 64-feature staging tile
 
 // ------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------
+// transpose != 0 packs T = (W[:, col0:col0+out_rows])^T: T[row][col] = W[col][col0 + row], kvalid = rows of W
 __global__ void __launch_bounds__(256) pack_linear_kernel(const float* __restrict__ W, int out_rows, int ld, int col0,
-                                                           int kvalid, int nkq, int njb, int stages,
+                                                           int kvalid, int nkq, int njb, int stages, int transpose,
                                                            float* __restrict__ dst) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)stages * STAGE_FLOATS;
@@ -62,7 +55,7 @@ __global__ void __launch_bounds__(256) pack_linear_kernel(const float* __restric
     if (p < nkq * njb) {
         const int kq = p / njb, jb = p % njb;
         const int row = 32 * jb + i, col = 8 * kq + 4 * hi + t;
-        if (row < out_rows && col < kvalid) v = W[(int64_t)row * ld + col0 + col];
+        if (row < out_rows && col < kvalid) v = transpose ? W[(int64_t)col * ld + col0 + row] : W[(int64_t)row * ld + col0 + col];
     }
     dst[idx] = v;
 }
@@ -112,214 +105,21 @@ int pack_linear(const float* W, int out_rows, int ld, int col0, int kvalid, floa
     const int stages = layer_stages(kvalid, out_rows);
     const int64_t total = (int64_t)stages * STAGE_FLOATS;
     hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, W, out_rows, ld, col0,
-                       kvalid, nkq, njb, stages, dst);
+                       kvalid, nkq, njb, stages, 0, dst);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
 
-// ------------------------------------------------------------------------------------------
-// device building blocks
-// ------------------------------------------------------------------------------------------
-struct WStream {
-    const float* base;  // stage 0 of this kernel's packed stream (global)
-    float* ring;        // LDS, 2 * STAGE_FLOATS
-    int total;          // stages per tile
-    int cur;            // next stage to consume (index within the tile sequence)
-    int parity;         // ring buffer holding stage `cur`
-    int lane, wave;
-};
-
-__device__ __forceinline__ void issue_stage(const WStream& ws, int stage, int buf) {
-#pragma unroll
-    for (int c = 0; c < STAGE_PIECES / 4; ++c) {
-        const int piece = c * 4 + ws.wave;  // one wave-instruction = one contiguous 1 KiB piece
-        const float* g = ws.base + (size_t)stage * STAGE_FLOATS + piece * PIECE_FLOATS + ws.lane * 4;
-        float* l = ws.ring + buf * STAGE_FLOATS + piece * PIECE_FLOATS;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-    }
-}
-
-// Workgroup barrier that orders LDS traffic only (does not drain global stores / loads in flight).
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// One Linear: acc[jb] += W(jb-block rows) . act.   NKQ = K/8 input octets, NJB = OUT/32 blocks.
-// `more` = another stage will be consumed after this layer's last one (this tile or the next).
-template <int NKQ, int NJB, int NKB>
-__device__ __forceinline__ void run_layer(floatx16 (&acc)[NJB], const floatx16 (&act)[NKB], WStream& ws, bool more_tiles) {
-    constexpr int NP = NKQ * NJB;
-    constexpr int NST = (NP + STAGE_PIECES - 1) / STAGE_PIECES;
-#pragma unroll
-    for (int s = 0; s < NST; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // stage `cur` has landed for every wave; the other buffer is free
-        int nxt = ws.cur + 1;
-        const bool wrap = nxt == ws.total;
-        if (wrap) nxt = 0;
-        {
-            // launder the stage index: otherwise every stage's DMA addresses are precomputed outside
-            // the tile loop and spilled
-            int st = nxt;
-            asm volatile("" : "+s"(st));
-            if (!wrap || more_tiles) issue_stage(ws, st, ws.parity ^ 1);
-            // keep the DMA issue HERE, right behind the barrier: the scheduler otherwise sinks it below
-            // the stage's MFMAs, next to the wait that needs it, and the copy no longer overlaps them
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const float* buf = ws.ring + ws.parity * STAGE_FLOATS + ws.lane * 4;
-        // A operands are fetched one group of pieces ahead of the MFMAs that consume them, so the LDS
-        // latency sits under the matrix pipe instead of in front of it.
-        constexpr int GP = NJB >= 2 ? 2 : 1;  // pieces per group
-        constexpr int NG = STAGE_PIECES / GP;
-        floatx4 a_cur[GP], a_nxt[GP];
-#pragma unroll
-        for (int q = 0; q < GP; ++q)
-            if (s * STAGE_PIECES + q < NP) a_cur[q] = *reinterpret_cast<const floatx4*>(buf + q * PIECE_FLOATS);
-#pragma unroll
-        for (int gidx = 0; gidx < NG; ++gidx) {
-            if (gidx + 1 < NG) {
-#pragma unroll
-                for (int q = 0; q < GP; ++q) {
-                    const int slot = (gidx + 1) * GP + q;
-                    if (s * STAGE_PIECES + slot < NP) a_nxt[q] = *reinterpret_cast<const floatx4*>(buf + slot * PIECE_FLOATS);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int q = 0; q < GP; ++q) {
-                    const int p = s * STAGE_PIECES + gidx * GP + q;
-                    if (p < NP) {
-                        const int kq = p / NJB, jb = p % NJB;
-                        acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][t], act[kq >> 2][(kq & 3) * 4 + t], acc[jb], 0, 0, 0);
-                    }
-                }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < GP; ++q) a_cur[q] = a_nxt[q];
-        }
-        ws.cur = nxt;
-        ws.parity ^= 1;
-    }
-}
-
-// registers <-> feature vectors.  v[kb][4g + t] <-> row[32 kb + 8 g + 4 hi + t]
-template <int NKB>
-__device__ __forceinline__ void load_feat(floatx16 (&v)[NKB], const float* __restrict__ row, int hi) {
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const floatx4 x = *reinterpret_cast<const floatx4*>(row + 32 * kb + 8 * g + 4 * hi);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[kb][4 * g + t] = x[t];
-        }
-}
-// v += row, one 32-feature block at a time (bounds the registers held by in-flight loads)
-template <int NKB>
-__device__ __forceinline__ void add_feat(floatx16 (&v)[NKB], const float* __restrict__ row, int hi) {
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const floatx4 x = *reinterpret_cast<const floatx4*>(row + 32 * kb + 8 * g + 4 * hi);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[kb][4 * g + t] += x[t];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-// guarded scalar loads for a raw input row of k (< 32*NKB) floats
-template <int NKB>
-__device__ __forceinline__ void load_feat_guard(floatx16 (&v)[NKB], const float* __restrict__ row, int hi, int k) {
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3);
-            v[kb][r] = f < k ? row[f] : 0.f;
-        }
-}
-template <int NKB>
-__device__ __forceinline__ void store_feat(const floatx16 (&v)[NKB], float* __restrict__ row, int hi) {
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            floatx4 x;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] = v[kb][4 * g + t];
-            *reinterpret_cast<floatx4*>(row + 32 * kb + 8 * g + 4 * hi) = x;
-        }
-}
-template <int NKB>
-__device__ __forceinline__ void relu_to(floatx16 (&dst)[NKB], const floatx16 (&src)[NKB]) {
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[kb][r] = fmaxf(src[kb][r], 0.f);
-}
-
-// LayerNorm over the H = 32*NJB features of each lane pair (n, hi=0/1); two-pass, float32.
-template <int NJB>
-__device__ __forceinline__ void layer_norm_regs(floatx16 (&acc)[NJB], const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, float eps, int hi) {
-    constexpr float INV_H = 1.0f / (32 * NJB);
-    float s = 0.f;
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[jb][r];
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * INV_H;
-    float q = 0.f;
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = acc[jb][r] - mean;
-            q += d * d;
-        }
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * INV_H + eps);
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb) {
-        // compiler-level memory barrier: keeps the gamma / beta loads of block jb from being hoisted
-        // above block jb-1 (all 128 values in flight at once cost 128 VGPRs and spill the accumulators)
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const floatx4 gm = *reinterpret_cast<const floatx4*>(gamma + 32 * jb + 8 * g + 4 * hi);
-            const floatx4 bt = *reinterpret_cast<const floatx4*>(beta + 32 * jb + 8 * g + 4 * hi);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[jb][4 * g + t] = (acc[jb][4 * g + t] - mean) * rstd * gm[t] + bt[t];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Two workgroups share a CU (two waves per SIMD).  The matrix pipe is the shared resource; everything
-// else a tile does (index / gather issue, LayerNorm, LDS staging, segmented reduction, stores) is a
-// latency-bound chain of few instructions.  Those phases run at raised priority so that they are never
-// starved by the partner workgroup's MFMA stream (measured: at equal or lower priority a workgroup's
-// epilogue stretches from ~12 us to ~27 us while its partner is in its MFMA phase); the MFMA phases
-// run at priority 0 and take whatever issue slots are left, which is all the pipe needs.
-__device__ __forceinline__ void prio_latency_phase() { __builtin_amdgcn_s_setprio(3); }
-__device__ __forceinline__ void prio_mfma_phase() { __builtin_amdgcn_s_setprio(0); }
-
-// hidden layers 2..NL and the output layer of an MLP whose layer 1 has just been accumulated
-template <int H, int NL>
-__device__ __forceinline__ void mlp_tail_layers(floatx16 (&acc)[H / 32], floatx16 (&act)[H / 32], const float* __restrict__ bias,
-                                                WStream& ws, bool more_tiles, int hi) {
-#pragma unroll
-    for (int l = 1; l <= NL; ++l) {
-        relu_to(act, acc);
-        load_feat(acc, bias + (l - 1) * H, hi);
-        run_layer<H / 8, H / 32, H / 32>(acc, act, ws, more_tiles);
-    }
+// Operand image of the TRANSPOSED sub-block (W[0:w_rows, col0:col0+ksub])^T, i.e. a Linear with ksub outputs and
+// w_rows inputs: the weight of the backward (input-gradient) product dX = dZ . W.
+int pack_linear_t(const float* W, int w_rows, int ld, int col0, int ksub, float* dst, hipStream_t s) {
+    const int nkq = (w_rows + 7) / 8, njb = (ksub + 31) / 32;
+    const int stages = layer_stages(w_rows, ksub);
+    const int64_t total = (int64_t)stages * STAGE_FLOATS;
+    hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, W, ksub, ld, col0,
+                       w_rows, nkq, njb, stages, 1, dst);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -3,30 +3,12 @@
 #include <vector>
 #include "common.h"
 #include "mlp.h"
+#include "model.h"
 
 using namespace gm;
 
-struct gm_model {
-    gm_model_desc d;
-    int H, NL, M;
-    float* packed = nullptr;  // operand image of every Linear, stage-aligned streams
-    float* packed16 = nullptr;  // 16x16x4 operand image of the edge MLPs (hidden 128)
-    size_t packed16_floats = 0, s16_enc_edge = 0;
-    std::vector<size_t> s16_edge;
-    float* vec = nullptr;     // per-MLP contiguous [bias_0..bias_NL, ln_gamma, ln_beta]
-    size_t packed_floats = 0, vec_floats = 0;
-    // stream offsets (floats) into packed
-    size_t s_enc_edge, s_enc_node;
-    std::vector<size_t> s_edge, s_node;
-    // vec offsets (floats): start of MLP block
-    size_t v_enc_edge, v_enc_node, v_dec;
-    std::vector<size_t> v_edge, v_node;
-    int S_HH, S_e0, S_n0, S_out;
-};
 
 namespace {
-
-int tensors_per_normed_mlp(int NL) { return 2 * (NL + 1) + 2; }
 
 int check_desc(const gm_model_desc* d, const char* who) {
     GM_REQUIRE(d != nullptr, GM_ERR_INVALID_ARGUMENT, "%s: null model descriptor", who);

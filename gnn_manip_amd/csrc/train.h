@@ -1,0 +1,82 @@
+// Argument blocks and launchers of the training kernels (train.hip), used by train_model.hip.
+#pragma once
+#include "common.h"
+
+namespace gm {
+
+// activation tape of one MLP (all in the row order the MLP ran in)
+struct TapePtr {
+    float* a1;    // [rows][H] post-ReLU output of Linear 1
+    float* a2;    // [rows][H] post-ReLU output of Linear 2
+    float* xhat;  // [rows][H] normalised, pre-affine LayerNorm output (normed MLPs)
+    float* rstd;  // [rows]    1 / sqrt(var + eps)
+};
+
+struct TrainFwdArgs {
+    int rows;
+    const float* x_in;     // encoders: raw features [.][k1]; processor edge: e [E][H]; processor node / decoder: h [N][H]
+    const int* rowidx;     // encoders: input row of output row p, or nullptr
+    int k1;
+    const float* agg;      // processor node: [N][H]
+    const int* dst;        // processor edge
+    const int* src;
+    const float* P;        // processor edge: [N][2H] = P_i (+ b1) | P_j
+    const float* wstream;  // packed forward stream of this MLP
+    const float* bias;     // bias of Linear 1 (unused by the processor edge MLP: it sits in P_i)
+    const float* bias_tail;  // biases of Linear 2, 3 (decoder: Linear 3's padded to 32)
+    const float* ln_g;
+    const float* ln_b;
+    float eps;
+    TapePtr tape;
+    float* out;            // [rows][H]; decoder: [rows][out_dim]
+    int residual;          // processor: out = y + x_in
+    int out_dim;
+};
+
+struct TrainBwdArgs {
+    int rows;
+    const float* dY;       // upstream gradient rows [.][H] (decoder: [rows][out_dim]); nullptr = zero
+    const int* dyidx;      // row of dY for row p, or nullptr
+    const float* dagg;     // edge: + dagg[dst[p]]
+    const int* dst;
+    const float* Gi;       // node MLPs: + W_i^T Gi[p] + W_j^T Gj[p] (next edge step's layer-1 input gradient), or nullptr
+    const float* Gj;
+    TapePtr tape;
+    const float* ln_g;
+    const float* wstream;  // packed TRANSPOSED stream: [W_i^T, W_j^T (if Gi)] W3^T W2^T [W1^T ...]
+    float* gy;             // [rows][H] total upstream gradient (for the LayerNorm parameter gradients)
+    float* dz3;            // [rows][H]
+    float* dz2;
+    float* dz1;
+    float* dx_resid;       // node: residual path; receives dY before dx adds the MLP's input gradient to it (may alias dY / dx)
+    float* dx;             // edge: de_in; node: dh_in; decoder: dh
+    float* dagg_out;       // node: [rows][H]
+    int residual;          // edge: de_in += dY
+    int out_dim;
+};
+
+struct ColsumJobs {
+    int n;
+    const float* A[5];
+    const float* B[5];  // optional element-wise factor
+    float* out[5];
+    int cols[5];
+    int ld[5];
+};
+
+int train_kernels_init();
+int launch_train_fwd(int H, int kind, const TrainFwdArgs& a, hipStream_t s);
+int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s);
+size_t wgrad_partial_floats(int64_t rows, int M, int K);
+// out[m][col0 + k] += sum_r dz[r][m] * X[xidx ? xidx[r] : r][k]
+int launch_wgrad(const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* part,
+                 float* out, int ldw, int col0, hipStream_t s);
+int launch_colsum(const ColsumJobs& j, int64_t rows, hipStream_t s);
+int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows, const float* scale, const float* shift, float* out,
+                       int64_t n, hipStream_t s);
+int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_t s);
+
+enum : int { TK_ENC_EDGE = 0, TK_ENC_NODE = 1, TK_PROC_EDGE = 2, TK_PROC_NODE = 3, TK_DEC = 4 };
+enum : int { TB_ENC = 0, TB_EDGE = 1, TB_NODE = 2, TB_DEC = 3 };
+
+}  // namespace gm

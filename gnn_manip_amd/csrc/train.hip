@@ -1,0 +1,555 @@
+// Training path of the encode-process-decode model: forward with an activation tape and the full
+// backward pass (callers: examples/train_dyn.py:45-72 -> loss.backward()).
+//
+// Design.  The per-row work (everything that is "one graph element through an MLP") reuses the
+// transposed fp32-MFMA chain of mlp.hip: a wave carries 32 rows x H features through consecutive
+// Linear layers in registers.  The backward of  y = LN(W3 relu(W2 relu(W1 x + b1) + b2) + b3)  is the
+// same kind of chain run with TRANSPOSED weights (pack_linear_t):
+//     dz3 = LN'(dy);  dz2 = (W3^T dz3) * [a2 > 0];  dz1 = (W2^T dz2) * [a1 > 0];  dx = W1^T dz1
+// so one kernel per MLP produces dz1..dz3 and the input gradient.  Everything that reduces over ROWS
+// (weight, bias and LayerNorm-parameter gradients) is done by two generic kernels on the arrays the
+// chain kernels leave in HBM: wgrad_kernel (dW = dz^T X as a split-K MFMA GEMM, operands read in
+// their natural row-major layout, deterministic two-stage reduction) and colsum_kernel.
+//
+// The layer-1 factorisation of the edge MLP (P = h [W_i|W_j]^T per node) carries over to the backward:
+// by linearity  dh_i = W_i^T sum_{edges into i} dz1  and  dW_i = (sum_{edges into i} dz1)^T h, so the
+// per-edge dz1 rows are first segment-summed per destination (G_i) and per source (G_j) node and both
+// products run over N rows instead of E.
+//
+// Tape (saved by the forward, one set per MLP): post-ReLU activations a1, a2, the normalised
+// pre-affine LayerNorm output xhat and 1/std per row; plus the block inputs h_k, e_k, agg_k.
+#include <vector>
+#include "common.h"
+#include "mlp.h"
+#include "mlp_dev.h"
+#include "train.h"
+
+namespace gm {
+
+// ------------------------------------------------------------------------------------------
+// small register helpers on the 32x32x2 feature layout (see mlp_dev.h)
+// ------------------------------------------------------------------------------------------
+template <int NKB>
+__device__ __forceinline__ void zero_feat(floatx16 (&v)[NKB]) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[kb][r] = 0.f;
+}
+// v = a > 0 ? v : 0   (ReLU backward; a = saved post-ReLU activation row)
+template <int NKB>
+__device__ __forceinline__ void mask_feat(floatx16 (&v)[NKB], const float* __restrict__ a_row, int hi) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 x = *reinterpret_cast<const floatx4*>(a_row + 32 * kb + 8 * g + 4 * hi);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[kb][4 * g + t] = x[t] > 0.f ? v[kb][4 * g + t] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// LayerNorm forward that also leaves xhat in `xh` (registers) and returns 1/std; acc <- xhat*gamma + beta
+template <int NJB>
+__device__ __forceinline__ float layer_norm_tape(floatx16 (&acc)[NJB], floatx16 (&xh)[NJB], const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps, int hi) {
+    constexpr float INV_H = 1.0f / (32 * NJB);
+    float s = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[jb][r];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * INV_H;
+    float q = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc[jb][r] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * INV_H + eps);
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 gm = *reinterpret_cast<const floatx4*>(gamma + 32 * jb + 8 * g + 4 * hi);
+            const floatx4 bt = *reinterpret_cast<const floatx4*>(beta + 32 * jb + 8 * g + 4 * hi);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float x = (acc[jb][4 * g + t] - mean) * rstd;
+                xh[jb][4 * g + t] = x;
+                acc[jb][4 * g + t] = x * gm[t] + bt[t];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return rstd;
+}
+
+// LayerNorm backward: dy in `g` (overwritten), xhat in `xh`; result dz = rstd (g*gamma - mean(g*gamma) - xhat mean(g*gamma*xhat)) -> xh
+template <int NJB>
+__device__ __forceinline__ void layer_norm_bwd(floatx16 (&g)[NJB], floatx16 (&xh)[NJB], const float* __restrict__ gamma, float rstd, int hi) {
+    constexpr float INV_H = 1.0f / (32 * NJB);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const floatx4 gm = *reinterpret_cast<const floatx4*>(gamma + 32 * jb + 8 * q + 4 * hi);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v = g[jb][4 * q + t] * gm[t];
+                g[jb][4 * q + t] = v;
+                s1 += v;
+                s2 += v * xh[jb][4 * q + t];
+            }
+        }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float m1 = s1 * INV_H, m2 = s2 * INV_H;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xh[jb][r] = rstd * (g[jb][r] - m1 - xh[jb][r] * m2);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward with tape
+// ------------------------------------------------------------------------------------------
+
+template <int H, int KIND>
+__global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(TrainFwdArgs A) {
+    constexpr int NJB = H / 32, NL = 2;
+    constexpr int SL = (H / 8) * NJB / STAGE_PIECES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ring = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
+    const int R = A.rows;
+    const int ntiles = (R + TILE - 1) / TILE;
+    WStream ws;
+    ws.base = A.wstream;
+    ws.ring = ring;
+    ws.total = KIND == TK_ENC_EDGE ? 1 + NL * SL
+             : KIND == TK_ENC_NODE ? (4 * NJB + STAGE_PIECES - 1) / STAGE_PIECES + NL * SL
+             : KIND == TK_PROC_EDGE ? (NL + 1) * SL
+             : KIND == TK_PROC_NODE ? (NL + 2) * SL
+                                   : NL * SL + (H / 8 + STAGE_PIECES - 1) / STAGE_PIECES;
+    ws.cur = 0;
+    ws.parity = 0;
+    ws.lane = lane;
+    ws.wave = wave;
+    if ((int)blockIdx.x < ntiles) issue_stage(ws, 0, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool more = tile + (int)gridDim.x < ntiles;
+        const int p = tile * TILE + wave * 32 + n;
+        const bool valid = p < R;
+        const int64_t pc = valid ? p : R - 1;
+        floatx16 acc[NJB], act[NJB];
+        if (KIND == TK_ENC_EDGE || KIND == TK_ENC_NODE) {
+            const int64_t rin = A.rowidx ? A.rowidx[pc] : pc;
+            load_feat_guard(act, A.x_in + rin * A.k1, hi, A.k1);
+            load_feat(acc, A.bias, hi);
+            if (KIND == TK_ENC_EDGE) run_layer<1, NJB, NJB>(acc, act, ws, more);
+            else run_layer<4, NJB, NJB>(acc, act, ws, more);
+        } else if (KIND == TK_PROC_EDGE) {
+            load_feat(acc, A.P + (int64_t)A.dst[pc] * (2 * H), hi);
+            add_feat(acc, A.P + (int64_t)A.src[pc] * (2 * H) + H, hi);
+            load_feat(act, A.x_in + pc * H, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+        } else if (KIND == TK_PROC_NODE) {
+            load_feat(act, A.x_in + pc * H, hi);
+            load_feat(acc, A.bias, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+            load_feat(act, A.agg + pc * H, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+        } else {
+            load_feat(act, A.x_in + pc * H, hi);
+            load_feat(acc, A.bias, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+        }
+        // hidden layers 2..NL and the output layer; bias_tail = bias of layer 2
+        relu_to(act, acc);
+        if (valid) store_feat(act, A.tape.a1 + pc * H, hi);
+        load_feat(acc, A.bias_tail, hi);
+        run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+        relu_to(act, acc);
+        if (valid) store_feat(act, A.tape.a2 + pc * H, hi);
+        if (KIND == TK_DEC) {
+            floatx16 o[1];
+            load_feat(o, A.bias_tail + H, hi);  // out bias, zero-padded to 32
+            run_layer<H / 8, 1, NJB>(o, act, ws, more);
+            if (valid && hi == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < A.out_dim) A.out[pc * A.out_dim + c] = o[0][c];
+            }
+        } else {
+            load_feat(acc, A.bias_tail + H, hi);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+            const float rstd = layer_norm_tape(acc, act, A.ln_g, A.ln_b, A.eps, hi);
+            if (valid) {
+                store_feat(act, A.tape.xhat + pc * H, hi);
+                if (hi == 0) A.tape.rstd[pc] = rstd;
+            }
+            if ((KIND == TK_PROC_EDGE || KIND == TK_PROC_NODE) && A.residual) add_feat(acc, A.x_in + pc * H, hi);
+            if (valid) store_feat(acc, A.out + pc * H, hi);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// backward chain
+// ------------------------------------------------------------------------------------------
+
+template <int H, int KIND>
+__global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(TrainBwdArgs A) {
+    constexpr int NJB = H / 32;
+    constexpr int SL = (H / 8) * NJB / STAGE_PIECES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ring = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
+    const int R = A.rows;
+    const int ntiles = (R + TILE - 1) / TILE;
+    const bool has_g = (KIND == TB_NODE || KIND == TB_ENC) && A.Gi != nullptr;
+    WStream ws;
+    ws.base = A.wstream;
+    ws.ring = ring;
+    ws.total = (has_g ? 2 * SL : 0) + (KIND == TB_ENC ? 2 * SL : KIND == TB_EDGE ? 3 * SL : KIND == TB_NODE ? 4 * SL : 1 + 2 * SL);
+    ws.cur = 0;
+    ws.parity = 0;
+    ws.lane = lane;
+    ws.wave = wave;
+    if ((int)blockIdx.x < ntiles) issue_stage(ws, 0, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool more = tile + (int)gridDim.x < ntiles;
+        const int p = tile * TILE + wave * 32 + n;
+        const bool valid = p < R;
+        const int64_t pc = valid ? p : R - 1;
+        floatx16 acc[NJB], act[NJB];
+        if (KIND == TB_DEC) {
+            // dz3 = dY [rows][out_dim]; first product has K = out_dim (one k-octet)
+            load_feat_guard(act, A.dY + pc * A.out_dim, hi, A.out_dim);
+            zero_feat(acc);
+            run_layer<1, NJB, NJB>(acc, act, ws, more);
+        } else {
+            // total upstream gradient of the MLP output row
+            if (A.dY) {
+                const int64_t rin = A.dyidx ? A.dyidx[pc] : pc;
+                load_feat(acc, A.dY + rin * H, hi);
+            } else {
+                zero_feat(acc);
+            }
+            if (KIND == TB_EDGE && A.dagg) add_feat(acc, A.dagg + (int64_t)A.dst[pc] * H, hi);
+            if (has_g) {  // + W_i^T G_i + W_j^T G_j : input gradient of the NEXT edge step's factorised layer 1
+                load_feat(act, A.Gi + pc * H, hi);
+                run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+                load_feat(act, A.Gj + pc * H, hi);
+                run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+            }
+            if (valid) {
+                store_feat(acc, A.gy + pc * H, hi);
+                if (KIND == TB_NODE && A.dx_resid) store_feat(acc, A.dx_resid + pc * H, hi);  // residual path: dh_in starts as dY
+            }
+            load_feat(act, A.tape.xhat + pc * H, hi);
+            layer_norm_bwd(acc, act, A.ln_g, A.tape.rstd[pc], hi);
+            if (valid) store_feat(act, A.dz3 + pc * H, hi);
+            zero_feat(acc);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);  // W3^T dz3
+        }
+        mask_feat(acc, A.tape.a2 + pc * H, hi);
+        if (valid) store_feat(acc, A.dz2 + pc * H, hi);
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
+        zero_feat(acc);
+        run_layer<H / 8, NJB, NJB>(acc, act, ws, more);  // W2^T dz2
+        mask_feat(acc, A.tape.a1 + pc * H, hi);
+        if (valid) store_feat(acc, A.dz1 + pc * H, hi);
+        if (KIND == TB_ENC) continue;
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
+        zero_feat(acc);
+        run_layer<H / 8, NJB, NJB>(acc, act, ws, more);  // W1^T dz1 (edge: W_e block; node: W_h block; decoder: W1)
+        if (KIND == TB_EDGE) {
+            // de_in = W_e^T dz1 (+ de_out through the residual), written over the row it came from
+            if (A.residual && A.dY) {
+                const int64_t rin = A.dyidx ? A.dyidx[pc] : pc;
+                add_feat(acc, A.dY + rin * H, hi);
+            }
+            if (valid) store_feat(acc, A.dx + pc * H, hi);
+        } else if (KIND == TB_NODE) {
+            if (A.dx_resid) add_feat(acc, A.dx_resid + pc * H, hi);  // same thread wrote this row above
+            if (valid) store_feat(acc, A.dx + pc * H, hi);
+            zero_feat(acc);
+            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);  // W_agg^T dz1
+            if (valid) store_feat(acc, A.dagg_out + pc * H, hi);
+        } else {
+            if (valid) store_feat(acc, A.dx + pc * H, hi);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// dW = dz^T X  (split over rows; partial[g][m][k])
+// ------------------------------------------------------------------------------------------
+constexpr int WG_U = 8;  // 2-row MFMA steps whose operands are requested together
+
+__global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(const float* __restrict__ dz, int ldz, int M, const float* __restrict__ X, int ldx,
+                                                            int K, const int* __restrict__ xidx, int rows, int chunk, float* __restrict__ part,
+                                                            int Mp, int Kp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
+    const int KT = Kp / 128;
+    const int mt = blockIdx.y / KT, kt = blockIdx.y % KT;
+    const int m0 = mt * 128 + 64 * (wave >> 1), k0 = kt * 128 + 64 * (wave & 1);
+    const int r_begin = blockIdx.x * chunk;
+    const int r_end = min(rows, r_begin + chunk);
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool mv0 = m0 + i < M, mv1 = m0 + 32 + i < M, kv0 = k0 + i < K, kv1 = k0 + 32 + i < K;
+    for (int r0 = r_begin; r0 < r_end; r0 += 2 * WG_U) {
+        float a0[WG_U], a1[WG_U], b0[WG_U], b1[WG_U];
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            const int r = r0 + 2 * u + hi;
+            const bool rv = r < r_end;
+            const int64_t rz = rv ? r : r_begin;
+            const int64_t rx = xidx ? xidx[rz] : rz;
+            const float* zr = dz + rz * ldz + m0 + i;
+            const float* xr = X + rx * ldx + k0 + i;
+            a0[u] = rv && mv0 ? zr[0] : 0.f;
+            a1[u] = rv && mv1 ? zr[32] : 0.f;
+            b0[u] = rv && kv0 ? xr[0] : 0.f;
+            b1[u] = rv && kv1 ? xr[32] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+        }
+    }
+    float* out = part + (size_t)blockIdx.x * Mp * Kp;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * a + 8 * (r >> 2) + 4 * hi + (r & 3);
+                const int k = k0 + 32 * b + i;
+                out[(size_t)m * Kp + k] = acc[a][b][r];
+            }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int G, int Mp, int Kp, int M, int K,
+                                                            float* __restrict__ out, int ldw, int col0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * K) return;
+    const int m = idx / K, k = idx % K;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[((size_t)g * Mp + m) * Kp + k];
+    out[(size_t)m * ldw + col0 + k] += s;
+}
+
+// ------------------------------------------------------------------------------------------
+// column sums: out_j[c] += sum_r A_j[r][c] * (B_j ? B_j[r][c] : 1), up to 5 jobs per launch
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) colsum_kernel(ColsumJobs J, int rows, int chunk) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int r_begin = blockIdx.x * chunk, r_end = min(rows, r_begin + chunk);
+    for (int j = 0; j < J.n; ++j) {
+        const int cols = J.cols[j], ld = J.ld[j];
+        const int per = 256 / cols >= 1 ? 256 / cols : 1;  // row phases (cols <= 256)
+        const int c = tid % cols, ph = tid / cols;
+        float s = 0.f;
+        if (ph < per) {
+            const float* A = J.A[j];
+            const float* B = J.B[j];
+            for (int r = r_begin + ph; r < r_end; r += per) {
+                const float a = A[(size_t)r * ld + c];
+                s += B ? a * B[(size_t)r * ld + c] : a;
+            }
+        }
+        red[tid] = s;
+        __syncthreads();
+        if (tid < cols) {
+            float t = 0.f;
+            for (int q = 0; q < per; ++q) t += red[q * cols + tid];
+            atomicAdd(J.out[j] + tid, t);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// segment sums over a CSR: out[i] = scale * sum_{p in [ptr[i], ptr[i+1])} rows[perm ? perm[p] : p] + cnt * shift
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(256) segment_sum_kernel(const int* __restrict__ ptr, const int* __restrict__ perm,
+                                                           const float* __restrict__ rows, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ out, int n) {
+    constexpr int H = 64 * W;
+    const int lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= n) return;
+    const int b = ptr[node], e = ptr[node + 1];
+    float s[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) s[w] = 0.f;
+    for (int p = b; p < e; ++p) {
+        const int64_t r = perm ? perm[p] : p;
+        const float* src = rows + r * H + lane * W;
+#pragma unroll
+        for (int w = 0; w < W; ++w) s[w] += src[w];
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        float v = s[w];
+        if (scale) v = v * scale[lane * W + w] + (float)(e - b) * shift[lane * W + w];
+        out[(size_t)node * H + lane * W + w] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) swap_index_kernel(const int* __restrict__ src_sorted, int e, int64_t* __restrict__ ei2) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= e) return;
+    ei2[p] = 0;                          // row 0: unused "source" role (any valid node index)
+    ei2[(size_t)e + p] = src_sorted[p];  // row 1: segment key = source node of sorted position p
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static int grid_tiles(int64_t rows) {
+    int64_t t = cdiv(rows, TILE);
+    if (t < 1) t = 1;
+    return (int)(t < 2048 ? t : 2048);
+}
+
+template <typename Kern>
+static int set_dyn_lds(Kern k, size_t bytes) {
+    GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return GM_OK;
+}
+
+template <int H>
+static int launch_train_fwd_h(int kind, const TrainFwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * STAGE_FLOATS * 4;
+    const int grid = grid_tiles(a.rows);
+    switch (kind) {
+        case TK_ENC_EDGE: hipLaunchKernelGGL((train_fwd_kernel<H, TK_ENC_EDGE>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        case TK_ENC_NODE: hipLaunchKernelGGL((train_fwd_kernel<H, TK_ENC_NODE>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        case TK_PROC_EDGE: hipLaunchKernelGGL((train_fwd_kernel<H, TK_PROC_EDGE>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        case TK_PROC_NODE: hipLaunchKernelGGL((train_fwd_kernel<H, TK_PROC_NODE>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        default: hipLaunchKernelGGL((train_fwd_kernel<H, TK_DEC>), dim3(grid), dim3(THREADS), lds, s, a); break;
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+int launch_train_fwd(int H, int kind, const TrainFwdArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return GM_OK;
+    return H == 128 ? launch_train_fwd_h<128>(kind, a, s) : launch_train_fwd_h<256>(kind, a, s);
+}
+
+template <int H>
+static int launch_train_bwd_h(int kind, const TrainBwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * STAGE_FLOATS * 4;
+    const int grid = grid_tiles(a.rows);
+    switch (kind) {
+        case TB_ENC: hipLaunchKernelGGL((train_bwd_kernel<H, TB_ENC>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        case TB_EDGE: hipLaunchKernelGGL((train_bwd_kernel<H, TB_EDGE>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        case TB_NODE: hipLaunchKernelGGL((train_bwd_kernel<H, TB_NODE>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        default: hipLaunchKernelGGL((train_bwd_kernel<H, TB_DEC>), dim3(grid), dim3(THREADS), lds, s, a); break;
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return GM_OK;
+    return H == 128 ? launch_train_bwd_h<128>(kind, a, s) : launch_train_bwd_h<256>(kind, a, s);
+}
+
+int wgrad_chunk(int64_t rows) {
+    // about one workgroup per CU; chunks are multiples of 16 rows (WG_U two-row steps)
+    int64_t c = cdiv(rows, 256);
+    if (c < 256) c = 256;
+    return (int)(cdiv(c, 16) * 16);
+}
+size_t wgrad_partial_floats(int64_t rows, int M, int K) {
+    const int Mp = (int)cdiv(M, 128) * 128, Kp = (int)cdiv(K, 128) * 128;
+    return (size_t)cdiv(rows > 0 ? rows : 1, wgrad_chunk(rows)) * Mp * Kp;
+}
+
+int launch_wgrad(const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* part,
+                 float* out, int ldw, int col0, hipStream_t s) {
+    if (rows <= 0 || M <= 0 || K <= 0) return GM_OK;
+    const int Mp = (int)cdiv(M, 128) * 128, Kp = (int)cdiv(K, 128) * 128;
+    const int chunk = wgrad_chunk(rows);
+    const int G = (int)cdiv(rows, chunk);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(G, (Mp / 128) * (Kp / 128)), dim3(THREADS), 0, s, dz, ldz, M, X, ldx, K, xidx, (int)rows, chunk,
+                       part, Mp, Kp);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int64_t)M * K, 256)), dim3(256), 0, s, part, G, Mp, Kp, M, K, out, ldw, col0);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_colsum(const ColsumJobs& j, int64_t rows, hipStream_t s) {
+    if (rows <= 0 || j.n <= 0) return GM_OK;
+    int64_t chunk = cdiv(rows, 512);
+    if (chunk < 64) chunk = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(rows, chunk)), dim3(256), 0, s, j, (int)rows, (int)chunk);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows, const float* scale, const float* shift, float* out,
+                       int64_t n, hipStream_t s) {
+    if (n <= 0) return GM_OK;
+    const unsigned grid = (unsigned)cdiv(n, 4);
+    if (H == 128) hipLaunchKernelGGL((segment_sum_kernel<2>), dim3(grid), dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n);
+    else hipLaunchKernelGGL((segment_sum_kernel<4>), dim3(grid), dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_t s) {
+    if (e <= 0) return GM_OK;
+    hipLaunchKernelGGL(swap_index_kernel, dim3((unsigned)cdiv(e, 256)), dim3(256), 0, s, src_sorted, (int)e, ei2);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int train_kernels_init() {
+    static bool done = false;
+    if (done) return GM_OK;
+    const size_t lds = (size_t)2 * STAGE_FLOATS * 4;
+    int rc = GM_OK;
+#define GM_SET(k) if (rc == GM_OK) rc = set_dyn_lds(k, lds)
+    GM_SET((train_fwd_kernel<128, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<128, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<128, TK_PROC_EDGE>));
+    GM_SET((train_fwd_kernel<128, TK_PROC_NODE>)); GM_SET((train_fwd_kernel<128, TK_DEC>));
+    GM_SET((train_fwd_kernel<256, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<256, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<256, TK_PROC_EDGE>));
+    GM_SET((train_fwd_kernel<256, TK_PROC_NODE>)); GM_SET((train_fwd_kernel<256, TK_DEC>));
+    GM_SET((train_bwd_kernel<128, TB_ENC>)); GM_SET((train_bwd_kernel<128, TB_EDGE>)); GM_SET((train_bwd_kernel<128, TB_NODE>)); GM_SET((train_bwd_kernel<128, TB_DEC>));
+    GM_SET((train_bwd_kernel<256, TB_ENC>)); GM_SET((train_bwd_kernel<256, TB_EDGE>)); GM_SET((train_bwd_kernel<256, TB_NODE>)); GM_SET((train_bwd_kernel<256, TB_DEC>));
+#undef GM_SET
+    if (rc == GM_OK) done = true;
+    return rc;
+}
+
+}  // namespace gm

@@ -1,0 +1,368 @@
+// Training entry points: forward with activation tape and backward of the whole
+// encode-process-decode model (host orchestration; kernels in train.hip / mlp.hip).
+// Reference call sites: examples/train_dyn.py:45-72 (model.forward -> loss.backward -> Adam),
+// gnn_manip/models/epd_gnn.py:86-105 (forward wiring the gradients flow back through).
+#include <vector>
+#include "common.h"
+#include "mlp.h"
+#include "model.h"
+#include "train.h"
+
+using namespace gm;
+
+namespace {
+
+struct Tape {
+    void *csr_dst, *csr_src;
+    size_t csr_bytes;
+    int64_t* ei2;
+    std::vector<float*> h, e, agg;  // block inputs: h[0..M], e[0..M], agg[0..M-1]
+    float* P;
+    TapePtr ee, en, dec;
+    std::vector<TapePtr> te, tn;
+    size_t bytes;
+};
+
+TapePtr take_tape(Carver& c, int64_t rows, int H, bool normed) {
+    TapePtr t{};
+    t.a1 = c.take<float>((size_t)rows * H);
+    t.a2 = c.take<float>((size_t)rows * H);
+    if (normed) {
+        t.xhat = c.take<float>((size_t)rows * H);
+        t.rstd = c.take<float>((size_t)rows);
+    }
+    return t;
+}
+
+Tape carve_tape(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
+    Tape t;
+    const int H = d->hidden_size, M = d->m_steps;
+    Carver c(ws);
+    t.csr_bytes = gm_csr_workspace_bytes(n, e);
+    t.csr_dst = c.take<char>(t.csr_bytes);
+    t.csr_src = c.take<char>(t.csr_bytes);
+    t.ei2 = c.take<int64_t>((size_t)2 * e);
+    t.h.resize(M + 1);
+    t.e.resize(M + 1);
+    t.agg.resize(M);
+    for (int k = 0; k <= M; ++k) t.h[k] = c.take<float>((size_t)n * H);
+    for (int k = 0; k <= M; ++k) t.e[k] = c.take<float>((size_t)e * H);
+    for (int k = 0; k < M; ++k) t.agg[k] = c.take<float>((size_t)n * H);
+    t.P = c.take<float>((size_t)n * 2 * H);
+    t.ee = take_tape(c, e, H, true);
+    t.en = take_tape(c, n, H, true);
+    t.te.resize(M);
+    t.tn.resize(M);
+    for (int k = 0; k < M; ++k) {
+        t.te[k] = take_tape(c, e, H, true);
+        t.tn[k] = take_tape(c, n, H, true);
+    }
+    t.dec = take_tape(c, n, H, false);
+    t.bytes = c.used();
+    return t;
+}
+
+struct BwdWs {
+    float *packT, *gy, *dz1, *dz2, *dz3, *de, *dh, *dagg, *Gi, *Gj, *part;
+    size_t off_dec, off_enc_edge, off_enc_node;
+    std::vector<size_t> off_edge, off_node;
+    size_t bytes;
+};
+
+BwdWs carve_bwd(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
+    BwdWs b;
+    const int H = d->hidden_size, M = d->m_steps;
+    const size_t U = (size_t)layer_stages(H, H) * kStageFloats;  // one HxH unit
+    size_t off = 0;
+    b.off_dec = off; off += (size_t)layer_stages(d->out_dim, H) * kStageFloats + 2 * U;
+    b.off_edge.resize(M);
+    b.off_node.resize(M);
+    for (int k = 0; k < M; ++k) {
+        b.off_node[k] = off; off += (k + 1 < M ? 2 * U : 0) + 4 * U;
+        b.off_edge[k] = off; off += 3 * U;
+    }
+    b.off_enc_node = off; off += 2 * U + 2 * U;
+    b.off_enc_edge = off; off += 2 * U;
+    Carver c(ws);
+    b.packT = c.take<float>(off);
+    const int64_t R = n > e ? n : e;
+    b.gy = c.take<float>((size_t)R * H);
+    b.dz1 = c.take<float>((size_t)R * H);
+    b.dz2 = c.take<float>((size_t)R * H);
+    b.dz3 = c.take<float>((size_t)R * H);
+    b.de = c.take<float>((size_t)e * H);
+    b.dh = c.take<float>((size_t)n * H);
+    b.dagg = c.take<float>((size_t)n * H);
+    b.Gi = c.take<float>((size_t)n * H);
+    b.Gj = c.take<float>((size_t)n * H);
+    const size_t Hp = (size_t)cdiv(H, 128) * 128;
+    b.part = c.take<float>((size_t)256 * Hp * Hp);
+    b.bytes = c.used();
+    return b;
+}
+
+int check_sizes(const gm_model* m, int64_t n, int64_t e, const char* who) {
+    GM_REQUIRE(m, GM_ERR_INVALID_ARGUMENT, "%s: null model", who);
+    GM_REQUIRE(n >= 1 && e >= 0 && n < ((int64_t)1 << 31) && e < ((int64_t)1 << 31) / m->H, GM_ERR_INVALID_ARGUMENT,
+               "%s: sizes out of range (n=%lld, e=%lld)", who, (long long)n, (long long)e);
+    return GM_OK;
+}
+
+const float* mlp_vec(const gm_model* m, size_t voff) { return m->vec + voff; }
+
+}  // namespace
+
+extern "C" {
+
+size_t gm_train_tape_bytes(const gm_model_desc* desc, int64_t n, int64_t e) {
+    if (!desc || n < 0 || e < 0) return 0;
+    return carve_tape(nullptr, desc, n, e).bytes;
+}
+
+size_t gm_train_backward_workspace_bytes(const gm_model_desc* desc, int64_t n, int64_t e) {
+    if (!desc || n < 0 || e < 0) return 0;
+    return carve_bwd(nullptr, desc, n, e).bytes;
+}
+
+int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, const int64_t* edge_index,
+                         int64_t e, float* out, void* tape, size_t tape_bytes, void* stream) {
+    int rc = check_sizes(m, n, e, "gm_epd_forward_train");
+    if (rc != GM_OK) return rc;
+    GM_REQUIRE(nodes && out && tape && (e == 0 || (edge_attr && edge_index)), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward_train: null pointer");
+    const int H = m->H, NL = m->NL, M = m->M;
+    Tape t = carve_tape(tape, &m->d, n, e);
+    GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_epd_forward_train: tape %zu < %zu", tape_bytes, t.bytes);
+    rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // destination-sorted edges (aggregation index i = edge_index[1]) and the source-grouped view of the sorted list
+    rc = gm_csr_from_edge_index(edge_index, n, e, t.csr_dst, t.csr_bytes, stream);
+    if (rc != GM_OK) return rc;
+    CsrWs c = carve_csr(t.csr_dst, n, e);
+    rc = launch_swap_index(c.src, e, t.ei2, s);
+    if (rc != GM_OK) return rc;
+    rc = gm_csr_from_edge_index(t.ei2, n, e, t.csr_src, t.csr_bytes, stream);
+    if (rc != GM_OK) return rc;
+
+    const size_t U = (size_t)m->S_HH * kStageFloats;
+    auto normed = [&](TrainFwdArgs& a, size_t voff) {
+        const float* v = mlp_vec(m, voff);
+        a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
+    };
+    {
+        TrainFwdArgs a{};
+        a.rows = (int)e; a.x_in = edge_attr; a.rowidx = c.eid; a.k1 = m->d.edge_dim; a.wstream = m->packed + m->s_enc_edge;
+        normed(a, m->v_enc_edge);
+        a.tape = t.ee; a.out = t.e[0];
+        rc = launch_train_fwd(H, TK_ENC_EDGE, a, s);
+        if (rc != GM_OK) return rc;
+    }
+    {
+        TrainFwdArgs a{};
+        a.rows = (int)n; a.x_in = nodes; a.k1 = m->d.node_dim; a.wstream = m->packed + m->s_enc_node;
+        normed(a, m->v_enc_node);
+        a.tape = t.en; a.out = t.h[0];
+        rc = launch_train_fwd(H, TK_ENC_NODE, a, s);
+        if (rc != GM_OK) return rc;
+    }
+    for (int k = 0; k < M; ++k) {
+        // P = h_k [W_i | W_j]^T (+ b1): the projection section of the preceding node stream
+        NodeArgs pa{};
+        pa.n_nodes = (int)n; pa.x_in = t.h[k];
+        pa.wstream = k == 0 ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
+                            : m->packed + m->s_node[k - 1] + (size_t)(NL + 2) * U;
+        pa.tail = 1; pa.proj_bias = m->vec + m->v_edge[k]; pa.P_out = t.P;
+        rc = launch_node(H, NL, 2, pa, s);
+        if (rc != GM_OK) return rc;
+        const float* ve = mlp_vec(m, m->v_edge[k]);
+        {
+            TrainFwdArgs a{};
+            a.rows = (int)e; a.x_in = t.e[k]; a.dst = c.dst; a.src = c.src; a.P = t.P; a.wstream = m->packed + m->s_edge[k];
+            normed(a, m->v_edge[k]);
+            a.tape = t.te[k]; a.out = t.e[k + 1]; a.residual = 1;
+            rc = launch_train_fwd(H, TK_PROC_EDGE, a, s);
+            if (rc != GM_OK) return rc;
+        }
+        // agg_i = sum over edges into i of e' = gamma * sum xhat + deg * beta
+        rc = launch_segment_sum(H, c.in_ptr, nullptr, t.te[k].xhat, ve + (size_t)(NL + 1) * H, ve + (size_t)(NL + 2) * H, t.agg[k], n, s);
+        if (rc != GM_OK) return rc;
+        {
+            TrainFwdArgs a{};
+            a.rows = (int)n; a.x_in = t.h[k]; a.agg = t.agg[k]; a.wstream = m->packed + m->s_node[k];
+            normed(a, m->v_node[k]);
+            a.tape = t.tn[k]; a.out = t.h[k + 1]; a.residual = 1;
+            rc = launch_train_fwd(H, TK_PROC_NODE, a, s);
+            if (rc != GM_OK) return rc;
+        }
+    }
+    {
+        TrainFwdArgs a{};
+        a.rows = (int)n; a.x_in = t.h[M]; a.wstream = m->packed + m->s_node[M - 1] + (size_t)(NL + 2) * U;
+        const float* v = mlp_vec(m, m->v_dec);
+        a.bias = v; a.bias_tail = v + H;
+        a.tape = t.dec; a.out = out; a.out_dim = m->d.out_dim;
+        rc = launch_train_fwd(H, TK_DEC, a, s);
+        if (rc != GM_OK) return rc;
+    }
+    return GM_OK;
+}
+
+int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, const float* nodes, const float* edge_attr, int64_t n,
+                    int64_t e, const float* grad_out, float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                    void* stream) {
+    int rc = check_sizes(m, n, e, "gm_epd_backward");
+    if (rc != GM_OK) return rc;
+    GM_REQUIRE(T && grads && nodes && grad_out && tape && ws && (e == 0 || edge_attr), GM_ERR_INVALID_ARGUMENT, "gm_epd_backward: null pointer");
+    GM_REQUIRE(n_tensors == gm_model_num_tensors(&m->d), GM_ERR_INVALID_ARGUMENT, "gm_epd_backward: expected %d tensors, got %d",
+               gm_model_num_tensors(&m->d), n_tensors);
+    for (int i = 0; i < n_tensors; ++i)
+        GM_REQUIRE(T[i] && grads[i], GM_ERR_INVALID_ARGUMENT, "gm_epd_backward: tensor / gradient %d is null", i);
+    const int H = m->H, NL = m->NL, M = m->M, OD = m->d.out_dim;
+    GM_REQUIRE(NL == 2, GM_ERR_UNSUPPORTED, "gm_epd_backward: num_layers=%d not instantiated", NL);
+    Tape t = carve_tape(tape, &m->d, n, e);
+    GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_epd_backward: tape %zu < %zu", tape_bytes, t.bytes);
+    BwdWs b = carve_bwd(ws, &m->d, n, e);
+    GM_REQUIRE(ws_bytes >= b.bytes, GM_ERR_WORKSPACE, "gm_epd_backward: workspace %zu < %zu", ws_bytes, b.bytes);
+    rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    CsrWs c = carve_csr(t.csr_dst, n, e);
+    CsrWs c2 = carve_csr(t.csr_src, n, e);
+    const int PM = tensors_per_normed_mlp(NL);
+    const int b_enc_edge = 0, b_enc_node = PM, b_dec = (2 + 2 * M) * PM;
+    auto b_edge = [&](int k) { return (2 + 2 * k) * PM; };
+    auto b_node = [&](int k) { return (3 + 2 * k) * PM; };
+    const size_t U = (size_t)m->S_HH * kStageFloats;
+
+    // ---- transposed operand images of every Linear on the backward path
+    {
+        auto packT = [&](const float* W, int w_rows, int ld, int col0, int ksub, size_t& off) {
+            if (rc != GM_OK) return;
+            rc = pack_linear_t(W, w_rows, ld, col0, ksub, b.packT + off, s);
+            off += (size_t)layer_stages(w_rows, ksub) * kStageFloats;
+        };
+        size_t off = b.off_dec;
+        packT(T[b_dec + 4], OD, H, 0, H, off);
+        packT(T[b_dec + 2], H, H, 0, H, off);
+        packT(T[b_dec + 0], H, H, 0, H, off);
+        for (int k = 0; k < M; ++k) {
+            off = b.off_node[k];
+            if (k + 1 < M) {
+                packT(T[b_edge(k + 1)], H, 3 * H, 0, H, off);
+                packT(T[b_edge(k + 1)], H, 3 * H, H, H, off);
+            }
+            packT(T[b_node(k) + 4], H, H, 0, H, off);
+            packT(T[b_node(k) + 2], H, H, 0, H, off);
+            packT(T[b_node(k)], H, 2 * H, 0, H, off);
+            packT(T[b_node(k)], H, 2 * H, H, H, off);
+            off = b.off_edge[k];
+            packT(T[b_edge(k) + 4], H, H, 0, H, off);
+            packT(T[b_edge(k) + 2], H, H, 0, H, off);
+            packT(T[b_edge(k)], H, 3 * H, 2 * H, H, off);
+        }
+        off = b.off_enc_node;
+        packT(T[b_edge(0)], H, 3 * H, 0, H, off);
+        packT(T[b_edge(0)], H, 3 * H, H, H, off);
+        packT(T[b_enc_node + 4], H, H, 0, H, off);
+        packT(T[b_enc_node + 2], H, H, 0, H, off);
+        off = b.off_enc_edge;
+        packT(T[b_enc_edge + 4], H, H, 0, H, off);
+        packT(T[b_enc_edge + 2], H, H, 0, H, off);
+        if (rc != GM_OK) return rc;
+    }
+
+    auto wgrad = [&](const float* dz, int ldz, int Mo, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* out, int ldw,
+                     int col0) {
+        if (rc == GM_OK) rc = launch_wgrad(dz, ldz, Mo, X, ldx, K, xidx, rows, b.part, out, ldw, col0, s);
+    };
+    // W3, W2 and the five vector gradients of a normed MLP whose chain kernel has just run over `rows`
+    auto normed_tail_grads = [&](int base, const TapePtr& tp, int64_t rows) {
+        wgrad(b.dz3, H, H, tp.a2, H, H, nullptr, rows, grads[base + 4], H, 0);
+        wgrad(b.dz2, H, H, tp.a1, H, H, nullptr, rows, grads[base + 2], H, 0);
+        ColsumJobs j{};
+        j.n = 5;
+        const float* As[5] = {b.dz1, b.dz2, b.dz3, b.gy, b.gy};
+        const float* Bs[5] = {nullptr, nullptr, nullptr, tp.xhat, nullptr};
+        float* Os[5] = {grads[base + 1], grads[base + 3], grads[base + 5], grads[base + 6], grads[base + 7]};
+        for (int q = 0; q < 5; ++q) { j.A[q] = As[q]; j.B[q] = Bs[q]; j.out[q] = Os[q]; j.cols[q] = H; j.ld[q] = H; }
+        if (rc == GM_OK) rc = launch_colsum(j, rows, s);
+    };
+    auto ln_gamma = [&](size_t voff) { return m->vec + voff + (size_t)(NL + 1) * H; };
+
+    // ---- decoder
+    {
+        TrainBwdArgs a{};
+        a.rows = (int)n; a.dY = grad_out; a.out_dim = OD; a.tape = t.dec; a.wstream = b.packT + b.off_dec;
+        a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx = b.dh;
+        rc = launch_train_bwd(H, TB_DEC, a, s);
+        if (rc != GM_OK) return rc;
+        wgrad(grad_out, OD, OD, t.dec.a2, H, H, nullptr, n, grads[b_dec + 4], H, 0);
+        wgrad(b.dz2, H, H, t.dec.a1, H, H, nullptr, n, grads[b_dec + 2], H, 0);
+        wgrad(b.dz1, H, H, t.h[M], H, H, nullptr, n, grads[b_dec + 0], H, 0);
+        ColsumJobs j{};
+        j.n = 3;
+        j.A[0] = b.dz1; j.out[0] = grads[b_dec + 1]; j.cols[0] = H; j.ld[0] = H;
+        j.A[1] = b.dz2; j.out[1] = grads[b_dec + 3]; j.cols[1] = H; j.ld[1] = H;
+        j.A[2] = grad_out; j.out[2] = grads[b_dec + 5]; j.cols[2] = OD; j.ld[2] = OD;
+        if (rc == GM_OK) rc = launch_colsum(j, n, s);
+        if (rc != GM_OK) return rc;
+    }
+    // ---- processor blocks, last to first
+    for (int k = M - 1; k >= 0; --k) {
+        const bool has_next = k + 1 < M;
+        {
+            TrainBwdArgs a{};
+            a.rows = (int)n; a.dY = b.dh; a.Gi = has_next ? b.Gi : nullptr; a.Gj = has_next ? b.Gj : nullptr;
+            a.tape = t.tn[k]; a.ln_g = ln_gamma(m->v_node[k]); a.wstream = b.packT + b.off_node[k];
+            a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
+            rc = launch_train_bwd(H, TB_NODE, a, s);
+            if (rc != GM_OK) return rc;
+            normed_tail_grads(b_node(k), t.tn[k], n);
+            wgrad(b.dz1, H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, 0);
+            wgrad(b.dz1, H, H, t.agg[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, H);
+            if (rc != GM_OK) return rc;
+        }
+        {
+            TrainBwdArgs a{};
+            a.rows = (int)e; a.dY = has_next ? b.de : nullptr; a.dagg = b.dagg; a.dst = c.dst;
+            a.tape = t.te[k]; a.ln_g = ln_gamma(m->v_edge[k]); a.wstream = b.packT + b.off_edge[k];
+            a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx = b.de; a.residual = 1;
+            rc = launch_train_bwd(H, TB_EDGE, a, s);
+            if (rc != GM_OK) return rc;
+            normed_tail_grads(b_edge(k), t.te[k], e);
+            wgrad(b.dz1, H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, 2 * H);
+            if (rc != GM_OK) return rc;
+            // node-level sums of dz1: everything the factorised layer 1 needs
+            rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dz1, nullptr, nullptr, b.Gi, n, s);
+            if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dz1, nullptr, nullptr, b.Gj, n, s);
+            wgrad(b.Gi, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, 0);
+            wgrad(b.Gj, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, H);
+            if (rc != GM_OK) return rc;
+        }
+    }
+    // ---- encoders
+    {
+        TrainBwdArgs a{};
+        a.rows = (int)n; a.dY = b.dh; a.Gi = b.Gi; a.Gj = b.Gj; a.tape = t.en; a.ln_g = ln_gamma(m->v_enc_node);
+        a.wstream = b.packT + b.off_enc_node;
+        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1;
+        rc = launch_train_bwd(H, TB_ENC, a, s);
+        if (rc != GM_OK) return rc;
+        normed_tail_grads(b_enc_node, t.en, n);
+        wgrad(b.dz1, H, H, nodes, m->d.node_dim, m->d.node_dim, nullptr, n, grads[b_enc_node], m->d.node_dim, 0);
+        if (rc != GM_OK) return rc;
+    }
+    if (e > 0) {
+        TrainBwdArgs a{};
+        a.rows = (int)e; a.dY = b.de; a.tape = t.ee; a.ln_g = ln_gamma(m->v_enc_edge); a.wstream = b.packT + b.off_enc_edge;
+        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1;
+        rc = launch_train_bwd(H, TB_ENC, a, s);
+        if (rc != GM_OK) return rc;
+        normed_tail_grads(b_enc_edge, t.ee, e);
+        wgrad(b.dz1, H, H, edge_attr, m->d.edge_dim, m->d.edge_dim, c.eid, e, grads[b_enc_edge], m->d.edge_dim, 0);
+        if (rc != GM_OK) return rc;
+    }
+    return GM_OK;
+}
+
+}  // extern "C"

@@ -10,7 +10,9 @@ operand image of them (re-packed when a parameter changes) and runs the fused HI
 Block semantics (the torch_graphnet source is absent from the reference tree; fixed by
 BASELINE.json north_star, see DESIGN.md): j = edge_index[0] (source), i = edge_index[1] (target);
 e' = phi_e(cat[h_i, h_j, e]); agg_i = sum_{e -> i} e'; h' = phi_v(cat[h, agg]); no residual inside
-the block.  Forward only (inference / planning); autograd is not implemented yet.
+the block.  ``EncProcDecGNN.forward`` is differentiable w.r.t. every parameter (``train_dyn.py``:
+forward with an activation tape + hand-written HIP backward, see csrc/train.hip); the two standalone
+blocks are forward-only.
 """
 import ctypes as C
 
@@ -196,6 +198,49 @@ def _run_block(handle, desc, k, x, edge_attr, edge_index, csr=None):
     return h_out, e_out, None
 
 
+class _EpdTrainFunction(torch.autograd.Function):
+    """``EncProcDecGNN.forward`` under autograd (examples/train_dyn.py:45-72): the forward records the
+    activation tape in one device buffer, the backward is gm_epd_backward.  Gradients are produced for the
+    parameters only; nodes / edge_attr / edge_index are data."""
+
+    @staticmethod
+    def forward(ctx, module, nodes, edge_attr, edge_index, *params):
+        L = lib()
+        n, e = int(nodes.shape[0]), int(edge_attr.shape[0])
+        h = module.device_handle(nodes.device)
+        d = ModelDesc(*module.model_desc())
+        tape = _ws(L.gm_train_tape_bytes(C.byref(d), n, e), nodes.device)
+        out = torch.empty((n, module.dims[2]), dtype=torch.float32, device=nodes.device)
+        ei = edge_index.contiguous()
+        check(L.gm_epd_forward_train(h, ptr(nodes), n, ptr(edge_attr), ptr(ei), e, ptr(out), ptr(tape), tape.numel(),
+                                     current_stream()))
+        ctx.module, ctx.handle, ctx.desc, ctx.tape = module, h, d, tape
+        ctx.sizes = (n, e)
+        ctx.save_for_backward(nodes, edge_attr, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L = lib()
+        nodes, edge_attr, *params = ctx.saved_tensors
+        n, e = ctx.sizes
+        dev = nodes.device
+        grad_out = grad_out.contiguous().float()
+        tensors = [p.detach().to(device=dev, dtype=torch.float32).contiguous() for p in params]
+        flat = torch.zeros(sum(t.numel() for t in tensors), dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for t in tensors:
+            views.append(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        t_arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        g_arr = (C.c_void_p * len(views))(*[v.data_ptr() for v in views])
+        ws = _ws(L.gm_train_backward_workspace_bytes(C.byref(ctx.desc), n, e), dev)
+        check(L.gm_epd_backward(ctx.handle, t_arr, len(tensors), ptr(nodes), ptr(edge_attr), n, e, ptr(grad_out), g_arr,
+                                ptr(ctx.tape), ctx.tape.numel(), ptr(ws), ws.numel(), current_stream()))
+        ctx.tape = None
+        return (None, None, None, None) + tuple(views)
+
+
 class EncProcDecGNN(nn.Module):
     """Drop-in for the reference ``EncProcDecGNN`` (gnn_manip/models/epd_gnn.py:11-105)."""
 
@@ -248,7 +293,6 @@ class EncProcDecGNN(nn.Module):
     def forward(self, nodes, edge_attr, edge_index):
         """epd_gnn.py:86-98: encoder -> m_steps x (InteractionNetwork + residuals) -> decoder, fused."""
         _need_cuda(nodes, "nodes")
-        _no_grad_guard(list(self.parameters()), "EncProcDecGNN.forward")
         nodes = nodes.contiguous().float()
         edge_attr = edge_attr.contiguous().float()
         n, e = int(nodes.shape[0]), int(edge_attr.shape[0])
@@ -256,6 +300,18 @@ class EncProcDecGNN(nn.Module):
             raise ValueError("nodes / edge_attr feature widths do not match the model")
         if edge_index.shape[1] != e:
             raise ValueError("edge_index and edge_attr disagree on the number of edges")
+        params = list(self.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            # training (examples/train_dyn.py:45-72): forward with tape, HIP backward
+            if nodes.requires_grad or edge_attr.requires_grad:
+                raise NotImplementedError("EncProcDecGNN: gradients w.r.t. nodes / edge_attr are not produced "
+                                          "(they are data in train_dyn.py); detach them")
+            _need_cuda(edge_index, "edge_index")
+            if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+                raise ValueError("edge_index must be int64 [2, E]")
+            if e and (int(edge_index.min()) < 0 or int(edge_index.max()) >= n):
+                raise ValueError("edge_index entry out of range [0, n_nodes)")
+            return _EpdTrainFunction.apply(self, nodes, edge_attr, edge_index, *params)
         h = self.device_handle(nodes.device)
         csr = DstCsr(edge_index, n)
         L = lib()

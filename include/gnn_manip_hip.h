@@ -180,6 +180,27 @@ int gm_interaction_network_forward(const gm_model* m, int block, const float* h,
                                    void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training: what examples/train_dyn.py:45-72 does with the model --
+ * `model.forward(x, edge_attr, edge_index)` under autograd, `loss.backward()`, optimiser step.
+ * gm_epd_forward_train == EncProcDecGNN.forward (epd_gnn.py:86-105) that also records the activation
+ * tape in the caller's buffer (gm_train_tape_bytes); edge_index is the caller's int64 [2, E]
+ * (j = row 0, aggregation index i = row 1).  gm_epd_backward consumes the tape and ACCUMULATES the
+ * gradient of every parameter into grads[t] (same order and shapes as the `tensors` of
+ * gm_model_create; the caller zeroes them), given grad_out = dLoss/d(out) [N, out_dim].  `tensors`
+ * are the parameter values the forward ran with (device pointers).  Inputs x / edge_attr get no
+ * gradient (they are data in train_dyn.py).  Weight gradients are reduced in a fixed order
+ * (deterministic); bias / LayerNorm gradients use float atomics. */
+size_t gm_train_tape_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t n_edges);
+size_t gm_train_backward_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t n_edges);
+int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n_nodes, const float* edge_attr,
+                         const int64_t* edge_index, int64_t n_edges, float* out, void* tape,
+                         size_t tape_bytes, void* stream);
+int gm_epd_backward(const gm_model* m, const float* const* tensors, int n_tensors, const float* nodes,
+                    const float* edge_attr, int64_t n_nodes, int64_t n_edges, const float* grad_out,
+                    float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * One device-resident rollout step = compute_rollout's loop body, rollout_utils.py:38-61 ==
  * cma_objective's, traj_utils.py:123-152:  state_pre -> node features -> radius graph -> csr ->
  * edge features -> forward -> integrate -> state_post.  No host synchronisation.

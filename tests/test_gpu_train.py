@@ -1,0 +1,120 @@
+"""Training path on the MI355X: forward with tape + HIP backward (csrc/train.hip) against the plain-PyTorch
+float64 CPU restatement oracle/torch_epd.py (reference call site examples/train_dyn.py:45-72).
+
+Tolerances (floating point, stated here): forward 1e-5 relative (north_star).  Gradients: max |g - g64| <=
+max(2e-4, 4 x the error of the SAME plain-PyTorch model run in float32) x max |g64| per tensor, g64 = float64
+oracle.  The second term exists because the gradient of a ReLU network with an L1 loss is discontinuous:
+one pre-activation whose sign differs between float32 and float64 arithmetic moves a whole row's contribution
+(~1e-3 of a tensor at these sizes) -- plain PyTorch float32 shows exactly the same deviations on the same tensors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import BOUNDS, CART, CTRL, MAT, STATS
+from oracle import epd_oracle as orc
+from oracle import torch_epd
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(stats=STATS, bounds=BOUNDS, conn_r=0.015, cartesian_idx=CART, material_idx=MAT)
+GRAD_TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _model(params, dims, dev):
+    from gnn_manip_amd import EncProcDecGNN
+    m = EncProcDecGNN(*dims)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return m.to(dev)
+
+
+def _graph(n, side, seed):
+    from gnn_manip_amd import scene
+    obs = scene.make_scene(n, seed=seed, side=side)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    return nodes, ea, np.stack((s, r))
+
+
+def _check(m, params, nodes, ea, ei, dims, dev, seed):
+    rng = np.random.default_rng(seed)
+    target = rng.standard_normal((nodes.shape[0], dims[2])).astype(np.float32)
+    out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+    loss = torch.nn.functional.l1_loss(out, _t(target, dev), reduction="sum") / out.shape[0]  # train_dyn.py:65
+    loss.backward()
+    ref_out, ref_loss, ref_g = torch_epd.loss_and_grads(params, nodes, ea, ei, target, dims[4], dims[5])
+    _, _, g32 = torch_epd.loss_and_grads(params, nodes, ea, ei, target, dims[4], dims[5], torch.float32)
+    assert np.abs(out.detach().cpu().numpy() - ref_out).max() <= 1e-5 * max(np.abs(ref_out).max(), 1e-3)
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-5 * abs(ref_loss)
+    worst = ("", 0.0)
+    for name, p in m.named_parameters():
+        assert p.grad is not None, name
+        g, r = p.grad.cpu().numpy(), ref_g[name]
+        assert g.shape == r.shape, name
+        scale = max(np.abs(r).max(), 1e-12)
+        err = np.abs(g - r).max() / scale
+        tol = max(GRAD_TOL, 4.0 * np.abs(g32[name] - r).max() / scale)
+        if err / tol > worst[1]:
+            worst = (name, err / tol, err, tol)
+    assert worst[1] <= 1.0, worst
+
+
+@pytest.mark.parametrize("n,side,seed,m_steps", [(900, 0.075, 91, 3), (130, 0.3, 92, 2), (2500, 0.1, 93, 10)])
+def test_backward_matches_torch_autograd(dev, n, side, seed, m_steps):
+    """All 22 + 8*m parameter gradients of the L1 training loss; dense, sparse (isolated nodes) and full-depth graphs."""
+    dims = (25, 4, 3, 128, 2, m_steps)
+    params = orc.init_params(*dims, seed)
+    m = _model(params, dims, dev)
+    nodes, ea, ei = _graph(n, side, seed)
+    _check(m, params, nodes, ea, ei, dims, dev, seed)
+
+
+def test_backward_hidden_256(dev):
+    dims = (25, 4, 3, 256, 2, 2)
+    params = orc.init_params(*dims, 94)
+    m = _model(params, dims, dev)
+    nodes, ea, ei = _graph(400, 0.07, 94)
+    _check(m, params, nodes, ea, ei, dims, dev, 94)
+
+
+def test_backward_collated_batch_of_two(dev, golden):
+    """The training loader's input: two graphs collated with the index offset (collate_utils.py:68-87)."""
+    g4 = golden("g4_features.npz")
+    nodes, ea, ei, _ = orc.process_collate([(g4["obs_a"], g4["tgt_a"]), (g4["obs_b"], g4["tgt_b"])], control_idx=CTRL, **KW)
+    dims = (25, 4, 3, 128, 2, 2)
+    params = orc.init_params(*dims, 95)
+    m = _model(params, dims, dev)
+    _check(m, params, nodes, ea, ei, dims, dev, 95)
+
+
+def test_training_step_reduces_loss_and_inference_sees_new_weights(dev):
+    """train_dyn.py:49-72: zero_grad / backward / Adam step, repeated; the fused inference path then runs on the
+    updated parameters (re-pack on change) and agrees with the training forward."""
+    dims = (25, 4, 3, 128, 2, 2)
+    params = orc.init_params(*dims, 96)
+    m = _model(params, dims, dev)
+    nodes, ea, ei = _graph(500, 0.06, 96)
+    x, a, idx = _t(nodes, dev), _t(ea, dev), _t(ei, dev)
+    tgt = torch.zeros((nodes.shape[0], 3), device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(5):
+        out = m.forward(x, a, idx)
+        loss = torch.nn.functional.l1_loss(out, tgt, reduction="sum") / out.shape[0]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]
+    out_train = m.forward(x, a, idx).detach()
+    with torch.no_grad():
+        out_inf = m.forward(x, a, idx)
+    assert (out_train - out_inf).abs().max() <= 1e-5 * out_inf.abs().max()

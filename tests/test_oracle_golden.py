@@ -152,3 +152,19 @@ def test_g8_rollout_loop(golden):
     np.testing.assert_allclose(end, g["end_coffee"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(recs[:, ~rigid][:, :, CART], g["coffee_states"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(recs[:, rigid][:, :, CART], g["cup_states"], rtol=0, atol=5e-6)
+
+
+def test_torch_restatement_matches_numpy_oracle():
+    """oracle/torch_epd.py (the differentiable restatement the backward tests use) == numpy oracle forward."""
+    import torch
+    from oracle import torch_epd
+    from gnn_manip_amd import scene
+    obs = scene.make_scene(300, seed=5, side=0.06)
+    params = orc.init_params(25, 4, 3, 128, 2, 3, 7)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    ei = np.stack((s, r))
+    ref = orc.epd_forward(params, nodes, ea, ei, 2, 3)
+    p = {k: torch.tensor(v, dtype=torch.float64) for k, v in params.items()}
+    out = torch_epd.epd_forward(p, torch.tensor(nodes, dtype=torch.float64), torch.tensor(ea, dtype=torch.float64),
+                                torch.tensor(ei), 2, 3).numpy()
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
