@@ -55,23 +55,27 @@ struct TrainBwdArgs {
     int out_dim;
 };
 
-struct ColsumJobs {
+struct PackTJob {
+    const float* W;   // row-major [w_rows][ld]
+    int w_rows, ld, col0, ksub;
+    size_t dst_off;   // floats from the base of the packed buffer
+};
+constexpr int kPackTJobsMax = 96;
+struct PackTJobs {
     int n;
-    const float* A[5];
-    const float* B[5];  // optional element-wise factor
-    float* out[5];
-    int cols[5];
-    int ld[5];
+    PackTJob job[kPackTJobsMax];
 };
 
 int train_kernels_init();
 int launch_train_fwd(int H, int kind, const TrainFwdArgs& a, hipStream_t s);
 int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s);
-size_t wgrad_partial_floats(int64_t rows, int M, int K);
-// out[m][col0 + k] += sum_r dz[r][m] * X[xidx ? xidx[r] : r][k]
+size_t wgrad_partial_floats(int H);
+// out[m][col0 + k] += sum_r dz[r][m] * X[xidx ? xidx[r] : r][k];  db[m] += sum_r dz[r][m] (db may be nullptr)
 int launch_wgrad(const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* part,
-                 float* out, int ldw, int col0, hipStream_t s);
-int launch_colsum(const ColsumJobs& j, int64_t rows, hipStream_t s);
+                 float* out, int ldw, int col0, float* db, hipStream_t s);
+// dgamma += colsum(gy * xhat), dbeta += colsum(gy)
+int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, float* dgamma, float* dbeta, hipStream_t s);
+int launch_pack_t_batch(const PackTJobs& jobs, float* base, hipStream_t s);
 int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows, const float* scale, const float* shift, float* out,
                        int64_t n, hipStream_t s);
 int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_t s);

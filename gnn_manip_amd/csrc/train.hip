@@ -9,7 +9,8 @@
 // so one kernel per MLP produces dz1..dz3 and the input gradient.  Everything that reduces over ROWS
 // (weight, bias and LayerNorm-parameter gradients) is done by two generic kernels on the arrays the
 // chain kernels leave in HBM: wgrad_kernel (dW = dz^T X as a split-K MFMA GEMM, operands read in
-// their natural row-major layout, deterministic two-stage reduction) and colsum_kernel.
+// their natural row-major layout, bias gradient = column sums of the same operand, deterministic
+// two-stage reduction) and ln_grads_kernel.
 //
 // The layer-1 factorisation of the edge MLP (P = h [W_i|W_j]^T per node) carries over to the backward:
 // by linearity  dh_i = W_i^T sum_{edges into i} dz1  and  dW_i = (sum_{edges into i} dz1)^T h, so the
@@ -299,13 +300,23 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
 }
 
 // ------------------------------------------------------------------------------------------
-// dW = dz^T X  (split over rows; partial[g][m][k])
+// dW = dz^T X  (+ db = column sums of dz), split over rows: partial[g][m][k], partial_b[g][m].
+// A wave owns a 64 x 64 block of dW (2 x 2 MFMA 32x32x2 tiles); per two-row step its A operands are
+// dz[r + hi][m0 + i], its B operands X[r + hi][k0 + i]: both are 128-byte coalesced reads of the
+// row-major arrays, no staging.  The operands of the next WG_U steps are requested before the MFMAs
+// of the current ones (register double buffer), so one wave per SIMD already keeps the matrix pipe
+// and the memory path busy at the same time.
 // ------------------------------------------------------------------------------------------
-constexpr int WG_U = 8;  // 2-row MFMA steps whose operands are requested together
+constexpr int WG_U = 8;  // 2-row MFMA steps per operand batch
 
+struct WgOperands {
+    float a0[WG_U], a1[WG_U], b0[WG_U], b1[WG_U];
+};
+
+template <bool HAS_IDX>
 __global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(const float* __restrict__ dz, int ldz, int M, const float* __restrict__ X, int ldx,
                                                             int K, const int* __restrict__ xidx, int rows, int chunk, float* __restrict__ part,
-                                                            int Mp, int Kp) {
+                                                            float* __restrict__ partb, int Mp, int Kp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
     const int KT = Kp / 128;
     const int mt = blockIdx.y / KT, kt = blockIdx.y % KT;
@@ -319,28 +330,64 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(const float* __restri
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const bool mv0 = m0 + i < M, mv1 = m0 + 32 + i < M, kv0 = k0 + i < K, kv1 = k0 + 32 + i < K;
-    for (int r0 = r_begin; r0 < r_end; r0 += 2 * WG_U) {
-        float a0[WG_U], a1[WG_U], b0[WG_U], b1[WG_U];
+    // Every load is unconditional from a clamped (always valid) address; out-of-range rows / columns are
+    // zeroed by a multiplication with 0 afterwards (a select would let the compiler sink the loads into
+    // branches, with a full wait behind each).  No branches, no dependent waits inside a batch.
+    const float mv0 = m0 + i < M ? 1.f : 0.f, mv1 = m0 + 32 + i < M ? 1.f : 0.f, kv0 = k0 + i < K ? 1.f : 0.f, kv1 = k0 + 32 + i < K ? 1.f : 0.f;
+    const int mc0 = min(m0 + i, M - 1), mc1 = min(m0 + 32 + i, M - 1), kc0 = min(k0 + i, K - 1), kc1 = min(k0 + 32 + i, K - 1);
+    float bs0 = 0.f, bs1 = 0.f;  // column sums of dz (bias gradient), kept by the waves of k-block 0
+    auto load = [&](WgOperands& o, int r0) {
+        int64_t rx[WG_U];
 #pragma unroll
         for (int u = 0; u < WG_U; ++u) {
-            const int r = r0 + 2 * u + hi;
-            const bool rv = r < r_end;
-            const int64_t rz = rv ? r : r_begin;
-            const int64_t rx = xidx ? xidx[rz] : rz;
-            const float* zr = dz + rz * ldz + m0 + i;
-            const float* xr = X + rx * ldx + k0 + i;
-            a0[u] = rv && mv0 ? zr[0] : 0.f;
-            a1[u] = rv && mv1 ? zr[32] : 0.f;
-            b0[u] = rv && kv0 ? xr[0] : 0.f;
-            b1[u] = rv && kv1 ? xr[32] : 0.f;
+            const int r = min(r0 + 2 * u + hi, r_end - 1);
+            rx[u] = HAS_IDX ? xidx[r] : r;
         }
 #pragma unroll
         for (int u = 0; u < WG_U; ++u) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+            const int rr = r0 + 2 * u + hi;
+            const int64_t rz = min(rr, r_end - 1);
+            const float* zr = dz + rz * ldz;
+            const float* xr = X + rx[u] * ldx;
+            o.a0[u] = zr[mc0];
+            o.a1[u] = zr[mc1];
+            o.b0[u] = xr[kc0];
+            o.b1[u] = xr[kc1];
+        }
+    };
+    // the masks are applied here, where the values are consumed: applying them in load() would put the wait
+    // for a batch right behind its own requests
+    auto fma = [&](const WgOperands& o, int r0) {
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            const float rv = r0 + 2 * u + hi < r_end ? 1.f : 0.f;
+            const float a0 = o.a0[u] * (rv * mv0), a1 = o.a1[u] * (rv * mv1), b0 = o.b0[u] * kv0, b1 = o.b1[u] * kv1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            bs0 += a0;
+            bs1 += a1;
+        }
+    };
+    WgOperands A, B;
+    int r0 = r_begin;
+    if (r0 < r_end) {
+        load(A, r0);
+        while (true) {
+            const int r1 = r0 + 2 * WG_U;
+            load(B, r1);  // unconditional (clamped): a conditional request would make every wait below conservative
+            __builtin_amdgcn_sched_barrier(0);
+            fma(A, r0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (r1 >= r_end) break;
+            const int r2 = r1 + 2 * WG_U;
+            load(A, r2);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(B, r1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (r2 >= r_end) break;
+            r0 = r2;
         }
     }
     float* out = part + (size_t)blockIdx.x * Mp * Kp;
@@ -354,46 +401,110 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(const float* __restri
                 const int k = k0 + 32 * b + i;
                 out[(size_t)m * Kp + k] = acc[a][b][r];
             }
+    if (partb && kt == 0 && (wave & 1) == 0) {
+        bs0 += __shfl_xor(bs0, 32, 64);
+        bs1 += __shfl_xor(bs1, 32, 64);
+        if (hi == 0) {
+            partb[(size_t)blockIdx.x * Mp + m0 + i] = bs0;
+            partb[(size_t)blockIdx.x * Mp + m0 + 32 + i] = bs1;
+        }
+    }
 }
 
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int G, int Mp, int Kp, int M, int K,
-                                                            float* __restrict__ out, int ldw, int col0) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= M * K) return;
-    const int m = idx / K, k = idx % K;
+// out[m][col0 + k] += sum_g part[g][m][k]; db[m] += sum_g partb[g][m].  32 outputs x 8 partial groups per
+// workgroup, fixed summation order (deterministic).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ partb, int G, int Mp,
+                                                            int Kp, int M, int K, float* __restrict__ out, int ldw, int col0,
+                                                            float* __restrict__ db) {
+    __shared__ float red[8][33];
+    const int tid = threadIdx.x, i = tid & 31, gg = tid >> 5;
+    const int o = blockIdx.x * 32 + i;
+    const int nw = M * K, total = nw + (db ? M : 0);
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[((size_t)g * Mp + m) * Kp + k];
-    out[(size_t)m * ldw + col0 + k] += s;
+    if (o < nw) {
+        const int m = o / K, k = o % K;
+        for (int g = gg; g < G; g += 8) s += part[((size_t)g * Mp + m) * Kp + k];
+    } else if (o < total) {
+        const int m = o - nw;
+        for (int g = gg; g < G; g += 8) s += partb[(size_t)g * Mp + m];
+    }
+    red[gg][i] = s;
+    __syncthreads();
+    if (gg == 0 && o < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][i];
+        if (o < nw) out[(size_t)(o / K) * ldw + col0 + (o % K)] += t;
+        else db[o - nw] += t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// column sums: out_j[c] += sum_r A_j[r][c] * (B_j ? B_j[r][c] : 1), up to 5 jobs per launch
+// LayerNorm parameter gradients: dgamma[c] += sum_r gy[r][c] * xhat[r][c],  dbeta[c] += sum_r gy[r][c]
+// (streaming; a thread owns 4 columns and every (256 / (H/4))-th row of its workgroup's chunk)
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) colsum_kernel(ColsumJobs J, int rows, int chunk) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
+template <int H>
+__global__ void __launch_bounds__(256) ln_grads_kernel(const float* __restrict__ gy, const float* __restrict__ xhat, int rows, int chunk,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int CT = H / 4, PH = 256 / CT;
+    __shared__ floatx4 rg[256], rb[256];
+    const int tid = threadIdx.x, c = tid % CT, ph = tid / CT;
     const int r_begin = blockIdx.x * chunk, r_end = min(rows, r_begin + chunk);
-    for (int j = 0; j < J.n; ++j) {
-        const int cols = J.cols[j], ld = J.ld[j];
-        const int per = 256 / cols >= 1 ? 256 / cols : 1;  // row phases (cols <= 256)
-        const int c = tid % cols, ph = tid / cols;
-        float s = 0.f;
-        if (ph < per) {
-            const float* A = J.A[j];
-            const float* B = J.B[j];
-            for (int r = r_begin + ph; r < r_end; r += per) {
-                const float a = A[(size_t)r * ld + c];
-                s += B ? a * B[(size_t)r * ld + c] : a;
-            }
+    floatx4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+    int r = r_begin + ph;
+    for (; r + 3 * PH < r_end; r += 4 * PH) {
+        floatx4 g[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            g[u] = *reinterpret_cast<const floatx4*>(gy + (size_t)(r + u * PH) * H + 4 * c);
+            x[u] = *reinterpret_cast<const floatx4*>(xhat + (size_t)(r + u * PH) * H + 4 * c);
         }
-        red[tid] = s;
-        __syncthreads();
-        if (tid < cols) {
-            float t = 0.f;
-            for (int q = 0; q < per; ++q) t += red[q * cols + tid];
-            atomicAdd(J.out[j] + tid, t);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sg += g[u] * x[u];
+            sb += g[u];
         }
-        __syncthreads();
+    }
+    for (; r < r_end; r += PH) {
+        const floatx4 g = *reinterpret_cast<const floatx4*>(gy + (size_t)r * H + 4 * c);
+        const floatx4 x = *reinterpret_cast<const floatx4*>(xhat + (size_t)r * H + 4 * c);
+        sg += g * x;
+        sb += g;
+    }
+    rg[tid] = sg;
+    rb[tid] = sb;
+    __syncthreads();
+    if (tid < CT) {
+        floatx4 tg = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < PH; ++q) {
+            tg += rg[q * CT + tid];
+            tb += rb[q * CT + tid];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            atomicAdd(dgamma + 4 * tid + t, tg[t]);
+            atomicAdd(dbeta + 4 * tid + t, tb[t]);
+        }
+    }
+}
+
+// Transposed operand images of many Linears in one launch (blockIdx.y = job)
+__global__ void __launch_bounds__(256) pack_t_batch_kernel(PackTJobs J, float* __restrict__ base) {
+    const PackTJob j = J.job[blockIdx.y];
+    const int nkq = (j.w_rows + 7) / 8, njb = (j.ksub + 31) / 32;
+    const int64_t total = (int64_t)((nkq * njb + STAGE_PIECES - 1) / STAGE_PIECES) * STAGE_FLOATS;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(idx / PIECE_FLOATS);
+        const int within = (int)(idx % PIECE_FLOATS);
+        const int lane = within >> 2, t = within & 3;
+        const int i = lane & 31, hi = lane >> 5;
+        float v = 0.f;
+        if (p < nkq * njb) {
+            const int kq = p / njb, jb = p % njb;
+            const int row = 32 * jb + i, col = 8 * kq + 4 * hi + t;
+            if (row < j.ksub && col < j.w_rows) v = j.W[(int64_t)col * j.ld + j.col0 + row];
+        }
+        base[j.dst_off + idx] = v;
     }
 }
 
@@ -486,34 +597,49 @@ int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s) {
 }
 
 int wgrad_chunk(int64_t rows) {
-    // about one workgroup per CU; chunks are multiples of 16 rows (WG_U two-row steps)
-    int64_t c = cdiv(rows, 256);
-    if (c < 256) c = 256;
+    // about two workgroups per CU; chunks are multiples of 16 rows (WG_U two-row steps), at least 64 rows
+    int64_t c = cdiv(rows, 512);
+    if (c < 64) c = 64;
     return (int)(cdiv(c, 16) * 16);
 }
-size_t wgrad_partial_floats(int64_t rows, int M, int K) {
-    const int Mp = (int)cdiv(M, 128) * 128, Kp = (int)cdiv(K, 128) * 128;
-    return (size_t)cdiv(rows > 0 ? rows : 1, wgrad_chunk(rows)) * Mp * Kp;
+size_t wgrad_partial_floats(int H) {
+    const size_t Hp = (size_t)cdiv(H, 128) * 128;
+    return (size_t)512 * Hp * Hp + (size_t)512 * Hp;
 }
 
 int launch_wgrad(const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* part,
-                 float* out, int ldw, int col0, hipStream_t s) {
+                 float* out, int ldw, int col0, float* db, hipStream_t s) {
     if (rows <= 0 || M <= 0 || K <= 0) return GM_OK;
     const int Mp = (int)cdiv(M, 128) * 128, Kp = (int)cdiv(K, 128) * 128;
     const int chunk = wgrad_chunk(rows);
     const int G = (int)cdiv(rows, chunk);
-    hipLaunchKernelGGL(wgrad_kernel, dim3(G, (Mp / 128) * (Kp / 128)), dim3(THREADS), 0, s, dz, ldz, M, X, ldx, K, xidx, (int)rows, chunk,
-                       part, Mp, Kp);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv((int64_t)M * K, 256)), dim3(256), 0, s, part, G, Mp, Kp, M, K, out, ldw, col0);
+    float* partb = part + (size_t)G * Mp * Kp;
+    if (xidx)
+        hipLaunchKernelGGL(wgrad_kernel<true>, dim3(G, (Mp / 128) * (Kp / 128)), dim3(THREADS), 0, s, dz, ldz, M, X, ldx, K, xidx, (int)rows,
+                           chunk, part, db ? partb : nullptr, Mp, Kp);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<false>, dim3(G, (Mp / 128) * (Kp / 128)), dim3(THREADS), 0, s, dz, ldz, M, X, ldx, K, xidx, (int)rows,
+                           chunk, part, db ? partb : nullptr, Mp, Kp);
+    const int total = M * K + (db ? M : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 32)), dim3(256), 0, s, part, partb, G, Mp, Kp, M, K, out, ldw, col0, db);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
 
-int launch_colsum(const ColsumJobs& j, int64_t rows, hipStream_t s) {
-    if (rows <= 0 || j.n <= 0) return GM_OK;
-    int64_t chunk = cdiv(rows, 512);
+int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, float* dgamma, float* dbeta, hipStream_t s) {
+    if (rows <= 0) return GM_OK;
+    int64_t chunk = cdiv(rows, 1024);
     if (chunk < 64) chunk = 64;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(rows, chunk)), dim3(256), 0, s, j, (int)rows, (int)chunk);
+    const unsigned grid = (unsigned)cdiv(rows, chunk);
+    if (H == 128) hipLaunchKernelGGL((ln_grads_kernel<128>), dim3(grid), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, dgamma, dbeta);
+    else hipLaunchKernelGGL((ln_grads_kernel<256>), dim3(grid), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, dgamma, dbeta);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_pack_t_batch(const PackTJobs& jobs, float* base, hipStream_t s) {
+    if (jobs.n <= 0) return GM_OK;
+    hipLaunchKernelGGL(pack_t_batch_kernel, dim3(16, jobs.n), dim3(256), 0, s, jobs, base);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

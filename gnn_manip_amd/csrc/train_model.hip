@@ -95,8 +95,7 @@ BwdWs carve_bwd(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
     b.dagg = c.take<float>((size_t)n * H);
     b.Gi = c.take<float>((size_t)n * H);
     b.Gj = c.take<float>((size_t)n * H);
-    const size_t Hp = (size_t)cdiv(H, 128) * 128;
-    b.part = c.take<float>((size_t)256 * Hp * Hp);
+    b.part = c.take<float>(wgrad_partial_floats(H));
     b.bytes = c.used();
     return b;
 }
@@ -234,11 +233,18 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     auto b_node = [&](int k) { return (3 + 2 * k) * PM; };
     const size_t U = (size_t)m->S_HH * kStageFloats;
 
-    // ---- transposed operand images of every Linear on the backward path
+    // ---- transposed operand images of every Linear on the backward path (batched: a few launches)
     {
+        PackTJobs jobs;
+        jobs.n = 0;
+        auto flush = [&]() {
+            if (rc == GM_OK && jobs.n > 0) rc = launch_pack_t_batch(jobs, b.packT, s);
+            jobs.n = 0;
+        };
         auto packT = [&](const float* W, int w_rows, int ld, int col0, int ksub, size_t& off) {
-            if (rc != GM_OK) return;
-            rc = pack_linear_t(W, w_rows, ld, col0, ksub, b.packT + off, s);
+            if (jobs.n == kPackTJobsMax) flush();
+            PackTJob& j = jobs.job[jobs.n++];
+            j.W = W; j.w_rows = w_rows; j.ld = ld; j.col0 = col0; j.ksub = ksub; j.dst_off = off;
             off += (size_t)layer_stages(w_rows, ksub) * kStageFloats;
         };
         size_t off = b.off_dec;
@@ -268,24 +274,20 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         off = b.off_enc_edge;
         packT(T[b_enc_edge + 4], H, H, 0, H, off);
         packT(T[b_enc_edge + 2], H, H, 0, H, off);
+        flush();
         if (rc != GM_OK) return rc;
     }
 
     auto wgrad = [&](const float* dz, int ldz, int Mo, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* out, int ldw,
-                     int col0) {
-        if (rc == GM_OK) rc = launch_wgrad(dz, ldz, Mo, X, ldx, K, xidx, rows, b.part, out, ldw, col0, s);
+                     int col0, float* db) {
+        if (rc == GM_OK) rc = launch_wgrad(dz, ldz, Mo, X, ldx, K, xidx, rows, b.part, out, ldw, col0, db, s);
     };
-    // W3, W2 and the five vector gradients of a normed MLP whose chain kernel has just run over `rows`
+    // W3 (+ b3), W2 (+ b2) and the LayerNorm gradients of a normed MLP whose chain kernel has just run over `rows`
+    // (b1 comes with the first-layer weight gradient at the call site)
     auto normed_tail_grads = [&](int base, const TapePtr& tp, int64_t rows) {
-        wgrad(b.dz3, H, H, tp.a2, H, H, nullptr, rows, grads[base + 4], H, 0);
-        wgrad(b.dz2, H, H, tp.a1, H, H, nullptr, rows, grads[base + 2], H, 0);
-        ColsumJobs j{};
-        j.n = 5;
-        const float* As[5] = {b.dz1, b.dz2, b.dz3, b.gy, b.gy};
-        const float* Bs[5] = {nullptr, nullptr, nullptr, tp.xhat, nullptr};
-        float* Os[5] = {grads[base + 1], grads[base + 3], grads[base + 5], grads[base + 6], grads[base + 7]};
-        for (int q = 0; q < 5; ++q) { j.A[q] = As[q]; j.B[q] = Bs[q]; j.out[q] = Os[q]; j.cols[q] = H; j.ld[q] = H; }
-        if (rc == GM_OK) rc = launch_colsum(j, rows, s);
+        wgrad(b.dz3, H, H, tp.a2, H, H, nullptr, rows, grads[base + 4], H, 0, grads[base + 5]);
+        wgrad(b.dz2, H, H, tp.a1, H, H, nullptr, rows, grads[base + 2], H, 0, grads[base + 3]);
+        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, grads[base + 6], grads[base + 7], s);
     };
     auto ln_gamma = [&](size_t voff) { return m->vec + voff + (size_t)(NL + 1) * H; };
 
@@ -296,15 +298,9 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx = b.dh;
         rc = launch_train_bwd(H, TB_DEC, a, s);
         if (rc != GM_OK) return rc;
-        wgrad(grad_out, OD, OD, t.dec.a2, H, H, nullptr, n, grads[b_dec + 4], H, 0);
-        wgrad(b.dz2, H, H, t.dec.a1, H, H, nullptr, n, grads[b_dec + 2], H, 0);
-        wgrad(b.dz1, H, H, t.h[M], H, H, nullptr, n, grads[b_dec + 0], H, 0);
-        ColsumJobs j{};
-        j.n = 3;
-        j.A[0] = b.dz1; j.out[0] = grads[b_dec + 1]; j.cols[0] = H; j.ld[0] = H;
-        j.A[1] = b.dz2; j.out[1] = grads[b_dec + 3]; j.cols[1] = H; j.ld[1] = H;
-        j.A[2] = grad_out; j.out[2] = grads[b_dec + 5]; j.cols[2] = OD; j.ld[2] = OD;
-        if (rc == GM_OK) rc = launch_colsum(j, n, s);
+        wgrad(grad_out, OD, OD, t.dec.a2, H, H, nullptr, n, grads[b_dec + 4], H, 0, grads[b_dec + 5]);
+        wgrad(b.dz2, H, H, t.dec.a1, H, H, nullptr, n, grads[b_dec + 2], H, 0, grads[b_dec + 3]);
+        wgrad(b.dz1, H, H, t.h[M], H, H, nullptr, n, grads[b_dec + 0], H, 0, grads[b_dec + 1]);
         if (rc != GM_OK) return rc;
     }
     // ---- processor blocks, last to first
@@ -318,8 +314,8 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             rc = launch_train_bwd(H, TB_NODE, a, s);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_node(k), t.tn[k], n);
-            wgrad(b.dz1, H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, 0);
-            wgrad(b.dz1, H, H, t.agg[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, H);
+            wgrad(b.dz1, H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, 0, grads[b_node(k) + 1]);
+            wgrad(b.dz1, H, H, t.agg[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, H, nullptr);
             if (rc != GM_OK) return rc;
         }
         {
@@ -330,13 +326,13 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             rc = launch_train_bwd(H, TB_EDGE, a, s);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_edge(k), t.te[k], e);
-            wgrad(b.dz1, H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, 2 * H);
+            wgrad(b.dz1, H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, 2 * H, grads[b_edge(k) + 1]);
             if (rc != GM_OK) return rc;
             // node-level sums of dz1: everything the factorised layer 1 needs
             rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dz1, nullptr, nullptr, b.Gi, n, s);
             if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dz1, nullptr, nullptr, b.Gj, n, s);
-            wgrad(b.Gi, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, 0);
-            wgrad(b.Gj, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, H);
+            wgrad(b.Gi, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, 0, nullptr);
+            wgrad(b.Gj, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, H, nullptr);
             if (rc != GM_OK) return rc;
         }
     }
@@ -349,7 +345,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
         normed_tail_grads(b_enc_node, t.en, n);
-        wgrad(b.dz1, H, H, nodes, m->d.node_dim, m->d.node_dim, nullptr, n, grads[b_enc_node], m->d.node_dim, 0);
+        wgrad(b.dz1, H, H, nodes, m->d.node_dim, m->d.node_dim, nullptr, n, grads[b_enc_node], m->d.node_dim, 0, grads[b_enc_node + 1]);
         if (rc != GM_OK) return rc;
     }
     if (e > 0) {
@@ -359,7 +355,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
         normed_tail_grads(b_enc_edge, t.ee, e);
-        wgrad(b.dz1, H, H, edge_attr, m->d.edge_dim, m->d.edge_dim, c.eid, e, grads[b_enc_edge], m->d.edge_dim, 0);
+        wgrad(b.dz1, H, H, edge_attr, m->d.edge_dim, m->d.edge_dim, c.eid, e, grads[b_enc_edge], m->d.edge_dim, 0, grads[b_enc_edge + 1]);
         if (rc != GM_OK) return rc;
     }
     return GM_OK;

@@ -103,7 +103,7 @@ def test_training_step_reduces_loss_and_inference_sees_new_weights(dev):
     m = _model(params, dims, dev)
     nodes, ea, ei = _graph(500, 0.06, 96)
     x, a, idx = _t(nodes, dev), _t(ea, dev), _t(ei, dev)
-    tgt = torch.zeros((nodes.shape[0], 3), device=dev)
+    tgt = torch.from_numpy(np.random.default_rng(96).standard_normal((nodes.shape[0], 3)).astype(np.float32)).to(dev)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     losses = []
     for _ in range(5):
@@ -117,4 +117,5 @@ def test_training_step_reduces_loss_and_inference_sees_new_weights(dev):
     out_train = m.forward(x, a, idx).detach()
     with torch.no_grad():
         out_inf = m.forward(x, a, idx)
-    assert (out_train - out_inf).abs().max() <= 1e-5 * out_inf.abs().max()
+    # two different kernel sets (tape-recording 32x32x2 chain vs fused inference kernels) on the updated weights
+    assert (out_train - out_inf).abs().max() <= 1e-5 * max(float(out_inf.abs().max()), 0.1)
