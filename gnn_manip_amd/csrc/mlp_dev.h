@@ -47,14 +47,23 @@ __device__ __forceinline__ void lds_barrier() {
 
 // One Linear: acc[jb] += W(jb-block rows) . act.   NKQ = K/8 input octets, NJB = OUT/32 blocks.
 // `more` = another stage will be consumed after this layer's last one (this tile or the next).
-template <int NKQ, int NJB, int NKB>
+// PEND: number of vector-memory instructions (stores of results that nothing in this layer reads) the
+// caller has issued, on EVERY path and in every wave, after the previous run_layer returned.  vmcnt
+// retires in issue order, so waiting for "at most PEND outstanding" still guarantees the stage's DMA
+// (issued earlier) has landed, without draining those stores in front of the MFMAs.
+template <int NKQ, int NJB, int NKB, int PEND = 0>
 __device__ __forceinline__ void run_layer(floatx16 (&acc)[NJB], const floatx16 (&act)[NKB], WStream& ws, bool more_tiles) {
     constexpr int NP = NKQ * NJB;
     constexpr int NST = (NP + STAGE_PIECES - 1) / STAGE_PIECES;
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // stage `cur` has landed for every wave; the other buffer is free
+        if (PEND > 0 && s == 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
+            lds_barrier();  // LDS-only barrier: __syncthreads() would drain the pending stores
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // stage `cur` has landed for every wave; the other buffer is free
+        }
         int nxt = ws.cur + 1;
         const bool wrap = nxt == ws.total;
         if (wrap) nxt = 0;

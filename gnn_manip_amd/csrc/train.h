@@ -74,7 +74,7 @@ size_t wgrad_partial_floats(int H);
 int launch_wgrad(const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* part,
                  float* out, int ldw, int col0, float* db, hipStream_t s);
 // dgamma += colsum(gy * xhat), dbeta += colsum(gy)
-int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, float* dgamma, float* dbeta, hipStream_t s);
+int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, float* part, float* dgamma, float* dbeta, hipStream_t s);
 int launch_pack_t_batch(const PackTJobs& jobs, float* base, hipStream_t s);
 int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows, const float* scale, const float* shift, float* out,
                        int64_t n, hipStream_t s);

@@ -177,12 +177,17 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
             run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
         }
         // hidden layers 2..NL and the output layer; bias_tail = bias of layer 2
+        // Tape stores are issued by every lane (rows past the end write a duplicate of the last row: same
+        // inputs, same values) so that their count is exact for run_layer<.., PEND>, which then does not
+        // drain them; the bias loads go first so that waiting for them does not wait for the stores either.
+        constexpr int NST = H / 8;  // vector stores of one store_feat
         relu_to(act, acc);
-        if (valid) store_feat(act, A.tape.a1 + pc * H, hi);
         load_feat(acc, A.bias_tail, hi);
-        run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+        store_feat(act, A.tape.a1 + pc * H, hi);
+        run_layer<H / 8, NJB, NJB, NST>(acc, act, ws, more);
         relu_to(act, acc);
-        if (valid) store_feat(act, A.tape.a2 + pc * H, hi);
+        if (KIND != TK_DEC) load_feat(acc, A.bias_tail + H, hi);
+        store_feat(act, A.tape.a2 + pc * H, hi);
         if (KIND == TK_DEC) {
             floatx16 o[1];
             load_feat(o, A.bias_tail + H, hi);  // out bias, zero-padded to 32
@@ -193,8 +198,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
                     if (c < A.out_dim) A.out[pc * A.out_dim + c] = o[0][c];
             }
         } else {
-            load_feat(acc, A.bias_tail + H, hi);
-            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+            run_layer<H / 8, NJB, NJB, NST>(acc, act, ws, more);
             const float rstd = layer_norm_tape(acc, act, A.ln_g, A.ln_b, A.eps, hi);
             if (valid) {
                 store_feat(act, A.tape.xhat + pc * H, hi);
@@ -262,23 +266,24 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
             }
             load_feat(act, A.tape.xhat + pc * H, hi);
             layer_norm_bwd(acc, act, A.ln_g, A.tape.rstd[pc], hi);
-            if (valid) store_feat(act, A.dz3 + pc * H, hi);
+            // dz stores: every lane (duplicates of the last row past the end), counted by run_layer<.., PEND>
+            store_feat(act, A.dz3 + pc * H, hi);
             zero_feat(acc);
-            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);  // W3^T dz3
+            run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);  // W3^T dz3
         }
         mask_feat(acc, A.tape.a2 + pc * H, hi);
-        if (valid) store_feat(acc, A.dz2 + pc * H, hi);
+        store_feat(acc, A.dz2 + pc * H, hi);
 #pragma unroll
         for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
         zero_feat(acc);
-        run_layer<H / 8, NJB, NJB>(acc, act, ws, more);  // W2^T dz2
+        run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);  // W2^T dz2
         mask_feat(acc, A.tape.a1 + pc * H, hi);
-        if (valid) store_feat(acc, A.dz1 + pc * H, hi);
+        store_feat(acc, A.dz1 + pc * H, hi);
         if (KIND == TB_ENC) continue;
 #pragma unroll
         for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
         zero_feat(acc);
-        run_layer<H / 8, NJB, NJB>(acc, act, ws, more);  // W1^T dz1 (edge: W_e block; node: W_h block; decoder: W1)
+        run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);  // W1^T dz1 (edge: W_e block; node: W_h block; decoder: W1)
         if (KIND == TB_EDGE) {
             // de_in = W_e^T dz1 (+ de_out through the residual), written over the row it came from
             if (A.residual && A.dY) {
@@ -445,7 +450,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------
 template <int H>
 __global__ void __launch_bounds__(256) ln_grads_kernel(const float* __restrict__ gy, const float* __restrict__ xhat, int rows, int chunk,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                        float* __restrict__ part /*[G][2H]*/) {
     constexpr int CT = H / 4, PH = 256 / CT;
     __shared__ floatx4 rg[256], rb[256];
     const int tid = threadIdx.x, c = tid % CT, ph = tid / CT;
@@ -480,11 +485,28 @@ __global__ void __launch_bounds__(256) ln_grads_kernel(const float* __restrict__
             tg += rg[q * CT + tid];
             tb += rb[q * CT + tid];
         }
+        float* o = part + (size_t)blockIdx.x * 2 * H;
+        *reinterpret_cast<floatx4*>(o + 4 * tid) = tg;
+        *reinterpret_cast<floatx4*>(o + H + 4 * tid) = tb;
+    }
+}
+
+// second stage: dgamma[c] += sum_g part[g][c], dbeta[c] += sum_g part[g][H + c]  (fixed order: deterministic)
+__global__ void __launch_bounds__(256) ln_grads_reduce_kernel(const float* __restrict__ part, int G, int H, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    __shared__ float red[8][33];
+    const int tid = threadIdx.x, i = tid & 31, gg = tid >> 5;
+    const int o = blockIdx.x * 32 + i;  // < 2H
+    float s = 0.f;
+    for (int g = gg; g < G; g += 8) s += part[(size_t)g * 2 * H + o];
+    red[gg][i] = s;
+    __syncthreads();
+    if (gg == 0) {
+        float t = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            atomicAdd(dgamma + 4 * tid + t, tg[t]);
-            atomicAdd(dbeta + 4 * tid + t, tb[t]);
-        }
+        for (int q = 0; q < 8; ++q) t += red[q][i];
+        if (o < H) dgamma[o] += t;
+        else dbeta[o - H] += t;
     }
 }
 
@@ -626,13 +648,14 @@ int launch_wgrad(const float* dz, int ldz, int M, const float* X, int ldx, int K
     return GM_OK;
 }
 
-int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, float* dgamma, float* dbeta, hipStream_t s) {
+int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, float* part, float* dgamma, float* dbeta, hipStream_t s) {
     if (rows <= 0) return GM_OK;
-    int64_t chunk = cdiv(rows, 1024);
+    int64_t chunk = cdiv(rows, 512);
     if (chunk < 64) chunk = 64;
-    const unsigned grid = (unsigned)cdiv(rows, chunk);
-    if (H == 128) hipLaunchKernelGGL((ln_grads_kernel<128>), dim3(grid), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, dgamma, dbeta);
-    else hipLaunchKernelGGL((ln_grads_kernel<256>), dim3(grid), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, dgamma, dbeta);
+    const int G = (int)cdiv(rows, chunk);
+    if (H == 128) hipLaunchKernelGGL((ln_grads_kernel<128>), dim3(G), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, part);
+    else hipLaunchKernelGGL((ln_grads_kernel<256>), dim3(G), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, part);
+    hipLaunchKernelGGL(ln_grads_reduce_kernel, dim3(2 * H / 32), dim3(256), 0, s, part, G, H, dgamma, dbeta);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

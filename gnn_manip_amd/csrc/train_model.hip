@@ -287,7 +287,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     auto normed_tail_grads = [&](int base, const TapePtr& tp, int64_t rows) {
         wgrad(b.dz3, H, H, tp.a2, H, H, nullptr, rows, grads[base + 4], H, 0, grads[base + 5]);
         wgrad(b.dz2, H, H, tp.a1, H, H, nullptr, rows, grads[base + 2], H, 0, grads[base + 3]);
-        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, grads[base + 6], grads[base + 7], s);
+        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 6], grads[base + 7], s);
     };
     auto ln_gamma = [&](size_t voff) { return m->vec + voff + (size_t)(NL + 1) * H; };
 

@@ -189,7 +189,7 @@ int gm_interaction_network_forward(const gm_model* m, int block, const float* h,
  * gm_model_create; the caller zeroes them), given grad_out = dLoss/d(out) [N, out_dim].  `tensors`
  * are the parameter values the forward ran with (device pointers).  Inputs x / edge_attr get no
  * gradient (they are data in train_dyn.py).  Weight gradients are reduced in a fixed order
- * (deterministic, so are the bias gradients); LayerNorm gradients use float atomics. */
+ * (deterministic, like the bias and LayerNorm-parameter gradients: no atomics on the backward path). */
 size_t gm_train_tape_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t n_edges);
 size_t gm_train_backward_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t n_edges);
 int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n_nodes, const float* edge_attr,
