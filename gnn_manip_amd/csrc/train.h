@@ -15,7 +15,7 @@ struct TapePtr {
 struct TrainFwdArgs {
     int rows;
     const float* x_in;     // encoders: raw features [.][k1]; processor edge: e [E][H]; processor node / decoder: h [N][H]
-    const int* rowidx;     // encoders: input row of output row p, or nullptr
+    const int* rowidx;     // encoders / processor edge: row of x_in (and of `out`, processor edge) for row p, or nullptr
     int k1;
     const float* agg;      // processor node: [N][H]
     const int* dst;        // processor edge
@@ -49,7 +49,8 @@ struct TrainBwdArgs {
     float* dz2;
     float* dz1;
     float* dx_resid;       // node: residual path; receives dY before dx adds the MLP's input gradient to it (may alias dY / dx)
-    float* dx;             // edge: de_in; node: dh_in; decoder: dh
+    float* dx;             // edge: de_in; node: dh_in; decoder: dh; projection: dh_in
+    const int* dxidx;      // edge: row of dx for row p (block API: the caller's edge order), or nullptr
     float* dagg_out;       // node: [rows][H]
     int residual;          // edge: de_in += dY
     int out_dim;
@@ -81,6 +82,6 @@ int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows
 int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_t s);
 
 enum : int { TK_ENC_EDGE = 0, TK_ENC_NODE = 1, TK_PROC_EDGE = 2, TK_PROC_NODE = 3, TK_DEC = 4 };
-enum : int { TB_ENC = 0, TB_EDGE = 1, TB_NODE = 2, TB_DEC = 3 };
+enum : int { TB_ENC = 0, TB_EDGE = 1, TB_NODE = 2, TB_DEC = 3, TB_PROJ = 4 };  // TB_PROJ: dx = dY + W_i^T Gi + W_j^T Gj only
 
 }  // namespace gm

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
         } else if (KIND == TK_PROC_EDGE) {
             load_feat(acc, A.P + (int64_t)A.dst[pc] * (2 * H), hi);
             add_feat(acc, A.P + (int64_t)A.src[pc] * (2 * H) + H, hi);
-            load_feat(act, A.x_in + pc * H, hi);
+            load_feat(act, A.x_in + (A.rowidx ? (int64_t)A.rowidx[pc] : pc) * H, hi);
             run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
         } else if (KIND == TK_PROC_NODE) {
             load_feat(act, A.x_in + pc * H, hi);
@@ -204,8 +204,9 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
                 store_feat(act, A.tape.xhat + pc * H, hi);
                 if (hi == 0) A.tape.rstd[pc] = rstd;
             }
-            if ((KIND == TK_PROC_EDGE || KIND == TK_PROC_NODE) && A.residual) add_feat(acc, A.x_in + pc * H, hi);
-            if (valid) store_feat(acc, A.out + pc * H, hi);
+            const int64_t orow = KIND == TK_PROC_EDGE && A.rowidx ? (int64_t)A.rowidx[pc] : pc;
+            if ((KIND == TK_PROC_EDGE || KIND == TK_PROC_NODE) && A.residual) add_feat(acc, A.x_in + orow * H, hi);
+            if (valid) store_feat(acc, A.out + orow * H, hi);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -224,11 +225,12 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
     const int R = A.rows;
     const int ntiles = (R + TILE - 1) / TILE;
-    const bool has_g = (KIND == TB_NODE || KIND == TB_ENC) && A.Gi != nullptr;
+    const bool has_g = (KIND == TB_NODE || KIND == TB_ENC || KIND == TB_PROJ) && A.Gi != nullptr;
     WStream ws;
     ws.base = A.wstream;
     ws.ring = ring;
-    ws.total = (has_g ? 2 * SL : 0) + (KIND == TB_ENC ? 2 * SL : KIND == TB_EDGE ? 3 * SL : KIND == TB_NODE ? 4 * SL : 1 + 2 * SL);
+    ws.total = (has_g ? 2 * SL : 0) +
+               (KIND == TB_ENC ? 2 * SL : KIND == TB_EDGE ? 3 * SL : KIND == TB_NODE ? 4 * SL : KIND == TB_PROJ ? 0 : 1 + 2 * SL);
     ws.cur = 0;
     ws.parity = 0;
     ws.lane = lane;
@@ -260,6 +262,10 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
                 load_feat(act, A.Gj + pc * H, hi);
                 run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
             }
+            if (KIND == TB_PROJ) {
+                if (valid) store_feat(acc, A.dx + pc * H, hi);
+                continue;
+            }
             if (valid) {
                 store_feat(acc, A.gy + pc * H, hi);
                 if (KIND == TB_NODE && A.dx_resid) store_feat(acc, A.dx_resid + pc * H, hi);  // residual path: dh_in starts as dY
@@ -290,7 +296,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
                 const int64_t rin = A.dyidx ? A.dyidx[pc] : pc;
                 add_feat(acc, A.dY + rin * H, hi);
             }
-            if (valid) store_feat(acc, A.dx + pc * H, hi);
+            if (valid) store_feat(acc, A.dx + (A.dxidx ? (int64_t)A.dxidx[pc] : pc) * H, hi);
         } else if (KIND == TB_NODE) {
             if (A.dx_resid) add_feat(acc, A.dx_resid + pc * H, hi);  // same thread wrote this row above
             if (valid) store_feat(acc, A.dx + pc * H, hi);
@@ -608,6 +614,7 @@ static int launch_train_bwd_h(int kind, const TrainBwdArgs& a, hipStream_t s) {
         case TB_ENC: hipLaunchKernelGGL((train_bwd_kernel<H, TB_ENC>), dim3(grid), dim3(THREADS), lds, s, a); break;
         case TB_EDGE: hipLaunchKernelGGL((train_bwd_kernel<H, TB_EDGE>), dim3(grid), dim3(THREADS), lds, s, a); break;
         case TB_NODE: hipLaunchKernelGGL((train_bwd_kernel<H, TB_NODE>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        case TB_PROJ: hipLaunchKernelGGL((train_bwd_kernel<H, TB_PROJ>), dim3(grid), dim3(THREADS), lds, s, a); break;
         default: hipLaunchKernelGGL((train_bwd_kernel<H, TB_DEC>), dim3(grid), dim3(THREADS), lds, s, a); break;
     }
     GM_LAUNCH_CHECK();
@@ -695,6 +702,7 @@ int train_kernels_init() {
     GM_SET((train_fwd_kernel<256, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<256, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<256, TK_PROC_EDGE>));
     GM_SET((train_fwd_kernel<256, TK_PROC_NODE>)); GM_SET((train_fwd_kernel<256, TK_DEC>));
     GM_SET((train_bwd_kernel<128, TB_ENC>)); GM_SET((train_bwd_kernel<128, TB_EDGE>)); GM_SET((train_bwd_kernel<128, TB_NODE>)); GM_SET((train_bwd_kernel<128, TB_DEC>));
+    GM_SET((train_bwd_kernel<128, TB_PROJ>)); GM_SET((train_bwd_kernel<256, TB_PROJ>));
     GM_SET((train_bwd_kernel<256, TB_ENC>)); GM_SET((train_bwd_kernel<256, TB_EDGE>)); GM_SET((train_bwd_kernel<256, TB_NODE>)); GM_SET((train_bwd_kernel<256, TB_DEC>));
 #undef GM_SET
     if (rc == GM_OK) done = true;

@@ -109,6 +109,48 @@ int check_sizes(const gm_model* m, int64_t n, int64_t e, const char* who) {
 
 const float* mlp_vec(const gm_model* m, size_t voff) { return m->vec + voff; }
 
+// ---- tapes of the two standalone blocks (torch_graphnet API surface)
+struct GiTape {
+    TapePtr ee, en;
+    size_t bytes;
+};
+GiTape carve_gi_tape(void* ws, int H, int64_t n, int64_t e) {
+    GiTape t;
+    Carver c(ws);
+    t.ee = take_tape(c, e, H, true);
+    t.en = take_tape(c, n, H, true);
+    t.bytes = c.used();
+    return t;
+}
+struct InTape {
+    void *csr_dst, *csr_src;
+    size_t csr_bytes;
+    int64_t* ei2;
+    float *P, *agg;
+    TapePtr te, tn;
+    size_t bytes;
+};
+InTape carve_in_tape(void* ws, int H, int64_t n, int64_t e) {
+    InTape t;
+    Carver c(ws);
+    t.csr_bytes = gm_csr_workspace_bytes(n, e);
+    t.csr_dst = c.take<char>(t.csr_bytes);
+    t.csr_src = c.take<char>(t.csr_bytes);
+    t.ei2 = c.take<int64_t>((size_t)2 * e);
+    t.P = c.take<float>((size_t)n * 2 * H);
+    t.agg = c.take<float>((size_t)n * H);
+    t.te = take_tape(c, e, H, true);
+    t.tn = take_tape(c, n, H, true);
+    t.bytes = c.used();
+    return t;
+}
+// backward scratch of a single block: same carve as the whole model with one processor step
+BwdWs carve_block_bwd(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
+    gm_model_desc d1 = *d;
+    d1.m_steps = 1;
+    return carve_bwd(ws, &d1, n, e);
+}
+
 }  // namespace
 
 extern "C" {
@@ -359,6 +401,229 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         if (rc != GM_OK) return rc;
     }
     return GM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// standalone blocks under autograd (the torch_graphnet surface, call sites epd_gnn.py:88,101)
+// ------------------------------------------------------------------------------------------
+size_t gm_block_tape_bytes(const gm_model_desc* desc, int interaction_network, int64_t n, int64_t e) {
+    if (!desc || n < 0 || e < 0) return 0;
+    return interaction_network ? carve_in_tape(nullptr, desc->hidden_size, n, e).bytes : carve_gi_tape(nullptr, desc->hidden_size, n, e).bytes;
+}
+
+size_t gm_block_backward_workspace_bytes(const gm_model_desc* desc, int64_t n, int64_t e) {
+    if (!desc || n < 0 || e < 0) return 0;
+    return carve_block_bwd(nullptr, desc, n, e).bytes;
+}
+
+int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_t n, const float* edge_attr, int64_t e, float* h_out,
+                                       float* e_out, void* tape, size_t tape_bytes, void* stream) {
+    int rc = check_sizes(m, n, e, "gm_graph_independent_forward_train");
+    if (rc != GM_OK) return rc;
+    GM_REQUIRE(x && h_out && tape && (e == 0 || (edge_attr && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_forward_train: null pointer");
+    const int H = m->H, NL = m->NL;
+    GiTape t = carve_gi_tape(tape, H, n, e);
+    GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_graph_independent_forward_train: tape %zu < %zu", tape_bytes, t.bytes);
+    rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    auto normed = [&](TrainFwdArgs& a, size_t voff) {
+        const float* v = mlp_vec(m, voff);
+        a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
+    };
+    TrainFwdArgs a{};
+    a.rows = (int)e; a.x_in = edge_attr; a.k1 = m->d.edge_dim; a.wstream = m->packed + m->s_enc_edge;
+    normed(a, m->v_enc_edge);
+    a.tape = t.ee; a.out = e_out;
+    rc = launch_train_fwd(H, TK_ENC_EDGE, a, s);
+    if (rc != GM_OK) return rc;
+    TrainFwdArgs b{};
+    b.rows = (int)n; b.x_in = x; b.k1 = m->d.node_dim; b.wstream = m->packed + m->s_enc_node;
+    normed(b, m->v_enc_node);
+    b.tape = t.en; b.out = h_out;
+    return launch_train_fwd(H, TK_ENC_NODE, b, s);
+}
+
+int gm_graph_independent_backward(const gm_model* m, const float* const* T, int n_tensors, const float* x, const float* edge_attr, int64_t n,
+                                  int64_t e, const float* dh, const float* de, float* const* grads, void* tape, size_t tape_bytes,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_sizes(m, n, e, "gm_graph_independent_backward");
+    if (rc != GM_OK) return rc;
+    GM_REQUIRE(T && grads && x && dh && tape && ws && (e == 0 || (edge_attr && de)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_backward: null pointer");
+    GM_REQUIRE(n_tensors == gm_model_num_tensors(&m->d), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_backward: expected %d tensors, got %d",
+               gm_model_num_tensors(&m->d), n_tensors);
+    const int H = m->H, NL = m->NL;
+    const int PM = tensors_per_normed_mlp(NL);
+    for (int i = 0; i < 2 * PM; ++i) GM_REQUIRE(T[i] && grads[i], GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_backward: tensor / gradient %d is null", i);
+    GiTape t = carve_gi_tape(tape, H, n, e);
+    GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_graph_independent_backward: tape %zu < %zu", tape_bytes, t.bytes);
+    BwdWs b = carve_block_bwd(ws, &m->d, n, e);
+    GM_REQUIRE(ws_bytes >= b.bytes, GM_ERR_WORKSPACE, "gm_graph_independent_backward: workspace %zu < %zu", ws_bytes, b.bytes);
+    rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t U = (size_t)m->S_HH * kStageFloats;
+    PackTJobs jobs;
+    jobs.n = 0;
+    auto packT = [&](const float* W, size_t off) {
+        PackTJob& j = jobs.job[jobs.n++];
+        j.W = W; j.w_rows = H; j.ld = H; j.col0 = 0; j.ksub = H; j.dst_off = off;
+    };
+    // node stream sits behind the (unused) projection slots of the model layout
+    packT(T[PM + 4], b.off_enc_node + 2 * U);
+    packT(T[PM + 2], b.off_enc_node + 3 * U);
+    packT(T[4], b.off_enc_edge);
+    packT(T[2], b.off_enc_edge + U);
+    rc = launch_pack_t_batch(jobs, b.packT, s);
+    if (rc != GM_OK) return rc;
+    auto run = [&](int base, const TapePtr& tp, int64_t rows, const float* dY, size_t voff, size_t woff, const float* X, int k1) {
+        if (rows <= 0 || rc != GM_OK) return;
+        TrainBwdArgs a{};
+        a.rows = (int)rows; a.dY = dY; a.tape = tp; a.ln_g = m->vec + voff + (size_t)(NL + 1) * H; a.wstream = b.packT + woff;
+        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1;
+        rc = launch_train_bwd(H, TB_ENC, a, s);
+        if (rc == GM_OK) rc = launch_wgrad(b.dz3, H, H, tp.a2, H, H, nullptr, rows, b.part, grads[base + 4], H, 0, grads[base + 5], s);
+        if (rc == GM_OK) rc = launch_wgrad(b.dz2, H, H, tp.a1, H, H, nullptr, rows, b.part, grads[base + 2], H, 0, grads[base + 3], s);
+        if (rc == GM_OK) rc = launch_wgrad(b.dz1, H, H, X, k1, k1, nullptr, rows, b.part, grads[base], k1, 0, grads[base + 1], s);
+        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 6], grads[base + 7], s);
+    };
+    run(PM, t.en, n, dh, m->v_enc_node, b.off_enc_node + 2 * U, x, m->d.node_dim);
+    run(0, t.ee, e, de, m->v_enc_edge, b.off_enc_edge, edge_attr, m->d.edge_dim);
+    return rc;
+}
+
+int gm_interaction_network_forward_train(const gm_model* m, int k, const float* h, int64_t n, const float* e_in, const int64_t* edge_index,
+                                         int64_t e, float* h_out, float* e_out, void* tape, size_t tape_bytes, void* stream) {
+    int rc = check_sizes(m, n, e, "gm_interaction_network_forward_train");
+    if (rc != GM_OK) return rc;
+    GM_REQUIRE(k >= 0 && k < m->M, GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward_train: block %d out of range", k);
+    GM_REQUIRE(h && h_out && tape && (e == 0 || (e_in && e_out && edge_index)), GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward_train: null pointer");
+    const int H = m->H, NL = m->NL;
+    InTape t = carve_in_tape(tape, H, n, e);
+    GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_forward_train: tape %zu < %zu", tape_bytes, t.bytes);
+    rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    rc = gm_csr_from_edge_index(edge_index, n, e, t.csr_dst, t.csr_bytes, stream);
+    if (rc != GM_OK) return rc;
+    CsrWs c = carve_csr(t.csr_dst, n, e);
+    rc = launch_swap_index(c.src, e, t.ei2, s);
+    if (rc != GM_OK) return rc;
+    rc = gm_csr_from_edge_index(t.ei2, n, e, t.csr_src, t.csr_bytes, stream);
+    if (rc != GM_OK) return rc;
+    const size_t U = (size_t)m->S_HH * kStageFloats;
+    NodeArgs pa{};
+    pa.n_nodes = (int)n; pa.x_in = h;
+    pa.wstream = k == 0 ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
+                        : m->packed + m->s_node[k - 1] + (size_t)(NL + 2) * U;
+    pa.tail = 1; pa.proj_bias = m->vec + m->v_edge[k]; pa.P_out = t.P;
+    rc = launch_node(H, NL, 2, pa, s);
+    if (rc != GM_OK) return rc;
+    auto normed = [&](TrainFwdArgs& a, size_t voff) {
+        const float* v = mlp_vec(m, voff);
+        a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
+    };
+    {
+        TrainFwdArgs a{};
+        a.rows = (int)e; a.x_in = e_in; a.rowidx = c.eid; a.dst = c.dst; a.src = c.src; a.P = t.P; a.wstream = m->packed + m->s_edge[k];
+        normed(a, m->v_edge[k]);
+        a.tape = t.te; a.out = e_out; a.residual = 0;
+        rc = launch_train_fwd(H, TK_PROC_EDGE, a, s);
+        if (rc != GM_OK) return rc;
+    }
+    const float* ve = mlp_vec(m, m->v_edge[k]);
+    rc = launch_segment_sum(H, c.in_ptr, nullptr, t.te.xhat, ve + (size_t)(NL + 1) * H, ve + (size_t)(NL + 2) * H, t.agg, n, s);
+    if (rc != GM_OK) return rc;
+    TrainFwdArgs a{};
+    a.rows = (int)n; a.x_in = h; a.agg = t.agg; a.wstream = m->packed + m->s_node[k];
+    normed(a, m->v_node[k]);
+    a.tape = t.tn; a.out = h_out; a.residual = 0;
+    return launch_train_fwd(H, TK_PROC_NODE, a, s);
+}
+
+int gm_interaction_network_backward(const gm_model* m, int k, const float* const* T, int n_tensors, const float* h, const float* e_in,
+                                    int64_t n, int64_t e, const float* dh_out, const float* de_out, float* dh_in, float* de_in,
+                                    float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_sizes(m, n, e, "gm_interaction_network_backward");
+    if (rc != GM_OK) return rc;
+    GM_REQUIRE(k >= 0 && k < m->M, GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_backward: block %d out of range", k);
+    GM_REQUIRE(T && grads && h && dh_out && dh_in && tape && ws && (e == 0 || (e_in && de_out && de_in)), GM_ERR_INVALID_ARGUMENT,
+               "gm_interaction_network_backward: null pointer");
+    GM_REQUIRE(n_tensors == gm_model_num_tensors(&m->d), GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_backward: expected %d tensors, got %d",
+               gm_model_num_tensors(&m->d), n_tensors);
+    const int H = m->H, NL = m->NL;
+    const int PM = tensors_per_normed_mlp(NL);
+    const int be = (2 + 2 * k) * PM, bn = (3 + 2 * k) * PM;
+    for (int i = be; i < bn + PM; ++i) GM_REQUIRE(T[i] && grads[i], GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_backward: tensor / gradient %d is null", i);
+    InTape t = carve_in_tape(tape, H, n, e);
+    GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_backward: tape %zu < %zu", tape_bytes, t.bytes);
+    BwdWs b = carve_block_bwd(ws, &m->d, n, e);
+    GM_REQUIRE(ws_bytes >= b.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_backward: workspace %zu < %zu", ws_bytes, b.bytes);
+    rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    CsrWs c = carve_csr(t.csr_dst, n, e);
+    CsrWs c2 = carve_csr(t.csr_src, n, e);
+    const size_t U = (size_t)m->S_HH * kStageFloats;
+    {
+        PackTJobs jobs;
+        jobs.n = 0;
+        auto packT = [&](const float* W, int ld, int col0, size_t off) {
+            PackTJob& j = jobs.job[jobs.n++];
+            j.W = W; j.w_rows = H; j.ld = ld; j.col0 = col0; j.ksub = H; j.dst_off = off;
+        };
+        packT(T[bn + 4], H, 0, b.off_node[0]);
+        packT(T[bn + 2], H, 0, b.off_node[0] + U);
+        packT(T[bn], 2 * H, 0, b.off_node[0] + 2 * U);
+        packT(T[bn], 2 * H, H, b.off_node[0] + 3 * U);
+        packT(T[be + 4], H, 0, b.off_edge[0]);
+        packT(T[be + 2], H, 0, b.off_edge[0] + U);
+        packT(T[be], 3 * H, 2 * H, b.off_edge[0] + 2 * U);
+        packT(T[be], 3 * H, 0, b.off_enc_node);       // W_i^T, W_j^T: projection backward
+        packT(T[be], 3 * H, H, b.off_enc_node + U);
+        rc = launch_pack_t_batch(jobs, b.packT, s);
+        if (rc != GM_OK) return rc;
+    }
+    auto wgrad = [&](const float* dz, const float* X, int64_t rows, float* out, int ldw, int col0, float* db) {
+        if (rc == GM_OK) rc = launch_wgrad(dz, H, H, X, H, H, nullptr, rows, b.part, out, ldw, col0, db, s);
+    };
+    // node MLP: dY = dh_out (no residual inside the block); dx = W_h^T dz1 -> b.dh, dagg -> b.dagg
+    {
+        TrainBwdArgs a{};
+        a.rows = (int)n; a.dY = dh_out; a.tape = t.tn; a.ln_g = m->vec + m->v_node[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_node[0];
+        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx = b.dh; a.dagg_out = b.dagg;
+        rc = launch_train_bwd(H, TB_NODE, a, s);
+        if (rc != GM_OK) return rc;
+        wgrad(b.dz3, t.tn.a2, n, grads[bn + 4], H, 0, grads[bn + 5]);
+        wgrad(b.dz2, t.tn.a1, n, grads[bn + 2], H, 0, grads[bn + 3]);
+        wgrad(b.dz1, h, n, grads[bn], 2 * H, 0, grads[bn + 1]);
+        wgrad(b.dz1, t.agg, n, grads[bn], 2 * H, H, nullptr);
+        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.tn.xhat, n, b.part, grads[bn + 6], grads[bn + 7], s);
+        if (rc != GM_OK) return rc;
+    }
+    if (e > 0) {
+        TrainBwdArgs a{};
+        a.rows = (int)e; a.dY = de_out; a.dyidx = c.eid; a.dagg = b.dagg; a.dst = c.dst; a.tape = t.te;
+        a.ln_g = m->vec + m->v_edge[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_edge[0];
+        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx = de_in; a.dxidx = c.eid; a.residual = 0;
+        rc = launch_train_bwd(H, TB_EDGE, a, s);
+        if (rc != GM_OK) return rc;
+        wgrad(b.dz3, t.te.a2, e, grads[be + 4], H, 0, grads[be + 5]);
+        wgrad(b.dz2, t.te.a1, e, grads[be + 2], H, 0, grads[be + 3]);
+        if (rc == GM_OK) rc = launch_wgrad(b.dz1, H, H, e_in, H, H, c.eid, e, b.part, grads[be], 3 * H, 2 * H, grads[be + 1], s);
+        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.te.xhat, e, b.part, grads[be + 6], grads[be + 7], s);
+        if (rc != GM_OK) return rc;
+    }
+    rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dz1, nullptr, nullptr, b.Gi, n, s);
+    if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dz1, nullptr, nullptr, b.Gj, n, s);
+    wgrad(b.Gi, h, n, grads[be], 3 * H, 0, nullptr);
+    wgrad(b.Gj, h, n, grads[be], 3 * H, H, nullptr);
+    if (rc != GM_OK) return rc;
+    // dh_in = W_h^T dz1 (node MLP) + W_i^T G_i + W_j^T G_j (edge MLP, factorised layer 1)
+    TrainBwdArgs a{};
+    a.rows = (int)n; a.dY = b.dh; a.Gi = b.Gi; a.Gj = b.Gj; a.wstream = b.packT + b.off_enc_node; a.dx = dh_in;
+    return launch_train_bwd(H, TB_PROJ, a, s);
 }
 
 }  // extern "C"

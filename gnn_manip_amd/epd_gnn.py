@@ -11,8 +11,9 @@ Block semantics (the torch_graphnet source is absent from the reference tree; fi
 BASELINE.json north_star, see DESIGN.md): j = edge_index[0] (source), i = edge_index[1] (target);
 e' = phi_e(cat[h_i, h_j, e]); agg_i = sum_{e -> i} e'; h' = phi_v(cat[h, agg]); no residual inside
 the block.  ``EncProcDecGNN.forward`` is differentiable w.r.t. every parameter (``train_dyn.py``:
-forward with an activation tape + hand-written HIP backward, see csrc/train.hip); the two standalone
-blocks are forward-only.
+forward with an activation tape + hand-written HIP backward, see csrc/train.hip), and so are the two
+standalone blocks (parameters; the InteractionNetwork also w.r.t. its inputs h, e), so the reference's own
+``EncProcDecGNN`` wiring trains with them as well.
 """
 import ctypes as C
 
@@ -74,11 +75,102 @@ class _Handle:
             pass
 
 
-def _no_grad_guard(params, who):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        raise NotImplementedError(
-            f"{who}: the HIP path is forward-only (no autograd yet, SURVEY.md section 8f-1); call it under "
-            "torch.no_grad() as the reference's rollout / planner do (rollout_utils.py:39, traj_utils.py:124)")
+def _grad_arrays(params, device):
+    """(tensors, flat gradient buffer, per-tensor views, ctypes arrays) for a backward call."""
+    tensors = [p.detach().to(device=device, dtype=torch.float32).contiguous() for p in params]
+    flat = torch.zeros(sum(t.numel() for t in tensors), dtype=torch.float32, device=device)
+    views, off = [], 0
+    for t in tensors:
+        views.append(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+    t_arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    g_arr = (C.c_void_p * len(views))(*[v.data_ptr() for v in views])
+    return tensors, views, t_arr, g_arr
+
+
+def _wants_grad(params, *inputs):
+    return torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(t.requires_grad for t in inputs))
+
+
+def _check_edge_index(edge_index, n, e):
+    _need_cuda(edge_index, "edge_index")
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.shape[1] != e:
+        raise ValueError("edge_index must be int64 [2, E]")
+    if e and (int(edge_index.min()) < 0 or int(edge_index.max()) >= n):
+        raise ValueError("edge_index entry out of range [0, n_nodes)")
+
+
+class _GraphIndependentFunction(torch.autograd.Function):
+    """GraphIndependent under autograd: gradients for the block's parameters (its inputs are data)."""
+
+    @staticmethod
+    def forward(ctx, block, n_own, x, edge_attr, *params):
+        L = lib()
+        desc, _ = block._standalone(x.device)
+        h = block._handle.get(desc, list(params), x.device)
+        d = ModelDesc(*desc)
+        n, e = int(x.shape[0]), int(edge_attr.shape[0])
+        tape = _ws(L.gm_block_tape_bytes(C.byref(d), 0, n, e), x.device)
+        h_out = torch.empty((n, desc[3]), dtype=torch.float32, device=x.device)
+        e_out = torch.empty((e, desc[3]), dtype=torch.float32, device=x.device)
+        check(L.gm_graph_independent_forward_train(h, ptr(x), n, ptr(edge_attr), e, ptr(h_out), ptr(e_out), ptr(tape),
+                                                   tape.numel(), current_stream()))
+        ctx.handle, ctx.desc, ctx.tape, ctx.n_own = h, d, tape, n_own
+        ctx.save_for_backward(x, edge_attr, *params)
+        return h_out, e_out
+
+    @staticmethod
+    def backward(ctx, dh, de):
+        L = lib()
+        x, edge_attr, *params = ctx.saved_tensors
+        n, e = int(x.shape[0]), int(edge_attr.shape[0])
+        dh = torch.zeros((n, ctx.desc.hidden_size), device=x.device) if dh is None else dh.contiguous().float()
+        de = torch.zeros((e, ctx.desc.hidden_size), device=x.device) if de is None else de.contiguous().float()
+        tensors, views, t_arr, g_arr = _grad_arrays(params, x.device)
+        ws = _ws(L.gm_block_backward_workspace_bytes(C.byref(ctx.desc), n, e), x.device)
+        check(L.gm_graph_independent_backward(ctx.handle, t_arr, len(tensors), ptr(x), ptr(edge_attr), n, e, ptr(dh), ptr(de),
+                                              g_arr, ptr(ctx.tape), ctx.tape.numel(), ptr(ws), ws.numel(), current_stream()))
+        ctx.tape = None
+        return (None, None, None, None) + tuple(v if i < ctx.n_own else None for i, v in enumerate(views))
+
+
+class _InteractionNetworkFunction(torch.autograd.Function):
+    """InteractionNetwork under autograd: gradients for its parameters and for both inputs (h, e)."""
+
+    @staticmethod
+    def forward(ctx, block, own, x, edge_attr, edge_index, *params):
+        L = lib()
+        desc, _ = block._standalone(x.device)
+        h = block._handle.get(desc, list(params), x.device)
+        d = ModelDesc(*desc)
+        n, e = int(x.shape[0]), int(edge_attr.shape[0])
+        tape = _ws(L.gm_block_tape_bytes(C.byref(d), 1, n, e), x.device)
+        h_out = torch.empty_like(x)
+        e_out = torch.empty_like(edge_attr)
+        ei = edge_index.contiguous()
+        check(L.gm_interaction_network_forward_train(h, 0, ptr(x), n, ptr(edge_attr), ptr(ei), e, ptr(h_out), ptr(e_out),
+                                                     ptr(tape), tape.numel(), current_stream()))
+        ctx.handle, ctx.desc, ctx.tape, ctx.own = h, d, tape, own
+        ctx.save_for_backward(x, edge_attr, *params)
+        return h_out, e_out
+
+    @staticmethod
+    def backward(ctx, dh, de):
+        L = lib()
+        x, edge_attr, *params = ctx.saved_tensors
+        n, e = int(x.shape[0]), int(edge_attr.shape[0])
+        dh = torch.zeros_like(x) if dh is None else dh.contiguous().float()
+        de = torch.zeros_like(edge_attr) if de is None else de.contiguous().float()
+        tensors, views, t_arr, g_arr = _grad_arrays(params, x.device)
+        dh_in = torch.empty_like(x)
+        de_in = torch.empty_like(edge_attr)
+        ws = _ws(L.gm_block_backward_workspace_bytes(C.byref(ctx.desc), n, e), x.device)
+        check(L.gm_interaction_network_backward(ctx.handle, 0, t_arr, len(tensors), ptr(x), ptr(edge_attr), n, e, ptr(dh), ptr(de),
+                                                ptr(dh_in), ptr(de_in), g_arr, ptr(ctx.tape), ctx.tape.numel(), ptr(ws), ws.numel(),
+                                                current_stream()))
+        ctx.tape = None
+        lo, hi = ctx.own
+        return (None, None, dh_in, de_in, None) + tuple(v if lo <= i < hi else None for i, v in enumerate(views))
 
 
 class DstCsr:
@@ -137,11 +229,17 @@ class GraphIndependent(nn.Module):
 
     def forward(self, x, edge_attr, edge_index=None):
         _need_cuda(x, "x")
-        _no_grad_guard(list(self.parameters()), "GraphIndependent")
         desc, params = self._standalone(x.device)
-        h = self._handle.get(desc, params, x.device)
         x = x.contiguous().float()
         edge_attr = edge_attr.contiguous().float()
+        own = list(self.parameters())
+        if _wants_grad(own, x, edge_attr):
+            if x.requires_grad or edge_attr.requires_grad:
+                raise NotImplementedError("GraphIndependent: gradients w.r.t. its inputs are not produced (they are data at "
+                                          "the reference's call site epd_gnn.py:88); detach them")
+            h_out, e_out = _GraphIndependentFunction.apply(self, len(own), x, edge_attr, *params)
+            return h_out, e_out, None
+        h = self._handle.get(desc, params, x.device)
         hidden = desc[3]
         h_out = torch.empty((x.shape[0], hidden), dtype=torch.float32, device=x.device)
         e_out = torch.empty((edge_attr.shape[0], hidden), dtype=torch.float32, device=x.device)
@@ -176,8 +274,15 @@ class InteractionNetwork(nn.Module):
 
     def forward(self, x, edge_attr, edge_index):
         _need_cuda(x, "x")
-        _no_grad_guard(list(self.parameters()), "InteractionNetwork")
         desc, params = self._standalone(x.device)
+        own = list(self.parameters())
+        if _wants_grad(own, x, edge_attr):
+            x = x.contiguous().float()
+            edge_attr = edge_attr.contiguous().float()
+            _check_edge_index(edge_index, x.shape[0], edge_attr.shape[0])
+            lo = len(self._pad[str(x.device)][0])  # placeholder encoder tensors come first
+            h_out, e_out = _InteractionNetworkFunction.apply(self, (lo, lo + len(own)), x, edge_attr, edge_index, *params)
+            return h_out, e_out, None
         h = self._handle.get(desc, params, x.device)
         return _run_block(h, desc, 0, x, edge_attr, edge_index)
 
@@ -226,14 +331,7 @@ class _EpdTrainFunction(torch.autograd.Function):
         n, e = ctx.sizes
         dev = nodes.device
         grad_out = grad_out.contiguous().float()
-        tensors = [p.detach().to(device=dev, dtype=torch.float32).contiguous() for p in params]
-        flat = torch.zeros(sum(t.numel() for t in tensors), dtype=torch.float32, device=dev)
-        views, off = [], 0
-        for t in tensors:
-            views.append(flat[off:off + t.numel()].view_as(t))
-            off += t.numel()
-        t_arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-        g_arr = (C.c_void_p * len(views))(*[v.data_ptr() for v in views])
+        tensors, views, t_arr, g_arr = _grad_arrays(params, dev)
         ws = _ws(L.gm_train_backward_workspace_bytes(C.byref(ctx.desc), n, e), dev)
         check(L.gm_epd_backward(ctx.handle, t_arr, len(tensors), ptr(nodes), ptr(edge_attr), n, e, ptr(grad_out), g_arr,
                                 ptr(ctx.tape), ctx.tape.numel(), ptr(ws), ws.numel(), current_stream()))
@@ -306,11 +404,7 @@ class EncProcDecGNN(nn.Module):
             if nodes.requires_grad or edge_attr.requires_grad:
                 raise NotImplementedError("EncProcDecGNN: gradients w.r.t. nodes / edge_attr are not produced "
                                           "(they are data in train_dyn.py); detach them")
-            _need_cuda(edge_index, "edge_index")
-            if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
-                raise ValueError("edge_index must be int64 [2, E]")
-            if e and (int(edge_index.min()) < 0 or int(edge_index.max()) >= n):
-                raise ValueError("edge_index entry out of range [0, n_nodes)")
+            _check_edge_index(edge_index, n, e)
             return _EpdTrainFunction.apply(self, nodes, edge_attr, edge_index, *params)
         h = self.device_handle(nodes.device)
         csr = DstCsr(edge_index, n)

@@ -200,6 +200,30 @@ int gm_epd_backward(const gm_model* m, const float* const* tensors, int n_tensor
                     float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* The two standalone blocks under autograd -- the torch_graphnet surface the reference's own
+ * EncProcDecGNN wiring calls (epd_gnn.py:30-33,42-45,88,101).  *_forward_train record a tape
+ * (gm_block_tape_bytes; interaction_network = 0 for GraphIndependent, 1 for InteractionNetwork);
+ * *_backward accumulate parameter gradients into grads[] (full-model tensor order, only the block's own
+ * entries are touched) and, for the InteractionNetwork, return the input gradients dh_in [N,H] and
+ * de_in [E,H] (caller's edge order).  GraphIndependent inputs are data: no input gradient. */
+size_t gm_block_tape_bytes(const gm_model_desc* desc, int interaction_network, int64_t n_nodes, int64_t n_edges);
+size_t gm_block_backward_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t n_edges);
+int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_t n_nodes, const float* edge_attr,
+                                       int64_t n_edges, float* h_out, float* e_out, void* tape, size_t tape_bytes,
+                                       void* stream);
+int gm_graph_independent_backward(const gm_model* m, const float* const* tensors, int n_tensors, const float* x,
+                                  const float* edge_attr, int64_t n_nodes, int64_t n_edges, const float* dh,
+                                  const float* de, float* const* grads, void* tape, size_t tape_bytes, void* ws,
+                                  size_t ws_bytes, void* stream);
+int gm_interaction_network_forward_train(const gm_model* m, int block, const float* h, int64_t n_nodes,
+                                         const float* e, const int64_t* edge_index, int64_t n_edges, float* h_out,
+                                         float* e_out, void* tape, size_t tape_bytes, void* stream);
+int gm_interaction_network_backward(const gm_model* m, int block, const float* const* tensors, int n_tensors,
+                                    const float* h, const float* e, int64_t n_nodes, int64_t n_edges,
+                                    const float* dh_out, const float* de_out, float* dh_in, float* de_in,
+                                    float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                                    void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * One device-resident rollout step = compute_rollout's loop body, rollout_utils.py:38-61 ==
  * cma_objective's, traj_utils.py:123-152:  state_pre -> node features -> radius graph -> csr ->
