@@ -91,6 +91,19 @@ def compute_acceleration(next_pos, pos_seq):
     return next_pos - 2 * pos_seq[-1, :, :] + pos_seq[-2, :, :]
 
 
+def random_walk_noise(pos_seq, noise_std, noise_sample=None, generator=None):
+    """Reference ``random_walk_noise`` (utils.py:96-115) on the device: per-step velocity noise
+    N(0, noise_std / sqrt(k-1)) accumulated twice over time (velocity, then position), zero for the first frame.
+    ``noise_sample`` ([k-1, N, 3]) replaces the draw (tests pin the arithmetic with the reference's own draw)."""
+    _need_cuda(pos_seq, "pos_seq")
+    k, n, d = pos_seq.shape
+    if noise_sample is None:
+        noise_sample = torch.randn((k - 1, n, d), dtype=torch.float32, device=pos_seq.device, generator=generator)
+        noise_sample = noise_sample * (float(noise_std) / (k - 1) ** 0.5)
+    noisy_pos = torch.cumsum(torch.cumsum(noise_sample.float(), dim=0), dim=0)
+    return torch.cat((torch.zeros((1, n, d), dtype=torch.float32, device=pos_seq.device), noisy_pos), dim=0)
+
+
 def _contiguous_cols(idx, name):
     idx = list(idx)
     if len(idx) != 3 or idx[1] != idx[0] + 1 or idx[2] != idx[0] + 2:
@@ -128,9 +141,6 @@ class GraphBoundedMultimaterial:
     """Mirror of the reference class of the same name (collate_utils.py:162-209)."""
 
     def __init__(self, conn_r, stats, cartesian_idx, material_idx, bounds, noise=None, max_neighbours=20):
-        if noise is not None:
-            raise NotImplementedError("training-time random-walk noise (collate_utils.py:169-193) is not on the "
-                                      "rollout path yet (SURVEY.md section 8f-3)")
         self.conn_r = conn_r
         self.stats = stats
         self.cartesian_idx = list(cartesian_idx)
@@ -138,8 +148,9 @@ class GraphBoundedMultimaterial:
         self.control_idx = None
         self.action_idx = None
         self.bounds = bounds
-        self.noise_std = None
+        self.noise_std = noise
         self.max_neighbours = max_neighbours
+        self.generator = None  # optional torch.Generator (device) for the noise draw
 
     # -- helpers
     def feature_desc(self, obs):
@@ -173,7 +184,28 @@ class GraphBoundedMultimaterial:
         std = torch.as_tensor(self.stats["acceleration_std"], dtype=torch.float32, device=dev)
         return (acc - mean) / std
 
-    def process(self, obs, tgt):
+    def process(self, obs, tgt, noise_sample=None):
+        """GraphAttributes.process (collate_utils.py:23-27): the noisy path when a noise std was given."""
+        if self.noise_std is None:
+            return self._process_simple(obs, tgt)
+        return self._process_noisy(obs, tgt, noise_sample)
+
+    def _process_noisy(self, obs, tgt, noise_sample=None):
+        """collate_utils.py:169-193: random-walk noise on the position columns of the window and on the target;
+        features, graph (with self.max_neighbours, :187) and target acceleration come from the noisy state."""
+        _need_cuda(obs, "obs")
+        obs = obs.contiguous().float()
+        c0 = self.cartesian_idx[0]
+        seq = random_walk_noise(obs[:, :, c0:c0 + 3], self.noise_std, noise_sample, self.generator)
+        noisy_obs = obs.clone()
+        noisy_obs[:, :, c0:c0 + 3] += seq
+        last_pos = noisy_obs[-1][:, c0:c0 + 3]
+        nodes = self.compute_nodes(noisy_obs)
+        senders, receivers = get_connectivity(last_pos, self.conn_r, self.max_neighbours)
+        edge_attr = self.compute_edges(noisy_obs, senders, receivers)
+        return nodes, edge_attr, senders, receivers, self.compute_target(noisy_obs, tgt + seq[-1])
+
+    def _process_simple(self, obs, tgt):
         """_process_simple (collate_utils.py:29-40).  NB: like the reference, the graph is built with
         the default max_neighbours=20 here (collate_utils.py:34 does not forward the attribute)."""
         obs = obs.contiguous().float()

@@ -235,6 +235,66 @@ def process_collate(batch, **kw):
     return np.concatenate(nl), np.concatenate(el), np.concatenate(il, axis=1), tgt
 
 
+def random_walk_noise(pos_seq, noise_std, noise_sample):
+    """random_walk_noise (utils.py:96-115) with the Normal(0, noise_std / sqrt(k-1)) draw passed in
+    (`noise_sample`, shape [k-1, N, 3]): velocity noise = cumsum over time, position noise = cumsum of
+    that, zero for the first frame."""
+    noise_sample = np.asarray(noise_sample, F32)
+    noisy_vel = np.cumsum(noise_sample, axis=0, dtype=F32)
+    noisy_pos = np.cumsum(noisy_vel, axis=0, dtype=F32)
+    return np.concatenate((np.zeros((1,) + noisy_pos.shape[1:], F32), noisy_pos), axis=0)
+
+
+def process_noisy(obs, tgt, noise_sample, stats, bounds, conn_r, cartesian_idx, material_idx, control_idx=None,
+                  max_neighbours=20):
+    """GraphBoundedMultimaterial._process_noisy (collate_utils.py:169-193): the position columns of the whole
+    window and the target get the random-walk noise; features, graph and target come from the noisy state."""
+    obs = np.asarray(obs, F32)
+    seq = random_walk_noise(obs[:, :, cartesian_idx], None, noise_sample)
+    noise = np.zeros_like(obs)
+    noise[:, :, cartesian_idx] = seq
+    noisy_obs = obs + noise
+    last_pos = noisy_obs[-1][:, cartesian_idx]
+    noisy_tgt = np.asarray(tgt, F32) + seq[-1]
+    nodes = compute_nodes(noisy_obs, stats, bounds, conn_r, cartesian_idx, material_idx, control_idx)
+    senders, receivers = get_connectivity(last_pos, conn_r, max_neighbours)
+    edge_attr = get_edges_displacement(last_pos, senders, receivers, conn_r)
+    return nodes, edge_attr, senders, receivers, compute_target(noisy_obs, noisy_tgt, stats, cartesian_idx)
+
+
+# --------------------------------------------------------------------------------------
+# on-disk formats (gnn_manip/utils/coffee_dataset.py)
+# --------------------------------------------------------------------------------------
+def read_metadata(metadata):
+    """read_metadata (coffee_dataset.py:18-43) on the parsed metadata.json dict."""
+    b = np.asarray(metadata["bounds"], F32)
+    bounds = {"upper_bounds": b[:, 1], "lower_bounds": b[:, 0]}
+    stats = {"velocity_mean": np.asarray(metadata["vel_mean"], F32), "velocity_std": np.asarray(metadata["vel_std"], F32),
+             "acceleration_mean": np.asarray(metadata["acc_mean"], F32), "acceleration_std": np.asarray(metadata["acc_std"], F32)}
+    return (metadata["data_dim"], metadata["sequence_length"], metadata["cartesian_idx"], metadata["control_idx"],
+            metadata["material_id"], bounds, stats)
+
+
+def dataset_samples(sim_tables, time_steps, data_dim, k, cartesian_idx, material_id, use_control):
+    """CoffeeDataset._load_data (coffee_dataset.py:73-102): every window of k frames of every simulation and the
+    position that follows it; with use_control the 3 control columns (next position - position for rigid rows
+    (material == 1), zero elsewhere) are appended to every frame of the window."""
+    obs_list, next_list = [], []
+    for table in sim_tables:
+        data = np.asarray(table, np.float64).reshape(time_steps, -1, data_dim)
+        pos = data[:, :, cartesian_idx]
+        for t in range(time_steps - k):
+            obs = data[t:t + k].astype(F32)
+            nxt = pos[t + k].astype(F32)
+            if use_control:
+                ctr = nxt[None] - obs[:, :, cartesian_idx]
+                ctr[obs[:, :, material_id] != 1] = 0
+                obs = np.concatenate((obs, ctr.astype(F32)), axis=-1)
+            obs_list.append(obs)
+            next_list.append(nxt)
+    return obs_list, next_list
+
+
 # --------------------------------------------------------------------------------------
 # K4-K9  encode-process-decode  (gnn_manip/models/epd_gnn.py)
 # --------------------------------------------------------------------------------------

@@ -282,6 +282,66 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g8_rollout.npz"), **g8)
     print("G8 done; end absmax", float(np.abs(g8["end_coffee"]).max()))
 
+    # ---------------- G9: on-disk dataset (CSV + metadata.json) and the training-time noise path
+    # coffee_dataset.py:18-113 (read_metadata, CoffeeDataset._load_data / graph_attr), utils.py:96-115 (random_walk_noise),
+    # collate_utils.py:169-193 (_process_noisy).  The dataset is synthetic and tiny; it is stored in the fixture as
+    # arrays and re-written to disk by the tests.
+    import json, tempfile
+    g9 = {}
+    T, N9, NR = 9, 60, 10
+    sims = []
+    for sid in (1, 2):
+        o = scene_obs(N9, NR, 0.05, 90 + sid, k=T)
+        sims.append(o[:, :, :5].astype(np.float32))  # on disk: [id, material, x, y, z]
+    vel = np.concatenate([np.diff(d[:, :, 2:5].astype(np.float64), axis=0).reshape(-1, 3) for d in sims])
+    acc = np.concatenate([np.diff(np.diff(d[:, :, 2:5].astype(np.float64), axis=0), axis=0).reshape(-1, 3) for d in sims])
+    meta = {"cartesian_idx": [2, 3, 4], "control_idx": [5, 6, 7], "material_id": 1, "bounds": [[0.1, 0.9]] * 3,
+            "sequence_length": T, "dim": 3, "data_dim": 5,
+            "vel_mean": list(vel.mean(0)), "vel_std": list(vel.std(0)), "acc_mean": list(acc.mean(0)), "acc_std": list(acc.std(0))}
+    with tempfile.TemporaryDirectory() as td:
+        root = td + "/"
+        os.makedirs(root + "train")
+        with open(root + "metadata.json", "w") as fp:
+            json.dump(meta, fp)
+        with open(root + "train/sim_data.csv", "w") as fp:
+            for sid in (1, 2):
+                fp.write(f"{sid},0\n")
+        for sid, d in zip((1, 2), sims):
+            np.savetxt(root + f"train/particles_{sid:06d}.csv", d.reshape(-1, 5).astype(np.float64), delimiter=",", fmt="%.9g")
+        for tag, use_control in (("ctl", True), ("noctl", False)):
+            ds = ref.dataset.CoffeeDataset.__new__(ref.dataset.CoffeeDataset)
+            ref.dataset.CoffeeDataset.__init__(ds, root, 6, 0.015, split="train", use_control=use_control)
+            g9[f"{tag}.len"] = np.array(len(ds))
+            for idx in (0, 4):
+                obs = ds.raw_samples["observations"][idx]
+                nxt = ds.raw_samples["next_positions"][idx]
+                nodes, ea, s_, r_, tgt = ds.graph_attr.process(obs, nxt)
+                assert orc.connectivity_is_tie_free(obs[-1][:, 2:5].numpy(), 0.015, 20)
+                g9[f"{tag}.{idx}.obs"], g9[f"{tag}.{idx}.next"] = obs.numpy(), nxt.numpy()
+                g9[f"{tag}.{idx}.nodes"], g9[f"{tag}.{idx}.edge_attr"] = nodes.numpy(), ea.numpy()
+                g9[f"{tag}.{idx}.senders"], g9[f"{tag}.{idx}.receivers"], g9[f"{tag}.{idx}.tgt"] = s_.numpy(), r_.numpy(), tgt.numpy()
+    g9["sims"] = np.stack(sims)
+    g9["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    # noise: the reference draws Normal(0, std / sqrt(k-1)) first thing after the seed; the same draw is stored as `sample`
+    std = 3e-4
+    obs = torch.from_numpy(scene_obs(120, 20, 0.06, 95))
+    pos_seq = obs[:, :, CART]
+    torch.manual_seed(11)
+    vel_seq = torch.diff(pos_seq, n=1, dim=0).float()
+    sample = torch.distributions.Normal(loc=torch.zeros_like(vel_seq), scale=std / vel_seq.shape[0] ** 0.5).sample().float()
+    torch.manual_seed(11)
+    ns = ref.utils.random_walk_noise(pos_seq, std)
+    g9["noise.obs"], g9["noise.sample"], g9["noise.sequence"], g9["noise.std"] = obs.numpy(), sample.numpy(), ns.numpy(), np.array(std)
+    tgt = obs[-1][:, 2:5] + 1e-3
+    gan = ref.collate.GraphBoundedMultimaterialControl(0.015, tstats(), CART, MAT, CTRL, tbounds(), noise=std)
+    torch.manual_seed(11)
+    nodes, ea, s_, r_, nacc = gan.process(obs, tgt)
+    g9["noise.tgt"] = tgt.numpy()
+    g9["noise.nodes"], g9["noise.edge_attr"], g9["noise.senders"], g9["noise.receivers"], g9["noise.acc"] = (
+        nodes.numpy(), ea.numpy(), s_.numpy(), r_.numpy(), nacc.numpy())
+    np.savez_compressed(os.path.join(HERE, "g9_dataset.npz"), **g9)
+    print("G9 done; samples", int(g9["ctl.len"]), "noise absmax", float(np.abs(g9["noise.sequence"]).max()))
+
 
 if __name__ == "__main__":
     main()

@@ -1,0 +1,103 @@
+"""Training-time data path on the device: dataset files -> resident tensors -> graphs,
+against fixture G9 (reference CoffeeDataset / random_walk_noise / _process_noisy outputs)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import BOUNDS, CART, CTRL, MAT, STATS
+from oracle import epd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _write_dataset(g, root):
+    """Re-create the synthetic dataset the fixture was generated from (same bytes as make_golden.py wrote)."""
+    os.makedirs(root + "train")
+    with open(root + "metadata.json", "w") as fp:
+        fp.write(bytes(g["meta_json"]).decode())
+    with open(root + "train/sim_data.csv", "w") as fp:
+        for sid in (1, 2):
+            fp.write(f"{sid},0\n")
+    for sid, d in zip((1, 2), g["sims"]):
+        np.savetxt(root + f"train/particles_{sid:06d}.csv", d.reshape(-1, 5).astype(np.float64), delimiter=",", fmt="%.9g")
+
+
+@pytest.mark.parametrize("tag,use_control", [("ctl", True), ("noctl", False)])
+def test_dataset_golden(golden, dev, tmp_path, tag, use_control):
+    from gnn_manip_amd import CoffeeDataset
+    g = golden("g9_dataset.npz")
+    root = str(tmp_path) + "/"
+    _write_dataset(g, root)
+    ds = CoffeeDataset(root, 6, 0.015, split="train", device=dev, use_control=use_control)
+    assert len(ds) == int(g[f"{tag}.len"])
+    for idx in (0, 4):
+        obs, nxt = ds.sample(idx)
+        np.testing.assert_array_equal(obs.cpu().numpy(), g[f"{tag}.{idx}.obs"])
+        np.testing.assert_array_equal(nxt.cpu().numpy(), g[f"{tag}.{idx}.next"])
+        d = ds[idx]
+        np.testing.assert_array_equal(d.edge_index[0].cpu().numpy(), g[f"{tag}.{idx}.senders"])  # bit-exact edge list
+        np.testing.assert_array_equal(d.edge_index[1].cpu().numpy(), g[f"{tag}.{idx}.receivers"])
+        np.testing.assert_allclose(d.x.cpu().numpy(), g[f"{tag}.{idx}.nodes"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(d.edge_attr.cpu().numpy(), g[f"{tag}.{idx}.edge_attr"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(d.y.cpu().numpy(), g[f"{tag}.{idx}.tgt"], rtol=1e-5, atol=2e-4)
+
+
+def test_loader_batches_like_the_reference_collate(golden, dev, tmp_path):
+    """batch_size=2 (train_dyn.py default): concatenated graphs, second graph's indices offset by N."""
+    from gnn_manip_amd import CoffeeDataset, GraphLoader
+    g = golden("g9_dataset.npz")
+    root = str(tmp_path) + "/"
+    _write_dataset(g, root)
+    ds = CoffeeDataset(root, 6, 0.015, split="train", device=dev, use_control=True)
+    batches = list(GraphLoader(ds, batch_size=2, shuffle=False))
+    assert len(batches) == 3
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    data_dim, T, cart, ctrl, mat, bounds, stats = orc.read_metadata(meta)
+    obs_list, next_list = orc.dataset_samples([s.reshape(-1, data_dim) for s in g["sims"]], T, data_dim, 6, cart, mat, True)
+    nodes, ea, ei, tgt = orc.process_collate([(obs_list[0], next_list[0]), (obs_list[1], next_list[1])], stats=stats, bounds=bounds,
+                                             conn_r=0.015, cartesian_idx=cart, material_idx=[mat], control_idx=ctrl)
+    b = batches[0]
+    np.testing.assert_array_equal(b.edge_index.cpu().numpy(), ei)
+    np.testing.assert_allclose(b.x.cpu().numpy(), nodes, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(b.edge_attr.cpu().numpy(), ea, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(b.y.cpu().numpy(), tgt, rtol=1e-5, atol=2e-4)
+
+
+def test_noise_path_golden(golden, dev):
+    """random_walk_noise / _process_noisy with the reference's own Normal draw injected."""
+    from gnn_manip_amd import GraphBoundedMultimaterialControl, random_walk_noise
+    g = golden("g9_dataset.npz")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    obs, sample, std = t(g["noise.obs"]), t(g["noise.sample"]), float(g["noise.std"])
+    seq = random_walk_noise(obs[:, :, 2:5], std, sample)
+    np.testing.assert_allclose(seq.cpu().numpy(), g["noise.sequence"], rtol=1e-6, atol=1e-9)
+    ga = GraphBoundedMultimaterialControl(0.015, STATS, CART, MAT, CTRL, BOUNDS, noise=std)
+    nodes, ea, s, r, acc = ga.process(obs, t(g["noise.tgt"]), noise_sample=sample)
+    np.testing.assert_array_equal(s.cpu().numpy(), g["noise.senders"])
+    np.testing.assert_array_equal(r.cpu().numpy(), g["noise.receivers"])
+    # one ulp of a noisy position (3e-8) is 1.5e-5 in a velocity feature (std 2e-3) and 2e-4 in the target (std 2e-4)
+    np.testing.assert_allclose(nodes.cpu().numpy(), g["noise.nodes"], rtol=2e-6, atol=3e-5)
+    np.testing.assert_allclose(ea.cpu().numpy(), g["noise.edge_attr"], rtol=2e-6, atol=4e-6)
+    np.testing.assert_allclose(acc.cpu().numpy(), g["noise.acc"], rtol=1e-5, atol=6e-4)
+
+
+def test_noise_draw_statistics(dev):
+    """The device draw has the reference's distribution: velocity noise of the last step has std noise_std
+    (utils.py:97-101), position noise of the first frame is zero."""
+    from gnn_manip_amd import random_walk_noise
+    gen = torch.Generator(device=dev).manual_seed(3)
+    pos = torch.zeros((6, 20000, 3), device=dev)
+    seq = random_walk_noise(pos, 3e-4, generator=gen)
+    assert not seq[0].any()
+    last_vel_noise = (seq[-1] - seq[-2]).cpu().numpy()
+    assert abs(last_vel_noise.std() / 3e-4 - 1.0) < 0.02
+    assert abs(last_vel_noise.mean()) < 1e-5

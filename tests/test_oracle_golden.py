@@ -168,3 +168,41 @@ def test_torch_restatement_matches_numpy_oracle():
     out = torch_epd.epd_forward(p, torch.tensor(nodes, dtype=torch.float64), torch.tensor(ea, dtype=torch.float64),
                                 torch.tensor(ei), 2, 3).numpy()
     assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+# ------------------------------------------------------------------ G9: dataset files and training-time noise
+def _g9_meta(g):
+    import json
+    return json.loads(bytes(g["meta_json"]).decode())
+
+
+@pytest.mark.parametrize("tag,use_control", [("ctl", True), ("noctl", False)])
+def test_dataset_samples_and_graphs_golden(golden, tag, use_control):
+    g = golden("g9_dataset.npz")
+    meta = _g9_meta(g)
+    data_dim, T, cart, ctrl, mat, bounds, stats = orc.read_metadata(meta)
+    obs_list, next_list = orc.dataset_samples([s.reshape(-1, data_dim) for s in g["sims"]], T, data_dim, 6, cart, mat, use_control)
+    assert len(obs_list) == int(g[f"{tag}.len"])
+    for idx in (0, 4):
+        np.testing.assert_array_equal(obs_list[idx], g[f"{tag}.{idx}.obs"])
+        np.testing.assert_array_equal(next_list[idx], g[f"{tag}.{idx}.next"])
+        nodes, ea, s, r, tgt = orc.process(obs_list[idx], next_list[idx], stats, bounds, 0.015, cart, [mat], ctrl if use_control else None)
+        np.testing.assert_array_equal(s, g[f"{tag}.{idx}.senders"])
+        np.testing.assert_array_equal(r, g[f"{tag}.{idx}.receivers"])
+        np.testing.assert_allclose(nodes, g[f"{tag}.{idx}.nodes"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(ea, g[f"{tag}.{idx}.edge_attr"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(tgt, g[f"{tag}.{idx}.tgt"], rtol=1e-5, atol=2e-4)
+
+
+def test_random_walk_noise_and_noisy_process_golden(golden):
+    g = golden("g9_dataset.npz")
+    seq = orc.random_walk_noise(g["noise.obs"][:, :, CART], float(g["noise.std"]), g["noise.sample"])
+    np.testing.assert_allclose(seq, g["noise.sequence"], rtol=1e-6, atol=1e-9)
+    assert not seq[0].any()
+    nodes, ea, s, r, acc = orc.process_noisy(g["noise.obs"], g["noise.tgt"], g["noise.sample"], control_idx=CTRL, **KW)
+    np.testing.assert_array_equal(s, g["noise.senders"])
+    np.testing.assert_array_equal(r, g["noise.receivers"])
+    # one ulp of a noisy position (3e-8) is 1.5e-5 in a velocity feature (std 2e-3) and 2e-4 in the target (std 2e-4)
+    np.testing.assert_allclose(nodes, g["noise.nodes"], rtol=2e-6, atol=3e-5)
+    np.testing.assert_allclose(ea, g["noise.edge_attr"], rtol=2e-6, atol=4e-6)
+    np.testing.assert_allclose(acc, g["noise.acc"], rtol=1e-5, atol=6e-4)
