@@ -76,6 +76,8 @@ PROTOTYPES = {
     "gm_graph_independent_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "gm_interaction_network_forward_train": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "gm_interaction_network_backward": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "gm_sinkhorn_workspace_bytes": (_sz, [_i64, _i64]),
+    "gm_sinkhorn_divergence": (_i32, [_vp, _i64, _vp, _i64, _f32, _f32, _vp, _vp, _sz, _vp]),
     "gm_rollout_workspace_bytes": (_sz, [_MD, _i64, _i32]),
     "gm_rollout_step": (_i32, [_vp, _vp, _i64, _FD, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gm_rollout_status": (_i32, [_vp, _MD, _i64, _i32, C.POINTER(_i64), _vp]),

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgnnmanip_hip.so")
-SOURCES = ["graph.hip", "features.hip", "mlp.hip", "model.hip", "train.hip", "train_model.hip"]
+SOURCES = ["graph.hip", "features.hip", "mlp.hip", "model.hip", "train.hip", "train_model.hip", "sinkhorn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-value"]
 
 

@@ -74,6 +74,17 @@ class CandidateEvaluator:
         import torch.distributed as dist
         return dist if (dist.is_available() and dist.is_initialized()) else None
 
+    def evaluate_blocks(self, population, block_fn):
+        """Like evaluate(), but the rank's whole block goes to block_fn(list of candidates) -> list of results at once
+        (batched rollouts on the device)."""
+        self._block_fn = block_fn
+        try:
+            return self.evaluate(population)
+        finally:
+            self._block_fn = None
+
+    _block_fn = None
+
     def evaluate(self, population):
         dist = self._dist()
         world = dist.get_world_size(self.group) if dist else 1
@@ -95,9 +106,14 @@ class CandidateEvaluator:
         per = -(-n // world)  # padded block so that all_gather sees equal shapes
         lo, hi = shard_range(n, world, rank)
         local = torch.zeros((per, self.result_dim), dtype=torch.float64, device=dev)
-        for j, c in enumerate(range(lo, hi)):
-            r = self.fn(pop_np[c])
-            local[j] = torch.as_tensor(r, dtype=torch.float64).reshape(-1).to(dev)
+        if self._block_fn is not None:
+            res = self._block_fn([pop_np[c] for c in range(lo, hi)]) if hi > lo else []
+            for j, r in enumerate(res):
+                local[j] = torch.as_tensor(r, dtype=torch.float64).reshape(-1).to(dev)
+        else:
+            for j, c in enumerate(range(lo, hi)):
+                r = self.fn(pop_np[c])
+                local[j] = torch.as_tensor(r, dtype=torch.float64).reshape(-1).to(dev)
         if not dist:
             return local[:n].cpu().numpy()
         gathered = [torch.empty_like(local) for _ in range(world)]
@@ -107,3 +123,153 @@ class CandidateEvaluator:
             a, b = shard_range(n, world, r)
             out[a:b] = gathered[r][:b - a].cpu().numpy()
         return out
+
+
+class TrajectoryCMAsolver:
+    """Mirror of the reference's ``TrajectoryCMAsolver`` (traj_utils.py:14-76,197-285) with the population of a
+    CMA-ES generation evaluated TOGETHER on the device(s) instead of one ``cma_objective`` call per candidate:
+
+    * ``cma_objective(x)``: one candidate, the reference's loop (rollout on the device, no PCIe per step);
+    * ``population_losses(X)``: the generation is cut into blocks of ``candidates_per_gpu`` block-diagonal
+      batched rollouts (``RolloutEngine(candidates=B)``) and, under ``torch.distributed``, sharded over the ranks
+      (``CandidateEvaluator``: one broadcast of X, one all-gather of the losses per generation);
+    * ``optimize_trajectory(desired_position)``: ``cmaes.fmin2`` over that (the reference: ``cma.fmin2``, :257).
+
+    Same constructor arguments as the reference (``state_init`` = (obs [k, N, D], next positions) on the device).
+    """
+
+    def __init__(self, model, graph_attr, state_init, rx_init, ty_init, scale_rot, scale_ty, alpha, beta, gamma, penalty,
+                 rho, device, cma_iter=10, cma_var=0.5, cma_popsize=21, cma_rand=1234, max_rot=1.9337, max_ty=6.67e-4,
+                 total_steps=300, traj_points=10, candidates_per_gpu=8):
+        from . import cmaes
+        from .losses import SamplesLoss
+        from .rollout import RolloutEngine
+        self.initial_state = state_init
+        self.rx_init = np.deg2rad(rx_init)
+        self.ty_init = ty_init
+        self.sample_traj = None
+        self.desired_pos = None
+        self.model, self.graph_attr = model, graph_attr
+        self.horizon = total_steps
+        self.device = torch.device(device)
+        self.scale_rot, self.scale_ty = scale_rot, scale_ty
+        self.nr_traj_points = traj_points
+        self.traj_points = int(self.horizon / self.nr_traj_points)
+        self.alpha, self.beta, self.gamma, self.penalty, self.rho = alpha, beta, gamma, penalty, rho
+        self.max_rot = np.deg2rad(max_rot)
+        self.max_ty = max_ty
+        self.total_steps = total_steps
+        # limits of the boundary penalties (traj_utils.py:57-61)
+        self.left_limit, self.right_limit = 0.3, 0.7
+        self.scale_ty = (self.ty_init[0] - self.left_limit) / self.scale_rot
+        self.rotation_limit = 2.8973
+        obs = self.initial_state[0]
+        mat = graph_attr.material_idx[0]
+        c0 = graph_attr.cartesian_idx[0]
+        self.rigid_particles_idx = obs[-1, :, mat] == 1
+        self.coffee_particles_idx = obs[-1, :, mat] == 0
+        self.rigid_particles = obs[-1, self.rigid_particles_idx, c0:c0 + 3].contiguous()
+        self.loss = SamplesLoss(loss="sinkhorn", p=2, blur=.05)
+        self.cma_options = cmaes.CMAOptions()
+        self.cma_options['seed'] = cma_rand
+        self.cma_options['maxiter'] = cma_iter
+        self.cma_options['popsize'] = cma_popsize
+        self.cma_initial_var = cma_var
+        self.candidates_per_gpu = int(candidates_per_gpu)
+        k, n, dd = obs.shape
+        self._mk_engine = lambda b: RolloutEngine(model, graph_attr, n, k_steps=k, data_dim=dd, device=self.device, candidates=b)
+        self._engines = {}
+
+    # ---- trajectory parametrisation (traj_utils.py:199-228)
+    def set_sample_traj(self, sample_traj):
+        sample_traj = np.asarray(sample_traj)
+        d = sample_traj[2:] - sample_traj[1:-1]
+        self.sample_traj = np.stack((np.deg2rad(d[:, 0] / self.scale_rot), d[:, 1] / self.scale_ty)).T
+
+    def interpolate_trajectory(self, x):
+        return interpolate_trajectory(x, self.sample_traj.shape[0], self.rx_init, self.scale_rot, self.scale_ty, self.max_rot,
+                                      self.max_ty)
+
+    def get_rigid_body_trajectory_from_diff(self, x, demo=False):
+        if demo:
+            traj_rot, traj_ty = x[:, 0], x[:, 1]
+        else:
+            traj_rot, traj_ty = self.interpolate_trajectory(x)
+        traj = get_rigid_body_trajectory(traj_rot, traj_ty, self.horizon, self.ty_init, self.rigid_particles)
+        actions = np.zeros((self.horizon, 2))
+        actions[:, 0] = traj_rot[:self.horizon]
+        actions[:, 1] = traj_ty[:self.horizon]
+        return traj, actions
+
+    # ---- loss terms (traj_utils.py:161-165,230-285)
+    @staticmethod
+    def compute_vel_acc(actions):
+        return actions[1:, :] - actions[:-1, :], actions[2:, :] - 2 * actions[1:-1, :] + actions[:-2, :]
+
+    def compute_vel_loss(self, vel):
+        return float(np.linalg.norm(vel / np.array([self.max_rot, self.max_ty])[None, :]))
+
+    def compute_acc_loss(self, acc):
+        return float(np.linalg.norm(acc / np.array([self.max_rot, self.max_ty])[None, :]))
+
+    def compute_boundaries_penalty(self, actions):
+        rot = actions[:, 0]
+        if rot.max() > self.rx_init + self.rotation_limit or rot.min() < self.rx_init - self.rotation_limit:
+            return 20.0
+        return 0.0
+
+    def compute_loss(self, end_position, actions, cup_states=None, coffee_states=None, x=None):
+        wasserstein_loss = float(self.loss(end_position, self.desired_pos).item())
+        vel, acc = self.compute_vel_acc(actions)
+        vel_loss, acc_loss = self.compute_vel_loss(vel), self.compute_acc_loss(acc)
+        bound_penalty = self.compute_boundaries_penalty(actions)
+        loss = self.beta * wasserstein_loss + self.penalty * bound_penalty + self.alpha * vel_loss + self.gamma * acc_loss
+        return loss, wasserstein_loss, vel_loss, acc_loss, bound_penalty, 0.0
+
+    # ---- objective
+    def _engine(self, b):
+        if b not in self._engines:
+            self._engines[b] = self._mk_engine(b)
+        return self._engines[b]
+
+    def _end_positions(self, final_states):
+        c0 = self.graph_attr.cartesian_idx[0]
+        return [fs[-1, self.coffee_particles_idx, c0:c0 + 3].contiguous() for fs in final_states]
+
+    def cma_objective(self, x):
+        """traj_utils.py:114-159 for one candidate."""
+        return self._block_losses([np.asarray(x, dtype=np.float64)])[0]
+
+    def _block_losses(self, xs):
+        trajs, acts = zip(*[self.get_rigid_body_trajectory_from_diff(x) for x in xs])
+        eng = self._engine(len(xs))
+        with torch.no_grad():
+            finals = eng.rollout_candidates(self.initial_state[0].contiguous(), torch.stack(trajs), horizon=self.horizon)
+        return [self.compute_loss(end, a)[0] for end, a in zip(self._end_positions(finals), acts)]
+
+    def population_losses(self, X):
+        """Losses of a whole generation.  Under torch.distributed rank 0's X is broadcast and every rank evaluates
+        a contiguous block; returns the full list on every rank."""
+        import torch.distributed as dist
+        X = [np.asarray(x, dtype=np.float64) for x in X]
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1:
+            ev = CandidateEvaluator(None, result_dim=1, device=self.device)
+            return ev.evaluate_blocks(X, self._local_losses).reshape(-1).tolist()
+        return self._local_losses(X)
+
+    def _local_losses(self, X):
+        out = []
+        for b in range(0, len(X), self.candidates_per_gpu):
+            out += self._block_losses(X[b:b + self.candidates_per_gpu])
+        return out
+
+    def optimize_trajectory(self, desired_position):
+        """traj_utils.py:247-259."""
+        from . import cmaes
+        initial_traj = np.zeros(int(self.sample_traj.shape[0] * 2))
+        initial_traj[:self.sample_traj.shape[0]] = self.sample_traj[:, 0]
+        initial_traj[self.sample_traj.shape[0]:] = self.sample_traj[:, 1]
+        self.desired_pos = desired_position.clone()
+        return cmaes.fmin2(self.cma_objective, initial_traj.tolist(), self.cma_initial_var, options=self.cma_options,
+                           parallel_objective=self.population_losses)

@@ -224,6 +224,15 @@ int gm_interaction_network_backward(const gm_model* m, int block, const float* c
                                     float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
                                     void* stream);
 
+/* Planner loss: geomloss.SamplesLoss(loss="sinkhorn", p=2, blur) between the final
+ * particle cloud x [N,3] and the desired one y [M,3], uniform weights -- traj_utils.py:69,279.  Debiased
+ * Sinkhorn divergence, cost |x-y|^2/2, epsilon-scaling with ratio `scaling` (geomloss default 0.5) from the
+ * bounding-box diameter down to blur.  Writes one float to loss_device.  One host synchronisation (the
+ * diameter fixes the length of the epsilon schedule). */
+size_t gm_sinkhorn_workspace_bytes(int64_t n, int64_t m);
+int gm_sinkhorn_divergence(const float* x, int64_t n, const float* y, int64_t m, float blur, float scaling,
+                           float* loss_device, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * One device-resident rollout step = compute_rollout's loop body, rollout_utils.py:38-61 ==
  * cma_objective's, traj_utils.py:123-152:  state_pre -> node features -> radius graph -> csr ->

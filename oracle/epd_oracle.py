@@ -500,3 +500,63 @@ def rollout(params, obs0, trajectory, horizon, stats, bounds, conn_r, cartesian_
     if record:
         return obs, np.stack(recs)
     return obs
+
+
+# --------------------------------------------------------------------------------------
+# planner loss (gnn_manip/utils/traj_utils.py:69,161-165,230-285)
+# --------------------------------------------------------------------------------------
+def sinkhorn_divergence(x, y, blur=0.05, scaling=0.5, dtype=np.float64):
+    """geomloss.SamplesLoss(loss="sinkhorn", p=2, blur=blur) between two uniform clouds (call sites
+    traj_utils.py:69,279).  geomloss is an un-vendored, un-pinned pip dependency (environment.yml:25): this is a
+    restatement of its published algorithm (Feydy et al. 2019; geomloss sinkhorn_divergence.py `sinkhorn_loop` /
+    `sinkhorn_cost`, tensorized backend): C = |x-y|^2 / 2, eps-scaling from diameter^2 to blur^2, symmetrised
+    log-domain updates with debiasing, one final extrapolation, S = <a, b_x - a_x> + <b, a_y - b_y>.
+    PARITY UNPINNED against geomloss itself (absent); pinned by known answers (tests)."""
+    x = np.asarray(x, dtype)
+    y = np.asarray(y, dtype)
+    n, m = x.shape[0], y.shape[0]
+    both = np.concatenate((x, y)).astype(np.float32)
+    diameter = float(np.sqrt(((both.max(0) - both.min(0)).astype(np.float32) ** 2).sum(dtype=np.float32)))
+    if diameter == 0.0:
+        return 0.0
+    eps_s = [diameter ** 2] + [float(np.exp(e)) for e in np.arange(2 * np.log(diameter), 2 * np.log(blur), 2 * np.log(scaling))] + [blur ** 2]
+
+    def cost(a, b):
+        return ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1) / 2
+
+    def softmin(eps, C, h):  # -eps * logsumexp_j (h_j - C_ij / eps)
+        v = h[None, :] - C / eps
+        mx = v.max(axis=1)
+        return -eps * (mx + np.log(np.exp(v - mx[:, None]).sum(axis=1)))
+
+    C_xx, C_yy, C_xy, C_yx = cost(x, x), cost(y, y), cost(x, y), cost(y, x)
+    la, lb = np.full(n, -np.log(n), dtype), np.full(m, -np.log(m), dtype)
+    eps = eps_s[0]
+    a_x, b_y = softmin(eps, C_xx, la), softmin(eps, C_yy, lb)
+    a_y, b_x = softmin(eps, C_yx, la), softmin(eps, C_xy, lb)
+    for eps in eps_s:
+        at_x, bt_y = softmin(eps, C_xx, la + a_x / eps), softmin(eps, C_yy, lb + b_y / eps)
+        at_y, bt_x = softmin(eps, C_yx, la + b_x / eps), softmin(eps, C_xy, lb + a_y / eps)
+        a_x, b_y = 0.5 * (a_x + at_x), 0.5 * (b_y + bt_y)
+        a_y, b_x = 0.5 * (a_y + at_y), 0.5 * (b_x + bt_x)
+    a_x, b_y = softmin(eps, C_xx, la + a_x / eps), softmin(eps, C_yy, lb + b_y / eps)
+    a_y, b_x = softmin(eps, C_yx, la + b_x / eps), softmin(eps, C_xy, lb + a_y / eps)
+    return float((b_x - a_x).mean() + (a_y - b_y).mean())
+
+
+def compute_vel_acc(actions):
+    """traj_utils.py:161-165."""
+    actions = np.asarray(actions, np.float64)
+    return actions[1:] - actions[:-1], actions[2:] - 2 * actions[1:-1] + actions[:-2]
+
+
+def planner_penalties(actions, rx_init, rotation_limit, vel_scale, acc_scale):
+    """(vel_loss, acc_loss, bound_penalty) of compute_loss (traj_utils.py:230-285): Frobenius norms of the
+    finite differences normalised per column (CMAESolver: max_rot / max_ty; TrajectoryCMAsolver: fixed means,
+    traj_utils.py:343-365), and the 20.0 rotation-range penalty."""
+    vel, acc = compute_vel_acc(actions)
+    vel_loss = float(np.linalg.norm(vel / np.asarray(vel_scale, np.float64)[None, :]))
+    acc_loss = float(np.linalg.norm(acc / np.asarray(acc_scale, np.float64)[None, :]))
+    rot = np.asarray(actions, np.float64)[:, 0]
+    penalty = 20.0 if (rot.max() > rx_init + rotation_limit or rot.min() < rx_init - rotation_limit) else 0.0
+    return vel_loss, acc_loss, penalty

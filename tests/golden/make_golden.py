@@ -282,6 +282,28 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g8_rollout.npz"), **g8)
     print("G8 done; end absmax", float(np.abs(g8["end_coffee"]).max()))
 
+    # ---------------- G10 planner loss terms (traj_utils.py:161-165,230-285) with the Wasserstein term stubbed
+    # (geomloss is absent): pins compute_vel_acc, compute_vel_loss, compute_acc_loss, compute_boundaries_penalty and
+    # the weighting in compute_loss.
+    g10 = {}
+    kw10 = dict(alpha=0.3, beta=1000.0, gamma=0.05, penalty=2.0, rho=0.0, device="cpu")
+    solver = ref.traj.TrajectoryCMAsolver(model, gc, state, 180, [0.5, 0.5, 0.4], scale_rot=1.0, scale_ty=1.0,
+                                          total_steps=horizon, **kw10)
+    solver.loss = lambda a, b: torch.tensor(0.125)
+    solver.desired_pos = state[1]
+    rng = np.random.Generator(np.random.PCG64(77))
+    for tag, spread in (("inside", 0.3), ("outside", 3.5)):
+        actions = np.zeros((40, 2))
+        actions[:, 0] = np.pi + spread * np.sin(np.linspace(0, 3, 40)) + 1e-3 * rng.standard_normal(40)
+        actions[:, 1] = 1e-3 * np.cumsum(rng.standard_normal(40))
+        out = solver.compute_loss(state[1], actions)
+        g10[f"{tag}.actions"] = actions
+        g10[f"{tag}.out"] = np.array([float(v) for v in out])
+    g10["cfg"] = np.array([solver.alpha, solver.beta, solver.gamma, solver.penalty, solver.rho, solver.max_rot, solver.max_ty,
+                           solver.rx_init, solver.rotation_limit])
+    np.savez_compressed(os.path.join(HERE, "g10_planner_loss.npz"), **g10)
+    print("G10 done", g10["inside.out"], g10["outside.out"])
+
     # ---------------- G9: on-disk dataset (CSV + metadata.json) and the training-time noise path
     # coffee_dataset.py:18-113 (read_metadata, CoffeeDataset._load_data / graph_attr), utils.py:96-115 (random_walk_noise),
     # collate_utils.py:169-193 (_process_noisy).  The dataset is synthetic and tiny; it is stored in the fixture as

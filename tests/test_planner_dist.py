@@ -86,3 +86,50 @@ def test_candidate_evaluator_single_process():
     ev = CandidateEvaluator(lambda x: [float(x.sum())], result_dim=1)
     pop = np.arange(12.0).reshape(4, 3)
     np.testing.assert_array_equal(ev.evaluate(pop)[:, 0], pop.sum(axis=1))
+
+
+def _worker_cma(rank, world, port, q):
+    """One CMA-ES generation loop whose populations are evaluated block-wise over the ranks (the shape of
+    TrajectoryCMAsolver.population_losses: rank 0's candidates are broadcast, each rank evaluates its contiguous
+    block in one batched call, every rank receives all losses)."""
+    import torch.distributed as dist
+    from gnn_manip_amd import cmaes
+    from gnn_manip_amd.planner import CandidateEvaluator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blocks = []
+
+    def block_fn(xs):  # stands in for one block-diagonal batched rollout + losses
+        blocks.append(len(xs))
+        return [float(np.sum((np.asarray(x) - 0.3) ** 2)) for x in xs]
+
+    ev = CandidateEvaluator(None, result_dim=1)
+    # every rank runs the same optimiser state machine; only rank 0's candidates count (they are broadcast)
+    es = cmaes.CMAEvolutionStrategy([0.0] * 5, 0.3, {"seed": 11 + rank, "popsize": 9, "maxiter": 25})
+    while not es.stop():
+        X = es.ask()
+        F = ev.evaluate_blocks(X if rank == 0 else None, block_fn).reshape(-1)
+        Xs = [X]  # non-root ranks adopt rank 0's population so that the optimiser states stay identical
+        dist.broadcast_object_list(Xs, src=0)
+        es.tell(Xs[0], F.tolist())
+    q.put((rank, es.result.fbest, es.result.xbest, blocks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cma_generation_loop_sharded_over_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_cma, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, f0, x0, b0), (r1, f1, x1, b1) = out
+    assert f0 == f1 and np.array_equal(x0, x1)          # identical optimiser state on both ranks
+    assert f0 < 1e-3 and np.abs(x0 - 0.3).max() < 0.05  # and it optimises
+    assert set(b0) == {5} and set(b1) == {4}            # 9 candidates -> blocks of 5 and 4, one batched call each
