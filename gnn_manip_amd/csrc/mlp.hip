@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(THREADS, 2) edge_kernel16(EdgeArgs A) {
                 if (!wrap || more_tiles) issue_stage(ws, stl, ws.parity ^ 1);
             }
             // drip-fed prefetch of the next tile's operands (previous stage's loads have landed: the wait above)
-            if (!ENC && more_tiles) {
+            if (!ENC && more_tiles && !(A.debug & 8)) {
                 if (s < 4) {
                     nact[2 * s] = *reinterpret_cast<const floatx4*>(A.e_in + (int64_t)jx.er * H + 16 * (2 * s) + 4 * g);
                     nact[2 * s + 1] = *reinterpret_cast<const floatx4*>(A.e_in + (int64_t)jx.er * H + 16 * (2 * s + 1) + 4 * g);
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(THREADS, 2) edge_kernel16(EdgeArgs A) {
             __builtin_amdgcn_sched_barrier(0);
             const float* buf = ws.ring + ws.parity * STAGE_FLOATS + lane * 4;
             if (ENC && s == 0) stage16<1, NB>(acc, act, buf, 0);
-            else stage16<H / 16, NB>(acc, act, buf, st_in_layer);
+            else if (!(A.debug & 1)) stage16<H / 16, NB>(acc, act, buf, st_in_layer);
             ws.cur = ws.cur + 1 == ws.total ? 0 : ws.cur + 1;
             ws.parity ^= 1;
             if (s == L1S - 1) GM_STAMP(1);
@@ -620,6 +620,13 @@ __global__ void __launch_bounds__(THREADS, 2) edge_kernel16(EdgeArgs A) {
         GM_STAMP(2);
         __builtin_amdgcn_sched_barrier(0);
         prio_latency_phase();
+        if (A.debug & 2) {  // ablation: no epilogue (keep the result alive)
+            if (acc[0][0] == 123.456f) A.e_out[p0] = acc[1][1] + acc[2][2] + acc[3][3];
+            if (!ENC && more_tiles) { nacc[NB - 2] += pj0; nacc[NB - 1] += pj1; }
+            ix = jx;
+            tpar ^= 1;
+            continue;
+        }
         layer_norm16(acc, lgamma, lbeta, A.eps, g);
         GM_STAMP(3);
 
@@ -627,7 +634,7 @@ __global__ void __launch_bounds__(THREADS, 2) edge_kernel16(EdgeArgs A) {
         const int p = p0 + wave * 16 + n;
         const bool valid = p < E;
         const int64_t out_row = !valid ? 0 : (!A.eid_out ? (int64_t)p : (A.eid_out == A.eid ? (int64_t)er_cur : (int64_t)A.eid_out[p]));
-        if (valid) {
+        if (valid && !(A.debug & 64)) {
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
                 floatx4 x = acc[kb];
@@ -641,7 +648,7 @@ __global__ void __launch_bounds__(THREADS, 2) edge_kernel16(EdgeArgs A) {
         // segments that cross a wave's rows or the tile are stitched from the per-wave head / tail
         // partials by wave 0 (columns 0..63) and wave 1 (columns 64..127) with scalar control flow.
         // Two LDS-only barriers per tile; the stitch is off the other waves' critical path.
-        if (!ENC) {
+        if (!ENC && !(A.debug & 4)) {
             float* part = headv + tpar * 1024;  // [2 halves][head 4x64 | tail 4x64], double-buffered per tile
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb)
