@@ -286,23 +286,6 @@ __global__ void __launch_bounds__(256) graph_clear_kernel(GraphHeader* hdr, int*
     }
 }
 
-__global__ void graph_init_kernel(GraphHeader* hdr) {
-    if (threadIdx.x == 0) {
-        hdr->n_edges = 0;
-        hdr->error_flags = 0;
-        hdr->ncells = 1;
-        for (int a = 0; a < 3; ++a) {
-            hdr->bbox_min[a] = 0xffffffffu;
-            hdr->bbox_max[a] = 0u;
-            hdr->dims[a] = 1;
-            hdr->origin[a] = 0.0;
-        }
-        hdr->inv_h = 1.0;
-        hdr->n_per_graph = 1;
-        hdr->ncells_local = 1;
-    }
-}
-
 __device__ void grid_params(GraphHeader* hdr, double r, int max_cells, int64_t n, int64_t n_per);
 
 // bounding box; the block that finishes last derives the grid from it (no separate launch)
@@ -582,10 +565,6 @@ __global__ void __launch_bounds__(BS) neighbor_kernel(const float4* __restrict__
     }
     cnt[qi] = kept;
     for (int s = 0; s < kept; ++s) nbr[(int64_t)qi * K + s] = ki[s * BS + t];
-}
-
-__global__ void set_total_kernel(GraphHeader* hdr, const int* __restrict__ out_ptr, int64_t n) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) hdr->n_edges = out_ptr[n];
 }
 
 __global__ void __launch_bounds__(256) emit_edges_kernel(const int* __restrict__ cnt, const int* __restrict__ out_ptr,

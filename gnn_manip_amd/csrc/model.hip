@@ -379,7 +379,7 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
 namespace {
 struct RolloutWs {
     void *graph, *csr, *fwd;
-    float *x, *edge_attr, *pred, *next_pos;
+    float *x, *edge_attr, *pred;
     size_t graph_bytes, csr_bytes, fwd_bytes, bytes;
 };
 RolloutWs carve_rollout(void* ws, const gm_model_desc* d, int64_t n, int K) {
@@ -395,7 +395,6 @@ RolloutWs carve_rollout(void* ws, const gm_model_desc* d, int64_t n, int K) {
     r.x = c.take<float>((size_t)n * 32);
     r.edge_attr = c.take<float>((size_t)cap * 4);
     r.pred = c.take<float>((size_t)n * 4);
-    r.next_pos = c.take<float>((size_t)n * 3);
     r.bytes = c.used();
     return r;
 }

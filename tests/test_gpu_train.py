@@ -154,3 +154,21 @@ def test_reference_wiring_over_standalone_blocks_trains(dev, n, side, seed, m_st
         if err / tol > worst[1]:
             worst = (name, err / tol, err, tol)
     assert worst[1] <= 1.0, worst
+
+
+@pytest.mark.parametrize("n,with_edges", [(5, False), (1, True), (130, False)])
+def test_backward_degenerate_graphs(dev, n, with_edges):
+    """No edges at all (every node isolated) and a single node with its self edge: the edge-side kernels get zero /
+    one row, the edge MLP gradients are exactly what autograd gives (zeros without edges)."""
+    dims = (25, 4, 3, 128, 2, 2)
+    params = orc.init_params(*dims, 99)
+    m = _model(params, dims, dev)
+    rng = np.random.default_rng(n)
+    nodes = rng.standard_normal((n, 25)).astype(np.float32)
+    if with_edges:
+        ei = np.stack((np.arange(n), np.arange(n))).astype(np.int64)
+        ea = np.zeros((n, 4), np.float32)
+    else:
+        ei = np.zeros((2, 0), np.int64)
+        ea = np.zeros((0, 4), np.float32)
+    _check(m, params, nodes, ea, ei, dims, dev, 99)
