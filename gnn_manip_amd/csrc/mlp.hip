@@ -1176,7 +1176,17 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
             done16 = true;
         }
         a.wstream = a.wstream16;
-        const int g16 = grid_for(cdiv(edge_capacity, T16));
+        // persistent grid: one workgroup per resident slot (2 per CU), so that every workgroup walks several tiles and
+        // the next tile's gathers / first weight stage are always in flight (at N = 5k a one-tile-per-workgroup grid
+        // costs 6 % per launch: no prefetch, 3x the prologues); GM_EDGE_GRID_CAP overrides
+        static const int grid_cap = [] {
+            if (getenv("GM_EDGE_GRID_CAP")) return atoi(getenv("GM_EDGE_GRID_CAP"));
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return 2 * cus;
+        }();
+        int g16 = grid_for(cdiv(edge_capacity, T16));
+        if (grid_cap > 0 && g16 > grid_cap) g16 = grid_cap;
         {
             ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
             if (enc) hipLaunchKernelGGL((edge_kernel16<2, 0>), dim3(g16), dim3(THREADS), l16, s, a);
