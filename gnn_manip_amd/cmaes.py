@@ -135,3 +135,39 @@ def fmin2(objective_function, x0, sigma0, options=None, parallel_objective=None)
         F = parallel_objective(X) if parallel_objective is not None else [objective_function(x) for x in X]
         es.tell(X, F)
     return es.result.xbest, es
+
+
+class _BestFeasible:
+    def __init__(self):
+        self.f, self.info = np.inf, None
+
+
+def fmin_con(objective_function, x0, sigma0, g=lambda x: [], options=None, parallel_objective=None):
+    """``cma.fmin_con``'s role (traj_utils.py:336): minimise f subject to g(x) <= 0 (vector valued).  Augmented
+    Lagrangian on top of the same CMA-ES: L = f + sum_i (lam_i g_i + mu/2 g_i^2 where the constraint is active,
+    -lam_i^2 / (2 mu) elsewhere), multipliers updated at the distribution mean once per generation.  Returns
+    (xbest of L, es) with ``es.best_feasible.f / .info`` (= {'x', 'f', 'g'}) tracking the best sampled point that
+    satisfies every constraint, as optimise_traj.py:196-200 reads it.  Like fmin2, not a clone of the package."""
+    es = CMAEvolutionStrategy(x0, sigma0, options)
+    es.best_feasible = _BestFeasible()
+    lam, mu = None, 1.0
+    while not es.stop():
+        X = es.ask()
+        F = np.asarray(parallel_objective(X) if parallel_objective is not None else [objective_function(x) for x in X], dtype=np.float64)
+        G = np.asarray([np.asarray(g(x), dtype=np.float64).reshape(-1) for x in X])
+        if lam is None:
+            lam = np.zeros(G.shape[1])
+            spread = np.ptp(F) if np.ptp(F) > 0 else 1.0
+            gs = np.abs(G).mean() if G.size and np.abs(G).mean() > 0 else 1.0
+            mu = spread / gs ** 2  # penalty on the scale of the objective's spread per unit of squared violation
+        L = F.copy()
+        if G.shape[1]:
+            active = G > -lam[None, :] / mu
+            L += np.where(active, lam[None, :] * G + 0.5 * mu * G * G, -lam[None, :] ** 2 / (2 * mu)).sum(axis=1)
+            for x, f, gv in zip(X, F, G):
+                if (gv <= 0).all() and f < es.best_feasible.f:
+                    es.best_feasible.f, es.best_feasible.info = float(f), {"x": np.array(x), "f": float(f), "g": gv.copy()}
+        es.tell(X, L.tolist())
+        if G.shape[1]:
+            lam = np.maximum(0.0, lam + mu * np.asarray(g(es.mean), dtype=np.float64).reshape(-1))
+    return es.result.xbest, es

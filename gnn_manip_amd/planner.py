@@ -273,3 +273,79 @@ class TrajectoryCMAsolver:
         self.desired_pos = desired_position.clone()
         return cmaes.fmin2(self.cma_objective, initial_traj.tolist(), self.cma_initial_var, options=self.cma_options,
                            parallel_objective=self.population_losses)
+
+
+class InterpolatedCMAsolver(TrajectoryCMAsolver):
+    """Mirror of the reference's ``InterpolatedCMAsolver`` (traj_utils.py:288-452): the search variables are key
+    points (every ``traj_points``-th step) of the rotation / translation, PCHIP-interpolated to one pose per step;
+    increments between key points are constrained (``ineq_constraint``, solved with ``cmaes.fmin_con``) and the
+    rotation is box-bounded.  Objective evaluation (batched rollouts, device loss) is inherited."""
+
+    def set_sample_traj(self, sample_traj):
+        sample_traj = np.asarray(sample_traj)
+        index_points = [i for i in range(self.nr_traj_points, sample_traj.shape[0], self.nr_traj_points)]
+        traj_points = sample_traj[index_points, :]
+        rotation_scaled = (np.deg2rad(traj_points[:, 0]) - self.rx_init) / self.scale_rot
+        translation_scaled = (traj_points[:, 1] - self.ty_init[0]) / self.scale_ty
+        self.sample_traj = np.stack((rotation_scaled, translation_scaled)).T
+
+    def interpolate_trajectory(self, x, type_interp='pchip'):
+        from scipy.interpolate import interp1d, pchip_interpolate
+        x = np.asarray(x, dtype=np.float64)
+        k = self.sample_traj.shape[0]
+        rot_points = [self.rx_init] + (self.rx_init + x[:k] * self.scale_rot).tolist()
+        ty_points = [0.0] + (x[k:] * self.scale_ty).tolist()
+        traj_idx = np.arange(0, self.horizon + 1, self.nr_traj_points)
+        idx_interp = np.arange(self.horizon)
+        if type_interp == 'cubic':
+            return (interp1d(x=traj_idx, y=rot_points, kind='cubic')(idx_interp),
+                    interp1d(x=traj_idx, y=ty_points, kind='cubic')(idx_interp))
+        return pchip_interpolate(traj_idx, rot_points, idx_interp), pchip_interpolate(traj_idx, ty_points, idx_interp)
+
+    def compute_acc_loss(self, acc):
+        return float(np.linalg.norm(acc / np.array([2.2e-4, 1.45e-4])[None, :]))  # fixed means, traj_utils.py:343-353
+
+    def compute_vel_loss(self, vel):
+        return float(np.linalg.norm(vel / np.array([1e-2, 4e-4])[None, :]))        # traj_utils.py:355-364
+
+    def compute_vel_noninterp(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        rot, ty = x[:self.traj_points] * self.scale_rot, x[self.traj_points:] * self.scale_ty
+        ineq_rot = np.abs(rot[1:] - rot[:-1]) - self.max_rot * self.nr_traj_points
+        ineq_ty = np.abs(ty[1:] - ty[:-1]) - self.max_ty * self.nr_traj_points
+        return float(np.exp(max(ineq_rot.max(), ineq_ty.max())))
+
+    def ineq_constraint(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        actions = np.zeros((self.traj_points + 1, 2))
+        actions[1:, 0] = x[:self.traj_points] * self.scale_rot
+        actions[1:, 1] = x[self.traj_points:] * self.scale_ty
+        vel, _ = self.compute_vel_acc(actions)
+        upper = np.abs(vel) - np.array([self.max_rot * self.nr_traj_points, self.max_ty * self.nr_traj_points])
+        return np.concatenate((upper[:, 0] / self.scale_rot, upper[:, 1] / self.scale_ty))
+
+    def compute_loss(self, end_position, actions, cup_states=None, coffee_states=None, x=None):
+        wasserstein_loss = float(self.loss(end_position, self.desired_pos).item())
+        vel, acc = self.compute_vel_acc(actions)
+        vel_loss, acc_loss = self.compute_vel_loss(vel), self.compute_acc_loss(acc)
+        interp_loss = self.compute_vel_noninterp(x) if x is not None else 0.0
+        loss = self.beta * wasserstein_loss + self.alpha * vel_loss + self.gamma * acc_loss + self.rho * interp_loss
+        return loss, wasserstein_loss, vel_loss, acc_loss, interp_loss, 0.0
+
+    def _block_losses(self, xs):
+        trajs, acts = zip(*[self.get_rigid_body_trajectory_from_diff(x) for x in xs])
+        eng = self._engine(len(xs))
+        with torch.no_grad():
+            finals = eng.rollout_candidates(self.initial_state[0].contiguous(), torch.stack(trajs), horizon=self.horizon)
+        return [self.compute_loss(end, a, x=x)[0] for end, a, x in zip(self._end_positions(finals), acts, xs)]
+
+    def optimize_trajectory(self, desired_position):
+        """traj_utils.py:324-337."""
+        from . import cmaes
+        self.cma_options['bounds'] = [-self.rotation_limit / self.scale_rot, self.rotation_limit / self.scale_rot]
+        initial_traj = np.zeros(int(self.sample_traj.shape[0] * 2))
+        initial_traj[:self.sample_traj.shape[0]] = self.sample_traj[:, 0]
+        initial_traj[self.sample_traj.shape[0]:] = self.sample_traj[:, 1]
+        self.desired_pos = desired_position.clone()
+        return cmaes.fmin_con(self.cma_objective, initial_traj.tolist(), self.cma_initial_var, g=self.ineq_constraint,
+                              options=self.cma_options, parallel_objective=self.population_losses)

@@ -560,3 +560,42 @@ def planner_penalties(actions, rx_init, rotation_limit, vel_scale, acc_scale):
     rot = np.asarray(actions, np.float64)[:, 0]
     penalty = 20.0 if (rot.max() > rx_init + rotation_limit or rot.min() < rx_init - rotation_limit) else 0.0
     return vel_loss, acc_loss, penalty
+
+
+# ---- InterpolatedCMAsolver (traj_utils.py:288-452): host-side float64 pieces
+def interp_set_sample_traj(sample_traj, nr_traj_points, rx_init, ty_init0, scale_rot, scale_ty):
+    """traj_utils.py:296-304: every nr_traj_points-th pose of the sample becomes a key point, scaled."""
+    sample_traj = np.asarray(sample_traj, np.float64)
+    pts = sample_traj[list(range(nr_traj_points, sample_traj.shape[0], nr_traj_points)), :]
+    return np.stack(((np.deg2rad(pts[:, 0]) - rx_init) / scale_rot, (pts[:, 1] - ty_init0) / scale_ty)).T
+
+
+def interp_interpolate_trajectory(x, n_key, horizon, nr_traj_points, rx_init, scale_rot, scale_ty):
+    """traj_utils.py:393-416 (pchip branch): key points -> one pose per step by PCHIP interpolation."""
+    from scipy.interpolate import pchip_interpolate
+    x = np.asarray(x, np.float64)
+    rot_points = [rx_init] + (rx_init + x[:n_key] * scale_rot).tolist()
+    ty_points = [0.0] + (x[n_key:] * scale_ty).tolist()
+    traj_idx = np.arange(0, horizon + 1, nr_traj_points)
+    idx = np.arange(horizon)
+    return pchip_interpolate(traj_idx, rot_points, idx), pchip_interpolate(traj_idx, ty_points, idx)
+
+
+def interp_vel_noninterp(x, traj_points, nr_traj_points, scale_rot, scale_ty, max_rot, max_ty):
+    """compute_vel_noninterp (traj_utils.py:418-436): exp of the largest key-point increment excess."""
+    x = np.asarray(x, np.float64)
+    rot, ty = x[:traj_points] * scale_rot, x[traj_points:] * scale_ty
+    ineq_rot = np.abs(rot[1:] - rot[:-1]) - max_rot * nr_traj_points
+    ineq_ty = np.abs(ty[1:] - ty[:-1]) - max_ty * nr_traj_points
+    return float(np.exp(max(ineq_rot.max(), ineq_ty.max())))
+
+
+def interp_ineq_constraint(x, traj_points, nr_traj_points, scale_rot, scale_ty, max_rot, max_ty):
+    """ineq_constraint (traj_utils.py:366-391): |key-point increments| - limits, de-normalised, rotation then translation."""
+    x = np.asarray(x, np.float64)
+    actions = np.zeros((traj_points + 1, 2))
+    actions[1:, 0] = x[:traj_points] * scale_rot
+    actions[1:, 1] = x[traj_points:] * scale_ty
+    vel = actions[1:] - actions[:-1]
+    upper = np.abs(vel) - np.array([max_rot * nr_traj_points, max_ty * nr_traj_points])
+    return np.concatenate((upper[:, 0] / scale_rot, upper[:, 1] / scale_ty))

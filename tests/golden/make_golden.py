@@ -301,6 +301,27 @@ def main():
         g10[f"{tag}.out"] = np.array([float(v) for v in out])
     g10["cfg"] = np.array([solver.alpha, solver.beta, solver.gamma, solver.penalty, solver.rho, solver.max_rot, solver.max_ty,
                            solver.rx_init, solver.rotation_limit])
+    # InterpolatedCMAsolver (traj_utils.py:288-452): key-point parametrisation, pchip interpolation, its loss terms and
+    # inequality constraints (Wasserstein term stubbed as above)
+    hz, npts = 40, 10
+    kw11 = dict(alpha=0.3, beta=1000.0, gamma=0.05, penalty=2.0, rho=0.7, device="cpu")
+    isol = ref.traj.InterpolatedCMAsolver(model, gc, state, 180, [0.5, 0.5, 0.4], scale_rot=np.pi, scale_ty=1.0,
+                                          total_steps=hz, traj_points=npts, **kw11)
+    isol.loss = lambda a, b: torch.tensor(0.125)
+    isol.desired_pos = state[1]
+    isol.set_sample_traj(sample[:hz + 1])
+    xi = np.concatenate((isol.sample_traj[:, 0], isol.sample_traj[:, 1]))
+    xi = xi + 0.02 * rng.standard_normal(xi.shape)
+    rot_i, ty_i = isol.interpolate_trajectory(xi)
+    act_i = np.stack((rot_i, ty_i), axis=1)
+    g10["interp.sample_in"] = sample[:hz + 1]
+    g10["interp.sample_traj"] = isol.sample_traj
+    g10["interp.x"] = xi
+    g10["interp.rot"], g10["interp.ty"] = np.asarray(rot_i), np.asarray(ty_i)
+    g10["interp.out"] = np.array([float(v) for v in isol.compute_loss(state[1], act_i, x=xi)])
+    g10["interp.ineq"] = isol.ineq_constraint(xi)
+    g10["interp.cfg"] = np.array([isol.alpha, isol.beta, isol.gamma, isol.penalty, isol.rho, isol.max_rot, isol.max_ty, isol.rx_init,
+                                  isol.rotation_limit, isol.scale_rot, isol.scale_ty, hz, npts])
     np.savez_compressed(os.path.join(HERE, "g10_planner_loss.npz"), **g10)
     print("G10 done", g10["inside.out"], g10["outside.out"])
 

@@ -64,3 +64,49 @@ def test_cmaes_minimises_standard_functions():
     x, es = cmaes.fmin2(None, [1.0] * 5, 0.4, {"seed": 1, "maxiter": 40, "popsize": 10},
                         parallel_objective=lambda X: calls.append(len(X)) or [float(np.sum(np.asarray(v) ** 2)) for v in X])
     assert calls == [10] * 40 and es.result.fbest < 1e-2
+
+
+def test_interpolated_solver_pieces_golden(golden):
+    """InterpolatedCMAsolver (traj_utils.py:288-452): key points from the sample, PCHIP interpolation, its loss terms
+    (fixed normalisation means, exp penalty of the key-point increments) and inequality constraints -- oracle and the
+    package's host-side mirror against the reference's outputs."""
+    import torch
+    from gnn_manip_amd.planner import InterpolatedCMAsolver
+    g = golden("g10_planner_loss.npz")
+    alpha, beta, gamma, penalty, rho, max_rot, max_ty, rx_init, rot_limit, scale_rot, scale_ty, hz, npts = g["interp.cfg"]
+    hz, npts = int(hz), int(npts)
+    st = orc.interp_set_sample_traj(g["interp.sample_in"], npts, rx_init, 0.5, scale_rot, scale_ty)
+    np.testing.assert_allclose(st, g["interp.sample_traj"], rtol=1e-13, atol=1e-15)
+    x = g["interp.x"]
+    rot, ty = orc.interp_interpolate_trajectory(x, st.shape[0], hz, npts, rx_init, scale_rot, scale_ty)
+    np.testing.assert_allclose(rot, g["interp.rot"], rtol=1e-13)
+    np.testing.assert_allclose(ty, g["interp.ty"], rtol=1e-12, atol=1e-16)
+    np.testing.assert_allclose(orc.interp_ineq_constraint(x, hz // npts, npts, scale_rot, scale_ty, max_rot, max_ty), g["interp.ineq"],
+                               rtol=1e-12, atol=1e-15)
+    ref = g["interp.out"]  # (loss, wasserstein, vel_loss, acc_loss, interp_loss, 0)
+    np.testing.assert_allclose(orc.interp_vel_noninterp(x, hz // npts, npts, scale_rot, scale_ty, max_rot, max_ty), ref[4], rtol=1e-12)
+    # host-side mirror (no GPU needed for these members)
+    obs = torch.zeros((6, 10, 8))
+    obs[-1, 5:, 1] = 1.0
+    s = InterpolatedCMAsolver(None, type("GA", (), {"material_idx": [1], "cartesian_idx": [2, 3, 4]})(), (obs, obs[-1, :, 2:5]), 180,
+                              [0.5, 0.5, 0.4], scale_rot=np.pi, scale_ty=1.0, alpha=alpha, beta=beta, gamma=gamma, penalty=penalty,
+                              rho=rho, device="cpu", total_steps=hz, traj_points=npts)
+    s.set_sample_traj(g["interp.sample_in"])
+    np.testing.assert_allclose(s.sample_traj, g["interp.sample_traj"], rtol=1e-13, atol=1e-15)
+    r2, t2 = s.interpolate_trajectory(x)
+    np.testing.assert_allclose(r2, g["interp.rot"], rtol=1e-13)
+    np.testing.assert_allclose(s.ineq_constraint(x), g["interp.ineq"], rtol=1e-12, atol=1e-15)
+    s.loss = lambda a, b: torch.tensor(0.125)
+    s.desired_pos = obs[-1, :, 2:5]
+    out = s.compute_loss(obs[-1, :, 2:5], np.stack((g["interp.rot"], g["interp.ty"]), axis=1), x=x)
+    np.testing.assert_allclose(out[:5], ref[:5], rtol=1e-10)
+
+
+def test_fmin_con_respects_constraints():
+    from gnn_manip_amd import cmaes
+    # minimise |x|^2 subject to x0 >= 1 (g = 1 - x0 <= 0): optimum (1, 0, 0)
+    x, es = cmaes.fmin_con(lambda v: float(np.sum(np.asarray(v) ** 2)), [2.0, 1.0, -1.0], 0.5, g=lambda v: [1.0 - v[0]],
+                           options={"seed": 5, "maxiter": 250})
+    assert es.best_feasible.info is not None and (es.best_feasible.info["g"] <= 0).all()
+    np.testing.assert_allclose(es.best_feasible.info["x"], [1.0, 0.0, 0.0], atol=2e-2)
+    assert abs(es.best_feasible.f - 1.0) < 3e-2
