@@ -53,6 +53,31 @@ int layer_stages16(int k, int out);
 int pack_linear16(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s);
 int pack_linear(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s);
 int pack_linear_t(const float* W, int w_rows, int ld, int col0, int ksub, float* dst, hipStream_t s);
+// Batched (device-resident weights): many Linears / vectors per launch.
+struct PackJob {
+    const float* W;   // row-major [rows][ld]
+    int out_rows, ld, col0, kvalid;
+    int layout;       // 0: 32x32x2 operand image, 1: 16x16x4
+    size_t dst_off;   // floats from the base passed to launch_pack_batch (per layout)
+};
+constexpr int kPackJobsMax = 80;
+struct PackJobs {
+    int n;
+    PackJob job[kPackJobsMax];
+};
+struct VecJob {
+    const float* src;
+    size_t dst_off;
+    int count;   // floats copied
+    int zero_to; // destination floats [count, zero_to) are zeroed (padding), 0 = none
+};
+constexpr int kVecJobsMax = 128;
+struct VecJobs {
+    int n;
+    VecJob job[kVecJobsMax];
+};
+int launch_pack_batch(const PackJobs& jobs, float* base32, float* base16, hipStream_t s);
+int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s);
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
 constexpr int kStageFloats = 4096;

@@ -122,6 +122,48 @@ int pack_linear_t(const float* W, int w_rows, int ld, int col0, int ksub, float*
     return GM_OK;
 }
 
+// one launch for many Linears (blockIdx.y = job): same images as pack_linear_kernel / pack_linear16_kernel
+__global__ void __launch_bounds__(256) pack_batch_kernel(PackJobs J, float* __restrict__ base32, float* __restrict__ base16) {
+    const PackJob j = J.job[blockIdx.y];
+    const int kw = j.layout ? 16 : 8, jw = j.layout ? 16 : 32;
+    const int nkq = (j.kvalid + kw - 1) / kw, njb = (j.out_rows + jw - 1) / jw;
+    const int64_t total = (int64_t)((nkq * njb + STAGE_PIECES - 1) / STAGE_PIECES) * STAGE_FLOATS;
+    float* dst = (j.layout ? base16 : base32) + j.dst_off;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(idx / PIECE_FLOATS);
+        const int within = (int)(idx % PIECE_FLOATS);
+        const int lane = within >> 2, t = within & 3;
+        float v = 0.f;
+        if (p < nkq * njb) {
+            const int kq = p / njb, jb = p % njb;
+            int row, col;
+            if (j.layout) { row = 16 * jb + (lane & 15); col = 16 * kq + 4 * (lane >> 4) + t; }
+            else { row = 32 * jb + (lane & 31); col = 8 * kq + 4 * (lane >> 5) + t; }
+            if (row < j.out_rows && col < j.kvalid) v = j.W[(int64_t)row * j.ld + j.col0 + col];
+        }
+        dst[idx] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) vec_batch_kernel(VecJobs J, float* __restrict__ base) {
+    const VecJob j = J.job[blockIdx.x];
+    for (int i = threadIdx.x; i < max(j.count, j.zero_to); i += blockDim.x) base[j.dst_off + i] = i < j.count ? j.src[i] : 0.f;
+}
+
+int launch_pack_batch(const PackJobs& jobs, float* base32, float* base16, hipStream_t s) {
+    if (jobs.n <= 0) return GM_OK;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(16, jobs.n), dim3(256), 0, s, jobs, base32, base16);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s) {
+    if (jobs.n <= 0) return GM_OK;
+    hipLaunchKernelGGL(vec_batch_kernel, dim3(jobs.n), dim3(256), 0, s, jobs, base);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // EDGE kernel
 // ------------------------------------------------------------------------------------------

@@ -62,8 +62,36 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
         if (hipMemcpyAsync(stage, T[ti], count * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) rc = GM_ERR_HIP;
         return stage;
     };
+    // device-resident weights: everything is queued and done by a handful of batched launches
+    PackJobs pj;
+    pj.n = 0;
+    VecJobs vj;
+    vj.n = 0;
+    auto flush_pack = [&]() {
+        if (rc == GM_OK && pj.n > 0) rc = launch_pack_batch(pj, m->packed, m->packed16, s);
+        pj.n = 0;
+    };
+    auto flush_vec = [&]() {
+        if (rc == GM_OK && vj.n > 0) rc = launch_vec_batch(vj, m->vec, s);
+        vj.n = 0;
+    };
+    auto queue_pack = [&](int ti, int out_rows, int ld, int col0, int k, size_t off, int layout) {
+        if (pj.n == kPackJobsMax) flush_pack();
+        PackJob& j = pj.job[pj.n++];
+        j.W = T[ti]; j.out_rows = out_rows; j.ld = ld; j.col0 = col0; j.kvalid = k; j.layout = layout; j.dst_off = off;
+    };
+    auto queue_vec = [&](const float* src, size_t off, int count, int zero_to) {
+        if (vj.n == kVecJobsMax) flush_vec();
+        VecJob& j = vj.job[vj.n++];
+        j.src = src; j.dst_off = off; j.count = count; j.zero_to = zero_to;
+    };
     auto pack = [&](int ti, int out_rows, int ld, int col0, int k, size_t& off) {
         if (rc != GM_OK) return;
+        if (on_device) {
+            queue_pack(ti, out_rows, ld, col0, k, off, 0);
+            off += (size_t)layer_stages(k, out_rows) * kStageFloats;
+            return;
+        }
         const float* W = weight(ti, (size_t)out_rows * ld);
         if (rc != GM_OK) return;
         rc = pack_linear(W, out_rows, ld, col0, k, m->packed + off, s);
@@ -72,6 +100,18 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
         if (!on_device && rc == GM_OK && hipStreamSynchronize(s) != hipSuccess) rc = GM_ERR_HIP;
     };
     auto vecs = [&](int base, bool normed, size_t voff) {  // biases (+ LN) of the MLP whose first tensor is `base`
+        if (on_device) {
+            for (int l = 0; l <= NL; ++l) {
+                const bool dec_out = !normed && l == NL;
+                if (dec_out) queue_vec(T[base + 2 * l + 1], voff + (size_t)NL * H, m->d.out_dim, 32);
+                else queue_vec(T[base + 2 * l + 1], voff + (size_t)l * H, H, 0);
+            }
+            if (normed) {
+                queue_vec(T[base + 2 * (NL + 1)], voff + (size_t)(NL + 1) * H, H, 0);
+                queue_vec(T[base + 2 * (NL + 1) + 1], voff + (size_t)(NL + 2) * H, H, 0);
+            }
+            return;
+        }
         for (int l = 0; l <= NL && rc == GM_OK; ++l) {
             const bool dec_out = !normed && l == NL;
             if (dec_out) {
@@ -118,6 +158,11 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
     if (m->packed16) {  // 16x16x4 image of the edge MLPs
         auto pack16 = [&](int ti, int out_rows, int ld, int col0, int k, size_t& o16) {
             if (rc != GM_OK) return;
+            if (on_device) {
+                queue_pack(ti, out_rows, ld, col0, k, o16, 1);
+                o16 += (size_t)layer_stages16(k, out_rows) * kStageFloats;
+                return;
+            }
             const float* W = weight(ti, (size_t)out_rows * ld);
             if (rc != GM_OK) return;
             rc = pack_linear16(W, out_rows, ld, col0, k, m->packed16 + o16, s);
@@ -140,6 +185,8 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
         vecs(b_node(k), true, m->v_node[k]);
     }
     vecs(b_dec, false, m->v_dec);
+    flush_pack();
+    flush_vec();
     if (stage) {
         hipStreamSynchronize(s);
         hipFree(stage);
