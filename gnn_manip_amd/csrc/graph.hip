@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const int* in, i
 // small arrays: one 1024-thread block walks the array in chunks with a running carry (one launch instead
 // of three; at N = 5k every scan of the graph build is this small)
 constexpr int SCAN1_THREADS = 1024;
-constexpr int64_t SCAN1_MAX = 1 << 17;
+constexpr int64_t SCAN1_MAX = 40000;  // one workgroup up to here (~10 us at 32k); above, the three-kernel scan (~15 us) wins
 __global__ void __launch_bounds__(SCAN1_THREADS) scan_single_kernel(const int* in, int64_t n, int* out, int* total_out) {
     __shared__ int wsum[SCAN1_THREADS / 64];
     __shared__ int carry_s;
@@ -311,12 +311,21 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pos
             mx[a] = max(mx[a], (unsigned)__shfl_xor((int)mx[a], d, 64));
         }
     }
+    // one set of atomics per workgroup (the six addresses are shared by the whole grid: per-wave atomics serialised
+    // to ~100 us at N = 100k)
+    __shared__ unsigned wmn[4][3], wmx[4][3];
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&hdr->bbox_min[a], mn[a]);
-            atomicMax(&hdr->bbox_max[a], mx[a]);
+            wmn[threadIdx.x >> 6][a] = mn[a];
+            wmx[threadIdx.x >> 6][a] = mx[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        atomicMin(&hdr->bbox_min[a], min(min(wmn[0][a], wmn[1][a]), min(wmn[2][a], wmn[3][a])));
+        atomicMax(&hdr->bbox_max[a], max(max(wmx[0][a], wmx[1][a]), max(wmx[2][a], wmx[3][a])));
     }
     if (bad) atomicOr(&hdr->error_flags, ERRF_NONFINITE_POS);
     // last block done -> grid parameters.  Every block's atomics are ordered before its ticket by the
@@ -782,7 +791,7 @@ int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t 
     }
     if (n > 0) {
         int nb = (int)cdiv(n, 256);
-        hipLaunchKernelGGL(bbox_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, pos, pos_stride, n, g.hdr, conn_r,
+        hipLaunchKernelGGL(bbox_kernel, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, pos, pos_stride, n, g.hdr, conn_r,
                            g.max_cells, n_per);
         hipLaunchKernelGGL(cell_assign_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.hdr, g.cell_of, g.cell_start);
         int rc = exclusive_scan_i32(g.cell_start, g.cell_start, (int64_t)g.max_cells + 1, nullptr, g.scan_tmp, s, nullptr);
