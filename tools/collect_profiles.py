@@ -1,18 +1,23 @@
 """Turn gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/."""
 import collections, csv, glob, json, os, shutil, sys
+
+
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 for wl in ("c2", "target"):
-    f = glob.glob(f"{src}/{wl}/*/*kernel_stats.csv")[0]
+    f = newest(f"{src}/{wl}/*/*kernel_stats.csv")
     shutil.copy(f, f"{dst}/{tag}_{wl}_kernel_stats.csv")
 EDGE = "edge_kernel16<2, 1>"
 out = {}
 for wl in ("c2", "target"):
     d = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = glob.glob(f"{src}/pmc_{c}_{wl}/*/*counter_collection.csv")[0]
+        f = newest(f"{src}/pmc_{c}_{wl}/*/*counter_collection.csv")
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == c and EDGE in r["Kernel_Name"]]
         d[c + "_KB_per_launch"] = sum(v) / len(v)
         d["launches_" + c] = len(v)
@@ -23,7 +28,7 @@ out["note"] = ("processor edge kernel " + EDGE + "; rocprofv3 --pmc FETCH_SIZE a
                "MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B for 16-B-per-lane loads; the kernel's row gathers are not the "
                "calibrated streaming pattern, so the corrected figure is an upper bound); Infinity-Cache hits are counted")
 json.dump(out, open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
-f = glob.glob(f"{src}/pmc_sq_target/*/*counter_collection.csv")[0]
+f = newest(f"{src}/pmc_sq_target/*/*counter_collection.csv")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
