@@ -1,0 +1,122 @@
+"""BASELINE.json's full sizes (N = 100k target scene, N = 50k C3 scene): bit-exact graph against the oracle where the
+oracle still runs in seconds, and size-independent properties for the rest (sortedness, stability, window shift,
+two independent kernel sets agreeing)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import BOUNDS, CART, CTRL, MAT, STATS
+from oracle import epd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def scene100k():
+    from gnn_manip_amd import scene
+    return scene.make_scene(100000, seed=5)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("n,seed", [(100000, 5), (50000, 6)])
+def test_radius_graph_full_size_bit_exact(dev, n, seed):
+    from gnn_manip_amd import get_connectivity, scene
+    pos = scene.make_scene(n, seed=seed)[-1][:, 2:5]
+    s_ref, r_ref = orc.get_connectivity(pos, 0.015, 20)
+    s, r = get_connectivity(_t(pos, dev), 0.015, 20)
+    np.testing.assert_array_equal(s.cpu().numpy(), s_ref)
+    np.testing.assert_array_equal(r.cpu().numpy(), r_ref)
+    # properties of the list itself: grouped by query, self edge first, distances ascending and inside the radius, cap 20
+    s_np, r_np = s.cpu().numpy(), r.cpu().numpy()
+    assert (np.diff(s_np) >= 0).all()
+    starts = np.flatnonzero(np.r_[True, np.diff(s_np) > 0])
+    assert (r_np[starts] == s_np[starts]).all()
+    counts = np.diff(np.r_[starts, len(s_np)])
+    assert counts.max() <= 20 and len(starts) == n
+    d = np.linalg.norm(pos[s_np].astype(np.float64) - pos[r_np].astype(np.float64), axis=1)
+    assert (d <= 0.015).all()
+    same = s_np[1:] == s_np[:-1]
+    p64 = pos.astype(np.float64)
+    d2 = ((p64[s_np] - p64[r_np]) ** 2).sum(axis=1)
+    assert (d2[1:][same] > d2[:-1][same]).all()  # strictly ascending: no tie among the kept neighbours (tie order is undefined)
+
+
+def test_csr_full_size_is_a_stable_sort(dev, scene100k):
+    from gnn_manip_amd import get_connectivity
+    from gnn_manip_amd.epd_gnn import DstCsr
+    from gnn_manip_amd._lib import lib
+    pos = scene100k[-1][:, 2:5]
+    s, r = get_connectivity(_t(pos, dev), 0.015, 20)
+    ei = torch.stack((s, r))
+    n, e = pos.shape[0], int(ei.shape[1])
+    csr = DstCsr(ei, n)
+    assert csr.validate() == e
+    # the workspace layout is internal; read it back through the same carve the library uses (ints after the header)
+    ws = csr.ws.cpu().numpy().view(np.int32)
+    # in_ptr is the first array after the 16-byte header, 256-byte aligned
+    in_ptr = ws[64:64 + n + 1]
+    assert in_ptr[0] == 0 and in_ptr[-1] == e and (np.diff(in_ptr) >= 0).all()
+    indeg = np.bincount(r.cpu().numpy(), minlength=n)
+    np.testing.assert_array_equal(np.diff(in_ptr), indeg)
+
+
+def test_forward_full_size_two_kernel_sets_agree(dev, scene100k):
+    """Fused inference kernels (16x16x4 edge kernel, in-kernel scatter-add with LDS stitching and atomics) against the
+    tape-recording training forward (32x32x2 chain, separate deterministic segment sums) on the target scene: E = 1.96 M."""
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl
+    ga = GraphBoundedMultimaterialControl(0.015, STATS, CART, MAT, CTRL, BOUNDS)
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 77)
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 10)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev)
+    with torch.no_grad():
+        nodes, ea, s, r, _ = ga.process(_t(scene100k, dev), None)
+        ei = torch.stack((s, r))
+        a = m.forward(nodes, ea, ei)
+    b = m.forward(nodes, ea, ei).detach()  # autograd enabled: training forward
+    assert torch.isfinite(a).all()
+    assert (a - b).abs().max() <= 1e-5 * a.abs().max()
+    # permutation of the edge list is immaterial (destination sort + deterministic order inside a segment)
+    perm = torch.randperm(ei.shape[1], device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    with torch.no_grad():
+        c = m.forward(nodes, ea[perm], ei[:, perm])
+    assert (a - c).abs().max() <= 1e-5 * a.abs().max()
+
+
+def test_rollout_full_size_state_properties(dev, scene100k):
+    """Three device-resident steps at N = 100k: the window shifts bit-exactly, rigid rows land on the scripted pose,
+    control columns hold pose - position, everything stays finite, the edge count is the graph's."""
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, RolloutEngine, get_connectivity, scene
+    ga = GraphBoundedMultimaterialControl(0.015, dict(STATS, acceleration_mean=[0.0, 0.0, 0.0]), CART, MAT, CTRL, BOUNDS)
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 78)
+    params["decoder.4.weight"] = params["decoder.4.weight"] * 1e-5
+    params["decoder.4.bias"] = params["decoder.4.bias"] * 1e-5
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 10)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev)
+    n = scene100k.shape[1]
+    obs = _t(scene100k, dev).clone()
+    eng = RolloutEngine(m, ga, n, device=dev)
+    n_rigid = eng.set_scene(obs)
+    rigid = obs[-1, :, 1] == 1
+    assert n_rigid == int(rigid.sum())
+    traj = _t(scene.rigid_drift_trajectory(scene100k, 3, seed=9, step_size=1e-5), dev)
+    with torch.no_grad():
+        for i in range(3):
+            before = obs.clone()
+            eng.step(obs, traj[i])
+            assert torch.equal(obs[:-1, :, 2:5], before[1:, :, 2:5])       # window shift
+            assert torch.equal(obs[-1, rigid, 2:5], traj[i])               # scripted pose written back
+            assert torch.equal(obs[-2, rigid, 5:8], traj[i] - before[-1, rigid, 2:5])  # control = pose - position
+            assert torch.isfinite(obs).all()
+    s, _ = get_connectivity(before[-1, :, 2:5], 0.015, 20)
+    assert eng.status() == int(s.shape[0])
