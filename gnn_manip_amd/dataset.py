@@ -123,6 +123,30 @@ class CoffeeDataset(torch.utils.data.Dataset):
                                          max_neighbours=self.max_neighbours)
 
 
+class CoffeeTestDataset(CoffeeDataset):
+    """Mirror of coffee_dataset.py:136-215: ONE simulation (``sim_id``) of a split; items are the raw
+    ``(obs_seq [k, N, D(+3)], next_pos [N, 3])`` pairs the rollout / planner start from (rollout_utils.py:110-130,
+    optimise_traj.py:253-259)."""
+
+    def __init__(self, directory, k, conn_r, split='train', noise=None, max_neighbours=20, device=torch.device('cuda:0'),
+                 use_control=False, sim_id=1):
+        self.dir, self.split = directory, split
+        self.files = [f'{self.dir}{self.split}/particles_{sim_id:06d}.csv']
+        self.metadata_file = f'{self.dir}metadata.json'
+        self.k, self.conn_r, self.max_neighbours = k, conn_r, max_neighbours
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("CoffeeTestDataset: gnn_manip_amd builds graphs on the HIP device only")
+        self.noise, self.use_control = noise, use_control
+        (self.data_dim, self.time_steps, self.cartesian_idx, self.control_idx, self.material_id, self.bounds,
+         self.stats) = read_metadata(self.metadata_file)
+        self._load_data(self.files)
+        self.graph_attr = self._get_graph_attr()
+
+    def __getitem__(self, index):
+        return self.sample(index)
+
+
 class GraphLoader:
     """What train_dyn.py gets from ``torch_geometric.data.DataLoader(dataset, batch_size, shuffle)``: an iterable of
     collated batches.  Everything stays on the dataset's device."""

@@ -101,3 +101,20 @@ def test_noise_draw_statistics(dev):
     last_vel_noise = (seq[-1] - seq[-2]).cpu().numpy()
     assert abs(last_vel_noise.std() / 3e-4 - 1.0) < 0.02
     assert abs(last_vel_noise.mean()) < 1e-5
+
+
+def test_test_dataset_items_are_raw_windows(golden, dev, tmp_path):
+    """CoffeeTestDataset (coffee_dataset.py:136-215): one simulation, items = (obs_seq, next_pos) as the rollout and
+    the planner consume them; its graph_attr builds the same graph as the training dataset's."""
+    from gnn_manip_amd import CoffeeTestDataset
+    g = golden("g9_dataset.npz")
+    root = str(tmp_path) + "/"
+    _write_dataset(g, root)
+    ds = CoffeeTestDataset(root, 6, 0.015, split="train", device=dev, use_control=True, sim_id=1)
+    assert len(ds) == 3
+    obs, nxt = ds[0]
+    np.testing.assert_array_equal(obs.cpu().numpy(), g["ctl.0.obs"])
+    np.testing.assert_array_equal(nxt.cpu().numpy(), g["ctl.0.next"])
+    nodes, ea, s, r, acc = ds.graph_attr.process(obs, nxt)
+    np.testing.assert_array_equal(s.cpu().numpy(), g["ctl.0.senders"])
+    assert nodes.shape[1] == 25 and ea.shape[1] == 4 and acc.shape[1] == 3  # what get_model reads (rollout_utils.py:123-130)
