@@ -123,3 +123,52 @@ class RolloutEngine:
         if record:
             return obs, torch.stack(recs)
         return obs
+
+
+def get_rigid_body_trajectory_from_diff(trajectory, horizon, ty_init, rigid_particles):
+    """rollout_utils.py:160-174: absolute (rotation [rad], translation) pairs -> [horizon, N_rigid, 3] poses on the device."""
+    from .planner import get_rigid_body_trajectory
+    return get_rigid_body_trajectory(trajectory[:, 0], trajectory[:, 1], horizon, ty_init, rigid_particles)
+
+
+def extract_groundtruth(dataset, nof_steps, nof_particles=None, data_dim=None):
+    """rollout_utils.py:84-93: last frame of every window, [nof_steps, N, D] (device)."""
+    return torch.stack([dataset[i][0][-1] for i in range(nof_steps)]).float()
+
+
+def compute_rollout(dataset, model, args):
+    """Mirror of ``compute_rollout`` (rollout_utils.py:12-67): roll the model out from the first window of a
+    ``CoffeeTestDataset``, driving the rigid body either with a planned trajectory (``args.cma_traj``: .npy of
+    absolute [rotation, translation] per step) or with the recorded ground truth.  Returns the reference's
+    ``prediction`` array [nof_steps, N, D] (numpy): the last frame of every step after the control overwrite.
+    The step itself (graph, features, model, integration, window shift) is gm_rollout_step on the device; only the
+    ground-truth mode's control / pose overwrite -- taken verbatim from recorded frames -- is done with tensor
+    indexing around it."""
+    import numpy as np
+    obs0, _ = dataset[0]
+    k, n, dd = obs0.shape
+    dev = obs0.device
+    nof_steps = dataset.time_steps if args.cma_traj is not None else dataset.time_steps - args.k_steps
+    eng = RolloutEngine(model, dataset.graph_attr, n, k_steps=k, data_dim=dd, max_neighbours=20, device=dev)
+    obs = obs0.clone().contiguous()
+    eng.set_scene(obs)
+    rigid = obs[0, :, dataset.material_id] == 1
+    c0, u0 = dataset.cartesian_idx[0], dataset.control_idx[0]
+    with torch.no_grad():
+        if args.cma_traj is not None:
+            npy_trajectory = np.load(args.cma_traj) if isinstance(args.cma_traj, str) else np.asarray(args.cma_traj)
+            rigid_pos = obs[-1, rigid, c0:c0 + 3].contiguous()
+            trajectory = get_rigid_body_trajectory_from_diff(npy_trajectory, nof_steps, [0.5, 0.5, 0.4], rigid_pos)
+            _, recs = eng.rollout(obs, trajectory, horizon=nof_steps, record=True)
+            return recs.cpu().numpy().astype(np.float64)
+        groundtruth = extract_groundtruth(dataset, nof_steps)
+        prediction = []
+        for i in range(nof_steps):
+            obs[-1, rigid, u0:u0 + 3] = groundtruth[i, rigid, u0:u0 + 3]          # control from the recording (:43)
+            prediction.append(obs[-1].clone())
+            eng.step(obs, None, use_rigid=False)                                  # predict, integrate, shift
+            new_rigid = prediction[-1][rigid].clone()                             # rigid rows keep the frame's attributes ...
+            new_rigid[:, c0:c0 + 3] = groundtruth[i, rigid, c0:c0 + 3]            # ... with the recorded pose (:57)
+            obs[-1, rigid] = new_rigid
+        eng.status()
+        return torch.stack(prediction).cpu().numpy().astype(np.float64)

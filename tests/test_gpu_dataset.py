@@ -118,3 +118,50 @@ def test_test_dataset_items_are_raw_windows(golden, dev, tmp_path):
     nodes, ea, s, r, acc = ds.graph_attr.process(obs, nxt)
     np.testing.assert_array_equal(s.cpu().numpy(), g["ctl.0.senders"])
     assert nodes.shape[1] == 25 and ea.shape[1] == 4 and acc.shape[1] == 3  # what get_model reads (rollout_utils.py:123-130)
+
+
+def test_compute_rollout_both_modes(golden, dev, tmp_path):
+    """compute_rollout (rollout_utils.py:12-67) over the mirrored CoffeeTestDataset: planned-trajectory mode against the
+    oracle's rollout loop (pinned by G8), ground-truth mode against a restatement of the reference loop built from oracle
+    pieces."""
+    import types
+    from gnn_manip_amd import CoffeeTestDataset, EncProcDecGNN
+    from gnn_manip_amd.rollout import compute_rollout
+    g = golden("g9_dataset.npz")
+    root = str(tmp_path) + "/"
+    _write_dataset(g, root)
+    ds = CoffeeTestDataset(root, 6, 0.015, split="train", device=dev, use_control=True, sim_id=1)
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    data_dim, T, cart, ctrl, mat, bounds, stats = orc.read_metadata(meta)
+    params = orc.init_params(25, 4, 3, 128, 2, 2, 44)
+    params["decoder.4.weight"] = params["decoder.4.weight"] * 1e-2
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 2)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev)
+    obs_list, next_list = orc.dataset_samples([g["sims"][0].reshape(-1, data_dim)], T, data_dim, 6, cart, mat, True)
+    # --- planned trajectory
+    traj_np = np.stack((np.pi - 0.01 * np.arange(T), 1e-4 * np.arange(T)), axis=1)
+    pred = compute_rollout(ds, m, types.SimpleNamespace(cma_traj=traj_np, k_steps=6, device=dev, plot=False))
+    rigid = obs_list[0][-1][:, mat] == 1
+    poses = orc.rigid_body_trajectory(traj_np[:, 0], traj_np[:, 1], T, [0.5, 0.5, 0.4], obs_list[0][-1][rigid][:, cart])
+    _, recs = orc.rollout(params, obs_list[0], poses, T, stats, bounds, 0.015, cart, [mat], ctrl, 2, 2, record=True)
+    assert pred.shape == (T, obs_list[0].shape[1], obs_list[0].shape[2])
+    np.testing.assert_allclose(pred, recs, rtol=0, atol=2e-5)
+    # --- ground truth mode: the reference loop restated with oracle pieces
+    steps = T - 6
+    pred_gt = compute_rollout(ds, m, types.SimpleNamespace(cma_traj=None, k_steps=6, device=dev, plot=False))
+    cur = obs_list[0].copy()
+    ci, ui = list(cart), list(ctrl)
+    for i in range(steps):
+        gt = obs_list[i][-1]
+        new_rigid = cur[-1][rigid].copy()
+        new_rigid[:, ui] = gt[rigid][:, ui]
+        cur[-1][rigid] = new_rigid
+        np.testing.assert_allclose(pred_gt[i], cur[-1], rtol=0, atol=2e-5)
+        nodes, ea, s, r, _ = orc.process(cur, None, stats, bounds, 0.015, cart, [mat], ctrl)
+        acc = orc.epd_forward(params, nodes, ea, np.stack((s, r)), 2, 2)
+        nxt = orc.get_position_from_prediction(stats, cart, acc, cur)
+        cur[:-1] = cur[1:].copy()
+        cur[-1][:, ci] = nxt
+        new_rigid[:, ci] = gt[rigid][:, ci]
+        cur[-1][rigid] = new_rigid
