@@ -9,7 +9,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
-for wl in ("c2", "target"):
+for wl in ("c2", "target", "train", "plan"):
+    if not glob.glob(f"{src}/{wl}/*/*kernel_stats.csv"):
+        continue
     f = newest(f"{src}/{wl}/*/*kernel_stats.csv")
     shutil.copy(f, f"{dst}/{tag}_{wl}_kernel_stats.csv")
 EDGE = "edge_kernel16<2, 1>"
