@@ -165,3 +165,41 @@ def test_compute_rollout_both_modes(golden, dev, tmp_path):
         cur[-1][:, ci] = nxt
         new_rigid[:, ci] = gt[rigid][:, ci]
         cur[-1][rigid] = new_rigid
+
+
+def test_training_loop_over_noisy_dataset(golden, dev, tmp_path):
+    """train_dyn.py's loop end to end on the device: noisy CoffeeDataset -> GraphLoader (batch of 2) -> model forward
+    with tape -> L1 loss -> HIP backward -> Adam; state_dict round trip through torch.save / load."""
+    from gnn_manip_amd import CoffeeDataset, EncProcDecGNN, GraphLoader
+    g = golden("g9_dataset.npz")
+    root = str(tmp_path) + "/"
+    _write_dataset(g, root)
+    # noise well below the synthetic data's acceleration scale, so that the target stays learnable
+    ds = CoffeeDataset(root, 6, 0.015, split="train", noise=1e-7, device=dev, use_control=True)
+    ds.graph_attr.generator = torch.Generator(device=dev).manual_seed(5)
+    loader = GraphLoader(ds, batch_size=2, shuffle=True, seed=1)
+    torch.manual_seed(0)
+    model = EncProcDecGNN(25, 4, 3, 128, 2, 2).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.L1Loss(reduction="sum")
+    first = last = None
+    for epoch in range(6):
+        tot = 0.0
+        for batch in loader:
+            pred = model.forward(batch.x, batch.edge_attr, batch.edge_index)
+            loss = crit(pred, batch.y) / pred.shape[0]
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            tot += float(loss.detach())
+        first = tot if first is None else first
+        last = tot
+    assert np.isfinite(last) and last < first, (first, last)
+    path = str(tmp_path) + "/gns_model.pth"
+    torch.save(model.state_dict(), path)
+    clone = EncProcDecGNN(25, 4, 3, 128, 2, 2).to(dev)
+    clone.load_state_dict(torch.load(path, map_location=dev))
+    b = next(iter(GraphLoader(ds, batch_size=1)))
+    with torch.no_grad():
+        np.testing.assert_array_equal(model.forward(b.x, b.edge_attr, b.edge_index).cpu().numpy(),
+                                      clone.forward(b.x, b.edge_attr, b.edge_index).cpu().numpy())
