@@ -73,7 +73,7 @@ PROTOTYPES = {
     "gm_block_tape_bytes": (_sz, [_MD, _i32, _i64, _i64]),
     "gm_block_backward_workspace_bytes": (_sz, [_MD, _i64, _i64]),
     "gm_graph_independent_forward_train": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "gm_graph_independent_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "gm_graph_independent_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "gm_interaction_network_forward_train": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "gm_interaction_network_backward": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "gm_sinkhorn_workspace_bytes": (_sz, [_i64, _i64]),

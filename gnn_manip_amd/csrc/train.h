@@ -51,6 +51,8 @@ struct TrainBwdArgs {
     float* dx_resid;       // node: residual path; receives dY before dx adds the MLP's input gradient to it (may alias dY / dx)
     float* dx;             // edge: de_in; node: dh_in; decoder: dh; projection: dh_in
     const int* dxidx;      // edge: row of dx for row p (block API: the caller's edge order), or nullptr
+    float* dx_in;          // encoders: gradient w.r.t. the raw input rows [rows][k1], or nullptr (then the chain stops at dz1)
+    int k1;
     float* dagg_out;       // node: [rows][H]
     int residual;          // edge: de_in += dY
     int out_dim;

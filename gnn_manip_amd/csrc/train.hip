@@ -229,8 +229,9 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
     WStream ws;
     ws.base = A.wstream;
     ws.ring = ring;
+    constexpr int S_IN = (H / 8 + STAGE_PIECES - 1) / STAGE_PIECES;  // W1^T of an encoder: one 32-row block of outputs
     ws.total = (has_g ? 2 * SL : 0) +
-               (KIND == TB_ENC ? 2 * SL : KIND == TB_EDGE ? 3 * SL : KIND == TB_NODE ? 4 * SL : KIND == TB_PROJ ? 0 : 1 + 2 * SL);
+               (KIND == TB_ENC ? 2 * SL + (A.dx_in ? S_IN : 0) : KIND == TB_EDGE ? 3 * SL : KIND == TB_NODE ? 4 * SL : KIND == TB_PROJ ? 0 : 1 + 2 * SL);
     ws.cur = 0;
     ws.parity = 0;
     ws.lane = lane;
@@ -285,7 +286,23 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
         run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);  // W2^T dz2
         mask_feat(acc, A.tape.a1 + pc * H, hi);
         store_feat(acc, A.dz1 + pc * H, hi);
-        if (KIND == TB_ENC) continue;
+        if (KIND == TB_ENC) {
+            if (A.dx_in) {  // gradient w.r.t. the raw input features: dX = dz1 . W1  (k1 <= 32 columns)
+#pragma unroll
+                for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
+                floatx16 o[1];
+                zero_feat(o);
+                run_layer<H / 8, 1, NJB, H / 8>(o, act, ws, more);
+                if (valid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = 8 * (r >> 2) + 4 * hi + (r & 3);
+                        if (f < A.k1) A.dx_in[pc * A.k1 + f] = o[0][r];
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
         zero_feat(acc);

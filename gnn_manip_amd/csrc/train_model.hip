@@ -81,8 +81,9 @@ BwdWs carve_bwd(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
         b.off_node[k] = off; off += (k + 1 < M ? 2 * U : 0) + 4 * U;
         b.off_edge[k] = off; off += 3 * U;
     }
-    b.off_enc_node = off; off += 2 * U + 2 * U;
-    b.off_enc_edge = off; off += 2 * U;
+    const size_t UIN = (size_t)layer_stages(H, 32) * kStageFloats;  // W1^T of an encoder (input gradient, block API)
+    b.off_enc_node = off; off += 2 * U + 2 * U + UIN;
+    b.off_enc_edge = off; off += 2 * U + UIN;
     Carver c(ws);
     b.packT = c.take<float>(off);
     const int64_t R = n > e ? n : e;
@@ -446,8 +447,8 @@ int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_
 }
 
 int gm_graph_independent_backward(const gm_model* m, const float* const* T, int n_tensors, const float* x, const float* edge_attr, int64_t n,
-                                  int64_t e, const float* dh, const float* de, float* const* grads, void* tape, size_t tape_bytes,
-                                  void* ws, size_t ws_bytes, void* stream) {
+                                  int64_t e, const float* dh, const float* de, float* dx, float* dedge_attr, float* const* grads,
+                                  void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_sizes(m, n, e, "gm_graph_independent_backward");
     if (rc != GM_OK) return rc;
     GM_REQUIRE(T && grads && x && dh && tape && ws && (e == 0 || (edge_attr && de)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_backward: null pointer");
@@ -475,12 +476,19 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
     packT(T[PM + 2], b.off_enc_node + 3 * U);
     packT(T[4], b.off_enc_edge);
     packT(T[2], b.off_enc_edge + U);
+    auto packT_in = [&](const float* W, int k1, size_t off) {  // (W1 [H, k1])^T as a Linear with k1 outputs, H inputs
+        PackTJob& j = jobs.job[jobs.n++];
+        j.W = W; j.w_rows = H; j.ld = k1; j.col0 = 0; j.ksub = k1; j.dst_off = off;
+    };
+    if (dx) packT_in(T[PM], m->d.node_dim, b.off_enc_node + 4 * U);
+    if (dedge_attr) packT_in(T[0], m->d.edge_dim, b.off_enc_edge + 2 * U);
     rc = launch_pack_t_batch(jobs, b.packT, s);
     if (rc != GM_OK) return rc;
-    auto run = [&](int base, const TapePtr& tp, int64_t rows, const float* dY, size_t voff, size_t woff, const float* X, int k1) {
+    auto run = [&](int base, const TapePtr& tp, int64_t rows, const float* dY, size_t voff, size_t woff, const float* X, int k1, float* dxin) {
         if (rows <= 0 || rc != GM_OK) return;
         TrainBwdArgs a{};
         a.rows = (int)rows; a.dY = dY; a.tape = tp; a.ln_g = m->vec + voff + (size_t)(NL + 1) * H; a.wstream = b.packT + woff;
+        a.dx_in = dxin; a.k1 = k1;
         a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1;
         rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc == GM_OK) rc = launch_wgrad(b.dz3, H, H, tp.a2, H, H, nullptr, rows, b.part, grads[base + 4], H, 0, grads[base + 5], s);
@@ -488,8 +496,8 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
         if (rc == GM_OK) rc = launch_wgrad(b.dz1, H, H, X, k1, k1, nullptr, rows, b.part, grads[base], k1, 0, grads[base + 1], s);
         if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 6], grads[base + 7], s);
     };
-    run(PM, t.en, n, dh, m->v_enc_node, b.off_enc_node + 2 * U, x, m->d.node_dim);
-    run(0, t.ee, e, de, m->v_enc_edge, b.off_enc_edge, edge_attr, m->d.edge_dim);
+    run(PM, t.en, n, dh, m->v_enc_node, b.off_enc_node + 2 * U, x, m->d.node_dim, dx);
+    run(0, t.ee, e, de, m->v_enc_edge, b.off_enc_edge, edge_attr, m->d.edge_dim, dedge_attr);
     return rc;
 }
 

@@ -12,7 +12,7 @@ BASELINE.json north_star): j = edge_index[0] (source), i = edge_i
 e' = phi_e(cat[h_i, h_j, e]); agg_i = sum_{e -> i} e'; h' = phi_v(cat[h, agg]); no residual inside
 the block.  ``EncProcDecGNN.forward`` is differentiable w.r.t. every parameter (``train_dyn.py``:
 forward with an activation tape + hand-written HIP backward, see csrc/train.hip), and so are the two
-standalone blocks (parameters; the InteractionNetwork also w.r.t. its inputs h, e), so the reference's own
+standalone blocks (parameters and inputs), so the reference's own
 ``EncProcDecGNN`` wiring trains with them as well.
 """
 import ctypes as C
@@ -128,10 +128,13 @@ class _GraphIndependentFunction(torch.autograd.Function):
         de = torch.zeros((e, ctx.desc.hidden_size), device=x.device) if de is None else de.contiguous().float()
         tensors, views, t_arr, g_arr = _grad_arrays(params, x.device)
         ws = _ws(L.gm_block_backward_workspace_bytes(C.byref(ctx.desc), n, e), x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[2] else None
+        dea = torch.empty_like(edge_attr) if ctx.needs_input_grad[3] else None
         check(L.gm_graph_independent_backward(ctx.handle, t_arr, len(tensors), ptr(x), ptr(edge_attr), n, e, ptr(dh), ptr(de),
-                                              g_arr, ptr(ctx.tape), ctx.tape.numel(), ptr(ws), ws.numel(), current_stream()))
+                                              ptr(dx), ptr(dea), g_arr, ptr(ctx.tape), ctx.tape.numel(), ptr(ws), ws.numel(),
+                                              current_stream()))
         ctx.tape = None
-        return (None, None, None, None) + tuple(v if i < ctx.n_own else None for i, v in enumerate(views))
+        return (None, None, dx, dea) + tuple(v if i < ctx.n_own else None for i, v in enumerate(views))
 
 
 class _InteractionNetworkFunction(torch.autograd.Function):
@@ -234,9 +237,6 @@ class GraphIndependent(nn.Module):
         edge_attr = edge_attr.contiguous().float()
         own = list(self.parameters())
         if _wants_grad(own, x, edge_attr):
-            if x.requires_grad or edge_attr.requires_grad:
-                raise NotImplementedError("GraphIndependent: gradients w.r.t. its inputs are not produced (they are data at "
-                                          "the reference's call site epd_gnn.py:88); detach them")
             h_out, e_out = _GraphIndependentFunction.apply(self, len(own), x, edge_attr, *params)
             return h_out, e_out, None
         h = self._handle.get(desc, params, x.device)

@@ -205,7 +205,8 @@ int gm_epd_backward(const gm_model* m, const float* const* tensors, int n_tensor
  * (gm_block_tape_bytes; interaction_network = 0 for GraphIndependent, 1 for InteractionNetwork);
  * *_backward accumulate parameter gradients into grads[] (full-model tensor order, only the block's own
  * entries are touched) and, for the InteractionNetwork, return the input gradients dh_in [N,H] and
- * de_in [E,H] (caller's edge order).  GraphIndependent inputs are data: no input gradient. */
+ * de_in [E,H] (caller's edge order); for the GraphIndependent the input gradients dx / dedge_attr are optional
+ * (NULL at the reference's call site, where the inputs are data). */
 size_t gm_block_tape_bytes(const gm_model_desc* desc, int interaction_network, int64_t n_nodes, int64_t n_edges);
 size_t gm_block_backward_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t n_edges);
 int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_t n_nodes, const float* edge_attr,
@@ -213,8 +214,9 @@ int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_
                                        void* stream);
 int gm_graph_independent_backward(const gm_model* m, const float* const* tensors, int n_tensors, const float* x,
                                   const float* edge_attr, int64_t n_nodes, int64_t n_edges, const float* dh,
-                                  const float* de, float* const* grads, void* tape, size_t tape_bytes, void* ws,
-                                  size_t ws_bytes, void* stream);
+                                  const float* de, float* dx /*[N,node_dim] or NULL*/,
+                                  float* dedge_attr /*[E,edge_dim] or NULL*/, float* const* grads, void* tape,
+                                  size_t tape_bytes, void* ws, size_t ws_bytes, void* stream);
 int gm_interaction_network_forward_train(const gm_model* m, int block, const float* h, int64_t n_nodes,
                                          const float* e, const int64_t* edge_index, int64_t n_edges, float* h_out,
                                          float* e_out, void* tape, size_t tape_bytes, void* stream);

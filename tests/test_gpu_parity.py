@@ -288,16 +288,6 @@ def test_weight_update_repacks(dev, golden):
     np.testing.assert_allclose(b - a, 1.0, atol=1e-5)
 
 
-def test_graph_independent_refuses_input_gradients(dev, golden):
-    """The encoder block's inputs are data (epd_gnn.py:88): asking for their gradient must fail loudly, not silently
-    return nothing (parameter gradients of the blocks: tests/test_gpu_train.py)."""
-    params = orc.init_params(25, 4, 3, 128, 2, 2, 81)
-    m = _model(params, (25, 4, 3, 128, 2, 2), dev)
-    nodes, ea, ei = _scene_graph(golden)
-    with pytest.raises(NotImplementedError):
-        m.encoder(_t(nodes, dev).requires_grad_(True), _t(ea, dev), _t(ei, dev))
-
-
 # ------------------------------------------------------------------ rollout
 def test_rollout_golden_g8(golden, dev):
     from gnn_manip_amd import RolloutEngine

@@ -172,3 +172,28 @@ def test_backward_degenerate_graphs(dev, n, with_edges):
         ei = np.zeros((2, 0), np.int64)
         ea = np.zeros((0, 4), np.float32)
     _check(m, params, nodes, ea, ei, dims, dev, 99)
+
+
+def test_graph_independent_input_gradients(dev):
+    """Encoder block alone with inputs that require grad (not the reference's use, where they are data, but part of the
+    module contract): d loss / d x and d loss / d edge_attr against float64 autograd."""
+    dims = (25, 4, 3, 128, 2, 2)
+    params = orc.init_params(*dims, 101)
+    m = _model(params, dims, dev)
+    nodes, ea, ei = _graph(300, 0.06, 101)
+    x = _t(nodes, dev).requires_grad_(True)
+    a = _t(ea, dev).requires_grad_(True)
+    h, e, _ = m.encoder(x, a, _t(ei, dev))
+    rng = np.random.default_rng(101)
+    wh = rng.standard_normal(h.shape).astype(np.float32)
+    we = rng.standard_normal(e.shape).astype(np.float32)
+    ((h * _t(wh, dev)).sum() + (e * _t(we, dev)).sum()).backward()
+    p64 = {k: torch.tensor(v, dtype=torch.float64) for k, v in params.items()}
+    x64 = torch.tensor(nodes, dtype=torch.float64, requires_grad=True)
+    a64 = torch.tensor(ea, dtype=torch.float64, requires_grad=True)
+    h64 = torch_epd.mlp(p64, "encoder.phi_node", x64, 2, True)
+    e64 = torch_epd.mlp(p64, "encoder.phi_edge", a64, 2, True)
+    ((h64 * torch.tensor(wh, dtype=torch.float64)).sum() + (e64 * torch.tensor(we, dtype=torch.float64)).sum()).backward()
+    for got, ref in ((x.grad, x64.grad), (a.grad, a64.grad)):
+        ref = ref.numpy()
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
