@@ -17,6 +17,7 @@ struct EdgeArgs {
     float* agg;            // [N][H] pre-zeroed, or nullptr
     const float* wstream;  // packed weights (32x32x2 operand image), stage 0
     const float* wstream16;  // same layers in the 16x16x4 operand image, or nullptr
+    const float* wstream_b3; // same layers as three bf16 parts for v_mfma_f32_32x32x16_bf16 (H = 128), or nullptr
     const float* bias;     // processor: biases of layers 2..; encoder: biases of layers 1..
     const float* ln_g;
     const float* ln_b;
@@ -78,6 +79,9 @@ struct VecJobs {
 };
 int launch_pack_batch(const PackJobs& jobs, float* base32, float* base16, hipStream_t s);
 int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s);
+// three-part bf16 image of an H x H (H = 128) Linear: 4 stages of 24 KiB (kB3StageFloats floats) per layer
+constexpr int kB3StageFloats = 6144;
+int pack_linear_b3(const float* W, int ld, int col0, float* dst, hipStream_t s);
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
 constexpr int kStageFloats = 4096;

@@ -781,6 +781,394 @@ __global__ void __launch_bounds__(THREADS, 2) edge_kernel16(EdgeArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// EDGE kernel on the bf16 matrix pipe with fp32 accuracy (processor phi_e, H = 128).
+//
+// A bf16 x bf16 product is exact in fp32, so with x = x_hi + x_mid + x_lo, w = w_hi + w_mid + w_lo (three bf16 parts
+// each, 24 mantissa bits) the six products  lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi  accumulated in fp32
+// reproduce an fp32 FMA chain to fp32 accuracy (measured through the whole model: 4.3e-7 against float64, plain
+// float32 9.7e-7; tools/bf16_split_study.py).  v_mfma_f32_32x32x16_bf16 does 32768 flop in the time the fp32
+// MFMA does 4096: six of them per fp32-equivalent product block is 2.7x the fp32 matrix rate (measured on an MLP chain:
+// 358 vs 146 TFLOP/s, tools/bf16x6_chain.hip).
+//
+// Structure: 128-edge tiles, one workgroup of 8 waves per CU; wave (eh, fh) owns edges 32 eh .. +31 and output
+// features 64 fh .. +63 (two accumulator blocks).  Weights are pre-split (pack_linear_b3) and streamed in 24 KiB
+// stages = 2 k-groups of 16 x 4 output blocks x 3 parts; a layer's input lives as fp32 in the LDS tile X (each wave
+// writes its ReLU'd half, the stage barrier publishes it) and every wave re-splits the 16 k-values it needs per
+// k-group in registers.  K slot (lane >> 5, e) of k-group ks carries feature 16 ks + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
+// in BOTH operands, which is exactly where the 32x32 accumulator layout keeps that feature: no cross-lane traffic.
+// Gathers (drip-fed), LayerNorm (pair merge), stores and the scatter-add follow the other edge kernels.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2v __attribute__((ext_vector_type(2)));
+constexpr int TSP = 132;                 // row stride (floats) of the X tile
+constexpr int TE3 = 128;                 // edges per tile
+constexpr int B3_THREADS = 512;
+constexpr int B3_STAGE_BYTES = 24 * 1024;
+constexpr int B3_STAGE_FLOATS = B3_STAGE_BYTES / 4;
+
+__device__ __forceinline__ unsigned short bf16_rne_bits(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_float(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// dst: [4 stages][2 ksl][4 jb][3 parts][64 lanes][8 bf16] of W[0:128, col0:col0+128] (row-major, leading dimension ld)
+__global__ void __launch_bounds__(256) pack_linear_b3_kernel(const float* __restrict__ W, int ld, int col0, unsigned short* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one (piece-without-part, lane, e)
+    if (idx >= 8 * 4 * 64 * 8) return;
+    const int e = idx & 7, lane = (idx >> 3) & 63, jb = (idx >> 9) & 3, ks = idx >> 11;
+    const int i = lane & 31, kg = lane >> 5;
+    const int k = 16 * ks + 8 * (e >> 2) + 4 * kg + (e & 3);
+    const float w = W[(size_t)(32 * jb + i) * ld + col0 + k];
+    const unsigned short hi = bf16_rne_bits(w);
+    const float r1 = w - bf16_bits_to_float(hi);
+    const unsigned short mid = bf16_rne_bits(r1);
+    const unsigned short lo = bf16_rne_bits(r1 - bf16_bits_to_float(mid));
+    const size_t piece0 = ((size_t)ks * 4 + jb) * 3;  // (stage = ks / 2, ksl = ks & 1) are contiguous in this order
+    dst[(piece0 + 0) * 512 + lane * 8 + e] = hi;
+    dst[(piece0 + 1) * 512 + lane * 8 + e] = mid;
+    dst[(piece0 + 2) * 512 + lane * 8 + e] = lo;
+}
+
+int pack_linear_b3(const float* W, int ld, int col0, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(pack_linear_b3_kernel, dim3(8 * 4 * 64 * 8 / 256), dim3(256), 0, s, W, ld, col0, reinterpret_cast<unsigned short*>(dst));
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+// three-way bf16 split of 8 floats (two float4 halves) -> B operand parts
+__device__ __forceinline__ void b3_split(const floatx4& a, const floatx4& b, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        floatx2v x;
+        x[0] = e < 4 ? a[e] : b[e - 4];
+        x[1] = e < 4 ? a[e + 1] : b[e - 3];
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const floatx2v r1 = x - __builtin_convertvector(h, floatx2v);
+        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+        const floatx2v r2 = r1 - __builtin_convertvector(m, floatx2v);
+        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+        hi[e] = h[0]; hi[e + 1] = h[1];
+        mid[e] = m[0]; mid[e + 1] = m[1];
+        lo[e] = l[0]; lo[e + 1] = l[1];
+    }
+}
+
+template <int NL, int MODE>
+__global__ void __launch_bounds__(B3_THREADS, 1) edge_kernel_b3(EdgeArgs A) {
+    constexpr int H = 128;
+    constexpr bool with_resid = MODE == 1;
+    constexpr int SL = 4;                    // stages per layer (2 k-groups of 16 each)
+    constexpr int TOTAL = (NL + 1) * SL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ring = reinterpret_cast<float*>(smem);                      // 2 x 24 KiB
+    float* X = ring + 2 * B3_STAGE_FLOATS;                             // [TE3][TSP] fp32 layer input / staging tile
+    int* sdst = reinterpret_cast<int*>(X + TE3 * TSP);                 // 2 x [TE3 + 4]
+    float* headv = reinterpret_cast<float*>(sdst + 2 * (TE3 + 4));    // 2 parities x (head[8][128] | tail[8][128])
+    float* vecs = headv + 2 * 2048;                                    // [NL][H] biases, gamma, beta
+    float* lnx = vecs + (NL + 2) * H;                                  // [8 waves][32][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hi = lane >> 5;
+    const int eh = wave >> 1, fh = wave & 1;
+    const int E = A.hdr ? A.hdr->n_edges : A.n_edges_host;
+    const int ntiles = (E + TE3 - 1) / TE3;
+    if ((int)blockIdx.x >= ntiles) return;
+
+    const float* wbase = A.wstream_b3;
+    int ws_cur = 0, ws_par = 0;  // next stage to consume (0 .. TOTAL-1), ring buffer holding it
+    auto issue = [&](int stage, int buf) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int piece = c * 8 + wave;  // 24 pieces of 1 KiB
+            const float* g = wbase + (size_t)stage * B3_STAGE_FLOATS + piece * 256 + lane * 4;
+            float* l = ring + buf * B3_STAGE_FLOATS + piece * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    for (int i = tid; i < NL * H; i += B3_THREADS) vecs[i] = A.bias[i];
+    for (int i = tid; i < H; i += B3_THREADS) {
+        vecs[NL * H + i] = A.ln_g[i];
+        vecs[(NL + 1) * H + i] = A.ln_b[i];
+    }
+    const float* lbias = vecs + 64 * fh;
+    const float* lgamma = vecs + NL * H + 64 * fh;
+    const float* lbeta = lgamma + H;
+    float* xrow = X + (32 * eh + n) * TSP;
+
+    struct TileIdx { int er, d, sr, dq, sd; };
+    auto fetch_idx = [&](int tile) {
+        TileIdx ix;
+        const int p0 = tile * TE3;
+        const int p = p0 + 32 * eh + n;
+        const int pc = p < E ? p : E - 1;
+        ix.er = A.eid ? A.eid[pc] : pc;
+        ix.d = A.dst[pc];
+        ix.sr = A.src[pc];
+        ix.dq = ix.sd = -1;
+        if (tid < TE3 + 2) {
+            const int pp = p0 - 1 + tid;
+            ix.sd = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+        }
+        if (lane < 18) {  // lane l: destination of row (16*wave - 1 + l) of the tile; -2 before edge 0, -1 past E
+            const int pp = p0 + 16 * wave - 1 + lane;
+            ix.dq = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+        }
+        return ix;
+    };
+
+    floatx16 acc[2], ekeep[2], nkeep[2], nacc[2];
+    TileIdx ix = fetch_idx(blockIdx.x);
+    load_feat(nkeep, A.e_in + (int64_t)ix.er * H + 64 * fh, hi);
+    load_feat(nacc, A.P + (int64_t)ix.d * (2 * H) + 64 * fh, hi);
+    add_feat(nacc, A.P + (int64_t)ix.sr * (2 * H) + H + 64 * fh, hi);
+    TileIdx nx = ix;
+    if ((int)(blockIdx.x + gridDim.x) < ntiles) nx = fetch_idx(blockIdx.x + gridDim.x);
+    __syncthreads();
+    int tpar = 0;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
+        const int p0 = tile * TE3;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            ekeep[jb] = nkeep[jb];
+            acc[jb] = nacc[jb];
+        }
+        store_feat(ekeep, xrow + 64 * fh, hi);
+        int* sd = sdst + tpar * (TE3 + 4);
+        if (tid < TE3 + 2) sd[tid] = ix.sd;
+        const int dq = ix.dq;
+        const int er_cur = ix.er;
+        const TileIdx jx = nx;
+        if (more_tiles && tile + 2 * (int)gridDim.x < ntiles) nx = fetch_idx(tile + 2 * gridDim.x);
+        floatx4 pj[2];
+        floatx4 xf[4], xn[4];  // fp32 k-values of this stage's two k-groups (two float4 each), and the next stage's
+#pragma unroll
+        for (int s = 0; s < TOTAL; ++s) {
+            const int layer = s / SL, st = s % SL;
+            if (st == 0 && layer > 0) {
+                floatx16 r[2];
+                relu_to(r, acc);
+                store_feat(r, xrow + 64 * fh, hi);
+                load_feat(acc, lbias + (layer - 1) * H, hi);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            {
+                int nxt = ws_cur + 1;
+                const bool wrap = nxt == TOTAL;
+                if (wrap) nxt = 0;
+                int stl = nxt;
+                asm volatile("" : "+s"(stl));
+                if (!wrap || more_tiles) issue(stl, ws_par ^ 1);
+            }
+            if (more_tiles) {  // drip-fed prefetch of the next tile's operands: 2 float4 per stage (8 e, 8 P_i, 8 P_j)
+                const int q = 2 * (s % 4);
+                if (s < 4) {
+                    const float* src = A.e_in + (int64_t)jx.er * H + 64 * fh + 4 * hi;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int f4 = q + u;
+                        const floatx4 x = *reinterpret_cast<const floatx4*>(src + 32 * (f4 >> 2) + 8 * (f4 & 3));
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) nkeep[f4 >> 2][4 * (f4 & 3) + t] = x[t];
+                    }
+                } else if (s < 8) {
+                    const float* src = A.P + (int64_t)jx.d * (2 * H) + 64 * fh + 4 * hi;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int f4 = q + u;
+                        const floatx4 x = *reinterpret_cast<const floatx4*>(src + 32 * (f4 >> 2) + 8 * (f4 & 3));
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) nacc[f4 >> 2][4 * (f4 & 3) + t] = x[t];
+                    }
+                } else {
+                    const float* src = A.P + (int64_t)jx.sr * (2 * H) + H + 64 * fh + 4 * hi;
+                    if (s > 8) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int f4 = q - 2 + u;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) nacc[f4 >> 2][4 * (f4 & 3) + t] += pj[u][t];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int f4 = q + u;
+                        pj[u] = *reinterpret_cast<const floatx4*>(src + 32 * (f4 >> 2) + 8 * (f4 & 3));
+                    }
+                }
+            }
+            // fp32 inputs of k-groups ks = 2 st, 2 st + 1: features 16 ks + {4 hi .. +3} and 16 ks + 8 + {4 hi .. +3}
+            if (st == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xf[c] = *reinterpret_cast<const floatx4*>(xrow + 16 * (c >> 1) + 8 * (c & 1) + 4 * hi);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xf[c] = xn[c];
+            }
+            if (st + 1 < SL) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xn[c] = *reinterpret_cast<const floatx4*>(xrow + 32 * (st + 1) + 16 * (c >> 1) + 8 * (c & 1) + 4 * hi);
+            }
+            const bf16x8* wst = reinterpret_cast<const bf16x8*>(ring + ws_par * B3_STAGE_FLOATS) + lane;
+#pragma unroll
+            for (int ksl = 0; ksl < 2; ++ksl) {
+                bf16x8 bh, bm, bl;
+                b3_split(xf[2 * ksl], xf[2 * ksl + 1], bh, bm, bl);
+#pragma unroll
+                for (int jbl = 0; jbl < 2; ++jbl) {
+                    const bf16x8* pw = wst + ((ksl * 4 + 2 * fh + jbl) * 3) * 64;  // piece stride: 64 lanes x 16 B
+                    const bf16x8 ah = pw[0], am = pw[64], al = pw[128];
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[jbl], 0, 0, 0);
+                }
+            }
+            ws_cur = ws_cur + 1 == TOTAL ? 0 : ws_cur + 1;
+            ws_par ^= 1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- LayerNorm (this wave: 64 of the 128 features of its 32 edges; pair merge through LDS)
+        {
+            float sm = 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sm += acc[jb][r];
+            sm += __shfl_xor(sm, 32, 64);
+            const float mh = sm * (1.0f / 64.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[jb][r] - mh;
+                    m2 += d * d;
+                }
+            m2 += __shfl_xor(m2, 32, 64);
+            if (hi == 0) {
+                lnx[(wave * 32 + n) * 2] = mh;
+                lnx[(wave * 32 + n) * 2 + 1] = m2;
+            }
+            lds_barrier();
+            const float mo = lnx[((wave ^ 1) * 32 + n) * 2], m2o = lnx[((wave ^ 1) * 32 + n) * 2 + 1];
+            const float mean = 0.5f * (mh + mo);
+            const float dlt = mh - mo;
+            const float var = (m2 + m2o + 32.0f * dlt * dlt) * (1.0f / 128.0f);
+            const float rstd = 1.0f / sqrtf(var + A.eps);
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const floatx4 gm = *reinterpret_cast<const floatx4*>(lgamma + 32 * jb + 8 * g + 4 * hi);
+                    const floatx4 bt = *reinterpret_cast<const floatx4*>(lbeta + 32 * jb + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[jb][4 * g + t] = (acc[jb][4 * g + t] - mean) * rstd * gm[t] + bt[t];
+                }
+            }
+        }
+        const int p = p0 + 32 * eh + n;
+        const bool valid = p < E;
+        const int64_t out_row = !valid ? 0 : (!A.eid_out ? (int64_t)p : (A.eid_out == A.eid ? (int64_t)er_cur : (int64_t)A.eid_out[p]));
+        if (valid) {
+            floatx16 o[2];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                o[jb] = acc[jb];
+                if (with_resid) o[jb] += ekeep[jb];
+            }
+            store_feat(o, A.e_out + out_row * H + 64 * fh, hi);
+        }
+        // ---- scatter-add: e' staged in X; wave q sums the destination segments inside rows 16q..16q+15 (8 waves = 128
+        // rows); waves 0 / 1 stitch the 8 quarters (64 columns each)
+        {
+            float* part = headv + tpar * 2048;
+            store_feat(acc, xrow + 64 * fh, hi);
+            lds_barrier();
+            {
+                typedef float floatx2 __attribute__((ext_vector_type(2)));
+                float* hv = part;          // head[8][128]
+                float* tl = part + 1024;   // tail[8][128]
+                const int r0 = 16 * wave;
+                floatx2 tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tv[r] = *reinterpret_cast<const floatx2*>(X + (r0 + r) * TSP + 2 * lane);
+                floatx2 run = {0.f, 0.f};
+                int d = __builtin_amdgcn_readlane(dq, 1);
+                bool first = d >= 0 && __builtin_amdgcn_readlane(dq, 0) == d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dn = __builtin_amdgcn_readlane(dq, r + 2);
+                    if (d >= 0) run += tv[r];
+                    if (dn != d && d >= 0) {
+                        if (first) *reinterpret_cast<floatx2*>(hv + wave * 128 + 2 * lane) = run;
+                        else *reinterpret_cast<floatx2*>(A.agg + (int64_t)d * H + 2 * lane) = run;
+                        run = floatx2{0.f, 0.f};
+                        first = false;
+                    }
+                    d = dn;
+                }
+                const int dl = __builtin_amdgcn_readlane(dq, 16);
+                if (dl >= 0 && __builtin_amdgcn_readlane(dq, 17) == dl) *reinterpret_cast<floatx2*>(tl + wave * 128 + 2 * lane) = run;
+            }
+            lds_barrier();
+            if (wave < 2) {
+                const int fc = wave;
+                const float* hv = part + 64 * fc;
+                const float* tl = part + 1024 + 64 * fc;
+                const int bl = lane & 31;  // lane 4q + j holds sd[16q + {0, 1, 16, 17}[j]], q = 0..7
+                const int bv = sd[16 * (bl >> 2) + ((bl & 3) < 2 ? (bl & 3) : 14 + (bl & 3))];
+                float carry = 0.f;
+                bool ext = false;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float hq = hv[q * 128 + lane], tq = tl[q * 128 + lane];
+                    const int dprev = __builtin_amdgcn_readlane(bv, 4 * q);
+                    const int df = __builtin_amdgcn_readlane(bv, 4 * q + 1);
+                    const int dlast = __builtin_amdgcn_readlane(bv, 4 * q + 2);
+                    const int dnext = __builtin_amdgcn_readlane(bv, 4 * q + 3);
+                    const bool cont_in = df >= 0 && dprev == df;
+                    const bool through = cont_in && dlast == df && dnext == df;
+                    if (cont_in) {
+                        if (q == 0) { carry = 0.f; ext = true; }
+                        if (through) {
+                            carry += tq;
+                        } else {
+                            const float tot = carry + hq;
+                            float* dstp = A.agg + (int64_t)df * H + 64 * fc + lane;
+                            if (ext) atomicAdd(dstp, tot); else *dstp = tot;
+                            carry = 0.f;
+                            ext = false;
+                        }
+                    }
+                    if (!through && dlast >= 0 && dnext == dlast) { carry = tq; ext = false; }
+                    if (q == 7 && dlast >= 0 && dnext == dlast)
+                        atomicAdd(A.agg + (int64_t)dlast * H + 64 * fc + lane, carry);
+                }
+            }
+        }
+        if (more_tiles) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) nacc[1][4 * (2 + u) + t] += pj[u][t];
+        }
+        ix = jx;
+        tpar ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
 // NODE kernel.  MODE 0: encoder MLP on raw node features; 1: processor phi_v on [h | agg];
 // 2: projection only (block API).  Tail (runtime, uniform): 0 none, 1 projection P = h'[W_i|W_j]^T
 // for the next edge step, 2 decoder.
@@ -1203,6 +1591,28 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     if (H == 256) {
         int rc = launch_edge_h<256>(enc, a, grid, lds, s);
         if (rc != GM_OK) return rc;
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
+    static const bool use_b3 = getenv("GM_EDGE_KERNEL") && !strcmp(getenv("GM_EDGE_KERNEL"), "b3");
+    if (H == 128 && use_b3 && !enc && a.wstream_b3 && a.agg) {
+        const size_t lb = (size_t)(2 * B3_STAGE_FLOATS + TE3 * TSP + 2 * (TE3 + 4) + 2 * 2048 + 4 * 128 + 8 * 32 * 2) * 4;
+        static bool doneb = false;
+        if (!doneb) {
+            int rc = set_lds(edge_kernel_b3<2, 1>, lb);
+            if (rc == GM_OK) rc = set_lds(edge_kernel_b3<2, 2>, lb);
+            if (rc != GM_OK) return rc;
+            doneb = true;
+        }
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int gb = grid_for(cdiv(edge_capacity, TE3));
+        if (gb > cus) gb = cus;
+        {
+            ProfScope prof(PROF_EDGE, s);
+            if (a.residual) hipLaunchKernelGGL((edge_kernel_b3<2, 1>), dim3(gb), dim3(B3_THREADS), lb, s, a);
+            else hipLaunchKernelGGL((edge_kernel_b3<2, 2>), dim3(gb), dim3(B3_THREADS), lb, s, a);
+        }
         GM_LAUNCH_CHECK();
         return GM_OK;
     }

@@ -178,6 +178,20 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
             for (int l = 1; l <= NL; ++l) pack16(b_edge(k) + 2 * l, H, H, 0, H, o16);
         }
     }
+    if (m->packed_b3 && !on_device) {  // host-side weights: this image is not maintained, fall back to the fp32 kernels
+        hipFree(m->packed_b3);
+        m->packed_b3 = nullptr;
+    }
+    if (m->packed_b3) {  // three-part bf16 image of the processor edge MLPs (device-resident weights only)
+        for (int k = 0; k < M && rc == GM_OK; ++k) {
+            float* base = m->packed_b3 + (size_t)k * 3 * 4 * kB3StageFloats;
+            if (on_device) {
+                rc = pack_linear_b3(T[b_edge(k)], 3 * H, 2 * H, base, s);
+                for (int l = 1; l <= NL && rc == GM_OK; ++l)
+                    rc = pack_linear_b3(T[b_edge(k) + 2 * l], H, 0, base + (size_t)l * 4 * kB3StageFloats, s);
+            }
+        }
+    }
     vecs(b_enc_edge, true, m->v_enc_edge);
     vecs(b_enc_node, true, m->v_enc_node);
     for (int k = 0; k < M; ++k) {
@@ -253,6 +267,13 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             return GM_ERR_HIP;
         }
     }
+    if (H == 128 && NL == 2 && on_device) {
+        if (hipMalloc(&m->packed_b3, (size_t)M * 3 * 4 * kB3StageFloats * sizeof(float)) != hipSuccess) {
+            gm::set_error("gm_model_create: hipMalloc failed");
+            gm_model_destroy(m);
+            return GM_ERR_HIP;
+        }
+    }
     if (hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess ||
         hipMalloc(&m->vec, m->vec_floats * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
@@ -277,6 +298,7 @@ void gm_model_destroy(gm_model* m) {
     if (!m) return;
     if (m->packed) hipFree(m->packed);
     if (m->packed16) hipFree(m->packed16);
+    if (m->packed_b3) hipFree(m->packed_b3);
     if (m->vec) hipFree(m->vec);
     delete m;
 }
@@ -307,6 +329,7 @@ EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, const CsrHeade
     a.P = P; a.e_in = e_in; a.e_out = e_out; a.agg = agg; a.residual = residual;
     a.wstream = m->packed + m->s_edge[k];
     a.wstream16 = m->packed16 ? m->packed16 + m->s16_edge[k] : nullptr;
+    a.wstream_b3 = m->packed_b3 ? m->packed_b3 + (size_t)k * 3 * 4 * kB3StageFloats : nullptr;
     const float* v = m->vec + m->v_edge[k];
     a.bias = v + m->H;  // layer-1 bias lives in P_i
     a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
