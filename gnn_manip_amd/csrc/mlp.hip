@@ -946,7 +946,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) edge_kernel_b3(EdgeArgs A) {
         const int er_cur = ix.er;
         const TileIdx jx = nx;
         if (more_tiles && tile + 2 * (int)gridDim.x < ntiles) nx = fetch_idx(tile + 2 * gridDim.x);
-        floatx4 pj[2];
+        floatx4 pj[4];  // P_j rows of the next tile: requested at stage s, added at stage s + 2 (the wait above covers them)
         floatx4 xf[4], xn[4];  // fp32 k-values of this stage's two k-groups (two float4 each), and the next stage's
 #pragma unroll
         for (int s = 0; s < TOTAL; ++s) {
@@ -957,8 +957,16 @@ __global__ void __launch_bounds__(B3_THREADS, 1) edge_kernel_b3(EdgeArgs A) {
                 store_feat(r, xrow + 64 * fh, hi);
                 load_feat(acc, lbias + (layer - 1) * H, hi);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            // This stage's DMA was issued one stage ago BEFORE that stage's two gathers (sched_barrier below): waiting for
+            // "at most two outstanding" proves it has landed and leaves the gathers another stage to arrive (a stage of
+            // this kernel is shorter than an HBM gather).
+            if (more_tiles && s > 0) {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                lds_barrier();
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
             {
                 int nxt = ws_cur + 1;
                 const bool wrap = nxt == TOTAL;
@@ -967,6 +975,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) edge_kernel_b3(EdgeArgs A) {
                 asm volatile("" : "+s"(stl));
                 if (!wrap || more_tiles) issue(stl, ws_par ^ 1);
             }
+            __builtin_amdgcn_sched_barrier(0);
             if (more_tiles) {  // drip-fed prefetch of the next tile's operands: 2 float4 per stage (8 e, 8 P_i, 8 P_j)
                 const int q = 2 * (s % 4);
                 if (s < 4) {
@@ -989,18 +998,18 @@ __global__ void __launch_bounds__(B3_THREADS, 1) edge_kernel_b3(EdgeArgs A) {
                     }
                 } else {
                     const float* src = A.P + (int64_t)jx.sr * (2 * H) + H + 64 * fh + 4 * hi;
-                    if (s > 8) {
+                    if (s > 9) {  // the pair requested two stages ago
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            const int f4 = q - 2 + u;
+                            const int f4 = q - 4 + u;
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) nacc[f4 >> 2][4 * (f4 & 3) + t] += pj[u][t];
+                            for (int t = 0; t < 4; ++t) nacc[f4 >> 2][4 * (f4 & 3) + t] += pj[2 * (s & 1) + u][t];
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int f4 = q + u;
-                        pj[u] = *reinterpret_cast<const floatx4*>(src + 32 * (f4 >> 2) + 8 * (f4 & 3));
+                        pj[2 * (s & 1) + u] = *reinterpret_cast<const floatx4*>(src + 32 * (f4 >> 2) + 8 * (f4 & 3));
                     }
                 }
             }
@@ -1156,11 +1165,14 @@ __global__ void __launch_bounds__(B3_THREADS, 1) edge_kernel_b3(EdgeArgs A) {
                 }
             }
         }
-        if (more_tiles) {
+        if (more_tiles) {  // the last two P_j pairs (requested at stages 10 and 11: f4 = 4, 5 and 6, 7)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) nacc[1][4 * (2 + u) + t] += pj[u][t];
+                for (int t = 0; t < 4; ++t) {
+                    nacc[1][4 * u + t] += pj[u][t];
+                    nacc[1][4 * (2 + u) + t] += pj[2 + u][t];
+                }
         }
         ix = jx;
         tpar ^= 1;
