@@ -86,5 +86,6 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacit
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
 constexpr int kStageFloats = 4096;
 void set_stamp_buffer(unsigned long long* p);
+void set_edge_kernel_choice(int c);  // 0 auto, 1 fp32 16x16x4, 2 fp32 32x32x2, 3 bf16-pipe 128-edge, 4 bf16-pipe 64-edge
 
 }  // namespace gm

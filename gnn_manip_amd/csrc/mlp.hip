@@ -1181,6 +1181,314 @@ __global__ void __launch_bounds__(B3_THREADS, 1) edge_kernel_b3(EdgeArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same bf16-pipe scheme on 64-edge tiles: 4 waves (edge half x feature half), TWO workgroups per CU, weight
+// stages of one k-group (12 KiB = 4 output blocks x 3 parts), 24 stages per tile.  Twice the rendezvous count of
+// edge_kernel_b3, but the second workgroup runs under the first one's epilogue and gather latency again.
+// ------------------------------------------------------------------------------------------
+constexpr int B3P_STAGE_FLOATS = 3072;  // 12 KiB
+
+template <int NL, int MODE>
+__global__ void __launch_bounds__(THREADS, 2) edge_kernel_b3p(EdgeArgs A) {
+    constexpr int H = 128;
+    constexpr bool with_resid = MODE == 1;
+    constexpr int SL = 8;                    // stages (k-groups of 16) per layer
+    constexpr int TOTAL = (NL + 1) * SL;     // 24
+    constexpr int NCH = H / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ring = reinterpret_cast<float*>(smem);                     // 2 x 12 KiB
+    float* X = ring + 2 * B3P_STAGE_FLOATS;                           // [T16][TSP]
+    int* sdst = reinterpret_cast<int*>(X + T16 * TSP);                // 2 x [T16 + 4]
+    float* headv = reinterpret_cast<float*>(sdst + 2 * (T16 + 4));   // 2 parities x (head[4][128] | tail[4][128])
+    float* vecs = headv + 2 * 1024;
+    float* lnx = vecs + (NL + 2) * H;                                 // [4 waves][32][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hi = lane >> 5;
+    const int eh = wave >> 1, fh = wave & 1;
+    const int E = A.hdr ? A.hdr->n_edges : A.n_edges_host;
+    const int ntiles = (E + T16 - 1) / T16;
+    if ((int)blockIdx.x >= ntiles) return;
+
+    const float* wbase = A.wstream_b3;
+    int ws_cur = 0, ws_par = 0;
+    auto issue = [&](int stage, int buf) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int piece = c * 4 + wave;  // 12 pieces of 1 KiB
+            const float* g = wbase + (size_t)stage * B3P_STAGE_FLOATS + piece * 256 + lane * 4;
+            float* l = ring + buf * B3P_STAGE_FLOATS + piece * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    for (int i = tid; i < NL * H; i += THREADS) vecs[i] = A.bias[i];
+    for (int i = tid; i < H; i += THREADS) {
+        vecs[NL * H + i] = A.ln_g[i];
+        vecs[(NL + 1) * H + i] = A.ln_b[i];
+    }
+    const float* lbias = vecs + 64 * fh;
+    const float* lgamma = vecs + NL * H + 64 * fh;
+    const float* lbeta = lgamma + H;
+    float* xrow = X + (32 * eh + n) * TSP;
+
+    struct TileIdx { int er, d, sr, dq, sd; };
+    auto fetch_idx = [&](int tile) {
+        TileIdx ix;
+        const int p0 = tile * T16;
+        const int p = p0 + 32 * eh + n;
+        const int pc = p < E ? p : E - 1;
+        ix.er = A.eid ? A.eid[pc] : pc;
+        ix.d = A.dst[pc];
+        ix.sr = A.src[pc];
+        ix.dq = ix.sd = -1;
+        if (tid < T16 + 2) {
+            const int pp = p0 - 1 + tid;
+            ix.sd = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+        }
+        if (lane < 18) {
+            const int pp = p0 + 16 * wave - 1 + lane;
+            ix.dq = pp < 0 ? -2 : (pp < E ? A.dst[pp] : -1);
+        }
+        return ix;
+    };
+
+    floatx16 acc[2], ekeep[2], nkeep[2], nacc[2];
+    TileIdx ix = fetch_idx(blockIdx.x);
+    load_feat(nkeep, A.e_in + (int64_t)ix.er * H + 64 * fh, hi);
+    load_feat(nacc, A.P + (int64_t)ix.d * (2 * H) + 64 * fh, hi);
+    add_feat(nacc, A.P + (int64_t)ix.sr * (2 * H) + H + 64 * fh, hi);
+    TileIdx nx = ix;
+    if ((int)(blockIdx.x + gridDim.x) < ntiles) nx = fetch_idx(blockIdx.x + gridDim.x);
+    __syncthreads();
+    int tpar = 0;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
+        const int p0 = tile * T16;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            ekeep[jb] = nkeep[jb];
+            acc[jb] = nacc[jb];
+        }
+        store_feat(ekeep, xrow + 64 * fh, hi);
+        int* sd = sdst + tpar * (T16 + 4);
+        if (tid < T16 + 2) sd[tid] = ix.sd;
+        const int dq = ix.dq;
+        const int er_cur = ix.er;
+        const TileIdx jx = nx;
+        if (more_tiles && tile + 2 * (int)gridDim.x < ntiles) nx = fetch_idx(tile + 2 * gridDim.x);
+        floatx4 pj[3];         // P_j float4s of the next tile: requested at stage s, added at stage s + 2
+        floatx4 xf[2], xn[2];  // fp32 k-values of this stage's k-group (two float4), and the next stage's
+        prio_mfma_phase();
+#pragma unroll
+        for (int s = 0; s < TOTAL; ++s) {
+            const int layer = s / SL, ks = s % SL;
+            if (ks == 0 && layer > 0) {
+                floatx16 r[2];
+                relu_to(r, acc);
+                store_feat(r, xrow + 64 * fh, hi);
+                load_feat(acc, lbias + (layer - 1) * H, hi);
+            }
+            // the stage's DMA is older than the one gather issued behind it a stage ago: counted wait
+            if (more_tiles && s > 0) {
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                lds_barrier();
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            {
+                int nxt = ws_cur + 1;
+                const bool wrap = nxt == TOTAL;
+                if (wrap) nxt = 0;
+                int stl = nxt;
+                asm volatile("" : "+s"(stl));
+                if (!wrap || more_tiles) issue(stl, ws_par ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more_tiles) {  // one float4 of the next tile's operands per stage: 8 e, 8 P_i, 8 P_j
+                const int f4 = s % 8;
+                const int off = 32 * (f4 >> 2) + 8 * (f4 & 3) + 64 * fh + 4 * hi;
+                if (s < 8) {
+                    const floatx4 x = *reinterpret_cast<const floatx4*>(A.e_in + (int64_t)jx.er * H + off);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) nkeep[f4 >> 2][4 * (f4 & 3) + t] = x[t];
+                } else if (s < 16) {
+                    const floatx4 x = *reinterpret_cast<const floatx4*>(A.P + (int64_t)jx.d * (2 * H) + off);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) nacc[f4 >> 2][4 * (f4 & 3) + t] = x[t];
+                } else {
+                    if (s >= 18) {
+                        const int g4 = f4 - 2;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) nacc[g4 >> 2][4 * (g4 & 3) + t] += pj[(s - 2) % 3][t];
+                    }
+                    pj[s % 3] = *reinterpret_cast<const floatx4*>(A.P + (int64_t)jx.sr * (2 * H) + H + off);
+                }
+            }
+            if (ks == 0) {
+                xf[0] = *reinterpret_cast<const floatx4*>(xrow + 4 * hi);
+                xf[1] = *reinterpret_cast<const floatx4*>(xrow + 8 + 4 * hi);
+            } else {
+                xf[0] = xn[0];
+                xf[1] = xn[1];
+            }
+            if (ks + 1 < SL) {
+                xn[0] = *reinterpret_cast<const floatx4*>(xrow + 16 * (ks + 1) + 4 * hi);
+                xn[1] = *reinterpret_cast<const floatx4*>(xrow + 16 * (ks + 1) + 8 + 4 * hi);
+            }
+            const bf16x8* wst = reinterpret_cast<const bf16x8*>(ring + ws_par * B3P_STAGE_FLOATS) + lane;
+            {
+                bf16x8 bh, bm, bl;
+                b3_split(xf[0], xf[1], bh, bm, bl);
+#pragma unroll
+                for (int jbl = 0; jbl < 2; ++jbl) {
+                    const bf16x8* pw = wst + ((2 * fh + jbl) * 3) * 64;
+                    const bf16x8 ah = pw[0], am = pw[64], al = pw[128];
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[jbl], 0, 0, 0);
+                    acc[jbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[jbl], 0, 0, 0);
+                }
+            }
+            ws_cur = ws_cur + 1 == TOTAL ? 0 : ws_cur + 1;
+            ws_par ^= 1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        prio_latency_phase();
+        {
+            float sm = 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sm += acc[jb][r];
+            sm += __shfl_xor(sm, 32, 64);
+            const float mh = sm * (1.0f / 64.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[jb][r] - mh;
+                    m2 += d * d;
+                }
+            m2 += __shfl_xor(m2, 32, 64);
+            if (hi == 0) {
+                lnx[(wave * 32 + n) * 2] = mh;
+                lnx[(wave * 32 + n) * 2 + 1] = m2;
+            }
+            lds_barrier();
+            const float mo = lnx[((wave ^ 1) * 32 + n) * 2], m2o = lnx[((wave ^ 1) * 32 + n) * 2 + 1];
+            const float mean = 0.5f * (mh + mo);
+            const float dlt = mh - mo;
+            const float var = (m2 + m2o + 32.0f * dlt * dlt) * (1.0f / 128.0f);
+            const float rstd = 1.0f / sqrtf(var + A.eps);
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const floatx4 gm = *reinterpret_cast<const floatx4*>(lgamma + 32 * jb + 8 * g + 4 * hi);
+                    const floatx4 bt = *reinterpret_cast<const floatx4*>(lbeta + 32 * jb + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[jb][4 * g + t] = (acc[jb][4 * g + t] - mean) * rstd * gm[t] + bt[t];
+                }
+            }
+        }
+        const int p = p0 + 32 * eh + n;
+        const bool valid = p < E;
+        const int64_t out_row = !valid ? 0 : (!A.eid_out ? (int64_t)p : (A.eid_out == A.eid ? (int64_t)er_cur : (int64_t)A.eid_out[p]));
+        if (valid) {
+            floatx16 o[2];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                o[jb] = acc[jb];
+                if (with_resid) o[jb] += ekeep[jb];
+            }
+            store_feat(o, A.e_out + out_row * H + 64 * fh, hi);
+        }
+        {
+            float* part = headv + tpar * 1024;
+            store_feat(acc, xrow + 64 * fh, hi);
+            lds_barrier();
+            {
+                typedef float floatx2 __attribute__((ext_vector_type(2)));
+                float* hv = part;
+                float* tl = part + 512;
+                const int r0 = 16 * wave;
+                floatx2 tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tv[r] = *reinterpret_cast<const floatx2*>(X + (r0 + r) * TSP + 2 * lane);
+                floatx2 run = {0.f, 0.f};
+                int d = __builtin_amdgcn_readlane(dq, 1);
+                bool first = d >= 0 && __builtin_amdgcn_readlane(dq, 0) == d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dn = __builtin_amdgcn_readlane(dq, r + 2);
+                    if (d >= 0) run += tv[r];
+                    if (dn != d && d >= 0) {
+                        if (first) *reinterpret_cast<floatx2*>(hv + wave * 128 + 2 * lane) = run;
+                        else *reinterpret_cast<floatx2*>(A.agg + (int64_t)d * H + 2 * lane) = run;
+                        run = floatx2{0.f, 0.f};
+                        first = false;
+                    }
+                    d = dn;
+                }
+                const int dl = __builtin_amdgcn_readlane(dq, 16);
+                if (dl >= 0 && __builtin_amdgcn_readlane(dq, 17) == dl) *reinterpret_cast<floatx2*>(tl + wave * 128 + 2 * lane) = run;
+            }
+            lds_barrier();
+            if (wave < NCH) {
+                const int fc = wave;
+                const float* hv = part + 64 * fc;
+                const float* tl = part + 512 + 64 * fc;
+                const int bl = lane & 15;
+                const int bv = sd[16 * (bl >> 2) + ((bl & 3) < 2 ? (bl & 3) : 14 + (bl & 3))];
+                float carry = 0.f;
+                bool ext = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float hq = hv[q * 128 + lane], tq = tl[q * 128 + lane];
+                    const int dprev = __builtin_amdgcn_readlane(bv, 4 * q);
+                    const int df = __builtin_amdgcn_readlane(bv, 4 * q + 1);
+                    const int dlast = __builtin_amdgcn_readlane(bv, 4 * q + 2);
+                    const int dnext = __builtin_amdgcn_readlane(bv, 4 * q + 3);
+                    const bool cont_in = df >= 0 && dprev == df;
+                    const bool through = cont_in && dlast == df && dnext == df;
+                    if (cont_in) {
+                        if (q == 0) { carry = 0.f; ext = true; }
+                        if (through) {
+                            carry += tq;
+                        } else {
+                            const float tot = carry + hq;
+                            float* dstp = A.agg + (int64_t)df * H + 64 * fc + lane;
+                            if (ext) atomicAdd(dstp, tot); else *dstp = tot;
+                            carry = 0.f;
+                            ext = false;
+                        }
+                    }
+                    if (!through && dlast >= 0 && dnext == dlast) { carry = tq; ext = false; }
+                    if (q == 3 && dlast >= 0 && dnext == dlast)
+                        atomicAdd(A.agg + (int64_t)dlast * H + 64 * fc + lane, carry);
+                }
+            }
+        }
+        if (more_tiles) {  // the last two P_j float4s (requested at stages 22, 23: f4 = 6, 7)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                nacc[1][4 * 2 + t] += pj[22 % 3][t];
+                nacc[1][4 * 3 + t] += pj[23 % 3][t];
+            }
+        }
+        ix = jx;
+        tpar ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
 // NODE kernel.  MODE 0: encoder MLP on raw node features; 1: processor phi_v on [h | agg];
 // 2: projection only (block API).  Tail (runtime, uniform): 0 none, 1 projection P = h'[W_i|W_j]^T
 // for the next edge step, 2 decoder.
@@ -1569,6 +1877,17 @@ static int set_lds(K kernel, size_t bytes) {
     return GM_OK;
 }
 
+enum : int { EK_AUTO = 0, EK_16 = 1, EK_CLASSIC = 2, EK_B3 = 3, EK_B3P = 4 };
+static int g_edge_choice = -1;
+static int edge_kernel_choice() {
+    if (g_edge_choice < 0) {
+        const char* e = getenv("GM_EDGE_KERNEL");
+        g_edge_choice = !e ? EK_AUTO : !strcmp(e, "16") ? EK_16 : !strcmp(e, "classic") ? EK_CLASSIC : !strcmp(e, "b3") ? EK_B3
+                        : !strcmp(e, "b3p") ? EK_B3P : EK_AUTO;
+    }
+    return g_edge_choice;
+}
+void set_edge_kernel_choice(int c) { g_edge_choice = c; }
 static unsigned long long* g_stamps = nullptr;
 void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 
@@ -1606,8 +1925,41 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         GM_LAUNCH_CHECK();
         return GM_OK;
     }
-    static const bool use_b3 = getenv("GM_EDGE_KERNEL") && !strcmp(getenv("GM_EDGE_KERNEL"), "b3");
-    if (H == 128 && use_b3 && !enc && a.wstream_b3 && a.agg) {
+    // Processor edge kernel choice (H = 128): "auto" = the bf16-pipe kernels (fp32-accurate six-product split) when the
+    // model carries their weight image -- 64-edge / two-workgroup form for small graphs, 128-edge form otherwise --
+    // else the fp32-MFMA 16x16x4 kernel.  GM_EDGE_KERNEL = 16 | classic | b3 | b3p, or gm_debug_set_edge_kernel().
+    const int choice = edge_kernel_choice();
+    int ncu = 256;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const bool b3_ok = H == 128 && !enc && a.wstream_b3 && a.agg;
+    const bool small = cdiv(edge_capacity, TE3) < 4 * (int64_t)ncu;
+    const bool use_b3p = b3_ok && (choice == EK_B3P || (choice == EK_AUTO && small));
+    const bool use_b3 = b3_ok && (choice == EK_B3 || (choice == EK_AUTO && !small));
+    if (use_b3p) {
+        const size_t lb = (size_t)(2 * B3P_STAGE_FLOATS + T16 * TSP + 2 * (T16 + 4) + 2 * 1024 + 4 * 128 + 4 * 32 * 2) * 4;
+        static bool donebp = false;
+        if (!donebp) {
+            int rc = set_lds(edge_kernel_b3p<2, 1>, lb);
+            if (rc == GM_OK) rc = set_lds(edge_kernel_b3p<2, 2>, lb);
+            if (rc != GM_OK) return rc;
+            donebp = true;
+        }
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int gb = grid_for(cdiv(edge_capacity, T16));
+        if (gb > 2 * cus) gb = 2 * cus;
+        {
+            ProfScope prof(PROF_EDGE, s);
+            if (a.residual) hipLaunchKernelGGL((edge_kernel_b3p<2, 1>), dim3(gb), dim3(THREADS), lb, s, a);
+            else hipLaunchKernelGGL((edge_kernel_b3p<2, 2>), dim3(gb), dim3(THREADS), lb, s, a);
+        }
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
+    if (use_b3) {
         const size_t lb = (size_t)(2 * B3_STAGE_FLOATS + TE3 * TSP + 2 * (TE3 + 4) + 2 * 2048 + 4 * 128 + 8 * 32 * 2) * 4;
         static bool doneb = false;
         if (!doneb) {
@@ -1628,7 +1980,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         GM_LAUNCH_CHECK();
         return GM_OK;
     }
-    static const bool use16 = !(getenv("GM_EDGE_KERNEL") && strcmp(getenv("GM_EDGE_KERNEL"), "16"));
+    const bool use16 = choice != EK_CLASSIC;
     if (H == 128 && use16 && a.wstream16) {
         const size_t l16 = edge16_lds_bytes();
         static bool done16 = false;

@@ -474,6 +474,12 @@ extern "C" {
 
 // diagnostics (tools/stamps.py): device buffer [tiles][8] u64 receiving per-tile phase stamps of the
 // processor edge kernel; nullptr disables.  Not used by any timed path.
+int gm_debug_set_edge_kernel(int choice) {
+    GM_REQUIRE(choice >= 0 && choice <= 4, GM_ERR_INVALID_ARGUMENT, "gm_debug_set_edge_kernel: choice %d out of range", choice);
+    gm::set_edge_kernel_choice(choice);
+    return GM_OK;
+}
+
 int gm_debug_set_stamp_buffer(void* device_buffer) {
     gm::set_stamp_buffer(static_cast<unsigned long long*>(device_buffer));
     return GM_OK;

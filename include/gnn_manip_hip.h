@@ -258,6 +258,10 @@ int gm_rollout_status(const void* rollout_ws, const gm_model_desc* desc, int64_t
  * gm_profile_query synchronises on the recorded events.
  * ------------------------------------------------------------------------------------------ */
 int gm_profile_enable(int kind_mask);
+/* Processor edge kernel selection for hidden 128 (default 0 = automatic): 1 = fp32 MFMA
+ * 16x16x4, 2 = fp32 MFMA 32x32x2, 3 / 4 = bf16 matrix pipe with fp32 accuracy (six exact partial products of
+ * three-way bf16 splits, fp32 accumulation), 128- / 64-edge tiles.  Also GM_EDGE_KERNEL=16|classic|b3|b3p. */
+int gm_debug_set_edge_kernel(int choice);
 int gm_debug_set_stamp_buffer(void* device_buffer /* u64 [tiles][8] or NULL */);
 int gm_profile_query(int kind, int64_t* launches, double* total_ms);
 
