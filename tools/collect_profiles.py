@@ -14,10 +14,14 @@ for wl in ("c2", "target", "train", "plan"):
         continue
     f = newest(f"{src}/{wl}/*/*kernel_stats.csv")
     shutil.copy(f, f"{dst}/{tag}_{wl}_kernel_stats.csv")
-EDGE = "edge_kernel16<2, 1>"
 out = {}
 for wl in ("c2", "target"):
     d = {}
+    # the processor edge kernel = the "<2, 1>" edge kernel with the largest total time in this workload's trace
+    stats = list(csv.DictReader(open(f"{dst}/{tag}_{wl}_kernel_stats.csv")))
+    EDGE = max((r for r in stats if "gm::edge_kernel" in r["Name"] and "<2, 1>" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))["Name"]
+    EDGE = EDGE[EDGE.index("gm::") + 4:EDGE.index("(")]
+    d["kernel"] = EDGE
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = newest(f"{src}/pmc_{c}_{wl}/*/*counter_collection.csv")
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == c and EDGE in r["Kernel_Name"]]
@@ -26,7 +30,7 @@ for wl in ("c2", "target"):
     d["traffic_bytes_per_launch"] = (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
     d["traffic_bytes_uncorrected"] = (d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
     out[wl] = d
-out["note"] = ("processor edge kernel " + EDGE + "; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per "
+out["note"] = ("processor edge kernel of each workload (see its `kernel`); rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per "
                "MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B for 16-B-per-lane loads; the kernel's row gathers are not the "
                "calibrated streaming pattern, so the corrected figure is an upper bound); Infinity-Cache hits are counted")
 json.dump(out, open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
