@@ -361,3 +361,26 @@ def test_candidate_batched_rollout_matches_independent_rollouts(dev):
             np.testing.assert_allclose(out[c][:, :, 2:8], one[:, :, 2:8], rtol=0, atol=2e-6)
     ref = orc.rollout(params, obs, trajs[1], steps, STATS, BOUNDS, 0.015, CART, MAT, CTRL)
     np.testing.assert_allclose(out[1][:, :, 2:5], ref[:, :, 2:5], rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("choice,name", [(1, "fp32 16x16x4"), (2, "fp32 32x32x2"), (3, "bf16 pipe, 128-edge tiles"), (4, "bf16 pipe, 64-edge tiles")])
+def test_every_processor_edge_kernel_form_vs_oracle(dev, choice, name):
+    """Each selectable form of the processor edge kernel (gm_debug_set_edge_kernel) on a multi-tile graph, a ragged
+    small one and a single node: same 1e-5 bar against the oracle.  (Automatic selection only ever picks the 128-edge
+    bf16 form for large graphs: this is its small / ragged-tile coverage.)"""
+    from gnn_manip_amd import _lib, scene
+    L = _lib.lib()
+    try:
+        _lib.check(L.gm_debug_set_edge_kernel(choice))
+        for n, side, seed in ((3000, 0.11, 61), (130, 0.3, 62), (1, 0.1, 63), (333, 0.05, 64)):
+            obs = scene.make_scene(n, seed=seed, side=side)
+            params = orc.init_params(25, 4, 3, 128, 2, 10, seed)
+            m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+            nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+            ei = np.stack((s, r))
+            with torch.no_grad():
+                out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+            ref = orc.epd_forward(params, nodes, ea, ei, 2, 10)
+            assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3), (name, n)
+    finally:
+        _lib.check(L.gm_debug_set_edge_kernel(0))
