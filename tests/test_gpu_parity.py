@@ -384,3 +384,31 @@ def test_every_processor_edge_kernel_form_vs_oracle(dev, choice, name):
             assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3), (name, n)
     finally:
         _lib.check(L.gm_debug_set_edge_kernel(0))
+
+
+@pytest.mark.parametrize("choice", [3, 4])
+def test_bf16_pipe_kernels_are_as_accurate_as_float32(dev, choice):
+    """The bf16-pipe forms compute fp32 results (six exact bf16 x bf16 partial products of three-way operand splits,
+    fp32 accumulation): against a float64 evaluation of the same model their error must be of the order of a plain
+    float32 evaluation's, not of a reduced-precision one (three products would give ~2.5e-5)."""
+    from gnn_manip_amd import _lib, scene
+    from oracle import torch_epd
+    L = _lib.lib()
+    obs = scene.make_scene(2500, seed=71, side=0.1)
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 71)
+    m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    ei = np.stack((s, r))
+    p64 = {k: torch.tensor(v, dtype=torch.float64) for k, v in params.items()}
+    ref = torch_epd.epd_forward(p64, torch.tensor(nodes, dtype=torch.float64), torch.tensor(ea, dtype=torch.float64),
+                                torch.tensor(ei), 2, 10).numpy()
+    f32 = orc.epd_forward(params, nodes, ea, ei, 2, 10)
+    err32 = np.abs(f32 - ref).max() / np.abs(ref).max()
+    try:
+        _lib.check(L.gm_debug_set_edge_kernel(choice))
+        with torch.no_grad():
+            out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    finally:
+        _lib.check(L.gm_debug_set_edge_kernel(0))
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err <= max(2.0 * err32, 2e-6), (err, err32)
