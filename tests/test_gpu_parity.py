@@ -351,6 +351,10 @@ def test_candidate_batched_rollout_matches_independent_rollouts(dev):
     obs = scene.make_scene(n, seed=95, side=0.075)
     trajs = np.stack([scene.rigid_drift_trajectory(obs, steps, seed=100 + c, step_size=3e-4) for c in range(b)])
     params = orc.init_params(25, 4, 3, 128, 2, 10, 96)
+    # damped decoder: with raw random weights the particles move ~1e-3 per step and a 1e-8 difference between the two
+    # runs (atomic order of tile-crossing segments) can flip an edge at the radius boundary in a later step
+    params["decoder.4.weight"] = params["decoder.4.weight"] * np.float32(0.05)
+    params["decoder.4.bias"] = params["decoder.4.bias"] * np.float32(0.05)
     m = _model(params, (25, 4, 3, 128, 2, 10), dev)
     with torch.no_grad():
         eng_b = RolloutEngine(m, _ga(), n, device=dev, candidates=b)
