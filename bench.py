@@ -74,9 +74,9 @@ def cpu_baseline(obs, traj, model, stats, scene):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--candidates", type=int, default=1,
                     help="candidate rollouts batched per GPU (block-diagonal); value counts candidates x steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
