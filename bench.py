@@ -37,7 +37,7 @@ WORKLOADS = {
 }
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-EDGE_KERNELS = {"auto": 0, "16": 1, "classic": 2, "b3": 3, "b3p": 4}
+EDGE_KERNELS = {"auto": 0, "16": 1, "classic": 2, "b3": 3, "b3p": 4, "sys": 5}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -133,16 +133,17 @@ def main():
         traj = (traj + 1e-7 * torch.arange(nb, device=dev).view(1, nb, 1, 1)).reshape(total, -1, 3).contiguous()
     eng.set_scene(obs)
     L = _lib.lib()
-    _lib.check(L.gm_debug_set_edge_kernel(EDGE_KERNELS[args.edge_kernel]))
+    model.set_edge_kernel(args.edge_kernel)
     # which kernel `auto` resolves to (mirror of launch_edge): bf16-pipe for hidden 128, 64-edge form for small graphs
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     tiles128 = -(-(n * nb * 20) // 128)
     ek = args.edge_kernel
     if ek == "auto":
-        ek = ("b3p" if tiles128 < 4 * cus else "b3") if hidden == 128 else "classic"
+        ek = "sys" if hidden == 128 else "classic"
     elif hidden != 128:
         ek = "classic"
     bf16_pipe = ek in ("b3", "b3p")
+    f16_pipe = ek == "sys"
 
     def barrier():
         if dist:
@@ -194,10 +195,11 @@ def main():
         # layer-1 factorisation, not MFMA speed (SURVEY.md 8d "utilisation uses F_issued").
         # bf16-pipe kernels: every fp32 product block is six bf16 MFMA product blocks; the pipe they are priced against
         # is the bf16 one
-        pipe_issued = issued * (6 if bf16_pipe else 1)
-        pipe_peak = MFMA_BF16_PEAK_TFLOPS if bf16_pipe else MFMA_F32_PEAK_TFLOPS
+        pipe_issued = issued * (6 if bf16_pipe else (3 if f16_pipe else 1))
+        pipe_peak = MFMA_BF16_PEAK_TFLOPS if (bf16_pipe or f16_pipe) else MFMA_F32_PEAK_TFLOPS
         achieved = pipe_issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        kname = {"16": "edge_kernel16<2,1>", "classic": f"edge_kernel<{hidden},2,1>", "b3": "edge_kernel_b3<2,1>", "b3p": "edge_kernel_b3p<2,1>"}[ek]
+        kname = {"16": "edge_kernel16<2,1>", "classic": f"edge_kernel<{hidden},2,1>", "b3": "edge_kernel_b3<2,1>", "b3p": "edge_kernel_b3p<2,1>",
+                 "sys": "sys_edge_kernel"}[ek]
         out = {
             "metric": f"rollout steps/sec (N particles, 10 MP steps, hidden={hidden})",
             "value": world * nb * args.steps / el,
@@ -205,13 +207,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not bf16_pipe else "f32 (products formed as six exact bf16 x bf16 partial products of three-way operand splits on the bf16 MFMA pipe, f32 accumulation; 4e-7 vs float64 through the model, plain f32: 1e-6)",
+            "dtype": ("f32 (products formed as three exact fp16 x fp16 partial products of two-way operand splits with power-of-two pre-scaled weights on the fp16 MFMA pipe, f32 accumulation; 1e-6 vs float64 through the model, like plain f32)" if f16_pipe else
+                      "f32 (products formed as six exact bf16 x bf16 partial products of three-way operand splits on the bf16 MFMA pipe, f32 accumulation; 4e-7 vs float64 through the model, plain f32: 1e-6)" if bf16_pipe else "f32"),
             "data": "synthetic (seeded dense scene; random-init weights, decoder output layer scaled 1e-5 so the "
                     "pile stays dense over the rollout)",
             "config": {"workload": wl["name"], "n_particles": n, "edges_last_step": edges, "k_steps": 6,
                        "candidates_per_gpu": nb, "parallelism": f"candidate-parallel x{world}"},
             "roofline": {"bound": "mfma", "kernel": kname + " (processor phi_e + scatter-add)",
-                         "pipe": "bf16 MFMA (2.5 PF dense)" if bf16_pipe else "fp32 MFMA",
+                         "pipe": "fp16 MFMA (2.5 PF dense)" if f16_pipe else ("bf16 MFMA (2.5 PF dense)" if bf16_pipe else "fp32 MFMA"),
                          "achieved": achieved, "peak": pipe_peak, "unit": "TFLOP/s",
                          "frac": achieved / pipe_peak, "traffic": None,
                          "avg_launch_ms": k_ms, "launches_timed": int(launches.value),
@@ -235,9 +238,9 @@ def main():
             _lib.check(L.gm_profile_query(kind, C.byref(launches), C.byref(ms)))
             br[name + "_ms_per_step"] = ms.value / max(launches.value, 1) * calls
         out["breakdown"] = br
-        if world == 1 and bf16_pipe:
+        if world == 1 and (bf16_pipe or f16_pipe):
             # the same workload on the fp32-MFMA kernel (untimed extra steps), for reference next to `value`
-            _lib.check(L.gm_debug_set_edge_kernel(EDGE_KERNELS["16"]))
+            model.set_edge_kernel("16")
             k2 = min(20, args.steps)
             with torch.no_grad():
                 for i in range(3):
@@ -248,7 +251,7 @@ def main():
                     eng.step(obs, traj[args.warmup + i])
                 torch.cuda.synchronize()
                 d2 = time.perf_counter() - t1
-            _lib.check(L.gm_debug_set_edge_kernel(EDGE_KERNELS[args.edge_kernel]))
+            model.set_edge_kernel(args.edge_kernel)
             out["fp32_mfma_kernel"] = {"value": nb * k2 / d2, "unit": "rollout steps/s", "ms_per_step": d2 / k2 * 1e3,
                                        "kernel": "edge_kernel16<2,1> (v_mfma_f32_16x16x4_f32)", "steps": k2}
         if world == 1 and not args.no_cpu_baseline:

@@ -82,8 +82,7 @@ PROTOTYPES = {
     "gm_rollout_step": (_i32, [_vp, _vp, _i64, _FD, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gm_rollout_status": (_i32, [_vp, _MD, _i64, _i32, C.POINTER(_i64), _vp]),
     "gm_profile_enable": (_i32, [_i32]),
-    "gm_debug_set_edge_kernel": (_i32, [_i32]),
-    "gm_debug_set_stamp_buffer": (_i32, [_vp]),
+    "gm_model_set_edge_kernel": (_i32, [_vp, _i32]),
     "gm_profile_query": (_i32, [_i32, C.POINTER(_i64), C.POINTER(_f64)]),
 }
 

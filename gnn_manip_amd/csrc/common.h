@@ -96,6 +96,7 @@ struct CsrWs {
     int* src;      // [cap]
     int* eid;      // [cap] original edge id (row in the caller's edge order)
     int* scan_tmp;
+    int* blocks;   // block / chunk tables for the systolic edge kernel (hedge.h: carve_edge_blocks)
     size_t bytes;
 };
 CsrWs carve_csr(void* ws, int64_t n, int64_t cap);

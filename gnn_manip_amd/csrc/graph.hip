@@ -7,6 +7,7 @@
 // ascending distance, first max_neighbours kept).
 #include <stdarg.h>
 #include "common.h"
+#include "hedge.h"
 
 namespace gm {
 
@@ -246,6 +247,7 @@ CsrWs carve_csr(void* ws, int64_t n, int64_t cap) {
     w.src = c.take<int>(cap);
     w.eid = c.take<int>(cap);
     w.scan_tmp = c.take<int>(scan_tmp_ints(n + 1));
+    w.blocks = c.take<int>(edge_blocks_ints(n, cap));
     w.bytes = c.used();
     return w;
 }
@@ -875,7 +877,8 @@ int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* c
         hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, pos, pos_stride, conn_r, edge_attr);
         GM_LAUNCH_CHECK();
     }
-    return GM_OK;
+    // 32-edge blocks aligned to every graph's first edge (the systolic processor edge kernel walks them)
+    return build_edge_blocks(c.in_ptr, n, cap, &g.hdr->n_per_graph, 0, carve_edge_blocks(c.blocks, n, cap), s);
 }
 }  // namespace gm
 
@@ -902,7 +905,7 @@ int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws
     if (n > 0)
         hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr);
     GM_LAUNCH_CHECK();
-    return GM_OK;
+    return build_edge_blocks(c.in_ptr, n, e, nullptr, (int)n, carve_edge_blocks(c.blocks, n, e), s);
 }
 
 int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream) {

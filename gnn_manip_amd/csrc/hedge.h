@@ -1,0 +1,49 @@
+// Systolic processor edge kernel (hedge.hip): weight image, block / chunk tables, launcher.
+#pragma once
+#include "common.h"
+#include "mlp.h"
+
+namespace gm {
+
+// ---- tables of 32-edge blocks over a destination-sorted edge list (one or more equal-sized graphs back to back)
+struct EdgeBlockHeader {
+    int n_blocks;
+    int n_chunks;
+    int chunk_blocks;   // blocks per chunk (the aggregation's carry resets at chunk starts)
+    int n_graphs;
+    int n_per_graph;
+    int pad[3];
+};
+struct EdgeBlocks {
+    EdgeBlockHeader* hdr;
+    int* gblk;          // [n_graphs + 1] first block of a graph
+    int* gch;           // [n_graphs + 1] first chunk of a graph
+    int* chunk_first;   // [n_chunks + 1] first block of a chunk
+    int2* blk;          // [n_blocks] (first edge, count | flags << 8); flags: 1 first block of its chunk, 2 last
+    int64_t max_blocks;
+};
+size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity);
+EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity);
+// n_per_graph: device pointer (GraphHeader::n_per_graph of the radius-graph build) or, if null, the host value
+// (<= 0: one graph)
+int build_edge_blocks(const int* in_ptr, int64_t n_nodes, int64_t edge_capacity, const int* n_per_graph_dev, int n_per_graph_host,
+                      const EdgeBlocks& t, hipStream_t s);
+
+// ---- weight image of one processor step's phi_e for the systolic kernel
+constexpr int kPackH3Max = 16;
+struct PackH3Job {
+    const float* W1;   // Linear 1 weight [H][3H] (the e block = columns 2H..3H is packed; W_i, W_j live in P)
+    const float* W2;   // [H][H]
+    const float* W3;   // [H][H]
+    const float* b2;
+    const float* b3;
+    const float* gamma;
+    const float* beta;
+    float* dst;        // h3_image_floats() floats
+};
+size_t h3_image_floats();
+int pack_h3(const PackH3Job* jobs, int n, hipStream_t s);
+
+int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s);
+
+}  // namespace gm

@@ -1,0 +1,704 @@
+// Processor edge kernel, systolic form, for hidden 128 / three Linears (num_layers = 2) on the fp16 matrix pipe with
+// fp32 accuracy:  e' = LayerNorm(phi_e([h_i, h_j, e])),  e_out = e + e',  agg_i = sum_{e -> i} e'
+// (epd_gnn.py:35-46,100-105; block semantics DESIGN.md section 2).
+//
+// Arithmetic.  Every fp32 operand is split into two fp16 parts, x = hi + lo (22 significant bits; the low parts may be
+// fp16 subnormals, which v_mfma_f32_32x32x16_f16 honours -- checked on gfx950).  A product of two fp16 values is exact in
+// fp32, so  lo*hi + hi*lo + hi*hi  accumulated in fp32 reproduces the fp32 product to 2^-22; through the whole model
+// this scheme is as accurate against float64 as plain float32 (tools/f16_split_study.py: 1.1e-6 vs 0.9e-6).  Weights are
+// pre-scaled by a power of two per Linear so that their low parts stay normal; the scales ride on through the
+// activations, biases and P and leave in the LayerNorm statistics: no run-time multiplies.
+//
+// Structure.  12 waves per workgroup, one workgroup per CU, three waves per SIMD.  Wave (role, jb): role = Linear 1 / 2 /
+// 3, jb = 32-feature output block; the wave keeps only ITS Linear's 32 weight rows in registers (64 VGPRs) for the whole
+// launch.  Work advances in ticks of one 32-edge block with ONE workgroup barrier per tick; every LDS buffer is
+// double-buffered by block parity:
+//   role 0: P_i[dst] + P_j[src] of block x -> accumulators, Linear 1 on the operand image E, ReLU, image X1;
+//   role 1: e of block x+1 -> image E; Linear 2 of block x-1 (X1 -> X2); LayerNorm + e_out = e + e' of block x-3;
+//   role 2: Linear 3 of block x-2 (X2 -> Z + LayerNorm partial statistics); aggregation of block x-3: segmented DPP scan
+//           over the destination-sorted edges with the carry of an open segment kept in registers, one row store per
+//           finished segment; only segments cut by a chunk boundary use atomics (two partials: order-independent).
+// A wave's MFMAs form one dependent chain, so its other work of the tick is placed BETWEEN them with the order pinned
+// (one MFMA shadows about three vector instructions of the same wave).  Global rows move as whole 128-byte lines
+// (8 lanes per row); the register <-> MFMA-fragment re-layouts go through XOR-swizzled, conflict-free LDS images.
+//
+// Blocks are aligned to each graph's first edge and grouped into chunks (the aggregation's carry resets there), both
+// listed by build_edge_blocks(): results do not depend on how many graphs share a launch.
+//
+// Built with -fno-slp-vectorize: packed fp32 VALU beside MFMAs is slow (guide) and hipcc's v_pk_fma_f32 form of the
+// LayerNorm epilogue returned wrong low lanes on gfx950 in this kernel.
+#include "common.h"
+#include "mlp.h"
+#include "hedge.h"
+
+namespace gm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int H = 128;
+constexpr int BE = 32;             // edges per block
+constexpr int SYS_THREADS = 768;
+constexpr int HW_HEADER_FLOATS = 4;            // T1, 1/T3, pad, pad
+constexpr int HW_VEC_FLOATS = 4 * H;           // b2*T2 | b3*T3 | gamma | beta
+constexpr int HW_IMAGE_HALF8 = 3 * 4 * 8 * 2 * 64;   // [layer][jb][ks][part][lane]
+
+struct SysArgs {
+    const CsrHeader* hdr;
+    const int* dst;
+    const int* src;
+    const float* P;        // [N][2H]  P_i (+ b1) | P_j, unscaled
+    const float* e_in;
+    float* e_out;
+    float* agg;
+    const float* hw;       // header | vec | weight image of this processor step
+    const int2* blk;
+    const int* chunk_first;
+    const EdgeBlockHeader* tab;
+    float eps;
+    int residual;
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) { unsigned u; asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b)); return u; }
+__device__ __forceinline__ float sub_lo(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
+__device__ __forceinline__ float sub_hi(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
+// compiler-visible on purpose: it is the first reader of MFMA results, and hipcc pads the MFMA -> VALU hazard only for
+// instructions it knows (an inline-asm reader sees stale accumulators)
+__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 65504.f); }
+
+// two-way fp16 split of 4 floats: hi / lo as two dwords each (elements in order)
+__device__ __forceinline__ void split4(float a, float b, float c, float d, uintx2& hi, uintx2& lo) {
+    hi[0] = cvt_pk(a, b);
+    hi[1] = cvt_pk(c, d);
+    lo[0] = cvt_pk(sub_lo(hi[0], a), sub_hi(hi[0], b));
+    lo[1] = cvt_pk(sub_lo(hi[1], c), sub_hi(hi[1], d));
+}
+
+// accumulator registers 8q..8q+7 of a wave's 32-feature block are the elements of B fragment ks = 2 jb + q (same lane):
+// K slot (lane >> 5, j) of k-group ks carries feature 16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) in both operands
+__device__ __forceinline__ void acc_to_image(const floatx16& a, uintx4* img, int jb, int lane) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = relu(a[8 * q + j]);
+        uintx2 h0, l0, h1, l1;
+        split4(v[0], v[1], v[2], v[3], h0, l0);
+        split4(v[4], v[5], v[6], v[7], h1, l1);
+        img[((2 * jb + q) * 2 + 0) * 64 + lane] = uintx4{h0[0], h0[1], h1[0], h1[1]};
+        img[((2 * jb + q) * 2 + 1) * 64 + lane] = uintx4{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
+// slot of lane (n, kg) inside a fragment of the row-written image E (conflict-free for the 8-byte row-major writes)
+__device__ __forceinline__ int eslot(int n, int kg, int ksbit) { return (n ^ (2 * (ksbit + 2 * kg))) + 32 * kg; }
+
+#define GM_SB __builtin_amdgcn_sched_barrier(0)
+// One Linear for this wave's 32 output features: 8 k-groups x 3 MFMAs (lo*hi, hi*lo, hi*hi).  side(slot), slot = 0..23, runs
+// after each MFMA with the instruction order pinned.  B fragments are fetched one k-group ahead.
+template <bool SWZ, class F>
+__device__ __forceinline__ void mlp_layer(floatx16& acc, const half8 (&wh)[8], const half8 (&wl)[8], const half8* img, int lane, F&& side) {
+    const int s0 = SWZ ? eslot(lane & 31, lane >> 5, 0) : lane;
+    const int s1 = SWZ ? eslot(lane & 31, lane >> 5, 1) : lane;
+    half8 bh = img[0 * 64 + s0], bl = img[1 * 64 + s0];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        half8 nh = bh, nl = bl;
+        GM_SB;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], bh, acc, 0, 0, 0);
+        GM_SB;
+        if (ks + 1 < 8) {
+            nh = img[((ks + 1) * 2 + 0) * 64 + (((ks + 1) & 1) ? s1 : s0)];
+            nl = img[((ks + 1) * 2 + 1) * 64 + (((ks + 1) & 1) ? s1 : s0)];
+        }
+        side(3 * ks);
+        GM_SB;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bl, acc, 0, 0, 0);
+        GM_SB;
+        side(3 * ks + 1);
+        GM_SB;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bh, acc, 0, 0, 0);
+        GM_SB;
+        side(3 * ks + 2);
+        bh = nh;
+        bl = nl;
+    }
+    GM_SB;
+}
+
+// x += lanes(x shifted) * f.  The value is produced by compiler code just before: the VALU -> DPP hazard (2 wait states) of
+// the first reader is padded by hand, hipcc pads nothing inside asm.
+#define DPP_FMAC(x, f, ctrl) asm volatile("v_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(x) : "v"(f))
+#define DPP_FMAC_NOP(x, f, ctrl) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(x) : "v"(f))
+
+// LayerNorm of an edge from the eight 16-feature partials (mean_p, M2_p) of the SCALED accumulators (one per wave and
+// lane half): parallel-variance merge; returns k, m with  x_hat = acc * k + m   (k = rstd / T, m = -mean_acc * k)
+__device__ __forceinline__ void ln_merge(const float* st, int n, float inv_T, float eps, float& k, float& m) {
+    float mw[8], m2 = 0.f, mean = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const float2v s = *reinterpret_cast<const float2v*>(st + (w * BE + n) * 2);
+        mw[w] = s[0];
+        m2 += s[1];
+        mean += s[0];
+    }
+    mean *= 0.125f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { const float d = mw[w] - mean; m2 = fmaf(16.0f * d, d, m2); }
+    const float var = m2 * (1.0f / 128.0f) * inv_T * inv_T;
+    k = inv_T / sqrtf(var + eps);
+    m = -mean * k;
+}
+
+// 32 rows x 8 quads (16 bytes) tile, quad index XORed with the row: conflict-free for row-major and for
+// accumulator-layout accesses.  Returns the float4 index inside the 4 KiB tile.
+__device__ __forceinline__ int tile_q(int row, int quad) { return row * 8 + (quad ^ (row & 7)); }
+
+constexpr size_t SYS_LDS_BYTES = 3 * 2 * 16384 + 2 * 16384 + 16384 + 2 * 8 * BE * 2 * 4 + 4 * BE * 2 * 4 + 4 * H * 4;
+
+__global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* Eimg = reinterpret_cast<half8*>(smem);            // [2][8 ks][2 parts][64]  2 x 16 KiB, eslot() order
+    half8* X1 = Eimg + 2 * 1024;
+    half8* X2 = X1 + 2 * 1024;
+    floatx4* Z = reinterpret_cast<floatx4*>(X2 + 2 * 1024);  // [2][4 jb][256] float4 (tile_q order): Linear-3 accumulators
+    floatx4* PS = Z + 2 * 1024;                               // [4 jb][256]: role-0 staging of P_i + P_j
+    float* ST = reinterpret_cast<float*>(PS + 1024);          // [2][4 jb][2 halves][32][2]: LayerNorm partials
+    float* KM = ST + 2 * 8 * BE * 2;                          // [4 jb][32][2]: role-1 merged statistics
+    float* vecs = KM + 4 * BE * 2;                            // 4 x 128: b2 T2 | b3 T3 | gamma | beta
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, jb = wave & 3;
+    const int E = A.hdr->n_edges;
+    const int nchunks = A.tab->n_chunks;
+    const int c0 = (int)((long long)blockIdx.x * nchunks / gridDim.x);
+    const int c1 = (int)((long long)(blockIdx.x + 1) * nchunks / gridDim.x);
+    if (c1 <= c0) return;
+    const int b0 = A.chunk_first[c0], b1 = A.chunk_first[c1];
+    const int nb = b1 - b0;
+    if (nb <= 0) return;
+    const float T1 = A.hw[0], inv_T = A.hw[1];
+    const float* hvec = A.hw + HW_HEADER_FLOATS;
+    const half8* wimg = reinterpret_cast<const half8*>(A.hw + HW_HEADER_FLOATS + HW_VEC_FLOATS);
+
+    half8 wh[8], wl[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        wh[ks] = wimg[(((role * 4 + jb) * 8 + ks) * 2 + 0) * 64 + lane0];
+        wl[ks] = wimg[(((role * 4 + jb) * 8 + ks) * 2 + 1) * 64 + lane0];
+    }
+    // every buffer starts finite: the pipeline's fill / drain ticks compute on them, and 0 * NaN would leak through the
+    // flag-multiplied scan
+    for (int i = tid; i < (int)((reinterpret_cast<char*>(vecs) - smem) / 16); i += SYS_THREADS) reinterpret_cast<uintx4*>(smem)[i] = uintx4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < 4 * H; i += SYS_THREADS) vecs[i] = hvec[i];
+    __syncthreads();
+    auto ok = [&](int x) { return x >= b0 && x < b1; };
+    auto nothing = [](int) {};
+
+    if (role == 0) {
+        // ------------------------------------------------------------------ role 0
+        floatx4 pi[4], pj[4];   // row-major quads of rows 8 j + rr: P_i / P_j of block x
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pi[j] = floatx4{0.f, 0.f, 0.f, 0.f}; pj[j] = pi[j]; }
+        floatx16 acc;
+        int dl1 = 0, sl1 = 0, dl2 = 0, sl2 = 0;   // destination / source of row (lane & 31): blocks x+1 and x+2
+        int2 bn = ok(b0 + 1) ? A.blk[b0 + 1] : make_int2(0, 0);   // table entry of the block the next fetch() handles
+        auto fetch = [&](int x, int2 bi, int& dl, int& sl) {
+            if (!ok(x)) return;
+            const int cnt = bi.y & 0xff, n = lane0 & 31;
+            const int p = bi.x + (n < cnt ? n : cnt - 1);
+            dl = A.dst[p];
+            sl = A.src[p];
+        };
+        fetch(b0, A.blk[b0], dl2, sl2);
+        floatx4* ps = PS + jb * 256;
+#pragma unroll 1
+        for (int t = -2; t <= nb + 2; ++t) {
+            const int x = b0 + t;
+            // per-tick copy of the lane coordinates, laundered so that the per-lane address arithmetic is recomputed per
+            // tick instead of being hoisted out of the loop (which costs registers the three-waves-per-SIMD budget lacks)
+            int lane_t = lane0;
+            asm volatile("" : "+v"(lane_t));
+            const int lane = lane_t, n = lane & 31, hi = lane >> 5, rr = lane >> 3, cq = lane & 7;
+            // accumulator = (P_i[dst] + P_j[src]) * T1: row-major sum -> tile -> accumulator layout
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ps[tile_q(8 * j + rr, cq)] = (pi[j] + pj[j]) * T1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 v = ps[tile_q(n, 2 * g + hi)];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
+            }
+            mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, nothing);
+            acc_to_image(acc, reinterpret_cast<uintx4*>(X1 + (x & 1) * 1024), jb, lane);
+            // requests: P rows of block x+1 (whole 128-byte lines: 8 lanes per row)
+            if (ok(x + 1)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, dl1);
+                    const int s = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, sl1);
+                    pi[j] = *reinterpret_cast<const floatx4*>(A.P + (unsigned)(d * (2 * H) + 32 * jb + 4 * cq));
+                    pj[j] = *reinterpret_cast<const floatx4*>(A.P + (unsigned)(s * (2 * H) + H + 32 * jb + 4 * cq));
+                }
+            }
+            dl1 = dl2; sl1 = sl2;
+            fetch(x + 3, bn, dl2, sl2);
+            if (ok(x + 4)) bn = A.blk[x + 4];
+            lds_barrier();
+        }
+    } else if (role == 1) {
+        // ------------------------------------------------------------------ role 1
+        floatx16 acc;
+        floatx4 er[4];                      // e rows (row-major quads) of block x-3 for the residual
+        floatx4 eq[4];                      // e rows of block x+1 on their way into the operand image E
+        int st_a = 0, cnt_a = 0, st_b = 0, cnt_b = 0;  // blocks x-3, x-2
+        int2 bi_c = make_int2(0, 0);                    // raw table entry of block x-1 (decoded a tick after its load)
+        int2 be = A.blk[b0];                            // raw table entry of block x+2 (its .x = first edge)
+        const float* vgm = vecs + 2 * H + 32 * jb + 4 * (lane0 & 7);
+        float* km = KM + jb * BE * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { er[j] = floatx4{0.f, 0.f, 0.f, 0.f}; eq[j] = er[j]; }
+#pragma unroll 1
+        for (int t = -2; t <= nb + 2; ++t) {
+            const int x = b0 + t;
+            int lane_t = lane0;
+            asm volatile("" : "+v"(lane_t));
+            const int lane = lane_t, n = lane & 31, hi = lane >> 5, rr = lane >> 3, cq = lane & 7;
+            const bool epi = ok(x - 3);
+            const int par3 = (x - 3) & 1;
+            {  // merged statistics of block x-3: lane n (both halves) -> km[n]
+                float k, m;
+                ln_merge(ST + par3 * 8 * BE * 2, n, inv_T, A.eps, k, m);
+                if (hi == 0) *reinterpret_cast<float2v*>(km + n * 2) = float2v{k, m};
+            }
+            const floatx4* zt = Z + (par3 * 4 + jb) * 256;
+            uintx2* ew = reinterpret_cast<uintx2*>(Eimg + ((x + 1) & 1) * 1024);
+            auto conv_e = [&](int j) {   // e of block x+1 -> operand image E (row group j)
+                const int r = 8 * j + rr;
+                uintx2 h, l;
+                split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
+                const int kks = 2 * jb + (cq >> 2), kg = cq & 1, half = (cq >> 1) & 1;
+                const int slot = eslot(r, kg, cq >> 2);
+                ew[((kks * 2 + 0) * 64 + slot) * 2 + half] = h;
+                ew[((kks * 2 + 1) * 64 + slot) * 2 + half] = l;
+            };
+            float2v kmr;
+            floatx4 zq, gm, bt;
+            auto side = [&](int slot) {   // LayerNorm + e_out of block x-3, row group slot / 6
+                const int j = slot / 6, r = 8 * j + rr;
+                if (slot % 6 == 0) {
+                    kmr = *reinterpret_cast<const float2v*>(km + r * 2);
+                    zq = zt[tile_q(r, cq)];
+                    gm = *reinterpret_cast<const floatx4*>(vgm);
+                    bt = *reinterpret_cast<const floatx4*>(vgm + H);
+                } else if (slot % 6 == 2) {
+                    floatx4 o;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const float xh = fmaf(zq[tt], kmr[0], kmr[1]);
+                        o[tt] = fmaf(xh, gm[tt], bt[tt]) + er[j][tt];
+                    }
+                    if (epi && r < cnt_a) *reinterpret_cast<floatx4*>(A.e_out + (unsigned)((st_a + r) * H + 32 * jb + 4 * cq)) = o;
+                }
+            };
+            {
+                const float* vb2 = vecs + 32 * jb;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const floatx4 v = *reinterpret_cast<const floatx4*>(vb2 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
+                }
+            }
+            conv_e(0); conv_e(1); conv_e(2); conv_e(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // km visible to this wave's own reads
+            mlp_layer<false>(acc, wh, wl, X1 + ((x - 1) & 1) * 1024, lane, side);
+            acc_to_image(acc, reinterpret_cast<uintx4*>(X2 + ((x - 1) & 1) * 1024), jb, lane);
+            st_a = st_b; cnt_a = cnt_b;
+            st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
+            if (ok(x - 2) && A.residual) {  // rows of block x-2: consumed next tick
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int row = st_a + 8 * j + rr;
+                    row = row < E ? row : E - 1;
+                    er[j] = *reinterpret_cast<const floatx4*>(A.e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
+                }
+            }
+            if (ok(x)) bi_c = A.blk[x];
+            if (ok(x + 2)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int row = be.x + 8 * j + rr;
+                    row = row < E ? row : E - 1;
+                    eq[j] = *reinterpret_cast<const floatx4*>(A.e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
+                }
+            }
+            if (ok(x + 3)) be = A.blk[x + 3];
+            lds_barrier();
+        }
+    } else {
+        // ------------------------------------------------------------------ role 2
+        floatx16 acc, carry;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) carry[r] = 0.f;
+        int dn_a = -1, nx_a = -2, fl_a = 0, cnt_a = 0, dn_b = -1, nx_b = -2, fl_b = 0, cnt_b = 0;  // blocks x-3, x-2
+        int head_a = -1, head_b = -1;   // destination whose segment began in an earlier chunk (its pieces are added atomically)
+        int prev_last_dst = -3;         // destination of lane 31 of the previous block while its segment is open, else -3
+        const float* vgam = vecs + 2 * H + 32 * jb;
+        const float* vbet = vecs + 3 * H + 32 * jb;
+        int2 bn = make_int2(0, 0);      // table entry of the block the next fetch() handles
+        auto fetch = [&](int x, int2 bi, int& dn, int& nx, int& fl, int& cnt, int& head) {
+            if (!ok(x)) return;
+            const int n = lane0 & 31;
+            cnt = bi.y & 0xff;
+            fl = bi.y >> 8;
+            const int p = bi.x + n;
+            dn = n < cnt ? A.dst[p] : -1 - n;
+            nx = (n < cnt && p + 1 < E) ? A.dst[p + 1] : -2;
+            if (fl & 1) {
+                const int first = A.dst[bi.x];
+                head = (bi.x > 0 && A.dst[bi.x - 1] == first) ? first : -1;
+            }
+        };
+#pragma unroll 1
+        for (int t = -2; t <= nb + 2; ++t) {
+            const int x = b0 + t;
+            int lane_t = lane0;
+            asm volatile("" : "+v"(lane_t));
+            const int lane = lane_t, n = lane & 31, hi = lane >> 5;
+            const bool agg_on = ok(x - 3);
+            float k, m, f1, f2, f4, f8, fb, fc;
+            const int dn = dn_a;
+            {
+                ln_merge(ST + ((x - 3) & 1) * 8 * BE * 2, n, inv_T, A.eps, k, m);
+                // same-destination flags of the scan steps (lanes past the block's end hold unique negative ids)
+                const int p1 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x111, 0xf, 0xf, false);
+                const int p2 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x112, 0xf, 0xf, false);
+                const int p4 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x114, 0xf, 0xf, false);
+                const int p8 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x118, 0xf, 0xf, false);
+                const int pb = __builtin_amdgcn_update_dpp(-1000000, dn, 0x142, 0xa, 0xf, false);
+                f1 = p1 == dn ? 1.f : 0.f; f2 = p2 == dn ? 1.f : 0.f; f4 = p4 == dn ? 1.f : 0.f; f8 = p8 == dn ? 1.f : 0.f;
+                fb = pb == dn ? 1.f : 0.f;
+                // the carry of the segment the previous block of this chunk left open enters at lane 0
+                fc = (n == 0 && !(fl_a & 1) && dn == prev_last_dst) ? 1.f : 0.f;
+            }
+            bool is_last = false, part = false;
+            if (agg_on) {
+                const bool lastf = (fl_a & 2) != 0;
+                is_last = n < cnt_a && (nx_a != dn || (lastf && n == cnt_a - 1));
+                part = dn == head_a || (lastf && n == cnt_a - 1 && nx_a == dn);
+            }
+            float* arow = A.agg + (unsigned)((dn < 0 ? 0 : dn) * H + 32 * jb + 4 * hi);
+            const floatx4* zt3 = Z + (((x - 3) & 1) * 4 + jb) * 256;
+            floatx4 zq, gmv, btv;
+            float y[4];
+            // aggregation of block x-3: chunk g = slot / 6 handles accumulator registers 4g..4g+3 = one 16-byte piece of
+            // the destination rows
+            auto side = [&](int slot) {
+                const int g = slot / 6;
+                switch (slot % 6) {
+                case 0:
+                    zq = zt3[tile_q(n, 2 * g + hi)];
+                    gmv = *reinterpret_cast<const floatx4*>(vgam + 8 * g + 4 * hi);
+                    btv = *reinterpret_cast<const floatx4*>(vbet + 8 * g + 4 * hi);
+                    break;
+                case 1:
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const float xh = fmaf(zq[tt], k, m);
+                        y[tt] = fmaf(carry[4 * g + tt], fc, fmaf(xh, gmv[tt], btv[tt]));
+                    }
+                    break;
+                case 2:
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], f1, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC(y[tt], f2, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+                    break;
+                case 3:
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], f4, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC(y[tt], f8, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+                    break;
+                case 4:
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], fb, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        carry[4 * g + tt] = __uint_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) * 4, __float_as_uint(y[tt])));
+                    break;
+                default:
+                    if (is_last) {
+                        if (part) {
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) atomicAdd(arow + 8 * g + tt, y[tt]);
+                        } else {
+                            *reinterpret_cast<floatx4*>(arow + 8 * g) = floatx4{y[0], y[1], y[2], y[3]};
+                        }
+                    }
+                    break;
+                }
+            };
+            const bool l3 = ok(x - 2);
+            const int par2 = (x - 2) & 1;
+            {
+                const float* vb3 = vecs + H + 32 * jb;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const floatx4 v = *reinterpret_cast<const floatx4*>(vb3 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
+                }
+            }
+            mlp_layer<false>(acc, wh, wl, X2 + par2 * 1024, lane, side);
+            if (agg_on) prev_last_dst = (cnt_a == BE && !(fl_a & 2)) ? __builtin_amdgcn_readlane(dn, 31) : -3;
+            {
+                // LayerNorm partial statistics of the scaled accumulators (16 features per lane); raw accumulators to Z
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[r];
+                const float mh = s * (1.0f / 16.0f);
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float d = acc[r] - mh; q = fmaf(d, d, q); }
+                if (l3) *reinterpret_cast<float2v*>(ST + ((par2 * 8 + jb * 2 + hi) * BE + n) * 2) = float2v{mh, q};
+                floatx4* zt = Z + (par2 * 4 + jb) * 256;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 z;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) z[tt] = acc[4 * g + tt];
+                    zt[tile_q(n, 2 * g + hi)] = z;
+                }
+            }
+            dn_a = dn_b; nx_a = nx_b; fl_a = fl_b; cnt_a = cnt_b;
+            if (fl_b & 1) head_a = head_b;
+            fetch(x - 1, bn, dn_b, nx_b, fl_b, cnt_b, head_b);
+            if (ok(x)) bn = A.blk[x];
+            lds_barrier();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight image: [T1, 1/T3, 0, 0 | b2 T2, b3 T3, gamma, beta | fp16 hi / lo fragments of t_l W_l]
+// One workgroup per processor step.  t_l = 2^k with max |W_l| t_l in [0.25, 0.5).
+// ------------------------------------------------------------------------------------------
+struct PackH3Jobs {
+    int n;
+    const float* W1[kPackH3Max];   // [H][3H]: the e block is columns 2H..3H
+    const float* W2[kPackH3Max];
+    const float* W3[kPackH3Max];
+    const float* b2[kPackH3Max];
+    const float* b3[kPackH3Max];
+    const float* gamma[kPackH3Max];
+    const float* beta[kPackH3Max];
+    float* dst[kPackH3Max];
+};
+
+__global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
+    __shared__ float red[256];
+    __shared__ float tsc[3];
+    const int job = blockIdx.x, tid = threadIdx.x;
+    const float* Wl[3] = {J.W1[job], J.W2[job], J.W3[job]};
+    const int ld[3] = {3 * H, H, H}, c0[3] = {2 * H, 0, 0};
+    for (int l = 0; l < 3; ++l) {
+        float mx = 0.f;
+        for (int i = tid; i < H * H; i += 256) mx = fmaxf(mx, fabsf(Wl[l][(size_t)(i / H) * ld[l] + c0[l] + (i % H)]));
+        red[tid] = mx;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const float m = red[0];
+            int ex = 0;
+            float t = 1.f;
+            if (m > 0.f && m < 3.0e38f) {
+                frexpf(m, &ex);
+                ex = ex < -20 ? -20 : (ex > 20 ? 20 : ex);
+                t = ldexpf(1.f, -ex - 1);
+            }
+            tsc[l] = t;
+        }
+        __syncthreads();
+    }
+    const float T1 = tsc[0], T2 = T1 * tsc[1], T3 = T2 * tsc[2];
+    float* dst = J.dst[job];
+    if (tid == 0) { dst[0] = T1; dst[1] = 1.0f / T3; dst[2] = 0.f; dst[3] = 0.f; }
+    float* vec = dst + HW_HEADER_FLOATS;
+    for (int i = tid; i < H; i += 256) {
+        vec[i] = J.b2[job][i] * T2;
+        vec[H + i] = J.b3[job][i] * T3;
+        vec[2 * H + i] = J.gamma[job][i];
+        vec[3 * H + i] = J.beta[job][i];
+    }
+    _Float16* img = reinterpret_cast<_Float16*>(dst + HW_HEADER_FLOATS + HW_VEC_FLOATS);
+    // element (l, w, ks, lane = (i, kg), j): W_l[32 w + i][16 ks + 8 (j >> 2) + 4 kg + (j & 3)]
+    for (int idx = tid; idx < 3 * 4 * 8 * 64 * 8; idx += 256) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 7, w = (idx >> 12) & 3, l = idx >> 14;
+        const int i = lane & 31, kg = lane >> 5;
+        const int kcol = 16 * ks + 8 * (j >> 2) + 4 * kg + (j & 3);
+        const float v = Wl[l][(size_t)(32 * w + i) * ld[l] + c0[l] + kcol] * tsc[l];
+        const _Float16 h = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)h);
+        const size_t base = ((((size_t)(l * 4 + w) * 8 + ks) * 2) * 64 + lane) * 8 + j;
+        img[base] = h;
+        img[base + 64 * 8] = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// block / chunk tables of a destination-sorted edge list that holds one or more equal-sized graphs back to back
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) edge_blocks_plan_kernel(const int* __restrict__ in_ptr, int n_nodes, const int* n_per_dev, int n_per_host,
+                                                               int n_cus, EdgeBlockHeader* tab, int* gblk, int* gch, int max_graphs) {
+    // one workgroup: per-graph block / chunk counts and their prefixes
+    __shared__ int s_total;
+    const int tid = threadIdx.x;
+    int n_per = n_per_dev ? *n_per_dev : n_per_host;
+    if (n_per <= 0) n_per = n_nodes > 0 ? n_nodes : 1;
+    int G = (n_nodes + n_per - 1) / n_per;
+    if (G > max_graphs) G = max_graphs;   // capacity of the prefix arrays (never hit: they hold n_nodes + 2 entries)
+    if (tid == 0) {
+        int tot = 0;
+        for (int g = 0; g < G; ++g) {
+            const int lo = g * n_per, hi = min(n_nodes, (g + 1) * n_per);
+            tot += (in_ptr[hi] - in_ptr[lo] + BE - 1) / BE;
+        }
+        s_total = tot;
+    }
+    __syncthreads();
+    const int tot = s_total;
+    int cb = (tot + 4 * n_cus - 1) / (4 * n_cus);
+    cb = cb < 4 ? 4 : (cb > 32 ? 32 : cb);
+    if (tid == 0) {
+        int pb = 0, pc = 0;
+        for (int g = 0; g < G; ++g) {
+            const int lo = g * n_per, hi = min(n_nodes, (g + 1) * n_per);
+            const int nbk = (in_ptr[hi] - in_ptr[lo] + BE - 1) / BE;
+            gblk[g] = pb;
+            gch[g] = pc;
+            pb += nbk;
+            pc += (nbk + cb - 1) / cb;
+        }
+        gblk[G] = pb;
+        gch[G] = pc;
+        tab->n_blocks = pb;
+        tab->n_chunks = pc;
+        tab->chunk_blocks = cb;
+        tab->n_graphs = G;
+        tab->n_per_graph = n_per;
+    }
+}
+
+__global__ void __launch_bounds__(256) edge_blocks_fill_kernel(const int* __restrict__ in_ptr, int n_nodes, const EdgeBlockHeader* tab,
+                                                               const int* __restrict__ gblk, const int* __restrict__ gch, int2* blk,
+                                                               int* chunk_first) {
+    const int nblk = tab->n_blocks, G = tab->n_graphs, cb = tab->chunk_blocks, n_per = tab->n_per_graph;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
+        int lo = 0, hi = G;   // graph g with gblk[g] <= b < gblk[g + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (gblk[mid] <= b) lo = mid; else hi = mid;
+        }
+        const int g = lo, j = b - gblk[g];
+        const int e0 = in_ptr[g * n_per], e1 = in_ptr[min(n_nodes, (g + 1) * n_per)];
+        const int start = e0 + j * BE;
+        const int cnt = min(BE, e1 - start);
+        const int nbk = gblk[g + 1] - gblk[g];
+        int fl = 0;
+        if (j % cb == 0) { fl |= 1; chunk_first[gch[g] + j / cb] = b; }
+        if (j % cb == cb - 1 || j == nbk - 1) fl |= 2;
+        blk[b] = make_int2(start, cnt | (fl << 8));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) chunk_first[tab->n_chunks] = nblk;
+}
+
+}  // namespace
+
+size_t h3_image_floats() { return (size_t)HW_HEADER_FLOATS + HW_VEC_FLOATS + (size_t)HW_IMAGE_HALF8 * 4; }
+
+int pack_h3(const PackH3Job* jobs, int n, hipStream_t s) {
+    for (int off = 0; off < n; off += kPackH3Max) {
+        PackH3Jobs J{};
+        J.n = n - off < kPackH3Max ? n - off : kPackH3Max;
+        for (int i = 0; i < J.n; ++i) {
+            const PackH3Job& j = jobs[off + i];
+            J.W1[i] = j.W1; J.W2[i] = j.W2; J.W3[i] = j.W3; J.b2[i] = j.b2; J.b3[i] = j.b3; J.gamma[i] = j.gamma; J.beta[i] = j.beta;
+            J.dst[i] = j.dst;
+        }
+        hipLaunchKernelGGL(pack_h3_kernel, dim3(J.n), dim3(256), 0, s, J);
+        GM_LAUNCH_CHECK();
+    }
+    return GM_OK;
+}
+
+size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity) {
+    const size_t nblk = (size_t)cdiv(edge_capacity, BE) + (size_t)n_nodes + 2;
+    // header | gblk[n+2] | gch[n+2] | chunk_first[nblk + 2] | blk[nblk] (int2)
+    return 8 + 2 * ((size_t)n_nodes + 2) + (nblk + 2) + 2 * nblk;
+}
+
+EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity) {
+    EdgeBlocks t;
+    const size_t nblk = (size_t)cdiv(edge_capacity, BE) + (size_t)n_nodes + 2;
+    t.hdr = reinterpret_cast<EdgeBlockHeader*>(base);
+    t.gblk = base + 8;
+    t.gch = t.gblk + n_nodes + 2;
+    t.chunk_first = t.gch + n_nodes + 2;
+    t.blk = reinterpret_cast<int2*>(t.chunk_first + nblk + 2);
+    t.max_blocks = (int64_t)nblk;
+    return t;
+}
+
+static int device_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+}
+
+int build_edge_blocks(const int* in_ptr, int64_t n_nodes, int64_t edge_capacity, const int* n_per_graph_dev, int n_per_graph_host,
+                      const EdgeBlocks& t, hipStream_t s) {
+    hipLaunchKernelGGL(edge_blocks_plan_kernel, dim3(1), dim3(256), 0, s, in_ptr, (int)n_nodes, n_per_graph_dev, n_per_graph_host,
+                       device_cus(), t.hdr, t.gblk, t.gch, (int)n_nodes + 1);
+    int gb = (int)cdiv(t.max_blocks, 256);
+    gb = gb < 1 ? 1 : (gb > 1024 ? 1024 : gb);
+    hipLaunchKernelGGL(edge_blocks_fill_kernel, dim3(gb), dim3(256), 0, s, in_ptr, (int)n_nodes, t.hdr, t.gblk, t.gch, t.blk, t.chunk_first);
+    GM_LAUNCH_CHECK();
+    (void)edge_capacity;
+    return GM_OK;
+}
+
+int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
+    GM_REQUIRE(a.hdr && a.wstream_h3 && a.agg && !a.eid && !a.eid_out, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: unsupported argument combination");
+    static bool attr_done[16] = {};
+    int dev = 0;
+    GM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16 && !attr_done[dev]) {
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
+        attr_done[dev] = true;
+    }
+    SysArgs A{};
+    A.hdr = a.hdr; A.dst = a.dst; A.src = a.src; A.P = a.P; A.e_in = a.e_in; A.e_out = a.e_out; A.agg = a.agg;
+    A.hw = a.wstream_h3; A.blk = t.blk; A.chunk_first = t.chunk_first; A.tab = t.hdr; A.eps = a.eps; A.residual = a.residual;
+    {
+        ProfScope prof(PROF_EDGE, s);
+        hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, A);
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+}  // namespace gm

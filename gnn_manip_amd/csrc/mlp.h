@@ -18,6 +18,10 @@ struct EdgeArgs {
     const float* wstream;  // packed weights (32x32x2 operand image), stage 0
     const float* wstream16;  // same layers in the 16x16x4 operand image, or nullptr
     const float* wstream_b3; // same layers as three bf16 parts for v_mfma_f32_32x32x16_bf16 (H = 128), or nullptr
+    const float* wstream_h3; // fp16 hi / lo image of the systolic kernel (hedge.h), or nullptr
+    const int* edge_blocks;  // block / chunk tables of the edge list (carve_edge_blocks), or nullptr
+    int64_t n_nodes_tab;     // n_nodes the tables were carved for
+    int kernel_choice;       // processor edge kernel: 0 automatic, 1 fp32 16x16x4, 2 fp32 32x32x2, 3 / 4 bf16 x 6, 5 systolic fp16 x 3
     const float* bias;     // processor: biases of layers 2..; encoder: biases of layers 1..
     const float* ln_g;
     const float* ln_b;
@@ -85,7 +89,5 @@ int pack_linear_b3(const float* W, int ld, int col0, float* dst, hipStream_t s);
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
 constexpr int kStageFloats = 4096;
-void set_stamp_buffer(unsigned long long* p);
-void set_edge_kernel_choice(int c);  // 0 auto, 1 fp32 16x16x4, 2 fp32 32x32x2, 3 bf16-pipe 128-edge, 4 bf16-pipe 64-edge
 
 }  // namespace gm

@@ -34,6 +34,7 @@
 #include "mlp.h"
 
 #include "mlp_dev.h"
+#include "hedge.h"
 
 namespace gm {
 
@@ -1877,19 +1878,7 @@ static int set_lds(K kernel, size_t bytes) {
     return GM_OK;
 }
 
-enum : int { EK_AUTO = 0, EK_16 = 1, EK_CLASSIC = 2, EK_B3 = 3, EK_B3P = 4 };
-static int g_edge_choice = -1;
-static int edge_kernel_choice() {
-    if (g_edge_choice < 0) {
-        const char* e = getenv("GM_EDGE_KERNEL");
-        g_edge_choice = !e ? EK_AUTO : !strcmp(e, "16") ? EK_16 : !strcmp(e, "classic") ? EK_CLASSIC : !strcmp(e, "b3") ? EK_B3
-                        : !strcmp(e, "b3p") ? EK_B3P : EK_AUTO;
-    }
-    return g_edge_choice;
-}
-void set_edge_kernel_choice(int c) { g_edge_choice = c; }
-static unsigned long long* g_stamps = nullptr;
-void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
+enum : int { EK_AUTO = 0, EK_16 = 1, EK_CLASSIC = 2, EK_B3 = 3, EK_B3P = 4, EK_SYS = 5 };
 
 template <int H>
 static int launch_edge_h(bool enc, const EdgeArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -1914,7 +1903,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     static const int extra_lds = getenv("GM_DEBUG_LDS") ? atoi(getenv("GM_DEBUG_LDS")) : 0;
     EdgeArgs a = a_in;
     a.debug = enc ? 0 : dbg;
-    a.stamps = enc ? nullptr : g_stamps;
+    a.stamps = nullptr;
     GM_REQUIRE((H == 128 || H == 256) && NL == 2, GM_ERR_UNSUPPORTED,
                "edge kernel: hidden_size=%d num_layers=%d not instantiated (128 or 256, 2)", H, NL);
     const int grid = grid_for(cdiv(edge_capacity, TILE));
@@ -1928,7 +1917,13 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     // Processor edge kernel choice (H = 128): "auto" = the bf16-pipe kernels (fp32-accurate six-product split) when the
     // model carries their weight image -- 64-edge / two-workgroup form for small graphs, 128-edge form otherwise --
     // else the fp32-MFMA 16x16x4 kernel.  GM_EDGE_KERNEL = 16 | classic | b3 | b3p, or gm_debug_set_edge_kernel().
-    const int choice = edge_kernel_choice();
+    const int choice = a.kernel_choice;
+    // the systolic fp16 x 3 kernel (hedge.hip): processor step of the fused forward (rows in sorted order, device-side
+    // edge count, block tables present)
+    const bool sys_ok = H == 128 && NL == 2 && !enc && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
+    if (sys_ok && (choice == EK_AUTO || choice == EK_SYS))
+        return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), s);
+    GM_REQUIRE(choice != EK_SYS, GM_ERR_UNSUPPORTED, "edge kernel 'sys' needs hidden 128, num_layers 2, device-resident weights and the fused forward path");
     int ncu = 256;
     {
         int dev = 0;

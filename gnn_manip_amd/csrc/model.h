@@ -10,6 +10,8 @@ struct gm_model {
     float* packed16 = nullptr;  // 16x16x4 operand image of the edge MLPs (hidden 128)
     size_t packed16_floats = 0, s16_enc_edge = 0;
     float* packed_b3 = nullptr;  // bf16 x 3 operand image of the processor edge MLPs (hidden 128): [M][3 layers][4 stages]
+    float* packed_h3 = nullptr;  // fp16 hi / lo image of the processor edge MLPs for the systolic kernel (hedge.h): [M][h3_image_floats]
+    int edge_kernel = 0;         // processor edge kernel of this model: 0 automatic, 1..5 see gm_model_set_edge_kernel
     std::vector<size_t> s16_edge;
     float* vec = nullptr;     // per-MLP contiguous [bias_0..bias_NL, ln_gamma, ln_beta]
     size_t packed_floats = 0, vec_floats = 0;

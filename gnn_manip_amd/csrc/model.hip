@@ -4,6 +4,8 @@
 #include "common.h"
 #include "mlp.h"
 #include "model.h"
+#include "hedge.h"
+#include <stdlib.h>
 
 using namespace gm;
 
@@ -192,6 +194,22 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
             }
         }
     }
+    if (m->packed_h3 && !on_device) {  // host-side weights: this image is not maintained either
+        hipFree(m->packed_h3);
+        m->packed_h3 = nullptr;
+    }
+    if (m->packed_h3 && rc == GM_OK) {  // fp16 hi / lo image of the systolic processor edge kernel
+        std::vector<PackH3Job> jobs((size_t)M);
+        for (int k = 0; k < M; ++k) {
+            PackH3Job& j = jobs[(size_t)k];
+            const int b = b_edge(k);
+            j.W1 = T[b]; j.W2 = T[b + 2]; j.W3 = T[b + 4];
+            j.b2 = T[b + 3]; j.b3 = T[b + 5];
+            j.gamma = T[b + 6]; j.beta = T[b + 7];
+            j.dst = m->packed_h3 + (size_t)k * h3_image_floats();
+        }
+        rc = pack_h3(jobs.data(), M, s);
+    }
     vecs(b_enc_edge, true, m->v_enc_edge);
     vecs(b_enc_node, true, m->v_enc_node);
     for (int k = 0; k < M; ++k) {
@@ -274,6 +292,18 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             return GM_ERR_HIP;
         }
     }
+    if (H == 128 && NL == 2 && on_device) {
+        if (hipMalloc(&m->packed_h3, (size_t)M * h3_image_floats() * sizeof(float)) != hipSuccess) {
+            gm::set_error("gm_model_create: hipMalloc failed");
+            gm_model_destroy(m);
+            return GM_ERR_HIP;
+        }
+    }
+    {
+        const char* e = getenv("GM_EDGE_KERNEL");  // initial value of the per-model choice (diagnostics)
+        m->edge_kernel = !e ? 0 : !strcmp(e, "16") ? 1 : !strcmp(e, "classic") ? 2 : !strcmp(e, "b3") ? 3 : !strcmp(e, "b3p") ? 4
+                         : !strcmp(e, "sys") ? 5 : 0;
+    }
     if (hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess ||
         hipMalloc(&m->vec, m->vec_floats * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
@@ -299,6 +329,7 @@ void gm_model_destroy(gm_model* m) {
     if (m->packed) hipFree(m->packed);
     if (m->packed16) hipFree(m->packed16);
     if (m->packed_b3) hipFree(m->packed_b3);
+    if (m->packed_h3) hipFree(m->packed_h3);
     if (m->vec) hipFree(m->vec);
     delete m;
 }
@@ -322,7 +353,7 @@ EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid
     a.bias = v; a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
     return a;
 }
-EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, const CsrHeader* hdr, int e_host, const int* eid,
+EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, int64_t n, const CsrHeader* hdr, int e_host, const int* eid,
                         const float* P, const float* e_in, float* e_out, float* agg, int residual) {
     EdgeArgs a{};
     a.hdr = hdr; a.n_edges_host = e_host; a.dst = c.dst; a.src = c.src; a.eid = eid; a.eid_out = eid;
@@ -330,6 +361,10 @@ EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, const CsrHeade
     a.wstream = m->packed + m->s_edge[k];
     a.wstream16 = m->packed16 ? m->packed16 + m->s16_edge[k] : nullptr;
     a.wstream_b3 = m->packed_b3 ? m->packed_b3 + (size_t)k * 3 * 4 * kB3StageFloats : nullptr;
+    a.wstream_h3 = m->packed_h3 ? m->packed_h3 + (size_t)k * h3_image_floats() : nullptr;
+    a.edge_blocks = c.blocks;
+    a.n_nodes_tab = n;
+    a.kernel_choice = m->edge_kernel;
     const float* v = m->vec + m->v_edge[k];
     a.bias = v + m->H;  // layer-1 bias lives in P_i
     a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
@@ -377,7 +412,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     // agg is zeroed once; afterwards every node kernel clears the rows it has consumed
     GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
     for (int k = 0; k < M; ++k) {
-        rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, 1), cap, s);
+        rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, 1), cap, s);
         if (rc != GM_OK) return rc;
         NodeArgs a{};
         a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.agg_clear = k + 1 < M ? f.agg : nullptr; a.h_out = f.h; a.residual = 1;
@@ -430,7 +465,7 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     int rc = launch_node(H, NL, 2, pa, s);
     if (rc != GM_OK) return rc;
     GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
-    rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, c.hdr, 0, c.eid, f.P, e, e_out, f.agg, 0), cap, s);
+    rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, c.eid, f.P, e, e_out, f.agg, 0), cap, s);
     if (rc != GM_OK) return rc;
     NodeArgs a{};
     a.n_nodes = (int)n; a.x_in = h; a.agg = f.agg; a.h_out = h_out; a.residual = 0;
@@ -472,16 +507,10 @@ RolloutWs carve_rollout(void* ws, const gm_model_desc* d, int64_t n, int K) {
 
 extern "C" {
 
-// diagnostics (tools/stamps.py): device buffer [tiles][8] u64 receiving per-tile phase stamps of the
-// processor edge kernel; nullptr disables.  Not used by any timed path.
-int gm_debug_set_edge_kernel(int choice) {
-    GM_REQUIRE(choice >= 0 && choice <= 4, GM_ERR_INVALID_ARGUMENT, "gm_debug_set_edge_kernel: choice %d out of range", choice);
-    gm::set_edge_kernel_choice(choice);
-    return GM_OK;
-}
-
-int gm_debug_set_stamp_buffer(void* device_buffer) {
-    gm::set_stamp_buffer(static_cast<unsigned long long*>(device_buffer));
+int gm_model_set_edge_kernel(gm_model* m, int choice) {
+    GM_REQUIRE(m, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: null model");
+    GM_REQUIRE(choice >= 0 && choice <= 5, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: choice %d out of range", choice);
+    m->edge_kernel = choice;
     return GM_OK;
 }
 

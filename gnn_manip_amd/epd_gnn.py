@@ -42,6 +42,7 @@ class _Handle:
         self.h = None
         self.key = None
         self.desc = None
+        self.edge_kernel = 0
 
     def get(self, desc_tuple, params, device):
         key = (desc_tuple, str(device), tuple((p.data_ptr(), p._version) for p in params))
@@ -58,10 +59,17 @@ class _Handle:
             out = C.c_void_p()
             check(L.gm_model_create(C.byref(d), arr, len(tensors), 1, current_stream(), C.byref(out)))
             self.h = out
+            if self.edge_kernel:
+                check(L.gm_model_set_edge_kernel(self.h, self.edge_kernel))
         torch.cuda.current_stream().synchronize()  # the temporaries above may be freed now
         self.key = key
         self.desc = d
         return self.h
+
+    def set_edge_kernel(self, choice):
+        self.edge_kernel = int(choice)
+        if self.h is not None:
+            check(lib().gm_model_set_edge_kernel(self.h, self.edge_kernel))
 
     def close(self):
         if self.h is not None:
@@ -387,6 +395,13 @@ class EncProcDecGNN(nn.Module):
     def device_handle(self, device):
         """gm_model* for the current parameters on `device` (packed once, re-packed on change)."""
         return self._handle.get(self.model_desc(), list(self.parameters()), device)
+
+    EDGE_KERNELS = {"auto": 0, "16": 1, "classic": 2, "b3": 3, "b3p": 4, "sys": 5}
+
+    def set_edge_kernel(self, choice):
+        """Processor edge kernel of this model (diagnostics / A-B measurements; no reference counterpart): 'auto',
+        'sys' (systolic fp16 x 3), 'b3' / 'b3p' (bf16 x 6), '16' / 'classic' (fp32 MFMA).  See include/gnn_manip_hip.h."""
+        self._handle.set_edge_kernel(self.EDGE_KERNELS.get(choice, choice))
 
     def forward(self, nodes, edge_attr, edge_index):
         """epd_gnn.py:86-98: encoder -> m_steps x (InteractionNetwork + residuals) -> decoder, fused."""

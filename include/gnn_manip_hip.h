@@ -158,6 +158,13 @@ int gm_model_update(gm_model* m, const float* const* tensors, int n_tensors, int
                     void* stream);
 void gm_model_destroy(gm_model* m);
 
+/* Processor edge kernel of THIS model (no reference counterpart; diagnostics / A-B measurements).  0 = automatic
+ * (the systolic fp16 x 3 kernel for hidden 128 / num_layers 2 in the fused forward, else the
+ * kernels below); 1 = fp32 MFMA 16x16x4; 2 = fp32 MFMA 32x32x2; 3 / 4 = bf16 matrix pipe, six partial products,
+ * 128- / 64-edge tiles; 5 = systolic fp16 x 3 (fails where it does not apply).  The environment variable
+ * GM_EDGE_KERNEL=16|classic|b3|b3p|sys sets the initial value of models created afterwards. */
+int gm_model_set_edge_kernel(gm_model* m, int choice);
+
 size_t gm_forward_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t edge_capacity);
 
 /* EncProcDecGNN.forward(nodes, edge_attr, edge_index)   epd_gnn.py:86-105.
@@ -258,11 +265,6 @@ int gm_rollout_status(const void* rollout_ws, const gm_model_desc* desc, int64_t
  * gm_profile_query synchronises on the recorded events.
  * ------------------------------------------------------------------------------------------ */
 int gm_profile_enable(int kind_mask);
-/* Processor edge kernel selection for hidden 128 (default 0 = automatic): 1 = fp32 MFMA
- * 16x16x4, 2 = fp32 MFMA 32x32x2, 3 / 4 = bf16 matrix pipe with fp32 accuracy (six exact partial products of
- * three-way bf16 splits, fp32 accumulation), 128- / 64-edge tiles.  Also GM_EDGE_KERNEL=16|classic|b3|b3p. */
-int gm_debug_set_edge_kernel(int choice);
-int gm_debug_set_stamp_buffer(void* device_buffer /* u64 [tiles][8] or NULL */);
 int gm_profile_query(int kind, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus
