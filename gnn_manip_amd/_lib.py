@@ -112,14 +112,24 @@ def check(status):
         raise GMError(status, msg.decode() if msg else "unknown error")
 
 
+_last_device = None
+
+
 def ptr(t):
     """Device (or host) address of a contiguous torch tensor, or None."""
+    global _last_device
     if t is None:
         return None
     assert t.is_contiguous(), "libgnnmanip_hip needs contiguous tensors"
+    if t.is_cuda:
+        _last_device = t.device
     return C.c_void_p(t.data_ptr())
 
 
-def current_stream():
+def current_stream(device=None):
+    """hipStream_t of torch's current stream on `device`; default: the device of the last tensor handed to ptr() --
+    i.e. of the tensors of the call being assembled (the stream argument comes last in every entry point).  The library
+    itself switches to the device that owns its pointer arguments (DevGuard in csrc/common.h)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = device if device is not None else _last_device
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

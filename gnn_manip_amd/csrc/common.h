@@ -30,6 +30,36 @@ void set_error(const char* fmt, ...);
 
 #define GM_LAUNCH_CHECK() GM_HIP_CHECK(hipGetLastError())
 
+// Makes the device that owns `p` current for the duration of an entry point (the caller may have tensors on cuda:N while
+// another device is current: launches, hipMalloc and the dynamic-LDS attributes all go by the current device).
+struct DevGuard {
+    int prev = -1, target = -1;
+    explicit DevGuard(const void* p) {
+        if (!p) return;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (a.type != hipMemoryTypeDevice) return;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur == a.device) return;
+        if (hipSetDevice(a.device) == hipSuccess) { prev = cur; target = a.device; }
+    }
+    ~DevGuard() { if (prev >= 0 && target >= 0) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembers, per call site, the devices it was done for
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool need() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

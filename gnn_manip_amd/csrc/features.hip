@@ -305,6 +305,7 @@ using namespace gm;
 extern "C" {
 
 int gm_node_features(const float* obs, int64_t n, const gm_feature_desc* desc, float* out, void* stream) {
+    gm::DevGuard dev_guard(obs);
     FeatParams P;
     int rc = to_params(desc, &P, "gm_node_features");
     if (rc != GM_OK) return rc;
@@ -317,6 +318,7 @@ int gm_node_features(const float* obs, int64_t n, const gm_feature_desc* desc, f
 
 int gm_edge_features(const float* pos, int64_t pos_stride, const int64_t* senders, const int64_t* receivers,
                      int64_t e, float conn_r, float* out, void* stream) {
+    gm::DevGuard dev_guard(pos);
     GM_REQUIRE(e >= 0 && (e == 0 || (pos && senders && receivers && out)), GM_ERR_INVALID_ARGUMENT, "gm_edge_features: null pointer");
     GM_REQUIRE(conn_r > 0.f && pos_stride >= 3, GM_ERR_INVALID_ARGUMENT, "gm_edge_features: bad conn_r / stride");
     if (e == 0) return GM_OK;
@@ -328,6 +330,7 @@ int gm_edge_features(const float* pos, int64_t pos_stride, const int64_t* sender
 
 int gm_edge_features_csr(const float* pos, int64_t pos_stride, const void* csr_ws, int64_t n, int64_t cap,
                          float conn_r, float* out, void* stream) {
+    gm::DevGuard dev_guard(pos);
     GM_REQUIRE(pos && csr_ws && out, GM_ERR_INVALID_ARGUMENT, "gm_edge_features_csr: null pointer");
     GM_REQUIRE(conn_r > 0.f && pos_stride >= 3, GM_ERR_INVALID_ARGUMENT, "gm_edge_features_csr: bad conn_r / stride");
     if (cap == 0) return GM_OK;
@@ -342,6 +345,7 @@ int gm_edge_features_csr(const float* pos, int64_t pos_stride, const void* csr_w
 
 int gm_integrate(const float* pred, const float* obs, int64_t n, const gm_feature_desc* desc, float* next_pos,
                  void* stream) {
+    gm::DevGuard dev_guard(obs);
     FeatParams P;
     int rc = to_params(desc, &P, "gm_integrate");
     if (rc != GM_OK) return rc;
@@ -354,6 +358,7 @@ int gm_integrate(const float* pred, const float* obs, int64_t n, const gm_featur
 
 int gm_rigid_rank(const float* obs, int64_t n, const gm_feature_desc* desc, int32_t* rank, int32_t* n_rigid_dev,
                   void* stream) {
+    gm::DevGuard dev_guard(obs);
     FeatParams P;
     int rc = to_params(desc, &P, "gm_rigid_rank");
     if (rc != GM_OK) return rc;
@@ -365,6 +370,7 @@ int gm_rigid_rank(const float* obs, int64_t n, const gm_feature_desc* desc, int3
 
 int gm_state_pre(float* obs, int64_t n, const gm_feature_desc* desc, const int32_t* rank, const float* target,
                  void* stream) {
+    gm::DevGuard dev_guard(obs);
     FeatParams P;
     int rc = to_params(desc, &P, "gm_state_pre");
     if (rc != GM_OK) return rc;
@@ -378,6 +384,7 @@ int gm_state_pre(float* obs, int64_t n, const gm_feature_desc* desc, const int32
 
 int gm_state_post(float* obs, int64_t n, const gm_feature_desc* desc, const float* next_pos, const int32_t* rank,
                   const float* target, void* stream) {
+    gm::DevGuard dev_guard(obs);
     FeatParams P;
     int rc = to_params(desc, &P, "gm_state_post");
     if (rc != GM_OK) return rc;
@@ -391,6 +398,7 @@ int gm_state_post(float* obs, int64_t n, const gm_feature_desc* desc, const floa
 
 int gm_rigid_transform(const float* rigid_init, int64_t nr, const float* cst, int64_t steps, const float ty_init[3],
                        float* out, void* stream) {
+    gm::DevGuard dev_guard(rigid_init);
     GM_REQUIRE(nr >= 0 && steps >= 0 && ty_init, GM_ERR_INVALID_ARGUMENT, "gm_rigid_transform: bad sizes");
     if (nr == 0 || steps == 0) return GM_OK;
     GM_REQUIRE(rigid_init && cst && out, GM_ERR_INVALID_ARGUMENT, "gm_rigid_transform: null pointer");

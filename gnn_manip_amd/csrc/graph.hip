@@ -773,6 +773,7 @@ int gm_radius_graph_build(const float* pos, int64_t pos_stride, int64_t n, doubl
 
 int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K,
                                   void* ws, size_t ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(pos);
     GM_REQUIRE(n_per >= 0 && (n_per == 0 || n % n_per == 0 || n_per >= n), GM_ERR_INVALID_ARGUMENT,
                "gm_radius_graph_build_batched: n_nodes=%lld is not a multiple of nodes_per_graph=%lld", (long long)n, (long long)n_per);
     GM_REQUIRE(n >= 0 && n < (int64_t)1 << 30, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: n_nodes=%lld out of range", (long long)n);
@@ -806,11 +807,22 @@ int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t 
         if (K <= 64) {
             constexpr int BS = 128;
             size_t lds = (size_t)K * BS * 12;
+            if (lds > 64 * 1024) {
+                static PerDeviceOnce big_lds;
+                if (big_lds.need())
+                    GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbor_kernel<BS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
             hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
                                g.hdr, n, r2, K, g.cnt, g.nbr);
         } else {
             constexpr int BS = 64;
             size_t lds = (size_t)K * BS * 12;
+            GM_REQUIRE(lds <= 160 * 1024, GM_ERR_UNSUPPORTED, "gm_radius_graph_build: max_neighbours=%d needs %zu bytes of LDS", K, lds);
+            if (lds > 64 * 1024) {
+                static PerDeviceOnce big_lds64;
+                if (big_lds64.need())
+                    GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbor_kernel<BS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
             hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
                                g.hdr, n, r2, K, g.cnt, g.nbr);
         }
@@ -823,6 +835,7 @@ int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t 
 }
 
 int gm_radius_graph_num_edges(const void* ws, int64_t* n_edges_host, void* stream) {
+    gm::DevGuard dev_guard(ws);
     GM_REQUIRE(ws && n_edges_host, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_num_edges: null pointer");
     GraphHeader h;
     GM_HIP_CHECK(hipMemcpyAsync(&h, ws, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -834,6 +847,7 @@ int gm_radius_graph_num_edges(const void* ws, int64_t* n_edges_host, void* strea
 
 int gm_radius_graph_edges(const void* ws, int64_t n, int K, int64_t* senders, int64_t* receivers, int64_t capacity,
                           void* stream) {
+    gm::DevGuard dev_guard(ws);
     GM_REQUIRE(ws && (capacity == 0 || (senders && receivers)), GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_edges: null pointer");
     if (n == 0 || capacity == 0) return GM_OK;
     GraphWs g = carve_graph(const_cast<void*>(ws), n, K);
@@ -849,6 +863,7 @@ size_t gm_csr_workspace_bytes(int64_t n_nodes, int64_t edge_capacity) {
 }
 
 int gm_csr_from_graph(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(graph_ws);
     return gm::csr_from_graph_with_features(graph_ws, n, K, csr_ws, csr_ws_bytes, nullptr, 3, 1.f, nullptr, (hipStream_t)stream);
 }
 
@@ -885,6 +900,7 @@ int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* c
 extern "C" {
 
 int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws, size_t csr_ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(csr_ws);
     GM_REQUIRE(csr_ws && (ei || e == 0), GM_ERR_INVALID_ARGUMENT, "gm_csr_from_edge_index: null pointer");
     GM_REQUIRE(n >= 0 && e >= 0 && e < ((int64_t)1 << 31) && n < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT,
                "gm_csr_from_edge_index: sizes out of range");
@@ -909,6 +925,7 @@ int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws
 }
 
 int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream) {
+    gm::DevGuard dev_guard(csr_ws);
     GM_REQUIRE(csr_ws && n_edges_host, GM_ERR_INVALID_ARGUMENT, "gm_csr_num_edges: null pointer");
     CsrHeader h;
     GM_HIP_CHECK(hipMemcpyAsync(&h, csr_ws, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -683,13 +683,9 @@ int build_edge_blocks(const int* in_ptr, int64_t n_nodes, int64_t edge_capacity,
 
 int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
     GM_REQUIRE(a.hdr && a.wstream_h3 && a.agg && !a.eid && !a.eid_out, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: unsupported argument combination");
-    static bool attr_done[16] = {};
-    int dev = 0;
-    GM_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 16 && !attr_done[dev]) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.need())
         GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
-        attr_done[dev] = true;
-    }
     SysArgs A{};
     A.hdr = a.hdr; A.dst = a.dst; A.src = a.src; A.P = a.P; A.e_in = a.e_in; A.e_out = a.e_out; A.agg = a.agg;
     A.hw = a.wstream_h3; A.blk = t.blk; A.chunk_first = t.chunk_first; A.tab = t.hdr; A.eps = a.eps; A.residual = a.residual;

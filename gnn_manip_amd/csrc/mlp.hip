@@ -1882,13 +1882,12 @@ enum : int { EK_AUTO = 0, EK_16 = 1, EK_CLASSIC = 2, EK_B3 = 3, EK_B3P = 4, EK_S
 
 template <int H>
 static int launch_edge_h(bool enc, const EdgeArgs& a, int grid, size_t lds, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done_dev;
+    if (attr_done_dev.need()) {
         int rc = set_lds(edge_kernel<H, 2, 0>, lds);
         if (rc == GM_OK) rc = set_lds(edge_kernel<H, 2, 1>, lds);
         if (rc == GM_OK) rc = set_lds(edge_kernel<H, 2, 2>, lds);
         if (rc != GM_OK) return rc;
-        attr_done = true;
     }
     ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
     if (enc) hipLaunchKernelGGL((edge_kernel<H, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a);
@@ -1899,15 +1898,13 @@ static int launch_edge_h(bool enc, const EdgeArgs& a, int grid, size_t lds, hipS
 
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capacity, hipStream_t s) {
     if (edge_capacity <= 0) return GM_OK;
-    static const int dbg = getenv("GM_DEBUG_SKIP") ? atoi(getenv("GM_DEBUG_SKIP")) : 0;
-    static const int extra_lds = getenv("GM_DEBUG_LDS") ? atoi(getenv("GM_DEBUG_LDS")) : 0;
     EdgeArgs a = a_in;
-    a.debug = enc ? 0 : dbg;
+    a.debug = 0;   // timing ablations are a development build's business (the kernels keep the hooks)
     a.stamps = nullptr;
     GM_REQUIRE((H == 128 || H == 256) && NL == 2, GM_ERR_UNSUPPORTED,
                "edge kernel: hidden_size=%d num_layers=%d not instantiated (128 or 256, 2)", H, NL);
     const int grid = grid_for(cdiv(edge_capacity, TILE));
-    const size_t lds = edge_lds_bytes() + (size_t)extra_lds;
+    const size_t lds = edge_lds_bytes();
     if (H == 256) {
         int rc = launch_edge_h<256>(enc, a, grid, lds, s);
         if (rc != GM_OK) return rc;
@@ -1935,12 +1932,11 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     const bool use_b3 = b3_ok && (choice == EK_B3 || (choice == EK_AUTO && !small));
     if (use_b3p) {
         const size_t lb = (size_t)(2 * B3P_STAGE_FLOATS + T16 * TSP + 2 * (T16 + 4) + 2 * 1024 + 4 * 128 + 4 * 32 * 2) * 4;
-        static bool donebp = false;
-        if (!donebp) {
+        static PerDeviceOnce donebp_dev;
+        if (donebp_dev.need()) {
             int rc = set_lds(edge_kernel_b3p<2, 1>, lb);
             if (rc == GM_OK) rc = set_lds(edge_kernel_b3p<2, 2>, lb);
             if (rc != GM_OK) return rc;
-            donebp = true;
         }
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1956,12 +1952,11 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     }
     if (use_b3) {
         const size_t lb = (size_t)(2 * B3_STAGE_FLOATS + TE3 * TSP + 2 * (TE3 + 4) + 2 * 2048 + 4 * 128 + 8 * 32 * 2) * 4;
-        static bool doneb = false;
-        if (!doneb) {
+        static PerDeviceOnce doneb_dev;
+        if (doneb_dev.need()) {
             int rc = set_lds(edge_kernel_b3<2, 1>, lb);
             if (rc == GM_OK) rc = set_lds(edge_kernel_b3<2, 2>, lb);
             if (rc != GM_OK) return rc;
-            doneb = true;
         }
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1978,13 +1973,12 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     const bool use16 = choice != EK_CLASSIC;
     if (H == 128 && use16 && a.wstream16) {
         const size_t l16 = edge16_lds_bytes();
-        static bool done16 = false;
-        if (!done16) {
+        static PerDeviceOnce done16_dev;
+        if (done16_dev.need()) {
             int rc = set_lds(edge_kernel16<2, 0>, l16);
             if (rc == GM_OK) rc = set_lds(edge_kernel16<2, 1>, l16);
             if (rc == GM_OK) rc = set_lds(edge_kernel16<2, 2>, l16);
             if (rc != GM_OK) return rc;
-            done16 = true;
         }
         a.wstream = a.wstream16;
         // persistent grid: one workgroup per resident slot (2 per CU), so that every workgroup walks several tiles and
@@ -2025,13 +2019,12 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
     const bool wide = H == 128 && (wide_env == 1 || (wide_env != 0 && cdiv(a.n_nodes, TILE) <= 64));
     if (wide) {
         const size_t wl = node_wide_lds_bytes();
-        static bool attr_done = false;
-        if (!attr_done) {
+        static PerDeviceOnce attr_done_dev;
+        if (attr_done_dev.need()) {
             int rc = set_lds(node_kernel_wide<128, 2, 0>, wl);
             if (rc == GM_OK) rc = set_lds(node_kernel_wide<128, 2, 1>, wl);
             if (rc == GM_OK) rc = set_lds(node_kernel_wide<128, 2, 2>, wl);
             if (rc != GM_OK) return rc;
-            attr_done = true;
         }
         const int wg = grid_for(cdiv(a.n_nodes, WTILE));
         ProfScope prof(mode == 1 ? PROF_NODE : PROF_ENC, s);

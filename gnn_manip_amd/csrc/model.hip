@@ -237,6 +237,7 @@ int gm_model_num_tensors(const gm_model_desc* d) {
 
 int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int n_tensors, int on_device, void* stream,
                     gm_model** out) {
+    gm::DevGuard dev_guard((on_device && tensors) ? tensors[0] : nullptr);
     GM_REQUIRE(out && tensors, GM_ERR_INVALID_ARGUMENT, "gm_model_create: null pointer");
     int rc = check_desc(desc, "gm_model_create");
     if (rc != GM_OK) return rc;
@@ -320,6 +321,7 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
 }
 
 int gm_model_update(gm_model* m, const float* const* tensors, int n_tensors, int on_device, void* stream) {
+    gm::DevGuard dev_guard((on_device && tensors) ? tensors[0] : nullptr);
     GM_REQUIRE(m && tensors, GM_ERR_INVALID_ARGUMENT, "gm_model_update: null pointer");
     return load_weights(m, tensors, n_tensors, on_device != 0, (hipStream_t)stream);
 }
@@ -390,6 +392,7 @@ extern "C" {
 
 int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, int attr_is_csr_order,
                    const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(out);
     GM_REQUIRE(m && csr_ws && fwd_ws, GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: null pointer");
     GM_REQUIRE(n >= 0 && cap >= 0 && n < ((int64_t)1 << 31) && cap < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: sizes out of range");
     if (n == 0) return GM_OK;
@@ -428,6 +431,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
 
 int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n, const float* edge_attr, int64_t e,
                                  float* h_out, float* e_out, void* stream) {
+    gm::DevGuard dev_guard(x ? (const void*)x : (const void*)edge_attr);
     GM_REQUIRE(m, GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_forward: null model");
     GM_REQUIRE(n >= 0 && e >= 0 && n < ((int64_t)1 << 31) && e < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "sizes out of range");
     GM_REQUIRE((n == 0 || (x && h_out)) && (e == 0 || (edge_attr && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_forward: null tensor");
@@ -446,6 +450,7 @@ int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n, c
 int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int64_t n, const float* e,
                                    const void* csr_ws, int64_t cap, float* h_out, float* e_out, void* fwd_ws,
                                    size_t fwd_ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(h);
     GM_REQUIRE(m && csr_ws && fwd_ws, GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward: null pointer");
     GM_REQUIRE(k >= 0 && k < m->M, GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward: block %d out of range", k);
     GM_REQUIRE(n >= 0 && cap >= 0 && n < ((int64_t)1 << 31) && cap < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "sizes out of range");
@@ -521,6 +526,7 @@ size_t gm_rollout_workspace_bytes(const gm_model_desc* desc, int64_t n, int K) {
 
 int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_desc* fd, int K, const int32_t* rigid_rank,
                     const float* rigid_target, float* pred_acc_out, void* ws, size_t ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(obs);
     GM_REQUIRE(m && obs && fd && ws, GM_ERR_INVALID_ARGUMENT, "gm_rollout_step: null pointer");
     const int F = 3 * (fd->k_steps - 1) + 7 + (fd->control_col >= 0 ? 3 : 0);
     GM_REQUIRE(m->d.node_dim == F, GM_ERR_INVALID_ARGUMENT, "gm_rollout_step: model node_dim=%d but features give %d", m->d.node_dim, F);
@@ -550,6 +556,7 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
 }
 
 int gm_rollout_status(const void* ws, const gm_model_desc* desc, int64_t n, int K, int64_t* n_edges_host, void* stream) {
+    gm::DevGuard dev_guard(ws);
     GM_REQUIRE(ws && desc && n_edges_host, GM_ERR_INVALID_ARGUMENT, "gm_rollout_status: null pointer");
     RolloutWs r = carve_rollout(const_cast<void*>(ws), desc, n, K);
     int rc = gm_radius_graph_num_edges(r.graph, n_edges_host, stream);

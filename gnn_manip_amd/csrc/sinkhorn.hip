@@ -155,6 +155,7 @@ size_t gm_sinkhorn_workspace_bytes(int64_t n, int64_t m) {
 
 int gm_sinkhorn_divergence(const float* x, int64_t n, const float* y, int64_t m, float blur, float scaling, float* loss_device,
                            void* ws, size_t ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(x);
     GM_REQUIRE(x && y && loss_device && ws, GM_ERR_INVALID_ARGUMENT, "gm_sinkhorn_divergence: null pointer");
     GM_REQUIRE(n >= 1 && m >= 1 && n < ((int64_t)1 << 30) && m < ((int64_t)1 << 30), GM_ERR_INVALID_ARGUMENT,
                "gm_sinkhorn_divergence: cloud sizes out of range (%lld, %lld)", (long long)n, (long long)m);

@@ -709,8 +709,8 @@ int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_
 }
 
 int train_kernels_init() {
-    static bool done = false;
-    if (done) return GM_OK;
+    static PerDeviceOnce done_dev;
+    if (!done_dev.need()) return GM_OK;
     const size_t lds = (size_t)2 * STAGE_FLOATS * 4;
     int rc = GM_OK;
 #define GM_SET(k) if (rc == GM_OK) rc = set_dyn_lds(k, lds)
@@ -722,7 +722,6 @@ int train_kernels_init() {
     GM_SET((train_bwd_kernel<128, TB_PROJ>)); GM_SET((train_bwd_kernel<256, TB_PROJ>));
     GM_SET((train_bwd_kernel<256, TB_ENC>)); GM_SET((train_bwd_kernel<256, TB_EDGE>)); GM_SET((train_bwd_kernel<256, TB_NODE>)); GM_SET((train_bwd_kernel<256, TB_DEC>));
 #undef GM_SET
-    if (rc == GM_OK) done = true;
     return rc;
 }
 

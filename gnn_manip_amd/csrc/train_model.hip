@@ -168,6 +168,7 @@ size_t gm_train_backward_workspace_bytes(const gm_model_desc* desc, int64_t n, i
 
 int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, const int64_t* edge_index,
                          int64_t e, float* out, void* tape, size_t tape_bytes, void* stream) {
+    gm::DevGuard dev_guard(nodes);
     int rc = check_sizes(m, n, e, "gm_epd_forward_train");
     if (rc != GM_OK) return rc;
     GM_REQUIRE(nodes && out && tape && (e == 0 || (edge_attr && edge_index)), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward_train: null pointer");
@@ -252,6 +253,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
 int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, const float* nodes, const float* edge_attr, int64_t n,
                     int64_t e, const float* grad_out, float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
                     void* stream) {
+    gm::DevGuard dev_guard(nodes);
     int rc = check_sizes(m, n, e, "gm_epd_backward");
     if (rc != GM_OK) return rc;
     GM_REQUIRE(T && grads && nodes && grad_out && tape && ws && (e == 0 || edge_attr), GM_ERR_INVALID_ARGUMENT, "gm_epd_backward: null pointer");
@@ -420,6 +422,7 @@ size_t gm_block_backward_workspace_bytes(const gm_model_desc* desc, int64_t n, i
 
 int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_t n, const float* edge_attr, int64_t e, float* h_out,
                                        float* e_out, void* tape, size_t tape_bytes, void* stream) {
+    gm::DevGuard dev_guard(x ? (const void*)x : (const void*)edge_attr);
     int rc = check_sizes(m, n, e, "gm_graph_independent_forward_train");
     if (rc != GM_OK) return rc;
     GM_REQUIRE(x && h_out && tape && (e == 0 || (edge_attr && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_forward_train: null pointer");
@@ -449,6 +452,7 @@ int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_
 int gm_graph_independent_backward(const gm_model* m, const float* const* T, int n_tensors, const float* x, const float* edge_attr, int64_t n,
                                   int64_t e, const float* dh, const float* de, float* dx, float* dedge_attr, float* const* grads,
                                   void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(x ? (const void*)x : (const void*)edge_attr);
     int rc = check_sizes(m, n, e, "gm_graph_independent_backward");
     if (rc != GM_OK) return rc;
     GM_REQUIRE(T && grads && x && dh && tape && ws && (e == 0 || (edge_attr && de)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_backward: null pointer");
@@ -503,6 +507,7 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
 
 int gm_interaction_network_forward_train(const gm_model* m, int k, const float* h, int64_t n, const float* e_in, const int64_t* edge_index,
                                          int64_t e, float* h_out, float* e_out, void* tape, size_t tape_bytes, void* stream) {
+    gm::DevGuard dev_guard(h);
     int rc = check_sizes(m, n, e, "gm_interaction_network_forward_train");
     if (rc != GM_OK) return rc;
     GM_REQUIRE(k >= 0 && k < m->M, GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward_train: block %d out of range", k);
@@ -553,6 +558,7 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
 int gm_interaction_network_backward(const gm_model* m, int k, const float* const* T, int n_tensors, const float* h, const float* e_in,
                                     int64_t n, int64_t e, const float* dh_out, const float* de_out, float* dh_in, float* de_in,
                                     float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(h);
     int rc = check_sizes(m, n, e, "gm_interaction_network_backward");
     if (rc != GM_OK) return rc;
     GM_REQUIRE(k >= 0 && k < m->M, GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_backward: block %d out of range", k);

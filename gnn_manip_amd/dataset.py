@@ -106,7 +106,9 @@ class CoffeeDataset(torch.utils.data.Dataset):
             ctr = next_pos.unsqueeze(0) - obs_seq[:, :, c0:c0 + 3]
             ctr = torch.where((obs_seq[:, :, self.material_id] != 1).unsqueeze(-1), torch.zeros_like(ctr), ctr)
             obs_seq = torch.cat((obs_seq, ctr), dim=-1)
-        return obs_seq.contiguous(), next_pos.contiguous()
+        # independent tensors, like the reference's stored samples: an in-place rollout step on a sample must not touch
+        # the resident simulation (the windows overlap)
+        return obs_seq.clone().contiguous(), next_pos.clone().contiguous()
 
     def __getitem__(self, idx):
         obs_seq, next_pos = self.sample(idx)

@@ -50,7 +50,7 @@ class _Handle:
             return self.h
         L = lib()
         tensors = [p.detach().to(device=device, dtype=torch.float32).contiguous() for p in params]
-        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        arr = (C.c_void_p * len(tensors))(*[ptr(t).value for t in tensors])
         d = ModelDesc(*desc_tuple)
         if self.h is not None and self.key[0] == desc_tuple and self.key[1] == str(device):
             check(L.gm_model_update(self.h, arr, len(tensors), 1, current_stream()))
@@ -61,7 +61,7 @@ class _Handle:
             self.h = out
             if self.edge_kernel:
                 check(L.gm_model_set_edge_kernel(self.h, self.edge_kernel))
-        torch.cuda.current_stream().synchronize()  # the temporaries above may be freed now
+        torch.cuda.current_stream(device).synchronize()  # the temporaries above may be freed now
         self.key = key
         self.desc = d
         return self.h

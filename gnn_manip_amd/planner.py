@@ -39,6 +39,9 @@ def get_rigid_body_trajectory(traj_rot, traj_ty, horizon, ty_init, rigid_particl
     builds the 4x4 float32 matrix (traj_utils.py:171-172)."""
     rp = rigid_particles.contiguous().float()
     assert rp.is_cuda
+    if len(traj_rot) < horizon or len(traj_ty) < horizon:
+        # the reference indexes traj[i] for i < horizon (traj_utils.py:97-99) and raises IndexError on a short trajectory
+        raise IndexError(f"trajectory of {min(len(traj_rot), len(traj_ty))} poses is shorter than the horizon {horizon}")
     rot = np.asarray(traj_rot[:horizon], dtype=np.float64)
     ty = np.asarray(traj_ty[:horizon], dtype=np.float64)
     cst = np.stack((np.cos(rot), np.sin(rot), float(ty_init[1]) + ty), axis=1).astype(np.float32)

@@ -74,8 +74,28 @@ class RolloutEngine:
         self.n_rigid = int(cnt.item())
         return self.n_rigid
 
+    def _check_state(self, obs, rigid_target, pred_out, use_rigid):
+        """The C entry takes raw pointers: shapes, dtypes and devices are checked here."""
+        if not (isinstance(obs, torch.Tensor) and obs.is_cuda and obs.device == self.device):
+            raise ValueError(f"obs must be a tensor on {self.device}")
+        if tuple(obs.shape) != (self.k, self.n, self.data_dim) or obs.dtype != torch.float32 or not obs.is_contiguous():
+            raise ValueError(f"obs must be contiguous float32 [{self.k}, {self.n}, {self.data_dim}], got {tuple(obs.shape)} {obs.dtype}")
+        if use_rigid and self.rigid_rank is None:
+            raise RuntimeError("RolloutEngine.set_scene(obs) must be called before step()")
+        if rigid_target is not None:
+            if not use_rigid:
+                raise ValueError("rigid_target needs use_rigid=True")
+            if (rigid_target.device != self.device or rigid_target.dtype != torch.float32 or not rigid_target.is_contiguous()
+                    or tuple(rigid_target.shape) != (self.n_rigid, 3)):
+                raise ValueError(f"rigid_target must be contiguous float32 [{self.n_rigid}, 3] on {self.device}, got {tuple(rigid_target.shape)}")
+        if pred_out is not None:
+            if (pred_out.device != self.device or pred_out.dtype != torch.float32 or not pred_out.is_contiguous()
+                    or pred_out.numel() != self.n * 3):
+                raise ValueError(f"pred_out must be contiguous float32 with {self.n * 3} elements on {self.device}")
+
     def step(self, obs, rigid_target=None, pred_out=None, use_rigid=True):
         """One rollout step in place on ``obs`` [k, N, D]; rigid_target: [N_rigid, 3] scripted pose or None."""
+        self._check_state(obs, rigid_target, pred_out, use_rigid)
         handle = self.model.device_handle(self.device)
         rr = self.rigid_rank if use_rigid else None
         check(lib().gm_rollout_step(handle, ptr(obs), self.n, C.byref(self.fdesc), self.max_neighbours, ptr(rr),
@@ -107,8 +127,7 @@ class RolloutEngine:
         """cma_objective's loop (traj_utils.py:119-152).  trajectory: [T, N_rigid, 3] device tensor of scripted
         rigid poses (or None: no rigid overwrite).  Returns the final state (and the recorded last frames)."""
         obs = obs0.clone().contiguous()
-        if self.rigid_rank is None:
-            self.set_scene(obs)
+        self.set_scene(obs)  # per call: the engine may be given another scene
         steps = horizon if horizon is not None else (trajectory.shape[0] if trajectory is not None else 0)
         recs = []
         for i in range(steps):
