@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Rollout-throughput bench for the MI355X rollout engine (contract: see DESIGN.md "Measurement").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|target|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c2|c3|c4|c5]
 
-A "step" is one full rollout step of the hot path (state update -> node features -> radius graph
--> destination sort -> edge features -> encode / 10x process / decode -> Euler integration) on a
-seeded synthetic dense granular scene resident in HBM.  N > 1 = candidate-parallel: every rank
-rolls out its own candidate of the same scene (weak scaling), one broadcast of the scripted
-trajectory before and one all-gather of the per-candidate result after the loop, over RCCL.
+A "step" is one full rollout step of the hot path (state update -> node features -> radius graph -> destination sort
+-> edge features -> encode / 10x process / decode -> Euler integration), the loop body of compute_rollout
+(gnn_manip/utils/rollout_utils.py:38-61), on a seeded synthetic dense granular scene resident in HBM.  The K timed steps
+run inside ONE library call (gm_rollout).  Default workload = the north_star target line (N = 100k, hidden 128, 10
+message-passing steps); at N = 1 the other single-GPU configurations of BASELINE.json (C2, C3, C4) are measured in the
+same process and reported as sub-records under "extra", each with its own roofline.
+
+N > 1 = candidate-parallel (weak scaling): every rank rolls out its own candidates of the same scene; the scripted
+trajectories are broadcast before and the per-candidate results all-gathered after the loop, over RCCL.
+--workload c5 is BASELINE config C5's shape: 64 CMA-ES candidates x 200-step rollouts at N = 5k, 64 / N candidates per
+rank in block-diagonal batches, one device Sinkhorn loss per candidate, broadcast / all-gather per generation.
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,19 +31,20 @@ import numpy as np
 import torch
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: the configuration the metric is quoted on at N=1
-    "c2": dict(name="C2: N=5k dense synthetic granular scene, conn_r=0.015, max_neighbours=20, hidden=128, "
-                    "10 MP steps, rollout", n=5000, hidden=128),
-    "c3": dict(name="C3: N=50k dense synthetic scene, conn_r=0.015, max_neighbours=20, hidden=128, 10 MP steps",
-               n=50000, hidden=128),
-    "target": dict(name="north_star target: N=100k dense synthetic scene, conn_r=0.015, hidden=128, 10 MP steps",
-                   n=100000, hidden=128),
-    "c4": dict(name="C4: N=100k dense synthetic scene, hidden=256, 10 MP steps (MFMA-bound MLP run)",
-               n=100000, hidden=256),
+    "target": dict(name="north_star target: N=100k dense synthetic scene, conn_r=0.015, max_neighbours=20, hidden=128, 10 MP steps",
+                   n=100000, hidden=128, steps=20, warmup=5),
+    # BASELINE.json configs[1..3]
+    "c2": dict(name="C2: N=5k dense synthetic granular scene, conn_r=0.015, max_neighbours=20, hidden=128, 10 MP steps, 100-step rollout",
+               n=5000, hidden=128, steps=100, warmup=10),
+    "c3": dict(name="C3: N=50k dense synthetic scene, conn_r=0.015, max_neighbours=20, hidden=128, 10 MP steps", n=50000, hidden=128,
+               steps=20, warmup=5),
+    "c4": dict(name="C4: N=100k dense synthetic scene, hidden=256, 10 MP steps (MFMA-bound MLP run)", n=100000, hidden=256,
+               steps=8, warmup=2),
+    "c5": dict(name="C5: CMA-ES generation, 64 candidate rollouts x 200 steps at N=5k (hidden=128, 10 MP steps) + one Sinkhorn loss per "
+                    "candidate, candidates sharded over the ranks", n=5000, hidden=128, steps=200, warmup=0),
 }
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-EDGE_KERNELS = {"auto": 0, "16": 1, "classic": 2, "b3": 3, "b3p": 4, "sys": 5}
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / fp16 MFMA
 HBM_PEAK_GBS = 8000.0
 
 
@@ -52,36 +59,283 @@ def edge_kernel_issued_flops(E, H=128, num_layers=2):
     return E * 2.0 * (H * H * (num_layers + 1))
 
 
-def cpu_baseline(obs, traj, model, stats, scene):
-    """The oracle (numpy restatement of the reference step) on the host cores, bounded sample."""
+def edge_kernel_alg_bytes(E, N, H=128):
+    """Compulsory HBM bytes of one launch: read e, write e', P (2H per node), agg (H per node), indices."""
+    return E * H * 4 * 2 + N * H * 4 * 3 + E * 12
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(obs, model, stats, scene, hidden, budget_s=25.0):
+    """The CPU restatement of the reference step: oracle graph build + featurisation (numpy, the
+    KD-tree query of the reference is single-threaded too) and the plain-torch forward of oracle/torch_epd.py with all host
+    threads, on the same scene and weights; bounded sample."""
     from oracle import epd_oracle as orc
-    params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    from oracle import torch_epd
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     t0 = time.perf_counter()
-    steps = 0
-    state = obs
-    while True:
-        state = orc.rollout(params, state, traj[steps:steps + 1], 1, stats, scene.BOUNDS, scene.CONN_R,
-                            scene.CART, scene.MAT, scene.CTRL, 2, 10)
-        steps += 1
+    last = np.asarray(obs[-1][:, scene.CART], np.float32)
+    s, r = orc.get_connectivity(last, scene.CONN_R, 20)
+    t_graph = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nodes = orc.compute_nodes(obs, stats, scene.BOUNDS, scene.CONN_R, scene.CART, scene.MAT, scene.CTRL)
+    ea = orc.get_edges_displacement(last, s, r, scene.CONN_R)
+    t_feat = time.perf_counter() - t0
+    tn, te, ti = torch.from_numpy(nodes), torch.from_numpy(ea), torch.from_numpy(np.stack((s, r)))
+    times = []
+    with torch.no_grad():
+        while True:
+            t0 = time.perf_counter()
+            out = torch_epd.epd_forward(params, tn, te, ti, 2, 10)
+            times.append(time.perf_counter() - t0)
+            if len(times) >= 4 or sum(times) + times[-1] > budget_s:
+                break
+    timed = times[1:] if len(times) > 1 else times  # the first pass is the warm-up when there is time for more
+    t_forward = sum(timed) / len(timed)
+    t0 = time.perf_counter()
+    orc.get_position_from_prediction(stats, scene.CART, out.numpy(), obs)
+    t_int = time.perf_counter() - t0
+    step = t_graph + t_feat + t_forward + t_int
+    return dict(value=1.0 / step, unit="rollout steps/s", cores=threads, kind="port", cpu=cpu_model_name(),
+                graph_build_ms_single_thread=t_graph * 1e3, features_ms=t_feat * 1e3, forward_ms=t_forward * 1e3,
+                integrate_ms=t_int * 1e3,
+                sample=f"one rollout step of the same scene and weights (N={obs.shape[1]}, E={len(s)}, hidden={hidden}): oracle graph "
+                       f"build + features (numpy, single thread) once, oracle/torch_epd.py forward with torch.set_num_threads({threads}) "
+                       f"averaged over {len(timed)} pass(es)" + (" after one warm-up pass" if len(times) > 1 else ""))
+
+
+def build_engine(wl, dev, rank, candidates, edge_kernel, total_steps):
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, RolloutEngine, scene
+    n, hidden = wl["n"], wl["hidden"]
+    # Stationary workload: a random-weight model would blow the pile apart within ~30 steps (edge count halves, kernels run
+    # on a shrinking graph).  The decoder's output layer is scaled by 1e-5, the acceleration mean is zero and the initial
+    # velocities are tiny, so the scene stays dense (E ~ 20 N) for the whole run; every kernel still runs the full
+    # architecture on random weights.
+    stats = dict(scene.STATS, acceleration_mean=[0.0, 0.0, 0.0])
+    obs_np = scene.make_scene(n, seed=1000 + rank, vel_scale=1e-6)
+    traj_np = scene.rigid_drift_trajectory(obs_np, total_steps, seed=2000 + rank, step_size=1e-6)
+    torch.manual_seed(1234)
+    model = EncProcDecGNN(25, 4, 3, hidden, 2, 10)
+    with torch.no_grad():
+        model.decoder[-1].weight.mul_(1e-5)
+        model.decoder[-1].bias.mul_(1e-5)
+    model = model.to(dev)
+    model.set_edge_kernel(edge_kernel)
+    ga = GraphBoundedMultimaterialControl(scene.CONN_R, stats, scene.CART, scene.MAT, scene.CTRL, scene.BOUNDS)
+    eng = RolloutEngine(model, ga, n, device=dev, candidates=candidates)
+    obs = torch.from_numpy(obs_np).to(dev)
+    traj = torch.from_numpy(traj_np).to(dev)
+    if candidates > 1:  # the same scene under `candidates` scripted trajectories, stored back to back
+        nb = candidates
+        obs = obs.unsqueeze(1).repeat(1, nb, 1, 1).reshape(obs.shape[0], nb * n, obs.shape[2]).contiguous()
+        traj = traj.unsqueeze(1).repeat(1, nb, 1, 1)
+        traj = (traj + 1e-7 * torch.arange(nb, device=dev).view(1, nb, 1, 1)).reshape(total_steps, -1, 3).contiguous()
+    eng.set_scene(obs)
+    return model, eng, obs, traj, obs_np, stats, scene
+
+
+def resolve_kernel(edge_kernel, hidden):
+    ek = edge_kernel
+    if hidden != 128:
+        ek = "classic"
+    elif ek == "auto":
+        ek = "sys"
+    return ek
+
+
+def roofline_record(L, _lib, ek, hidden, edges, n_nodes, workload_key):
+    launches, ms = C.c_int64(0), C.c_double(0.0)
+    _lib.check(L.gm_profile_query(0, C.byref(launches), C.byref(ms)))
+    k_ms = ms.value / max(launches.value, 1)
+    alg = edge_kernel_alg_flops(edges, hidden)
+    issued = edge_kernel_issued_flops(edges, hidden)
+    # MFMA utilisation is priced on the flops the kernel ISSUES (3 HxH products per edge; SURVEY.md 8d "utilisation uses
+    # F_issued"); the split-operand kernels issue 3 (fp16 two-way split) or 6 (bf16 three-way split) matrix-pipe product
+    # blocks per fp32-equivalent block and are priced against the 16-bit pipe.
+    mult = {"sys": 3, "b3": 6, "b3p": 6}.get(ek, 1)
+    peak = MFMA_16BIT_PEAK_TFLOPS if mult > 1 else MFMA_F32_PEAK_TFLOPS
+    achieved = issued * mult / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    kname = {"16": "edge_kernel16<2,1>", "classic": f"edge_kernel<{hidden},2,1>", "b3": "edge_kernel_b3<2,1>", "b3p": "edge_kernel_b3p<2,1>",
+             "sys": "sys_edge_kernel"}[ek]
+    alg_bytes = edge_kernel_alg_bytes(edges, n_nodes, hidden)
+    hbm = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    rec = {"bound": "mfma", "kernel": kname + " (processor phi_e + scatter-add)",
+           "pipe": {"sys": "fp16 MFMA (2.5 PF dense)", "b3": "bf16 MFMA (2.5 PF dense)", "b3p": "bf16 MFMA (2.5 PF dense)"}.get(ek, "fp32 MFMA"),
+           "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+           "avg_launch_ms": k_ms, "launches_timed": int(launches.value),
+           "issued_flops_per_launch": issued * mult, "fp32_equivalent_flops_per_launch": issued,
+           "fp32_equivalent_tflops": issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
+           "alg_flops_per_launch": alg, "alg_tflops": alg / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
+           "alg_bytes_per_launch": alg_bytes,
+           "hbm": {"achieved_GBs": hbm, "peak_GBs": HBM_PEAK_GBS, "frac": hbm / HBM_PEAK_GBS}}
+    # HBM traffic of the same kernel from rocprofv3 PMC passes of THIS round's build (collected separately with
+    # tools/profile_round.sh, committed under profiles/); absent or of another kernel: null
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        ent = tr.get(workload_key)
+        if ent and ent.get("kernel") == kname:
+            rec["traffic"] = ent["traffic_bytes_per_launch"]
+            rec["traffic_source"] = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this "
+                                     "round's build, FETCH doubled per the guide)")
+    except (OSError, ValueError, KeyError):
+        pass
+    return rec, k_ms
+
+
+def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidates=1):
+    from gnn_manip_amd import _lib
+    wl = WORKLOADS[wl_key]
+    total = steps + warmup
+    model, eng, obs, traj, obs_np, stats, scene = build_engine(wl, dev, rank, candidates, args.edge_kernel, total)
+    ek = resolve_kernel(args.edge_kernel, wl["hidden"])
+    L = _lib.lib()
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        if warmup:
+            eng.run(obs, traj[:warmup].contiguous(), warmup)
+        eng.status()
+        timed_traj = traj[warmup:].contiguous()
+        barrier()
+        L.gm_profile_enable(1)  # HIP events around the dominant kernel only (kind 0: processor edge kernel)
+        t0 = time.perf_counter()
+        if dist:  # per-generation exchange of the candidate-parallel planner: scripted poses out ...
+            first = timed_traj[0].to(cdev)
+            dist.broadcast(first, src=0)
+            timed_traj[0].copy_(first)
+        eng.run(obs, timed_traj, steps)  # K steps, one library call
+        result = obs[-1, :, 2:5].mean(dim=0)
+        if dist:  # ... per-candidate results back
+            result = result.to(cdev)
+            gathered = [torch.empty_like(result) for _ in range(world)]
+            dist.all_gather(gathered, result)
+        barrier()
         el = time.perf_counter() - t0
-        if el > 12.0 or steps >= 8 or steps >= traj.shape[0]:
-            break
-    return dict(value=steps / el, unit="rollout steps/s", cores=os.cpu_count(), kind="port",
-                sample=f"{steps} rollout step(s) of the same scene and weights with oracle/epd_oracle.py "
-                       f"(numpy float32, multithreaded BLAS), {el:.1f} s")
+    L.gm_profile_enable(0)
+    edges = eng.status()  # edge count of the last timed step
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    rec = None
+    if rank == 0:
+        roof, k_ms = roofline_record(L, _lib, ek, wl["hidden"], edges, wl["n"] * candidates, wl_key)
+        # breakdown of the other kernels: a few extra, untimed steps with their events on
+        L.gm_profile_enable(14)
+        with torch.no_grad():
+            k2 = min(5, steps)
+            eng.run(obs, timed_traj[:k2].contiguous(), k2)
+        torch.cuda.synchronize()
+        L.gm_profile_enable(0)
+        launches, ms = C.c_int64(0), C.c_double(0.0)
+        br = {"edge_kernel_ms_per_step": k_ms * 10}
+        for name, (kind, calls) in {"node_kernel": (1, 10), "graph_build": (2, 1), "encoder_kernels": (3, 2)}.items():
+            _lib.check(L.gm_profile_query(kind, C.byref(launches), C.byref(ms)))
+            br[name + "_ms_per_step"] = ms.value / max(launches.value, 1) * calls
+        rec = {"value": world * candidates * steps / el, "unit": "rollout steps/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": el / steps * 1e3,
+               "config": {"workload": wl["name"], "n_particles": wl["n"], "hidden": wl["hidden"], "edges_last_step": edges, "k_steps": 6,
+                          "candidates_per_gpu": candidates, "parallelism": f"candidate-parallel x{world}"},
+               "roofline": roof, "breakdown": br}
+    return rec, (model, obs_np, stats, scene, ek)
+
+
+def run_c5(dev, rank, world, dist, cdev, args):
+    """One CMA-ES generation of BASELINE config C5: 64 candidates x 200 rollout steps at N = 5k sharded over the ranks in
+    block-diagonal batches, one device Sinkhorn loss per candidate, candidates broadcast and losses all-gathered inside the
+    timed region (planner.CandidateEvaluator)."""
+    from gnn_manip_amd import GraphBoundedMultimaterialControl, RolloutEngine, planner
+    from gnn_manip_amd.losses import SamplesLoss
+    wl = WORKLOADS["c5"]
+    popsize, horizon = args.candidates_total, args.steps if args.steps > 0 else wl["steps"]
+    model, eng0, obs, traj, obs_np, stats, scn = build_engine(wl, dev, 0, 1, args.edge_kernel, horizon)
+    del eng0
+    per_rank = -(-popsize // world)
+    batch = max(1, min(args.batch, per_rank))
+    ga = GraphBoundedMultimaterialControl(scn.CONN_R, stats, scn.CART, scn.MAT, scn.CTRL, scn.BOUNDS)
+    eng = RolloutEngine(model, ga, wl["n"], device=dev, candidates=batch)
+    coffee = obs[-1, :, 1] != 1
+    target_cloud = (obs[-1, coffee, 2:5] + 0.01).contiguous()
+    loss_fn = SamplesLoss("sinkhorn", p=2, blur=0.05)
+
+    def objective(block):  # block: [b, dim] candidate parameters (here: an offset of the scripted cup drift per candidate)
+        block = np.asarray(block, np.float64)
+        out = []
+        for lo in range(0, block.shape[0], batch):
+            cand = block[lo:lo + batch]
+            b = cand.shape[0]
+            offs = torch.as_tensor(np.asarray(cand[:, :3], np.float32), device=dev)
+            if b < batch:
+                offs = torch.cat((offs, offs[-1:].repeat(batch - b, 1)))
+            trajs = (traj.unsqueeze(0) + 1e-6 * offs.view(batch, 1, 1, 3)).contiguous()
+            with torch.no_grad():
+                final = eng.rollout_candidates(obs, trajs, horizon)
+            for c in range(b):
+                cloud = final[c, -1][coffee][:, 2:5].contiguous()
+                out.append(float(loss_fn(cloud, target_cloud)))
+        return np.asarray(out, np.float64)
+
+    ev = planner.CandidateEvaluator(None, result_dim=1, group=None, device=cdev)
+    rng = np.random.Generator(np.random.PCG64(7))
+    X = rng.standard_normal((popsize, 8))
+
+    def generation(pop):  # broadcast of the population, contiguous block per rank, all-gather of the losses
+        return ev.evaluate_blocks(pop, lambda lst: list(objective(np.stack(lst))) if lst else [])[:, 0]
+
+    generation(X[:max(world, 1) * 1])  # warm-up: one candidate per rank
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = generation(X)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        return None
+    return {"metric": "rollout steps/sec (N particles, 10 MP steps, hidden=128)", "value": popsize * horizon / el, "unit": "rollout steps/s",
+            "n_gpus": world, "steps": horizon, "warmup": 0, "ms_per_step": el / (per_rank * horizon) * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (fp16 two-way split operands on the matrix pipe, f32 accumulation)" if args.edge_kernel in ("auto", "sys") else "f32",
+            "data": "synthetic (seeded dense scene; random-init weights; a candidate = an offset of the scripted cup drift)",
+            "config": {"workload": wl["name"], "n_particles": wl["n"], "candidates": popsize, "candidates_per_rank": per_rank,
+                       "block_diagonal_batch": batch, "horizon": horizon, "generation_s": el, "loss_mean": float(np.mean(losses)),
+                       "parallelism": f"candidate-parallel x{world}"}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: per workload)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (default: per workload)")
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--candidates", type=int, default=1,
                     help="candidate rollouts batched per GPU (block-diagonal); value counts candidates x steps")
+    ap.add_argument("--candidates-total", type=int, default=64, help="c5: CMA-ES population size")
+    ap.add_argument("--batch", type=int, default=8, help="c5: candidates per block-diagonal batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--edge-kernel", default="auto", choices=sorted(EDGE_KERNELS),
-                    help="processor edge kernel: auto = bf16-pipe kernels with fp32 accuracy (DESIGN.md 5.1), 16 / classic = fp32 MFMA")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C3 / C4 sub-records")
+    ap.add_argument("--edge-kernel", default="auto", choices=["auto", "16", "classic", "b3", "b3p", "sys"],
+                    help="processor edge kernel (per-model option): auto = systolic fp16 x 3 kernel for hidden 128 (DESIGN.md 5.1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,8 +344,8 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
-    # GM_BENCH_REHEARSE=1: all ranks on cuda:0 with gloo (multi-rank rehearsal on a one-GPU box; RCCL
-    # refuses two ranks per device).  Never set by the driver.
+    # GM_BENCH_REHEARSE=1: all ranks on cuda:0 with gloo (multi-rank rehearsal on a one-GPU box; RCCL refuses two ranks per
+    # device).  Never set by the driver.
     rehearse = os.environ.get("GM_BENCH_REHEARSE") == "1"
     dev = torch.device("cuda:0" if rehearse else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
@@ -104,159 +358,38 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     cdev = torch.device("cpu") if rehearse else dev  # where collective payloads live
 
-    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, RolloutEngine, _lib, scene
-
-    wl = WORKLOADS[args.workload]
-    n, hidden = wl["n"], wl["hidden"]
-    total = args.steps + args.warmup
-    # Stationary workload: a random-weight model would blow the pile apart within ~30 steps (edge count
-    # halves, kernels run on a shrinking graph).  The decoder's output layer is scaled by 1e-5, the
-    # acceleration mean is zero and the initial velocities are tiny, so the scene stays dense (E ~ 20 N)
-    # for the whole run; every kernel still runs the full architecture on random weights.
-    stats = dict(scene.STATS, acceleration_mean=[0.0, 0.0, 0.0])
-    obs_np = scene.make_scene(n, seed=1000 + rank, vel_scale=1e-6)
-    traj_np = scene.rigid_drift_trajectory(obs_np, total, seed=2000 + rank, step_size=1e-6)
-    torch.manual_seed(1234)
-    model = EncProcDecGNN(25, 4, 3, hidden, 2, 10)
-    with torch.no_grad():
-        model.decoder[-1].weight.mul_(1e-5)
-        model.decoder[-1].bias.mul_(1e-5)
-    model = model.to(dev)
-    ga = GraphBoundedMultimaterialControl(scene.CONN_R, stats, scene.CART, scene.MAT, scene.CTRL, scene.BOUNDS)
-    nb = args.candidates
-    eng = RolloutEngine(model, ga, n, device=dev, candidates=nb)
-    obs = torch.from_numpy(obs_np).to(dev)
-    traj = torch.from_numpy(traj_np).to(dev)
-    if nb > 1:  # the same scene under nb scripted trajectories, stored back to back
-        obs = obs.unsqueeze(1).repeat(1, nb, 1, 1).reshape(obs.shape[0], nb * n, obs.shape[2]).contiguous()
-        traj = traj.unsqueeze(1).repeat(1, nb, 1, 1)
-        traj = (traj + 1e-7 * torch.arange(nb, device=dev).view(1, nb, 1, 1)).reshape(total, -1, 3).contiguous()
-    eng.set_scene(obs)
-    L = _lib.lib()
-    model.set_edge_kernel(args.edge_kernel)
-    # which kernel `auto` resolves to (mirror of launch_edge): bf16-pipe for hidden 128, 64-edge form for small graphs
-    cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    tiles128 = -(-(n * nb * 20) // 128)
-    ek = args.edge_kernel
-    if ek == "auto":
-        ek = "sys" if hidden == 128 else "classic"
-    elif hidden != 128:
-        ek = "classic"
-    bf16_pipe = ek in ("b3", "b3p")
-    f16_pipe = ek == "sys"
-
-    def barrier():
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        for i in range(args.warmup):
-            eng.step(obs, traj[i])
-        eng.status()
-        barrier()
-        L.gm_profile_enable(1)  # HIP events around the dominant kernel only (kind 0: processor edge kernel)
-        t0 = time.perf_counter()
-        if dist:  # per-generation exchange of the candidate-parallel planner: scripted poses out ...
-            first = traj[args.warmup].to(cdev)
-            dist.broadcast(first, src=0)
-            traj[args.warmup].copy_(first)
-        for i in range(args.steps):
-            eng.step(obs, traj[args.warmup + i])
-        result = obs[-1, :, 2:5].mean(dim=0)
-        if dist:  # ... per-candidate results back
-            result = result.to(cdev)
-            gathered = [torch.empty_like(result) for _ in range(world)]
-            dist.all_gather(gathered, result)
-        barrier()
-        el = time.perf_counter() - t0
-    L.gm_profile_enable(0)
-    edges = eng.status()  # edge count of the last timed step
-    # breakdown of the other kernels: a few extra, untimed steps with their events on
-    L.gm_profile_enable(14)
-    with torch.no_grad():
-        for i in range(min(10, args.steps)):
-            eng.step(obs, traj[args.warmup + i])
-    torch.cuda.synchronize()
-    L.gm_profile_enable(0)
-    if dist:
-        t = torch.tensor([el], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
-    if rank == 0:
-        launches, ms = C.c_int64(0), C.c_double(0.0)
-        _lib.check(L.gm_profile_query(0, C.byref(launches), C.byref(ms)))
-        k_ms = ms.value / max(launches.value, 1)
-        alg = edge_kernel_alg_flops(edges, hidden)
-        issued = edge_kernel_issued_flops(edges, hidden)
-        # MFMA utilisation is priced on the flops the kernel ISSUES (3 HxH products per edge); the
-        # algorithmic figure (5 HxH) is reported beside it -- the difference is the
-        # layer-1 factorisation, not MFMA speed (SURVEY.md 8d "utilisation uses F_issued").
-        # bf16-pipe kernels: every fp32 product block is six bf16 MFMA product blocks; the pipe they are priced against
-        # is the bf16 one
-        pipe_issued = issued * (6 if bf16_pipe else (3 if f16_pipe else 1))
-        pipe_peak = MFMA_BF16_PEAK_TFLOPS if (bf16_pipe or f16_pipe) else MFMA_F32_PEAK_TFLOPS
-        achieved = pipe_issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        kname = {"16": "edge_kernel16<2,1>", "classic": f"edge_kernel<{hidden},2,1>", "b3": "edge_kernel_b3<2,1>", "b3p": "edge_kernel_b3p<2,1>",
-                 "sys": "sys_edge_kernel"}[ek]
-        out = {
-            "metric": f"rollout steps/sec (N particles, 10 MP steps, hidden={hidden})",
-            "value": world * nb * args.steps / el,
-            "unit": "rollout steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (products formed as three exact fp16 x fp16 partial products of two-way operand splits with power-of-two pre-scaled weights on the fp16 MFMA pipe, f32 accumulation; 1e-6 vs float64 through the model, like plain f32)" if f16_pipe else
-                      "f32 (products formed as six exact bf16 x bf16 partial products of three-way operand splits on the bf16 MFMA pipe, f32 accumulation; 4e-7 vs float64 through the model, plain f32: 1e-6)" if bf16_pipe else "f32"),
-            "data": "synthetic (seeded dense scene; random-init weights, decoder output layer scaled 1e-5 so the "
-                    "pile stays dense over the rollout)",
-            "config": {"workload": wl["name"], "n_particles": n, "edges_last_step": edges, "k_steps": 6,
-                       "candidates_per_gpu": nb, "parallelism": f"candidate-parallel x{world}"},
-            "roofline": {"bound": "mfma", "kernel": kname + " (processor phi_e + scatter-add)",
-                         "pipe": "fp16 MFMA (2.5 PF dense)" if f16_pipe else ("bf16 MFMA (2.5 PF dense)" if bf16_pipe else "fp32 MFMA"),
-                         "achieved": achieved, "peak": pipe_peak, "unit": "TFLOP/s",
-                         "frac": achieved / pipe_peak, "traffic": None,
-                         "avg_launch_ms": k_ms, "launches_timed": int(launches.value),
-                         "issued_flops_per_launch": pipe_issued, "fp32_equivalent_flops_per_launch": issued,
-                         "fp32_equivalent_tflops": issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
-                         "alg_flops_per_launch": alg,
-                         "alg_tflops": alg / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0},
-        }
-        # HBM traffic of the same kernel from rocprofv3 PMC passes (collected separately, committed under profiles/)
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if args.workload in tr and args.candidates == 1:  # only for the profiled configuration
-                out["roofline"]["traffic"] = tr[args.workload]["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per guide)"
-        except (OSError, ValueError, KeyError):
-            pass
-        out["roofline"]["alg_bytes_per_launch"] = edges * hidden * 4 * 2 + n * hidden * 4 * 3 + edges * 12
-        per_step = {"node_kernel": (1, 10), "graph_build": (2, 1), "encoder_kernels": (3, 2)}
-        br = {"edge_kernel_ms_per_step": k_ms * 10}
-        for name, (kind, calls) in per_step.items():
-            _lib.check(L.gm_profile_query(kind, C.byref(launches), C.byref(ms)))
-            br[name + "_ms_per_step"] = ms.value / max(launches.value, 1) * calls
-        out["breakdown"] = br
-        if world == 1 and (bf16_pipe or f16_pipe):
-            # the same workload on the fp32-MFMA kernel (untimed extra steps), for reference next to `value`
-            model.set_edge_kernel("16")
-            k2 = min(20, args.steps)
-            with torch.no_grad():
-                for i in range(3):
-                    eng.step(obs, traj[args.warmup + i])
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(k2):
-                    eng.step(obs, traj[args.warmup + i])
-                torch.cuda.synchronize()
-                d2 = time.perf_counter() - t1
-            model.set_edge_kernel(args.edge_kernel)
-            out["fp32_mfma_kernel"] = {"value": nb * k2 / d2, "unit": "rollout steps/s", "ms_per_step": d2 / k2 * 1e3,
-                                       "kernel": "edge_kernel16<2,1> (v_mfma_f32_16x16x4_f32)", "steps": k2}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(obs_np, traj_np, model, stats, scene)
-        print(json.dumps(out))
+    if args.workload == "c5":
+        out = run_c5(dev, rank, world, dist, cdev, args)
+        if rank == 0:
+            print(json.dumps(out))
+    else:
+        wl = WORKLOADS[args.workload]
+        steps = args.steps if args.steps > 0 else wl["steps"]
+        warmup = args.warmup if args.warmup >= 0 else wl["warmup"]
+        rec, (model, obs_np, stats, scene, ek) = measure(args.workload, dev, rank, world, dist, cdev, args, steps, warmup, args.candidates)
+        if rank == 0:
+            hidden = wl["hidden"]
+            out = {"metric": f"rollout steps/sec (N particles, 10 MP steps, hidden={hidden})",
+                   "value": rec["value"], "unit": "rollout steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                   "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": {"sys": "f32 (products formed as three exact fp16 x fp16 partial products of two-way operand splits with power-of-two "
+                                    "pre-scaled weights on the fp16 MFMA pipe, f32 accumulation; 1e-6 vs float64 through the model, like plain f32)",
+                             "b3": "f32 (six exact bf16 x bf16 partial products of three-way operand splits, f32 accumulation)",
+                             "b3p": "f32 (six exact bf16 x bf16 partial products of three-way operand splits, f32 accumulation)"}.get(ek, "f32"),
+                   "data": "synthetic (seeded dense scene; random-init weights, decoder output layer scaled 1e-5 so the pile stays dense "
+                           "over the rollout)",
+                   "config": rec["config"], "roofline": rec["roofline"], "breakdown": rec["breakdown"]}
+            if world == 1 and not args.no_extra and args.workload == "target" and args.candidates == 1:
+                extra = {}
+                for key in ("c2", "c3", "c4"):
+                    w2 = WORKLOADS[key]
+                    r2, _ = measure(key, dev, rank, world, None, cdev, args, w2["steps"], w2["warmup"], 1)
+                    extra[key] = r2
+                    torch.cuda.empty_cache()
+                out["extra"] = extra
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(obs_np, model, stats, scene, hidden)
+            print(json.dumps(out))
     if dist:
         dist.barrier()
         dist.destroy_process_group()

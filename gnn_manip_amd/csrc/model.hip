@@ -555,6 +555,31 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
     return gm::rollout_integrate_post(obs, n, fd, r.pred, rigid_rank, rigid_target, pred_acc_out, hs);
 }
 
+int gm_rollout(const gm_model* m, float* obs, int64_t n, const gm_feature_desc* fd, int K, const int32_t* rigid_rank,
+               const float* rigid_targets, int64_t n_targets, int64_t n_rigid, int64_t steps, float* record_last, void* ws,
+               size_t ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(obs);
+    GM_REQUIRE(m && obs && fd && ws, GM_ERR_INVALID_ARGUMENT, "gm_rollout: null pointer");
+    GM_REQUIRE(steps >= 0 && n_targets >= 0 && n_rigid >= 0, GM_ERR_INVALID_ARGUMENT, "gm_rollout: negative count");
+    GM_REQUIRE(rigid_targets || n_targets == 0, GM_ERR_INVALID_ARGUMENT, "gm_rollout: n_targets > 0 without rigid_targets");
+    GM_REQUIRE(!rigid_targets || rigid_rank, GM_ERR_INVALID_ARGUMENT, "gm_rollout: rigid_targets need rigid_rank");
+    hipStream_t hs = (hipStream_t)stream;
+    const size_t frame = (size_t)n * fd->data_dim;
+    float* last = obs + (size_t)(fd->k_steps - 1) * frame;
+    for (int64_t i = 0; i < steps; ++i) {
+        // traj_utils.py:126-134: steps past the scripted trajectory keep the rigid body where it is (control = 0 displacement)
+        const float* target = i < n_targets ? rigid_targets + (size_t)i * n_rigid * 3 : nullptr;
+        if (record_last) {  // the reference records the last frame after the control overwrite (rollout_utils.py:49, traj_utils.py:137)
+            int rc = gm_state_pre(obs, n, fd, rigid_rank, target, stream);
+            if (rc != GM_OK) return rc;
+            GM_HIP_CHECK(hipMemcpyAsync(record_last + (size_t)i * frame, last, frame * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        }
+        int rc = gm_rollout_step(m, obs, n, fd, K, rigid_rank, target, nullptr, ws, ws_bytes, stream);
+        if (rc != GM_OK) return rc;
+    }
+    return GM_OK;
+}
+
 int gm_rollout_status(const void* ws, const gm_model_desc* desc, int64_t n, int K, int64_t* n_edges_host, void* stream) {
     gm::DevGuard dev_guard(ws);
     GM_REQUIRE(ws && desc && n_edges_host, GM_ERR_INVALID_ARGUMENT, "gm_rollout_status: null pointer");

@@ -107,6 +107,23 @@ class RolloutEngine:
         check(lib().gm_rollout_status(ptr(self.ws), C.byref(self.mdesc), self.n, self.max_neighbours, C.byref(e), current_stream()))
         return int(e.value)
 
+    def run(self, obs, trajectory=None, steps=None, record=False):
+        """`steps` rollout steps in place on ``obs`` inside ONE library call (gm_rollout): no Python between steps.
+        trajectory: [T, N_rigid, 3] contiguous device tensor of scripted poses or None.  Returns the recorded last
+        frames [steps, N, D] when asked (the reference's per-step record), else None."""
+        T = 0 if trajectory is None else int(trajectory.shape[0])
+        steps = T if steps is None else int(steps)
+        self._check_state(obs, None, None, True)
+        if trajectory is not None:
+            if (trajectory.device != self.device or trajectory.dtype != torch.float32 or not trajectory.is_contiguous()
+                    or tuple(trajectory.shape[1:]) != (self.n_rigid, 3)):
+                raise ValueError(f"trajectory must be contiguous float32 [T, {self.n_rigid}, 3] on {self.device}, got {tuple(trajectory.shape)}")
+        recs = torch.empty((steps, self.n, self.data_dim), dtype=torch.float32, device=self.device) if record else None
+        handle = self.model.device_handle(self.device)  # resolved once per rollout
+        check(lib().gm_rollout(handle, ptr(obs), self.n, C.byref(self.fdesc), self.max_neighbours, ptr(self.rigid_rank),
+                               ptr(trajectory), T, self.n_rigid, steps, ptr(recs), ptr(self.ws), self.ws.numel(), current_stream()))
+        return recs
+
     def rollout_candidates(self, obs0, trajectories, horizon=None):
         """Roll `candidates` copies of one initial state [k, N, D] under per-candidate scripted rigid poses
         `trajectories` [B, T, N_rigid, 3] (the CMA-ES population of traj_utils.py:247-259, evaluated together
@@ -116,10 +133,9 @@ class RolloutEngine:
         obs = obs0.unsqueeze(1).repeat(1, b, 1, 1).reshape(k, b * n, self.data_dim).contiguous()
         self.set_scene(obs)
         steps = horizon if horizon is not None else trajectories.shape[1]
-        traj_t = trajectories.permute(1, 0, 2, 3).contiguous()  # [T, B, Nr, 3]: one step's poses are contiguous
-        for i in range(steps):
-            tgt = traj_t[i].reshape(-1, 3) if i < traj_t.shape[0] else None
-            self.step(obs, tgt)
+        # [T, B * Nr, 3]: one step's poses of all candidates are contiguous, candidate-major like the rigid rows
+        traj_t = trajectories.permute(1, 0, 2, 3).reshape(trajectories.shape[1], -1, 3).contiguous().float()
+        self.run(obs, traj_t, steps)
         self.status()
         return obs.reshape(k, b, n, self.data_dim).permute(1, 0, 2, 3).contiguous()
 
@@ -129,18 +145,11 @@ class RolloutEngine:
         obs = obs0.clone().contiguous()
         self.set_scene(obs)  # per call: the engine may be given another scene
         steps = horizon if horizon is not None else (trajectory.shape[0] if trajectory is not None else 0)
-        recs = []
-        for i in range(steps):
-            tgt = trajectory[i] if (trajectory is not None and i < trajectory.shape[0]) else None
-            if record:
-                # the reference records the last frame after the control overwrite, before the prediction
-                from ._lib import lib as _l
-                check(_l().gm_state_pre(ptr(obs), self.n, C.byref(self.fdesc), ptr(self.rigid_rank), ptr(tgt), current_stream()))
-                recs.append(obs[-1].clone())
-            self.step(obs, tgt)
+        traj = None if trajectory is None else trajectory.contiguous().float()
+        recs = self.run(obs, traj, steps, record=record)
         self.status()
         if record:
-            return obs, torch.stack(recs)
+            return obs, recs
         return obs
 
 

@@ -252,6 +252,15 @@ int gm_rollout_step(const gm_model* m, float* obs /*[k,N,D] in/out*/, int64_t n_
                     const gm_feature_desc* fdesc, int max_neighbours, const int32_t* rigid_rank,
                     const float* rigid_target /*[Nr,3] or NULL*/, float* pred_acc_out /*[N,3] or NULL*/,
                     void* rollout_ws, size_t rollout_ws_bytes, void* stream);
+/* `steps` device-resident rollout steps without returning to the caller: compute_rollout's loop (rollout_utils.py:38-61)
+ * == cma_objective's (traj_utils.py:123-152).  rigid_targets: [n_targets, n_rigid, 3] scripted poses, step i uses pose i;
+ * steps beyond n_targets keep the rigid body in place (traj_utils.py:130-131); NULL / 0: no scripted poses.
+ * record_last: [steps, N, D] or NULL -- the last frame of the window after the control overwrite of every step, i.e. what
+ * the reference appends to `prediction` / `positions` (rollout_utils.py:49, traj_utils.py:137).  No host synchronisation. */
+int gm_rollout(const gm_model* m, float* obs /*[k,N,D] in/out*/, int64_t n_nodes, const gm_feature_desc* fdesc,
+               int max_neighbours, const int32_t* rigid_rank, const float* rigid_targets, int64_t n_targets,
+               int64_t n_rigid, int64_t steps, float* record_last, void* rollout_ws, size_t rollout_ws_bytes,
+               void* stream);
 /* Error flags / edge count of the last step (synchronises). */
 int gm_rollout_status(const void* rollout_ws, const gm_model_desc* desc, int64_t n_nodes,
                       int max_neighbours, int64_t* n_edges_host, void* stream);
