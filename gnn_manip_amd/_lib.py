@@ -31,7 +31,10 @@ class FeatureDesc(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("node_dim", C.c_int32), ("edge_dim", C.c_int32), ("out_dim", C.c_int32),
                 ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("m_steps", C.c_int32),
-                ("ln_eps", C.c_float)]
+                ("ln_eps", C.c_float),
+                # InteractionNetwork convention (all zero = default)
+                ("flow", C.c_int32), ("col_i", C.c_int32), ("col_j", C.c_int32), ("col_e", C.c_int32),
+                ("node_agg_first", C.c_int32)]
 
 
 _vp, _i64, _i32, _sz, _f32, _f64 = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float, C.c_double
@@ -49,6 +52,8 @@ PROTOTYPES = {
     "gm_csr_workspace_bytes": (_sz, [_i64, _i64]),
     "gm_csr_from_graph": (_i32, [_vp, _i64, _i32, _vp, _sz, _vp]),
     "gm_csr_from_edge_index": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp]),
+    "gm_csr_from_graph_flow": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp]),
+    "gm_csr_from_edge_index_flow": (_i32, [_vp, _i64, _i64, _i32, _vp, _sz, _vp]),
     "gm_csr_num_edges": (_i32, [_vp, C.POINTER(_i64), _vp]),
     "gm_edge_features": (_i32, [_vp, _i64, _vp, _vp, _i64, _f32, _vp, _vp]),
     "gm_edge_features_csr": (_i32, [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp]),

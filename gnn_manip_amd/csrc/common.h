@@ -148,7 +148,7 @@ int rollout_integrate_post(float* obs, int64_t n, const gm_feature_desc* d, cons
                            const float* target, float* pred_out, hipStream_t s);
 // destination sort of the radius graph with the edge features computed in the same pass (graph.hip)
 int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, const float* pos,
-                                 int64_t pos_stride, float conn_r, float* edge_attr, hipStream_t s);
+                                 int64_t pos_stride, float conn_r, float* edge_attr, int flow, hipStream_t s);
 
 int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s, int* total_out);
 size_t scan_tmp_ints(int64_t n_max);

@@ -610,50 +610,51 @@ __global__ void __launch_bounds__(256) csr_clear_kernel(CsrHeader* hdr, int* __r
 }
 
 // mode 0: slots of the radius graph (source = query i, destination = neighbour)
+// flow 0: the aggregation node of edge (query i -> neighbour) is the neighbour (edge_index[1]); 1: the query (edge_index[0])
 __global__ void __launch_bounds__(256) indeg_graph_kernel(const int* __restrict__ cnt, const int* __restrict__ nbr,
-                                                           int64_t n, int K, int* __restrict__ indeg) {
+                                                           int64_t n, int K, int flow, int* __restrict__ indeg) {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n * K) return;
     int64_t i = id / K;
     if ((int)(id - i * K) >= cnt[i]) return;
-    atomicAdd(&indeg[nbr[id]], 1);
+    atomicAdd(&indeg[flow ? (int)i : nbr[id]], 1);
 }
 
 __global__ void __launch_bounds__(256) fill_graph_kernel(const int* __restrict__ cnt, const int* __restrict__ out_ptr,
                                                           const int* __restrict__ nbr, int64_t n, int K,
                                                           const int* __restrict__ in_ptr, int* __restrict__ cursor,
-                                                          int64_t cap, int* __restrict__ dst, int* __restrict__ src,
+                                                          int64_t cap, int flow, int* __restrict__ dst, int* __restrict__ src,
                                                           int* __restrict__ eid, CsrHeader* hdr) {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n * K) return;
     int64_t i = id / K;
     int s = (int)(id - i * K);
     if (s >= cnt[i]) return;
-    int d = nbr[id];
+    const int d = flow ? (int)i : nbr[id];
     int p = in_ptr[d] + atomicAdd(&cursor[d], 1);
     if (p >= cap) { atomicOr(&hdr->error_flags, ERRF_CAPACITY); return; }
     dst[p] = d;
-    src[p] = (int)i;
+    src[p] = flow ? nbr[id] : (int)i;
     eid[p] = out_ptr[i] + s;
 }
 
 // mode 1: caller-supplied edge_index [2, E] (int64)
-__global__ void __launch_bounds__(256) indeg_ei_kernel(const int64_t* __restrict__ ei, int64_t n, int64_t e,
+__global__ void __launch_bounds__(256) indeg_ei_kernel(const int64_t* __restrict__ ei, int64_t n, int64_t e, int flow,
                                                         int* __restrict__ indeg, CsrHeader* hdr) {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= e) return;
-    int64_t s = ei[id], d = ei[e + id];
+    int64_t s = ei[flow ? e + id : id], d = ei[flow ? id : e + id];
     if (s < 0 || s >= n || d < 0 || d >= n) { atomicOr(&hdr->error_flags, ERRF_BAD_EDGE_INDEX); return; }
     atomicAdd(&indeg[d], 1);
 }
 
-__global__ void __launch_bounds__(256) fill_ei_kernel(const int64_t* __restrict__ ei, int64_t n, int64_t e,
+__global__ void __launch_bounds__(256) fill_ei_kernel(const int64_t* __restrict__ ei, int64_t n, int64_t e, int flow,
                                                        const int* __restrict__ in_ptr, int* __restrict__ cursor,
                                                        int* __restrict__ dst, int* __restrict__ src,
                                                        int* __restrict__ eid) {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= e) return;
-    int64_t s = ei[id], d = ei[e + id];
+    int64_t s = ei[flow ? e + id : id], d = ei[flow ? id : e + id];
     if (s < 0 || s >= n || d < 0 || d >= n) return;
     int p = in_ptr[d] + atomicAdd(&cursor[d], 1);
     dst[p] = (int)d;
@@ -670,7 +671,7 @@ constexpr int SEG_STRIDE = SEG_CAP + 1;
 __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict__ in_ptr, int64_t n,
                                                             int* __restrict__ src, int* __restrict__ eid,
                                                             CsrHeader* hdr, const float* __restrict__ pos,
-                                                            int64_t pos_stride, float conn_r, float* __restrict__ edge_attr) {
+                                                            int64_t pos_stride, float conn_r, float* __restrict__ edge_attr, int flow) {
     __shared__ int se[32 * SEG_STRIDE];
     __shared__ int ss[32 * SEG_STRIDE];
     const int tid = threadIdx.x, sub = tid & 7, sl = tid >> 3;
@@ -700,7 +701,8 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
                 float d[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    d[c] = __fdiv_rn(__fsub_rn(pos[(int64_t)ls[a] * pos_stride + c], pos[i * pos_stride + c]), conn_r);
+                    d[c] = flow ? __fdiv_rn(__fsub_rn(pos[i * pos_stride + c], pos[(int64_t)ls[a] * pos_stride + c]), conn_r)
+                                : __fdiv_rn(__fsub_rn(pos[(int64_t)ls[a] * pos_stride + c], pos[i * pos_stride + c]), conn_r);
                 float q = __fmul_rn(d[0], d[0]);
                 q = __fadd_rn(q, __fmul_rn(d[1], d[1]));
                 q = __fadd_rn(q, __fmul_rn(d[2], d[2]));
@@ -723,7 +725,8 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
             for (int a = b; a < e; ++a) {
                 float d[3];
                 for (int c = 0; c < 3; ++c)
-                    d[c] = __fdiv_rn(__fsub_rn(pos[(int64_t)src[a] * pos_stride + c], pos[i * pos_stride + c]), conn_r);
+                    d[c] = flow ? __fdiv_rn(__fsub_rn(pos[i * pos_stride + c], pos[(int64_t)src[a] * pos_stride + c]), conn_r)
+                                : __fdiv_rn(__fsub_rn(pos[(int64_t)src[a] * pos_stride + c], pos[i * pos_stride + c]), conn_r);
                 float q = __fmul_rn(d[0], d[0]);
                 q = __fadd_rn(q, __fmul_rn(d[1], d[1]));
                 q = __fadd_rn(q, __fmul_rn(d[2], d[2]));
@@ -759,7 +762,7 @@ int gm_profile_query(int kind, int64_t* launches, double* total_ms) {
     }
     return GM_OK;
 }
-int gm_abi_version(void) { return 1; }
+int gm_abi_version(void) { return 2; }
 
 size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours) {
     if (n_nodes < 0 || max_neighbours < 1) return 0;
@@ -863,16 +866,21 @@ size_t gm_csr_workspace_bytes(int64_t n_nodes, int64_t edge_capacity) {
 }
 
 int gm_csr_from_graph(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, void* stream) {
+    return gm_csr_from_graph_flow(graph_ws, n, K, 0, csr_ws, csr_ws_bytes, stream);
+}
+
+int gm_csr_from_graph_flow(const void* graph_ws, int64_t n, int K, int flow, void* csr_ws, size_t csr_ws_bytes, void* stream) {
     gm::DevGuard dev_guard(graph_ws);
-    return gm::csr_from_graph_with_features(graph_ws, n, K, csr_ws, csr_ws_bytes, nullptr, 3, 1.f, nullptr, (hipStream_t)stream);
+    return gm::csr_from_graph_with_features(graph_ws, n, K, csr_ws, csr_ws_bytes, nullptr, 3, 1.f, nullptr, flow, (hipStream_t)stream);
 }
 
 }  // extern "C"
 
 namespace gm {
 int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, const float* pos,
-                                 int64_t pos_stride, float conn_r, float* edge_attr, hipStream_t stream) {
+                                 int64_t pos_stride, float conn_r, float* edge_attr, int flow, hipStream_t stream) {
     GM_REQUIRE(graph_ws && csr_ws, GM_ERR_INVALID_ARGUMENT, "gm_csr_from_graph: null pointer");
+    GM_REQUIRE(flow == 0 || flow == 1, GM_ERR_INVALID_ARGUMENT, "gm_csr_from_graph: flow must be 0 or 1");
     const int64_t cap = n * K;
     GraphWs g = carve_graph(const_cast<void*>(graph_ws), n, K);
     CsrWs c = carve_csr(csr_ws, n, cap);
@@ -884,12 +892,12 @@ int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* c
     }
     if (n > 0) {
         unsigned nb = (unsigned)cdiv(cap, 256);
-        hipLaunchKernelGGL(indeg_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.nbr, n, K, c.in_ptr);
+        hipLaunchKernelGGL(indeg_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.nbr, n, K, flow, c.in_ptr);
         int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s, nullptr);
         if (rc != GM_OK) return rc;
         hipLaunchKernelGGL(fill_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.out_ptr, g.nbr, n, K, c.in_ptr,
-                           c.cursor, cap, c.dst, c.src, c.eid, c.hdr);
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, pos, pos_stride, conn_r, edge_attr);
+                           c.cursor, cap, flow, c.dst, c.src, c.eid, c.hdr);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, pos, pos_stride, conn_r, edge_attr, flow);
         GM_LAUNCH_CHECK();
     }
     // 32-edge blocks aligned to every graph's first edge (the systolic processor edge kernel walks them)
@@ -900,7 +908,12 @@ int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* c
 extern "C" {
 
 int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws, size_t csr_ws_bytes, void* stream) {
+    return gm_csr_from_edge_index_flow(ei, n, e, 0, csr_ws, csr_ws_bytes, stream);
+}
+
+int gm_csr_from_edge_index_flow(const int64_t* ei, int64_t n, int64_t e, int flow, void* csr_ws, size_t csr_ws_bytes, void* stream) {
     gm::DevGuard dev_guard(csr_ws);
+    GM_REQUIRE(flow == 0 || flow == 1, GM_ERR_INVALID_ARGUMENT, "gm_csr_from_edge_index: flow must be 0 or 1");
     GM_REQUIRE(csr_ws && (ei || e == 0), GM_ERR_INVALID_ARGUMENT, "gm_csr_from_edge_index: null pointer");
     GM_REQUIRE(n >= 0 && e >= 0 && e < ((int64_t)1 << 31) && n < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT,
                "gm_csr_from_edge_index: sizes out of range");
@@ -913,13 +926,13 @@ int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws
     }
     if (e > 0) {
         unsigned nb = (unsigned)cdiv(e, 256);
-        hipLaunchKernelGGL(indeg_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, c.in_ptr, c.hdr);
+        hipLaunchKernelGGL(indeg_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, flow, c.in_ptr, c.hdr);
         int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s, nullptr);
         if (rc != GM_OK) return rc;
-        hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, c.in_ptr, c.cursor, c.dst, c.src, c.eid);
+        hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, flow, c.in_ptr, c.cursor, c.dst, c.src, c.eid);
     }
     if (n > 0)
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0);
     GM_LAUNCH_CHECK();
     return build_edge_blocks(c.in_ptr, n, e, nullptr, (int)n, carve_edge_blocks(c.blocks, n, e), s);
 }

@@ -32,7 +32,8 @@ int build_edge_blocks(const int* in_ptr, int64_t n_nodes, int64_t edge_capacity,
 // ---- weight image of one processor step's phi_e for the systolic kernel
 constexpr int kPackH3Max = 16;
 struct PackH3Job {
-    const float* W1;   // Linear 1 weight [H][3H] (the e block = columns 2H..3H is packed; W_i, W_j live in P)
+    const float* W1;   // Linear 1 weight [H][3H]: the block that multiplies e is packed (W_i, W_j live in P)
+    int W1_col0;       // first column of that block (2H with the default concat order)
     const float* W2;   // [H][H]
     const float* W3;   // [H][H]
     const float* b2;

@@ -496,7 +496,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
 // ------------------------------------------------------------------------------------------
 struct PackH3Jobs {
     int n;
-    const float* W1[kPackH3Max];   // [H][3H]: the e block is columns 2H..3H
+    const float* W1[kPackH3Max];   // [H][3H]: the e block starts at column c1[]
+    int c1[kPackH3Max];
     const float* W2[kPackH3Max];
     const float* W3[kPackH3Max];
     const float* b2[kPackH3Max];
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
     __shared__ float tsc[3];
     const int job = blockIdx.x, tid = threadIdx.x;
     const float* Wl[3] = {J.W1[job], J.W2[job], J.W3[job]};
-    const int ld[3] = {3 * H, H, H}, c0[3] = {2 * H, 0, 0};
+    const int ld[3] = {3 * H, H, H}, c0[3] = {J.c1[job], 0, 0};
     for (int l = 0; l < 3; ++l) {
         float mx = 0.f;
         for (int i = tid; i < H * H; i += 256) mx = fmaxf(mx, fabsf(Wl[l][(size_t)(i / H) * ld[l] + c0[l] + (i % H)]));
@@ -636,7 +637,7 @@ int pack_h3(const PackH3Job* jobs, int n, hipStream_t s) {
         J.n = n - off < kPackH3Max ? n - off : kPackH3Max;
         for (int i = 0; i < J.n; ++i) {
             const PackH3Job& j = jobs[off + i];
-            J.W1[i] = j.W1; J.W2[i] = j.W2; J.W3[i] = j.W3; J.b2[i] = j.b2; J.b3[i] = j.b3; J.gamma[i] = j.gamma; J.beta[i] = j.beta;
+            J.W1[i] = j.W1; J.c1[i] = j.W1_col0; J.W2[i] = j.W2; J.W3[i] = j.W3; J.b2[i] = j.b2; J.b3[i] = j.b3; J.gamma[i] = j.gamma; J.beta[i] = j.beta;
             J.dst[i] = j.dst;
         }
         hipLaunchKernelGGL(pack_h3_kernel, dim3(J.n), dim3(256), 0, s, J);

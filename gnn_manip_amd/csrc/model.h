@@ -6,6 +6,8 @@
 struct gm_model {
     gm_model_desc d;
     int H, NL, M;
+    int ci = 0, cj = 1, ce = 2;   // column block of phi_e's first Linear that multiplies h_i, h_j, e (gm_model_desc.col_*)
+    int ch = 0, ca = 1;           // column block of phi_v's first Linear for h, agg (gm_model_desc.node_agg_first)
     float* packed = nullptr;  // operand image of every Linear, stage-aligned streams
     float* packed16 = nullptr;  // 16x16x4 operand image of the edge MLPs (hidden 128)
     size_t packed16_floats = 0, s16_enc_edge = 0;

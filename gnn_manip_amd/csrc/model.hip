@@ -24,6 +24,13 @@ int check_desc(const gm_model_desc* d, const char* who) {
     GM_REQUIRE(d->node_dim >= 1 && d->node_dim <= 32, GM_ERR_UNSUPPORTED, "%s: node_dim=%d unsupported (1..32)", who, d->node_dim);
     GM_REQUIRE(d->out_dim >= 1 && d->out_dim <= 4, GM_ERR_UNSUPPORTED, "%s: out_dim=%d unsupported (1..4)", who, d->out_dim);
     GM_REQUIRE(d->ln_eps > 0.f, GM_ERR_INVALID_ARGUMENT, "%s: ln_eps must be > 0", who);
+    GM_REQUIRE(d->flow == 0 || d->flow == 1, GM_ERR_INVALID_ARGUMENT, "%s: flow must be 0 (aggregate at edge_index[1]) or 1", who);
+    GM_REQUIRE(d->node_agg_first == 0 || d->node_agg_first == 1, GM_ERR_INVALID_ARGUMENT, "%s: node_agg_first must be 0 or 1", who);
+    if (d->col_i || d->col_j || d->col_e) {
+        const int a = d->col_i, b = d->col_j, c = d->col_e;
+        GM_REQUIRE(a >= 0 && a < 3 && b >= 0 && b < 3 && c >= 0 && c < 3 && a != b && a != c && b != c, GM_ERR_INVALID_ARGUMENT,
+                   "%s: col_i, col_j, col_e must be a permutation of 0, 1, 2", who);
+    }
     return GM_OK;
 }
 
@@ -139,19 +146,19 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
     off = m->s_enc_node;
     pack(b_enc_node, H, m->d.node_dim, 0, m->d.node_dim, off);
     hidden(b_enc_node, off);
-    pack(b_edge(0), H, 3 * H, 0, H, off);  // W_i of processor 0
-    pack(b_edge(0), H, 3 * H, H, H, off);  // W_j
+    pack(b_edge(0), H, 3 * H, m->ci * H, H, off);  // W_i of processor 0
+    pack(b_edge(0), H, 3 * H, m->cj * H, H, off);  // W_j
     for (int k = 0; k < M; ++k) {
         off = m->s_edge[k];
-        pack(b_edge(k), H, 3 * H, 2 * H, H, off);  // W_e
+        pack(b_edge(k), H, 3 * H, m->ce * H, H, off);  // W_e
         hidden(b_edge(k), off);
         off = m->s_node[k];
-        pack(b_node(k), H, 2 * H, 0, H, off);  // W_h
-        pack(b_node(k), H, 2 * H, H, H, off);  // W_agg
+        pack(b_node(k), H, 2 * H, m->ch * H, H, off);  // W_h
+        pack(b_node(k), H, 2 * H, m->ca * H, H, off);  // W_agg
         hidden(b_node(k), off);
         if (k + 1 < M) {
-            pack(b_edge(k + 1), H, 3 * H, 0, H, off);
-            pack(b_edge(k + 1), H, 3 * H, H, H, off);
+            pack(b_edge(k + 1), H, 3 * H, m->ci * H, H, off);
+            pack(b_edge(k + 1), H, 3 * H, m->cj * H, H, off);
         } else {
             for (int l = 0; l < NL; ++l) pack(b_dec + 2 * l, H, H, 0, H, off);
             pack(b_dec + 2 * NL, m->d.out_dim, H, 0, H, off);
@@ -176,7 +183,7 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
         for (int l = 1; l <= NL; ++l) pack16(b_enc_edge + 2 * l, H, H, 0, H, o16);
         for (int k = 0; k < M; ++k) {
             o16 = m->s16_edge[k];
-            pack16(b_edge(k), H, 3 * H, 2 * H, H, o16);
+            pack16(b_edge(k), H, 3 * H, m->ce * H, H, o16);
             for (int l = 1; l <= NL; ++l) pack16(b_edge(k) + 2 * l, H, H, 0, H, o16);
         }
     }
@@ -188,7 +195,7 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
         for (int k = 0; k < M && rc == GM_OK; ++k) {
             float* base = m->packed_b3 + (size_t)k * 3 * 4 * kB3StageFloats;
             if (on_device) {
-                rc = pack_linear_b3(T[b_edge(k)], 3 * H, 2 * H, base, s);
+                rc = pack_linear_b3(T[b_edge(k)], 3 * H, m->ce * H, base, s);
                 for (int l = 1; l <= NL && rc == GM_OK; ++l)
                     rc = pack_linear_b3(T[b_edge(k) + 2 * l], H, 0, base + (size_t)l * 4 * kB3StageFloats, s);
             }
@@ -203,7 +210,7 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
         for (int k = 0; k < M; ++k) {
             PackH3Job& j = jobs[(size_t)k];
             const int b = b_edge(k);
-            j.W1 = T[b]; j.W2 = T[b + 2]; j.W3 = T[b + 4];
+            j.W1 = T[b]; j.W1_col0 = m->ce * H; j.W2 = T[b + 2]; j.W3 = T[b + 4];
             j.b2 = T[b + 3]; j.b3 = T[b + 5];
             j.gamma = T[b + 6]; j.beta = T[b + 7];
             j.dst = m->packed_h3 + (size_t)k * h3_image_floats();
@@ -244,6 +251,8 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
     gm_model* m = new gm_model();
     m->d = *desc;
     const int H = m->H = desc->hidden_size, NL = m->NL = desc->num_layers, M = m->M = desc->m_steps;
+    if (desc->col_i || desc->col_j || desc->col_e) { m->ci = desc->col_i; m->cj = desc->col_j; m->ce = desc->col_e; }
+    if (desc->node_agg_first) { m->ch = 1; m->ca = 0; }
     m->S_HH = layer_stages(H, H);
     m->S_e0 = layer_stages(desc->edge_dim, H);
     m->S_n0 = layer_stages(desc->node_dim, H);
@@ -547,7 +556,7 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
     if (rc != GM_OK) return rc;
     // destination sort; the edge features are written by the same pass that fixes each segment's order
     rc = gm::csr_from_graph_with_features(r.graph, n, K, r.csr, r.csr_bytes, last_pos, fd->data_dim, (float)fd->conn_r,
-                                          r.edge_attr, hs);
+                                          r.edge_attr, m->d.flow, hs);
     if (rc != GM_OK) return rc;
     rc = gm_epd_forward(m, r.x, n, r.edge_attr, 1, r.csr, cap, r.pred, r.fwd, r.fwd_bytes, stream);
     if (rc != GM_OK) return rc;

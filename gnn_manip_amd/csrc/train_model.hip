@@ -179,7 +179,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     // destination-sorted edges (aggregation index i = edge_index[1]) and the source-grouped view of the sorted list
-    rc = gm_csr_from_edge_index(edge_index, n, e, t.csr_dst, t.csr_bytes, stream);
+    rc = gm_csr_from_edge_index_flow(edge_index, n, e, m->d.flow, t.csr_dst, t.csr_bytes, stream);
     if (rc != GM_OK) return rc;
     CsrWs c = carve_csr(t.csr_dst, n, e);
     rc = launch_swap_index(c.src, e, t.ei2, s);
@@ -299,21 +299,21 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         for (int k = 0; k < M; ++k) {
             off = b.off_node[k];
             if (k + 1 < M) {
-                packT(T[b_edge(k + 1)], H, 3 * H, 0, H, off);
-                packT(T[b_edge(k + 1)], H, 3 * H, H, H, off);
+                packT(T[b_edge(k + 1)], H, 3 * H, m->ci * H, H, off);
+                packT(T[b_edge(k + 1)], H, 3 * H, m->cj * H, H, off);
             }
             packT(T[b_node(k) + 4], H, H, 0, H, off);
             packT(T[b_node(k) + 2], H, H, 0, H, off);
-            packT(T[b_node(k)], H, 2 * H, 0, H, off);
-            packT(T[b_node(k)], H, 2 * H, H, H, off);
+            packT(T[b_node(k)], H, 2 * H, m->ch * H, H, off);
+            packT(T[b_node(k)], H, 2 * H, m->ca * H, H, off);
             off = b.off_edge[k];
             packT(T[b_edge(k) + 4], H, H, 0, H, off);
             packT(T[b_edge(k) + 2], H, H, 0, H, off);
-            packT(T[b_edge(k)], H, 3 * H, 2 * H, H, off);
+            packT(T[b_edge(k)], H, 3 * H, m->ce * H, H, off);
         }
         off = b.off_enc_node;
-        packT(T[b_edge(0)], H, 3 * H, 0, H, off);
-        packT(T[b_edge(0)], H, 3 * H, H, H, off);
+        packT(T[b_edge(0)], H, 3 * H, m->ci * H, H, off);
+        packT(T[b_edge(0)], H, 3 * H, m->cj * H, H, off);
         packT(T[b_enc_node + 4], H, H, 0, H, off);
         packT(T[b_enc_node + 2], H, H, 0, H, off);
         off = b.off_enc_edge;
@@ -359,8 +359,8 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             rc = launch_train_bwd(H, TB_NODE, a, s);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_node(k), t.tn[k], n);
-            wgrad(b.dz1, H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, 0, grads[b_node(k) + 1]);
-            wgrad(b.dz1, H, H, t.agg[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, H, nullptr);
+            wgrad(b.dz1, H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ch * H, grads[b_node(k) + 1]);
+            wgrad(b.dz1, H, H, t.agg[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ca * H, nullptr);
             if (rc != GM_OK) return rc;
         }
         {
@@ -371,13 +371,13 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             rc = launch_train_bwd(H, TB_EDGE, a, s);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_edge(k), t.te[k], e);
-            wgrad(b.dz1, H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, 2 * H, grads[b_edge(k) + 1]);
+            wgrad(b.dz1, H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, m->ce * H, grads[b_edge(k) + 1]);
             if (rc != GM_OK) return rc;
             // node-level sums of dz1: everything the factorised layer 1 needs
             rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dz1, nullptr, nullptr, b.Gi, n, s);
             if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dz1, nullptr, nullptr, b.Gj, n, s);
-            wgrad(b.Gi, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, 0, nullptr);
-            wgrad(b.Gj, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, H, nullptr);
+            wgrad(b.Gi, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, m->ci * H, nullptr);
+            wgrad(b.Gj, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, m->cj * H, nullptr);
             if (rc != GM_OK) return rc;
         }
     }
@@ -518,7 +518,7 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
     rc = train_kernels_init();
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    rc = gm_csr_from_edge_index(edge_index, n, e, t.csr_dst, t.csr_bytes, stream);
+    rc = gm_csr_from_edge_index_flow(edge_index, n, e, m->d.flow, t.csr_dst, t.csr_bytes, stream);
     if (rc != GM_OK) return rc;
     CsrWs c = carve_csr(t.csr_dst, n, e);
     rc = launch_swap_index(c.src, e, t.ei2, s);
@@ -589,13 +589,13 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         };
         packT(T[bn + 4], H, 0, b.off_node[0]);
         packT(T[bn + 2], H, 0, b.off_node[0] + U);
-        packT(T[bn], 2 * H, 0, b.off_node[0] + 2 * U);
-        packT(T[bn], 2 * H, H, b.off_node[0] + 3 * U);
+        packT(T[bn], 2 * H, m->ch * H, b.off_node[0] + 2 * U);
+        packT(T[bn], 2 * H, m->ca * H, b.off_node[0] + 3 * U);
         packT(T[be + 4], H, 0, b.off_edge[0]);
         packT(T[be + 2], H, 0, b.off_edge[0] + U);
-        packT(T[be], 3 * H, 2 * H, b.off_edge[0] + 2 * U);
-        packT(T[be], 3 * H, 0, b.off_enc_node);       // W_i^T, W_j^T: projection backward
-        packT(T[be], 3 * H, H, b.off_enc_node + U);
+        packT(T[be], 3 * H, m->ce * H, b.off_edge[0] + 2 * U);
+        packT(T[be], 3 * H, m->ci * H, b.off_enc_node);       // W_i^T, W_j^T: projection backward
+        packT(T[be], 3 * H, m->cj * H, b.off_enc_node + U);
         rc = launch_pack_t_batch(jobs, b.packT, s);
         if (rc != GM_OK) return rc;
     }
@@ -611,8 +611,8 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         if (rc != GM_OK) return rc;
         wgrad(b.dz3, t.tn.a2, n, grads[bn + 4], H, 0, grads[bn + 5]);
         wgrad(b.dz2, t.tn.a1, n, grads[bn + 2], H, 0, grads[bn + 3]);
-        wgrad(b.dz1, h, n, grads[bn], 2 * H, 0, grads[bn + 1]);
-        wgrad(b.dz1, t.agg, n, grads[bn], 2 * H, H, nullptr);
+        wgrad(b.dz1, h, n, grads[bn], 2 * H, m->ch * H, grads[bn + 1]);
+        wgrad(b.dz1, t.agg, n, grads[bn], 2 * H, m->ca * H, nullptr);
         if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.tn.xhat, n, b.part, grads[bn + 6], grads[bn + 7], s);
         if (rc != GM_OK) return rc;
     }
@@ -625,14 +625,14 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         if (rc != GM_OK) return rc;
         wgrad(b.dz3, t.te.a2, e, grads[be + 4], H, 0, grads[be + 5]);
         wgrad(b.dz2, t.te.a1, e, grads[be + 2], H, 0, grads[be + 3]);
-        if (rc == GM_OK) rc = launch_wgrad(b.dz1, H, H, e_in, H, H, c.eid, e, b.part, grads[be], 3 * H, 2 * H, grads[be + 1], s);
+        if (rc == GM_OK) rc = launch_wgrad(b.dz1, H, H, e_in, H, H, c.eid, e, b.part, grads[be], 3 * H, m->ce * H, grads[be + 1], s);
         if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.te.xhat, e, b.part, grads[be + 6], grads[be + 7], s);
         if (rc != GM_OK) return rc;
     }
     rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dz1, nullptr, nullptr, b.Gi, n, s);
     if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dz1, nullptr, nullptr, b.Gj, n, s);
-    wgrad(b.Gi, h, n, grads[be], 3 * H, 0, nullptr);
-    wgrad(b.Gj, h, n, grads[be], 3 * H, H, nullptr);
+    wgrad(b.Gi, h, n, grads[be], 3 * H, m->ci * H, nullptr);
+    wgrad(b.Gj, h, n, grads[be], 3 * H, m->cj * H, nullptr);
     if (rc != GM_OK) return rc;
     // dh_in = W_h^T dz1 (node MLP) + W_i^T G_i + W_j^T G_j (edge MLP, factorised layer 1)
     TrainBwdArgs a{};

@@ -24,6 +24,22 @@ from ._lib import ModelDesc, check, current_stream, lib, ptr
 from .graph import _need_cuda, _ws
 
 
+FLOWS = {"source_to_target": 0, "target_to_source": 1}
+
+
+def _convention(flow, concat, node_concat):
+    """(flow, col_i, col_j, col_e, node_agg_first) of gm_model_desc from the block's keyword arguments."""
+    if flow not in FLOWS:
+        raise ValueError("flow must be 'source_to_target' (aggregate at edge_index[1]) or 'target_to_source'")
+    concat = tuple(concat)
+    if sorted(concat) != ["e", "i", "j"]:
+        raise ValueError("concat must be a permutation of ('i', 'j', 'e')")
+    node_concat = tuple(node_concat)
+    if sorted(node_concat) != ["agg", "h"]:
+        raise ValueError("node_concat must be ('h', 'agg') or ('agg', 'h')")
+    return (FLOWS[flow], concat.index("i"), concat.index("j"), concat.index("e"), 1 if node_concat[0] == "agg" else 0)
+
+
 def _mlp_params(seq):
     """Parameters of a reference-style MLP in state_dict order."""
     return [p for _, p in seq.named_parameters()]
@@ -187,7 +203,7 @@ class _InteractionNetworkFunction(torch.autograd.Function):
 class DstCsr:
     """Destination-sorted edge structure of an edge_index [2, E] (int64) on the device."""
 
-    def __init__(self, edge_index, n_nodes):
+    def __init__(self, edge_index, n_nodes, flow=0):
         _need_cuda(edge_index, "edge_index")
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be int64 [2, E]")
@@ -196,7 +212,7 @@ class DstCsr:
         self.e = int(ei.shape[1])
         L = lib()
         self.ws = _ws(L.gm_csr_workspace_bytes(self.n, self.e), ei.device)
-        check(L.gm_csr_from_edge_index(ptr(ei), self.n, self.e, ptr(self.ws), self.ws.numel(), current_stream()))
+        check(L.gm_csr_from_edge_index_flow(ptr(ei), self.n, self.e, int(flow), ptr(self.ws), self.ws.numel(), current_stream()))
 
     def validate(self):
         e = C.c_int64(0)
@@ -257,12 +273,18 @@ class GraphIndependent(nn.Module):
 
 
 class InteractionNetwork(nn.Module):
-    """``torch_graphnet.InteractionNetwork(phi_edge=, phi_node=)``: (h, e, idx) -> (h', e', None)."""
+    """``torch_graphnet.InteractionNetwork(phi_edge=, phi_node=)``: (h, e, idx) -> (h', e', None).
 
-    def __init__(self, phi_edge, phi_node):
+    The block's source is absent from the reference tree (.gitmodules:1-3); the defaults are the convention of DESIGN.md
+    section 2.  ``flow`` / ``concat`` / ``node_concat`` select another one so that a checkpoint trained with the real block can
+    be matched: flow='target_to_source' aggregates at edge_index[0]; concat is the order in which (h_i, h_j, e) enter phi_e;
+    node_concat the order of (h, agg) in phi_v.  They act when the weights are packed and the edges are sorted, not at run time."""
+
+    def __init__(self, phi_edge, phi_node, flow="source_to_target", concat=("i", "j", "e"), node_concat=("h", "agg")):
         super().__init__()
         self.phi_edge = phi_edge
         self.phi_node = phi_node
+        self.convention = _convention(flow, concat, node_concat)
         self._handle = _Handle()
         self._pad = {}
 
@@ -272,7 +294,7 @@ class InteractionNetwork(nn.Module):
         if le[0].in_features != 3 * hidden:
             raise ValueError("InteractionNetwork.phi_edge must take 3*hidden inputs ([h_i, h_j, e])")
         eps = ne[0].eps if ne else 1e-5
-        desc = (1, 1, 1, hidden, nl, 1, float(eps))
+        desc = (1, 1, 1, hidden, nl, 1, float(eps)) + self.convention
         if str(device) not in self._pad:
             self._pad[str(device)] = (_zeros_mlp(1, hidden, hidden, nl, True, device) + _zeros_mlp(1, hidden, hidden, nl, True, device),
                                       _zeros_mlp(hidden, hidden, 1, nl, False, device))
@@ -300,7 +322,7 @@ def _run_block(handle, desc, k, x, edge_attr, edge_index, csr=None):
     edge_attr = edge_attr.contiguous().float()
     n, e = x.shape[0], edge_attr.shape[0]
     if csr is None:
-        csr = DstCsr(edge_index, n)
+        csr = DstCsr(edge_index, n, flow=desc[7] if len(desc) > 7 else 0)
     L = lib()
     d = ModelDesc(*desc)
     fwd = _ws(L.gm_forward_workspace_bytes(C.byref(d), n, 0), x.device)
@@ -350,7 +372,10 @@ class _EpdTrainFunction(torch.autograd.Function):
 class EncProcDecGNN(nn.Module):
     """Drop-in for the reference ``EncProcDecGNN`` (gnn_manip/models/epd_gnn.py:11-105)."""
 
-    def __init__(self, node_dim, edge_dim, out_dim, hidden_size, num_layers, m_steps, norm_type='LayerNorm'):
+    def __init__(self, node_dim, edge_dim, out_dim, hidden_size, num_layers, m_steps, norm_type='LayerNorm', *,
+                 flow="source_to_target", concat=("i", "j", "e"), node_concat=("h", "agg")):
+        """Positional arguments as the reference (epd_gnn.py:13-14).  The keyword-only flow / concat / node_concat choose the
+        InteractionNetwork convention (see ``InteractionNetwork``); the defaults are the documented one."""
         super().__init__()
         assert (num_layers >= 2), "The number of layers num_layers must be at least 2"
         assert (m_steps >= 1), "The number of m_steps message pasting steps must be at least 1"
@@ -358,11 +383,13 @@ class EncProcDecGNN(nn.Module):
             # the reference's BatchNorm2d / InstanceNorm2d branches (epd_gnn.py:53-58) cannot run on its 2-D inputs
             raise NotImplementedError("only norm_type='LayerNorm' is supported")
         self.dims = (node_dim, edge_dim, out_dim, hidden_size, num_layers, m_steps)
+        self.convention = _convention(flow, concat, node_concat)
         self.encoder = GraphIndependent(phi_edge=self._build_mlp(edge_dim, hidden_size, hidden_size, num_layers, norm=True),
                                         phi_node=self._build_mlp(node_dim, hidden_size, hidden_size, num_layers, norm=True))
         self.processor = nn.ModuleList([
             InteractionNetwork(phi_edge=self._build_mlp(3 * hidden_size, hidden_size, hidden_size, num_layers, norm=True),
-                               phi_node=self._build_mlp(2 * hidden_size, hidden_size, hidden_size, num_layers, norm=True))
+                               phi_node=self._build_mlp(2 * hidden_size, hidden_size, hidden_size, num_layers, norm=True),
+                               flow=flow, concat=concat, node_concat=node_concat)
             for _ in range(m_steps)])
         self.decoder = self._build_mlp(hidden_size, hidden_size, out_dim, num_layers, norm=False)
         self._handle = _Handle()
@@ -390,7 +417,7 @@ class EncProcDecGNN(nn.Module):
     # -- device handle
     def model_desc(self):
         eps = self.encoder.phi_edge[-1].eps
-        return tuple(int(v) for v in self.dims) + (float(eps),)
+        return tuple(int(v) for v in self.dims) + (float(eps),) + self.convention
 
     def device_handle(self, device):
         """gm_model* for the current parameters on `device` (packed once, re-packed on change)."""
@@ -422,7 +449,7 @@ class EncProcDecGNN(nn.Module):
             _check_edge_index(edge_index, n, e)
             return _EpdTrainFunction.apply(self, nodes, edge_attr, edge_index, *params)
         h = self.device_handle(nodes.device)
-        csr = DstCsr(edge_index, n)
+        csr = DstCsr(edge_index, n, flow=self.convention[0])
         L = lib()
         d = ModelDesc(*self.model_desc())
         fwd = _ws(L.gm_forward_workspace_bytes(C.byref(d), n, e), nodes.device)

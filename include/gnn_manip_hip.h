@@ -76,6 +76,11 @@ int gm_csr_from_graph(const void* graph_ws, int64_t n_nodes, int max_neighbours,
                       void* csr_ws, size_t csr_ws_bytes, void* stream);
 int gm_csr_from_edge_index(const int64_t* edge_index /* [2,E] row-major */, int64_t n_nodes,
                            int64_t n_edges, void* csr_ws, size_t csr_ws_bytes, void* stream);
+/* The same with the aggregation index chosen by `flow` (gm_model_desc.flow): 0 = edge_index[1] (default), 1 = edge_index[0]. */
+int gm_csr_from_graph_flow(const void* graph_ws, int64_t n_nodes, int max_neighbours, int flow,
+                           void* csr_ws, size_t csr_ws_bytes, void* stream);
+int gm_csr_from_edge_index_flow(const int64_t* edge_index, int64_t n_nodes, int64_t n_edges, int flow,
+                                void* csr_ws, size_t csr_ws_bytes, void* stream);
 /* Synchronises; copies E and error flags to the host. */
 int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream);
 
@@ -149,6 +154,12 @@ typedef struct gm_model_desc {
     int32_t num_layers;    /* >= 2: hidden layers per MLP (epd_gnn.py:26) */
     int32_t m_steps;       /* >= 1 */
     float ln_eps;          /* 1e-5 */
+    /* Convention of the torch_graphnet.InteractionNetwork block, whose source is absent from the reference tree
+     * (.gitmodules:1-3).  All zero = the default of DESIGN.md section 2 (BASELINE.json north_star wording, PyG
+     * source_to_target).  Exposed so that a checkpoint trained with another convention can be matched. */
+    int32_t flow;          /* 0: j = edge_index[0], aggregation index i = edge_index[1]; 1: i = edge_index[0], j = edge_index[1] */
+    int32_t col_i, col_j, col_e; /* column block (0, 1, 2) of phi_e's first Linear that multiplies h_i, h_j, e; all zero = (0, 1, 2) */
+    int32_t node_agg_first; /* 0: phi_v(cat[h, agg]); 1: phi_v(cat[agg, h]) */
 } gm_model_desc;
 
 int gm_model_num_tensors(const gm_model_desc* desc);

@@ -331,29 +331,37 @@ def graph_independent(params, prefix, x, edge_attr, num_layers):
             mlp(params, f"{prefix}.phi_edge", edge_attr, num_layers, True))
 
 
-def interaction_network(params, prefix, h, e, edge_index, num_layers):
+def interaction_network(params, prefix, h, e, edge_index, num_layers, flow="source_to_target", concat=("i", "j", "e"),
+                        node_concat=("h", "agg")):
     """InteractionNetwork block (call site epd_gnn.py:101); semantics per north_star.
 
-    j = edge_index[0] (source), i = edge_index[1] (target / aggregation index).
+    Default convention: j = edge_index[0] (source), i = edge_index[1] (target / aggregation index),
     e' = phi_e(cat[h_i, h_j, e]); agg_i = sum_{e->i} e'; h' = phi_v(cat[h, agg]).
     No residual inside the block (added by the caller, epd_gnn.py:103-104).
+    The block's source is absent from the reference tree: flow / concat / node_concat restate the other conventions a
+    PyG-style block could have (flow 'target_to_source': i = edge_index[0]; concat: order of (h_i, h_j, e); node_concat:
+    order of (h, agg)), so that the product's switch for them can be checked.
     """
-    j = np.asarray(edge_index[0])
-    i = np.asarray(edge_index[1])
-    e_in = np.concatenate((h[i], h[j], e), axis=-1)
+    if flow == "source_to_target":
+        j, i = np.asarray(edge_index[0]), np.asarray(edge_index[1])
+    else:
+        i, j = np.asarray(edge_index[0]), np.asarray(edge_index[1])
+    parts = {"i": h[i], "j": h[j], "e": e}
+    e_in = np.concatenate([parts[c] for c in concat], axis=-1)
     e_new = mlp(params, f"{prefix}.phi_edge", e_in, num_layers, True)
     agg = np.zeros_like(h)
     np.add.at(agg, i, e_new)
-    h_in = np.concatenate((h, agg), axis=-1)
+    nparts = {"h": h, "agg": agg}
+    h_in = np.concatenate([nparts[c] for c in node_concat], axis=-1)
     h_new = mlp(params, f"{prefix}.phi_node", h_in, num_layers, True)
     return h_new, e_new
 
 
-def epd_forward(params, nodes, edge_attr, edge_index, num_layers=2, m_steps=10):
+def epd_forward(params, nodes, edge_attr, edge_index, num_layers=2, m_steps=10, **convention):
     """EncProcDecGNN.forward (epd_gnn.py:86-105)."""
     h, e = graph_independent(params, "encoder", nodes, edge_attr, num_layers)
     for k in range(m_steps):
-        hn, en = interaction_network(params, f"processor.{k}", h, e, edge_index, num_layers)
+        hn, en = interaction_network(params, f"processor.{k}", h, e, edge_index, num_layers, **convention)
         h = hn + h  # epd_gnn.py:103
         e = en + e  # epd_gnn.py:104
     return mlp(params, "decoder", h, num_layers, False)

@@ -92,6 +92,25 @@ def test_forward_full_size_two_kernel_sets_agree(dev, scene100k):
     assert (a - c).abs().max() <= 1e-5 * a.abs().max()
 
 
+def test_forward_c3_size_against_the_oracle(dev):
+    """EncProcDecGNN.forward at BASELINE config C3's size (N = 50k, E ~ 1M) with m_steps = 2 against the numpy oracle on
+    the same graph and weights: 1e-5 relative (north_star).  The production path of this size: systolic fp16 x 3 edge kernel."""
+    from gnn_manip_amd import EncProcDecGNN, scene
+    obs = scene.make_scene(50000, seed=6)
+    params = orc.init_params(25, 4, 3, 128, 2, 2, 79)
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 2)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev)
+    nodes, ea, s, r, _ = orc.process(obs, None, STATS, BOUNDS, 0.015, CART, MAT, CTRL)
+    ei = np.stack((s, r))
+    assert ei.shape[1] > 900000
+    with torch.no_grad():
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    ref = orc.epd_forward(params, nodes, ea, ei, 2, 2)
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
 def test_rollout_full_size_state_properties(dev, scene100k):
     """Three device-resident steps at N = 100k: the window shifts bit-exactly, rigid rows land on the scripted pose,
     control columns hold pose - position, everything stays finite, the edge count is the graph's."""

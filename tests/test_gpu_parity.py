@@ -408,3 +408,84 @@ def test_split_operand_kernels_are_as_accurate_as_float32(dev, choice):
         out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
     err = np.abs(out - ref).max() / np.abs(ref).max()
     assert err <= max(2.5 * err32, 2.5e-6), (err, err32)
+
+
+# ------------------------------------------------------------------ a9: the block-convention switch
+CONVENTIONS = [
+    dict(flow="target_to_source"),
+    dict(concat=("e", "j", "i"), node_concat=("agg", "h")),
+    dict(flow="target_to_source", concat=("j", "e", "i")),
+]
+
+
+@pytest.mark.parametrize("conv", CONVENTIONS)
+def test_block_convention_switch_forward_block_and_rollout(dev, conv):
+    """torch_graphnet's source is absent from the reference: the aggregation row (flow) and the concat orders of the
+    InteractionNetwork are selectable.  Each choice must equal the oracle restated with the same choice -- in the fused
+    forward (systolic edge kernel), in the standalone block and in the device-resident rollout (graph -> sort path)."""
+    from gnn_manip_amd import EncProcDecGNN, RolloutEngine, scene
+    n = 900
+    obs = scene.make_scene(n, seed=95, side=0.075)
+    params = orc.init_params(25, 4, 3, 128, 2, 3, 96)
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 3, **conv)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.to(dev)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    ei = np.stack((s, r))
+    with torch.no_grad():
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    ref = orc.epd_forward(params, nodes, ea, ei, 2, 3, **conv)
+    dflt = orc.epd_forward(params, nodes, ea, ei, 2, 3)
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(ref - dflt).max() > 1e-3 * np.abs(ref).max()   # the conventions really differ on this (asymmetric) graph
+    # standalone block
+    h0, e0 = orc.graph_independent(params, "encoder", nodes, ea, 2)
+    with torch.no_grad():
+        h1, e1, _ = m.processor[0](_t(h0, dev), _t(e0, dev), _t(ei, dev))
+    h1o, e1o = orc.interaction_network(params, "processor.0", h0, e0, ei, 2, **conv)
+    np.testing.assert_allclose(e1.cpu().numpy(), e1o, rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), h1o, rtol=1e-5, atol=5e-6)
+    # rollout: the destination sort of the radius graph follows the flow
+    traj = scene.rigid_drift_trajectory(obs, 2)
+    eng = RolloutEngine(m, _ga(), n, device=dev)
+    with torch.no_grad():
+        final = eng.rollout(_t(obs, dev), _t(traj, dev), horizon=2).cpu().numpy()
+    fwd = lambda nn, ee, ii: orc.epd_forward(params, nn, ee, ii, 2, 3, **conv)
+    refs = orc.rollout(params, obs, traj, 2, STATS, BOUNDS, 0.015, CART, MAT, CTRL, forward_fn=fwd)
+    np.testing.assert_allclose(final[:, :, 2:5], refs[:, :, 2:5], rtol=0, atol=5e-6)
+
+
+def test_block_convention_switch_trains(dev):
+    """The training path packs the same column blocks: loss gradients of a non-default convention against autograd through
+    a plain-torch restatement of that convention."""
+    import torch.nn.functional as F
+    from gnn_manip_amd import EncProcDecGNN, scene
+    conv = dict(flow="target_to_source", concat=("e", "j", "i"), node_concat=("agg", "h"))
+    n = 300
+    obs = scene.make_scene(n, seed=97, side=0.06)
+    params = orc.init_params(25, 4, 3, 128, 2, 2, 98)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    ei = np.stack((s, r))
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 2, **conv)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.to(dev)
+    out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+    out.abs().sum().backward()
+    # float64 torch restatement of the same convention
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    from oracle import torch_epd
+    x, e_t, idx = torch.tensor(nodes, dtype=torch.float64), torch.tensor(ea, dtype=torch.float64), torch.tensor(ei)
+    i, j = idx[0], idx[1]
+    h = torch_epd.mlp(p, "encoder.phi_node", x, 2, True)
+    e = torch_epd.mlp(p, "encoder.phi_edge", e_t, 2, True)
+    for k in range(2):
+        en = torch_epd.mlp(p, f"processor.{k}.phi_edge", torch.cat((e, h[j], h[i]), dim=1), 2, True)
+        agg = torch.zeros_like(h).index_add_(0, i, en)
+        hn = torch_epd.mlp(p, f"processor.{k}.phi_node", torch.cat((agg, h), dim=1), 2, True)
+        h, e = h + hn, e + en
+    ref = torch_epd.mlp(p, "decoder", h, 2, False)
+    ref.abs().sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for name, prm in m.named_parameters():
+        g, gr = prm.grad.cpu().numpy(), p[name].grad.numpy()
+        assert np.abs(g - gr).max() <= 2e-3 * max(np.abs(gr).max(), 1e-6), name
