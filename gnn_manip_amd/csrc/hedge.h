@@ -9,10 +9,11 @@ namespace gm {
 struct EdgeBlockHeader {
     int n_blocks;
     int n_chunks;
-    int chunk_blocks;   // blocks per chunk (the aggregation's carry resets at chunk starts)
+    int chunk_blocks;   // unused (chunk sizes are per graph: edge_chunk_blocks)
     int n_graphs;
     int n_per_graph;
-    int pad[3];
+    int n_cus;          // CU count the chunk sizes were derived with
+    int pad[2];
 };
 struct EdgeBlocks {
     EdgeBlockHeader* hdr;

@@ -30,15 +30,9 @@
 #include "common.h"
 #include "mlp.h"
 #include "hedge.h"
+#include "hmma_dev.h"
 
 namespace gm {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float float2v __attribute__((ext_vector_type(2)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
-typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -64,23 +58,6 @@ struct SysArgs {
     float eps;
     int residual;
 };
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ unsigned cvt_pk(float a, float b) { unsigned u; asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b)); return u; }
-__device__ __forceinline__ float sub_lo(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
-__device__ __forceinline__ float sub_hi(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
-// compiler-visible on purpose: it is the first reader of MFMA results, and hipcc pads the MFMA -> VALU hazard only for
-// instructions it knows (an inline-asm reader sees stale accumulators)
-__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 65504.f); }
-
-// two-way fp16 split of 4 floats: hi / lo as two dwords each (elements in order)
-__device__ __forceinline__ void split4(float a, float b, float c, float d, uintx2& hi, uintx2& lo) {
-    hi[0] = cvt_pk(a, b);
-    hi[1] = cvt_pk(c, d);
-    lo[0] = cvt_pk(sub_lo(hi[0], a), sub_hi(hi[0], b));
-    lo[1] = cvt_pk(sub_lo(hi[1], c), sub_hi(hi[1], d));
-}
 
 // accumulator registers 8q..8q+7 of a wave's 32-feature block are the elements of B fragment ks = 2 jb + q (same lane):
 // K slot (lane >> 5, j) of k-group ks carries feature 16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) in both operands
@@ -133,11 +110,6 @@ __device__ __forceinline__ void mlp_layer(floatx16& acc, const half8 (&wh)[8], c
     }
     GM_SB;
 }
-
-// x += lanes(x shifted) * f.  The value is produced by compiler code just before: the VALU -> DPP hazard (2 wait states) of
-// the first reader is padded by hand, hipcc pads nothing inside asm.
-#define DPP_FMAC(x, f, ctrl) asm volatile("v_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(x) : "v"(f))
-#define DPP_FMAC_NOP(x, f, ctrl) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(x) : "v"(f))
 
 // LayerNorm of an edge from the eight 16-feature partials (mean_p, M2_p) of the SCALED accumulators (one per wave and
 // lane half): parallel-variance merge; returns k, m with  x_hat = acc * k + m   (k = rstd / T, m = -mean_acc * k)
@@ -563,51 +535,48 @@ __global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
 // ------------------------------------------------------------------------------------------
 // block / chunk tables of a destination-sorted edge list that holds one or more equal-sized graphs back to back
 // ------------------------------------------------------------------------------------------
+__host__ __device__ inline int edge_blocks_padded(int n_edges) { return ((n_edges + BE - 1) / BE + 3) & ~3; }
+// blocks per chunk of a graph with nbk blocks: about 4 chunks per CU for one big graph, between 4 and 32 blocks, multiple of 4
+__host__ __device__ inline int edge_chunk_blocks(int nbk, int n_cus) {
+    int cb = (nbk + 4 * n_cus - 1) / (4 * n_cus);
+    cb = (cb + 3) & ~3;
+    return cb < 4 ? 4 : (cb > 32 ? 32 : cb);
+}
+
 __global__ void __launch_bounds__(256) edge_blocks_plan_kernel(const int* __restrict__ in_ptr, int n_nodes, const int* n_per_dev, int n_per_host,
                                                                int n_cus, EdgeBlockHeader* tab, int* gblk, int* gch, int max_graphs) {
-    // one workgroup: per-graph block / chunk counts and their prefixes
-    __shared__ int s_total;
-    const int tid = threadIdx.x;
+    // one thread: per-graph block / chunk counts and their prefixes.  Every graph is padded to a multiple of 4 blocks (the
+    // row group of a wave in hmlp.hip) and its chunk size depends on ITS block count only: the partial sums of a graph do
+    // not depend on what else shares the launch.
+    if (threadIdx.x != 0) return;
     int n_per = n_per_dev ? *n_per_dev : n_per_host;
     if (n_per <= 0) n_per = n_nodes > 0 ? n_nodes : 1;
     int G = (n_nodes + n_per - 1) / n_per;
     if (G > max_graphs) G = max_graphs;   // capacity of the prefix arrays (never hit: they hold n_nodes + 2 entries)
-    if (tid == 0) {
-        int tot = 0;
-        for (int g = 0; g < G; ++g) {
-            const int lo = g * n_per, hi = min(n_nodes, (g + 1) * n_per);
-            tot += (in_ptr[hi] - in_ptr[lo] + BE - 1) / BE;
-        }
-        s_total = tot;
+    int pb = 0, pc = 0;
+    for (int g = 0; g < G; ++g) {
+        const int lo = g * n_per, hi = min(n_nodes, (g + 1) * n_per);
+        const int nbk = edge_blocks_padded(in_ptr[hi] - in_ptr[lo]);
+        const int cb = edge_chunk_blocks(nbk, n_cus);
+        gblk[g] = pb;
+        gch[g] = pc;
+        pb += nbk;
+        pc += (nbk + cb - 1) / cb;
     }
-    __syncthreads();
-    const int tot = s_total;
-    int cb = (tot + 4 * n_cus - 1) / (4 * n_cus);
-    cb = cb < 4 ? 4 : (cb > 32 ? 32 : cb);
-    if (tid == 0) {
-        int pb = 0, pc = 0;
-        for (int g = 0; g < G; ++g) {
-            const int lo = g * n_per, hi = min(n_nodes, (g + 1) * n_per);
-            const int nbk = (in_ptr[hi] - in_ptr[lo] + BE - 1) / BE;
-            gblk[g] = pb;
-            gch[g] = pc;
-            pb += nbk;
-            pc += (nbk + cb - 1) / cb;
-        }
-        gblk[G] = pb;
-        gch[G] = pc;
-        tab->n_blocks = pb;
-        tab->n_chunks = pc;
-        tab->chunk_blocks = cb;
-        tab->n_graphs = G;
-        tab->n_per_graph = n_per;
-    }
+    gblk[G] = pb;
+    gch[G] = pc;
+    tab->n_blocks = pb;
+    tab->n_chunks = pc;
+    tab->chunk_blocks = 0;
+    tab->n_graphs = G;
+    tab->n_per_graph = n_per;
+    tab->n_cus = n_cus;
 }
 
 __global__ void __launch_bounds__(256) edge_blocks_fill_kernel(const int* __restrict__ in_ptr, int n_nodes, const EdgeBlockHeader* tab,
                                                                const int* __restrict__ gblk, const int* __restrict__ gch, int2* blk,
                                                                int* chunk_first) {
-    const int nblk = tab->n_blocks, G = tab->n_graphs, cb = tab->chunk_blocks, n_per = tab->n_per_graph;
+    const int nblk = tab->n_blocks, G = tab->n_graphs, n_per = tab->n_per_graph;
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
         int lo = 0, hi = G;   // graph g with gblk[g] <= b < gblk[g + 1]
         while (hi - lo > 1) {
@@ -616,9 +585,10 @@ __global__ void __launch_bounds__(256) edge_blocks_fill_kernel(const int* __rest
         }
         const int g = lo, j = b - gblk[g];
         const int e0 = in_ptr[g * n_per], e1 = in_ptr[min(n_nodes, (g + 1) * n_per)];
-        const int start = e0 + j * BE;
-        const int cnt = min(BE, e1 - start);
         const int nbk = gblk[g + 1] - gblk[g];
+        const int cb = edge_chunk_blocks(nbk, tab->n_cus);
+        const int start = min(e0 + j * BE, e1);          // padding blocks: (end of the graph, 0 edges)
+        const int cnt = min(BE, e1 - start);
         int fl = 0;
         if (j % cb == 0) { fl |= 1; chunk_first[gch[g] + j / cb] = b; }
         if (j % cb == cb - 1 || j == nbk - 1) fl |= 2;
@@ -647,14 +617,14 @@ int pack_h3(const PackH3Job* jobs, int n, hipStream_t s) {
 }
 
 size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity) {
-    const size_t nblk = (size_t)cdiv(edge_capacity, BE) + (size_t)n_nodes + 2;
+    const size_t nblk = (size_t)cdiv(edge_capacity, BE) + 4 * (size_t)n_nodes + 4;   // each graph: up to 3 padding blocks + 1 partial
     // header | gblk[n+2] | gch[n+2] | chunk_first[nblk + 2] | blk[nblk] (int2)
     return 8 + 2 * ((size_t)n_nodes + 2) + (nblk + 2) + 2 * nblk;
 }
 
 EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity) {
     EdgeBlocks t;
-    const size_t nblk = (size_t)cdiv(edge_capacity, BE) + (size_t)n_nodes + 2;
+    const size_t nblk = (size_t)cdiv(edge_capacity, BE) + 4 * (size_t)n_nodes + 4;   // each graph: up to 3 padding blocks + 1 partial
     t.hdr = reinterpret_cast<EdgeBlockHeader*>(base);
     t.gblk = base + 8;
     t.gch = t.gblk + n_nodes + 2;

@@ -1,0 +1,723 @@
+// Fused MLP kernels of the encode-process-decode model on the fp16 matrix pipe with fp32 accuracy, for hidden sizes
+// 64 / 128 / 256 and any num_layers >= 2 (epd_gnn.py:63-84 builds num_layers + 1 Linears for any value; train_dyn.py:237-238
+// exposes both as options):
+//   hm_edge_kernel<H, ENC>   encoder phi_e (ENC) or processor phi_e + LayerNorm + residual + scatter-add (epd_gnn.py:35-46,100-105)
+//   hm_node_kernel<H, MODE>  encoder phi_v (0), processor phi_v (1), projection only (2); tails: the next step's
+//                            P = h [W_i | W_j]^T + b1, or the decoder MLP (epd_gnn.py:47-48,107)
+//
+// Arithmetic: hmma_dev.h (two-way fp16 operand split, three exact partial products per multiply, fp32 accumulation).
+// Every Linear is pre-scaled by a power of two t (hmlp.h); the scale is removed where the accumulators are read
+// (ReLU / LayerNorm statistics / outputs), so activations keep their natural magnitude whatever the depth.
+//
+// Structure.  One 8-wave workgroup per CU walks over tiles of M rows with M * H = 32768: the fp16 hi / lo operand image of
+// a tile's activations is exactly 128 KiB of LDS.  Wave (rg, jb) owns output block jb (32 features) of the 128 rows of row
+// group rg: 4 accumulator tiles.  Per k-group it reads its A fragments (weights: 1 KiB, wave-private, prefetched two
+// k-groups ahead straight from L2 -- the weights of a Linear do not fit registers or LDS next to the image at H = 256) and
+// 8 B fragments from the image, and issues 12 MFMAs.  Between Linears: barrier, accumulators -> ReLU -> split -> image,
+// barrier.  LayerNorm statistics are merged across the waves of a row through LDS (parallel-variance merge); outputs,
+// the residual and the scatter-add work directly on the accumulator layout (16-byte pieces of the rows).
+//
+// The scatter-add is the one of hedge.hip: segmented DPP scan over the destination-sorted rows, one row store per finished
+// segment, atomics only for the (at most two) partial segments at the ends of a wave's 4-block group; groups are aligned
+// to each graph's first block (build_edge_blocks pads every graph to a multiple of 4 blocks), so a graph gives the same
+// sums alone or inside a batch.
+//
+// Built with -fno-slp-vectorize like hedge.hip.
+#include "common.h"
+#include "mlp.h"
+#include "hedge.h"
+#include "hmlp.h"
+#include "hmma_dev.h"
+
+namespace gm {
+
+namespace {
+
+constexpr int HM_THREADS = 512;
+constexpr int HM_WAVES = 8;
+constexpr int BE = 32;
+constexpr size_t HM_IMG_BYTES = 131072;
+constexpr size_t HM_ST_BYTES = 16384;    // [NRB][2 NJB partials][32 rows] float2  (NRB * 2 NJB = 64)
+constexpr size_t HM_BLK_BYTES = 2 * 16 * sizeof(int2);
+constexpr size_t HM_LDS_BYTES = HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES + 2 * 256 * sizeof(float);   // + gamma | beta
+
+template <int H>
+struct Cfg {
+    static constexpr int NJB = H / 32;           // output blocks = waves per row group
+    static constexpr int KS = H / 16;            // k-groups of an H-wide input
+    static constexpr int NRG = HM_WAVES / NJB;   // row groups
+    static constexpr int NRB = 4 * NRG;          // 32-row blocks per tile
+    static constexpr int M = 32 * NRB;           // rows per tile
+};
+
+struct Lin {
+    float t, inv_t;
+    const float* bias;
+    const half8* frag;
+};
+__device__ __forceinline__ Lin lin_at(const float* p, int out_pad) {
+    Lin L;
+    L.t = p[0];
+    L.inv_t = p[1];
+    L.bias = p + 4;
+    L.frag = reinterpret_cast<const half8*>(p + 4 + out_pad);
+    return L;
+}
+
+// accumulators of the wave's 4 row blocks <- bias (already scaled) of output block jbv
+__device__ __forceinline__ void init_bias(floatx16 (&acc)[4], const float* bias, int jbv, int hi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const floatx4 v = *reinterpret_cast<const floatx4*>(bias + 32 * jbv + 8 * g + 4 * hi);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[rb][4 * g + tt] = v[tt];
+    }
+}
+
+// acc[rb] += W[jb block, k-groups ks0 .. ks0 + nks) x image rows of row block rb.
+//   wf : this wave's fragments of the first k-group, + lane  (k-group stride 128 half8)
+//   im : image of the wave's first row block at k-group 0, + lane  (row-block stride img_ksn * 128, k-group stride 128)
+__device__ __forceinline__ void gemm(floatx16 (&acc)[4], const half8* __restrict__ wf, const half8* im, int img_ksn, int nks) {
+    half8 ah0 = wf[0], al0 = wf[64], ah1 = ah0, al1 = al0;
+    if (nks > 1) { ah1 = wf[128]; al1 = wf[192]; }
+    half8 bh[4], bl[4], ch[4], cl[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) { bh[rb] = im[rb * img_ksn * 128]; bl[rb] = im[rb * img_ksn * 128 + 64]; }
+#pragma unroll 1
+    for (int ks = 0; ks < nks; ks += 2) {
+        if (ks + 1 < nks) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) { ch[rb] = im[(rb * img_ksn + ks + 1) * 128]; cl[rb] = im[(rb * img_ksn + ks + 1) * 128 + 64]; }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[rb], acc[rb], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[rb], acc[rb], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[rb], acc[rb], 0, 0, 0);
+        if (ks + 2 < nks) { ah0 = wf[(ks + 2) * 128]; al0 = wf[(ks + 2) * 128 + 64]; }
+        if (ks + 1 < nks) {
+            if (ks + 2 < nks) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) { bh[rb] = im[(rb * img_ksn + ks + 2) * 128]; bl[rb] = im[(rb * img_ksn + ks + 2) * 128 + 64]; }
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, ch[rb], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, cl[rb], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, ch[rb], acc[rb], 0, 0, 0);
+            if (ks + 3 < nks) { ah1 = wf[(ks + 3) * 128]; al1 = wf[(ks + 3) * 128 + 64]; }
+        }
+    }
+}
+
+// accumulators (scaled by 1/s) -> [ReLU] -> fp16 hi / lo -> the wave's two k-groups of the image of row block rb
+template <bool RELU>
+__device__ __forceinline__ void acc_to_img(const floatx16& a, float s, uintx4* img_rb, int jb, int lane) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (RELU ? relu(a[8 * q + j]) : a[8 * q + j]) * s;
+        uintx2 h0, l0, h1, l1;
+        split4(v[0], v[1], v[2], v[3], h0, l0);
+        split4(v[4], v[5], v[6], v[7], h1, l1);
+        img_rb[((2 * jb + q) * 2 + 0) * 64 + lane] = uintx4{h0[0], h0[1], h1[0], h1[1]};
+        img_rb[((2 * jb + q) * 2 + 1) * 64 + lane] = uintx4{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
+// rows of H floats -> image (k-group count KS).  64 units of (16 rows, 2 k-groups) per tile, 8 per wave; lane = (row, k-group
+// parity, kg) reads the two 16-byte pieces that make its 8 K slots.  row_of(rbg, n) returns the source row (or -1: zeros).
+template <int H, int UNR, class R, class Z>
+__device__ __forceinline__ void rows_to_image(const float* __restrict__ src, uintx4* img, int wave, int lane, R&& row_of, Z&& after) {
+    using C = Cfg<H>;
+#pragma unroll UNR
+    for (int it = 0; it < 8; ++it) {
+        const int u = it * 8 + wave;
+        const int rowhalf = u % (2 * C::NRB), kspair = u / (2 * C::NRB);
+        const int rbg = rowhalf >> 1, nn = 16 * (rowhalf & 1) + (lane & 15), c = lane >> 4, ks = 2 * kspair + (c >> 1), kg = c & 1;
+        const long long row = row_of(rbg, nn);
+        const float* p = src + row * H + 16 * ks + 4 * kg;
+        const floatx4 v0 = *reinterpret_cast<const floatx4*>(p);
+        const floatx4 v1 = *reinterpret_cast<const floatx4*>(p + 8);
+        after(const_cast<float*>(p));
+        uintx2 h0, l0, h1, l1;
+        split4(v0[0], v0[1], v0[2], v0[3], h0, l0);
+        split4(v1[0], v1[1], v1[2], v1[3], h1, l1);
+        img[((rbg * C::KS + ks) * 2 + 0) * 64 + nn + 32 * kg] = uintx4{h0[0], h0[1], h1[0], h1[1]};
+        img[((rbg * C::KS + ks) * 2 + 1) * 64 + nn + 32 * kg] = uintx4{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
+// rows of k1 <= 16 KSN floats -> image with KSN k-groups (zero-padded)
+template <int H, int KSN, class R>
+__device__ __forceinline__ void narrow_rows_to_image(const float* __restrict__ src, int k1, uintx4* img, int tid, R&& row_of) {
+    using C = Cfg<H>;
+    for (int i = tid; i < C::NRB * KSN * 64; i += HM_THREADS) {
+        const int rbg = i / (KSN * 64), rem = i % (KSN * 64), ks = rem >> 6, l = rem & 63, nn = l & 31, kg = l >> 5;
+        const long long row = row_of(rbg, nn);
+        const float* p = src + row * k1;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = 16 * ks + 8 * (j >> 2) + 4 * kg + (j & 3);
+            v[j] = f < k1 ? p[f] : 0.f;
+        }
+        uintx2 h0, l0, h1, l1;
+        split4(v[0], v[1], v[2], v[3], h0, l0);
+        split4(v[4], v[5], v[6], v[7], h1, l1);
+        img[((rbg * KSN + ks) * 2 + 0) * 64 + l] = uintx4{h0[0], h0[1], h1[0], h1[1]};
+        img[((rbg * KSN + ks) * 2 + 1) * 64 + l] = uintx4{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
+// LayerNorm statistics of the wave's rows.  Each lane first publishes (mean, M2) of its 16 accumulator values per row
+// block; after the barrier every wave merges the 2 NJB partials of its rows: x_hat = acc * k + m.
+template <int H>
+__device__ __forceinline__ void ln_publish(const floatx16 (&acc)[4], float* ST, int rg, int jb, int n, int hi) {
+    using C = Cfg<H>;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[rb][r];
+        const float mh = s * (1.0f / 16.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc[rb][r] - mh; q = fmaf(d, d, q); }
+        *reinterpret_cast<float2v*>(ST + ((((4 * rg + rb) * 2 * C::NJB) + 2 * jb + hi) * BE + n) * 2) = float2v{mh, q};
+    }
+}
+template <int H>
+__device__ __forceinline__ void ln_merge(const float* ST, int rbg, int n, float t, float eps, float& k, float& m) {
+    using C = Cfg<H>;
+    constexpr int NP = 2 * C::NJB;
+    const float* st = ST + (rbg * NP * BE + n) * 2;
+    float mw[NP], m2 = 0.f, mean = 0.f;
+#pragma unroll
+    for (int w = 0; w < NP; ++w) {
+        const float2v s = *reinterpret_cast<const float2v*>(st + w * BE * 2);
+        mw[w] = s[0];
+        m2 += s[1];
+        mean += s[0];
+    }
+    mean *= 1.0f / NP;
+#pragma unroll
+    for (int w = 0; w < NP; ++w) { const float d = mw[w] - mean; m2 = fmaf(16.0f * d, d, m2); }
+    // accumulators carry the Linear's scale t: (acc - mean) / sqrt(var_acc + eps t^2) is the normalised value
+    k = 1.0f / sqrtf(m2 * (1.0f / H) + eps * t * t);
+    m = -mean * k;
+}
+
+// ------------------------------------------------------------------------------------------
+// edge kernel
+// ------------------------------------------------------------------------------------------
+template <int H, bool ENC>
+__global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
+    using C = Cfg<H>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uintx4* img = reinterpret_cast<uintx4*>(smem);
+    const half8* imgh = reinterpret_cast<const half8*>(smem);
+    float* ST = reinterpret_cast<float*>(smem + HM_IMG_BYTES);
+    int2* s_blk = reinterpret_cast<int2*>(smem + HM_IMG_BYTES + HM_ST_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jb = wave % C::NJB, rg = wave / C::NJB;
+    const int n = lane & 31, hi = lane >> 5;
+    const int E = A.hdr ? A.hdr->n_edges : A.n_edges_host;
+    if (E <= 0) return;
+    const int nblk = ENC ? (E + BE - 1) / BE : A.tab->n_blocks;
+    const int ntiles = (nblk + C::NRB - 1) / C::NRB;
+    constexpr int KS0 = ENC ? 1 : C::KS;   // k-groups of the first Linear's input image
+    const size_t lin0 = hm_lin_floats(H, 16 * KS0), linh = hm_lin_floats(H, H);
+
+    float* GB = reinterpret_cast<float*>(smem + HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES);   // gamma[H] | beta[H]
+    for (int i = tid; i < H; i += HM_THREADS) { GB[i] = A.ln_g[i]; GB[H + i] = A.ln_b[i]; }
+    const float* gamp = GB + 32 * jb + 4 * hi;
+    const float* betp = GB + H + 32 * jb + 4 * hi;
+
+    int iter = 0;
+#pragma unroll 1
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++iter) {
+        int2* sb = s_blk + (iter & 1) * 16;
+        if (tid < C::NRB) {
+            const int b = t * C::NRB + tid;
+            int2 e = make_int2(E, 0);
+            if (b < nblk) {
+                if (ENC) e = make_int2(b * BE, min(BE, E - b * BE));
+                else { e = A.blk[b]; e.y &= 0xff; }
+            }
+            sb[tid] = e;
+        }
+        __syncthreads();
+        // source position of row n of row block rbg (rows past a block's end repeat its last row; their results are dropped)
+        auto pos_of = [&](int rbg, int nn) -> int {
+            const int2 bi = sb[rbg];
+            const int p = bi.x + (nn < bi.y ? nn : bi.y - 1);
+            return p < 0 ? 0 : p;
+        };
+        auto in_row = [&](int rbg, int nn) -> long long {
+            const int p = pos_of(rbg, nn);
+            return A.eid ? A.eid[p] : p;
+        };
+        if (ENC) narrow_rows_to_image<H, 1>(A.e_in, A.k1, img, tid, in_row);
+        else rows_to_image<H, 8>(A.e_in, img, wave, lane, in_row, [](float*) {});
+        __syncthreads();
+
+        const float* wp = A.w;
+        Lin L = lin_at(wp, H);
+        floatx16 acc[4];
+        int pe[4], dn[4];
+        if (ENC) {
+            init_bias(acc, L.bias, jb, hi);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) { pe[rb] = pos_of(4 * rg + rb, n); dn[rb] = 0; }
+        } else {
+            // layer-1 factorisation: P_i[dst] (+ b1) + P_j[src], brought to the weight scale of the e-block
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const int p = pos_of(4 * rg + rb, n);
+                pe[rb] = p;
+                const int d = A.dst[p], sr = A.src[p];
+                dn[rb] = d;
+                const float* pi = A.P + (size_t)d * 2 * H + 32 * jb + 4 * hi;
+                const float* pj = A.P + (size_t)sr * 2 * H + H + 32 * jb + 4 * hi;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const floatx4 a = *reinterpret_cast<const floatx4*>(pi + 8 * g);
+                    const floatx4 b = *reinterpret_cast<const floatx4*>(pj + 8 * g);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[rb][4 * g + tt] = (a[tt] + b[tt]) * L.t;
+                }
+            }
+        }
+        gemm(acc, L.frag + (size_t)jb * KS0 * 128 + lane, imgh + (size_t)(4 * rg) * KS0 * 128 + lane, KS0, KS0);
+        wp += lin0;
+#pragma unroll 1
+        for (int l = 1; l <= A.nl; ++l) {
+            __syncthreads();
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc_to_img<true>(acc[rb], L.inv_t, img + (size_t)(4 * rg + rb) * C::KS * 128, jb, lane);
+            __syncthreads();
+            L = lin_at(wp, H);
+            init_bias(acc, L.bias, jb, hi);
+            gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+            wp += linh;
+        }
+        // LayerNorm
+        ln_publish<H>(acc, ST, rg, jb, n, hi);
+        __syncthreads();
+        float carry[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) carry[r] = 0.f;
+        int prev_last = -3, head = -1;
+        if (!ENC && A.agg) {
+            const int2 b0 = sb[4 * rg];
+            if (b0.y > 0 && b0.x > 0) {
+                const int first = A.dst[b0.x];
+                if (A.dst[b0.x - 1] == first) head = first;
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int rbg = 4 * rg + rb;
+            const int cnt = sb[rbg].y;
+            float k, m;
+            ln_merge<H>(ST, rbg, n, L.t, A.eps, k, m);
+            const bool valid = n < cnt;
+            const int p = pe[rb];
+            const long long orow = A.eid_out ? A.eid_out[p] : p;
+            float* outp = A.e_out + orow * H + 32 * jb + 4 * hi;
+            if (ENC || !A.agg) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 y;
+                    const floatx4 gm4 = *reinterpret_cast<const floatx4*>(gamp + 8 * g), bt4 = *reinterpret_cast<const floatx4*>(betp + 8 * g);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) y[tt] = fmaf(fmaf(acc[rb][4 * g + tt], k, m), gm4[tt], bt4[tt]);
+                    if (valid) {
+                        if (!ENC && A.residual) {
+                            const floatx4 e0 = *reinterpret_cast<const floatx4*>(outp + 8 * g);
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) y[tt] += e0[tt];
+                        }
+                        *reinterpret_cast<floatx4*>(outp + 8 * g) = y;
+                    }
+                }
+            } else {
+                const int dnv = valid ? dn[rb] : -1 - n;
+                const int nxv = (valid && p + 1 < E) ? A.dst[p + 1] : -2;
+                float f1, f2, f4, f8, fb, fc;
+                {
+                    const int p1 = __builtin_amdgcn_update_dpp(-1000000, dnv, 0x111, 0xf, 0xf, false);
+                    const int p2 = __builtin_amdgcn_update_dpp(-1000000, dnv, 0x112, 0xf, 0xf, false);
+                    const int p4 = __builtin_amdgcn_update_dpp(-1000000, dnv, 0x114, 0xf, 0xf, false);
+                    const int p8 = __builtin_amdgcn_update_dpp(-1000000, dnv, 0x118, 0xf, 0xf, false);
+                    const int pb = __builtin_amdgcn_update_dpp(-1000000, dnv, 0x142, 0xa, 0xf, false);
+                    f1 = p1 == dnv ? 1.f : 0.f; f2 = p2 == dnv ? 1.f : 0.f; f4 = p4 == dnv ? 1.f : 0.f; f8 = p8 == dnv ? 1.f : 0.f;
+                    fb = pb == dnv ? 1.f : 0.f;
+                    fc = (n == 0 && dnv == prev_last) ? 1.f : 0.f;
+                }
+                const bool lastblk = rb == 3;
+                const bool is_last = valid && (nxv != dnv || (lastblk && n == cnt - 1));
+                const bool part = dnv == head || (lastblk && n == cnt - 1 && nxv == dnv);
+                float* arow = A.agg + (size_t)(dnv < 0 ? 0 : dnv) * H + 32 * jb + 4 * hi;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float y[4];
+                    const floatx4 gm4 = *reinterpret_cast<const floatx4*>(gamp + 8 * g), bt4 = *reinterpret_cast<const floatx4*>(betp + 8 * g);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) y[tt] = fmaf(fmaf(acc[rb][4 * g + tt], k, m), gm4[tt], bt4[tt]);
+                    if (valid) {
+                        floatx4 eo = floatx4{y[0], y[1], y[2], y[3]};
+                        if (A.residual) {
+                            const floatx4 e0 = *reinterpret_cast<const floatx4*>(outp + 8 * g);
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) eo[tt] += e0[tt];
+                        }
+                        *reinterpret_cast<floatx4*>(outp + 8 * g) = eo;
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) y[tt] = fmaf(carry[4 * g + tt], fc, y[tt]);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], f1, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], f2, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], f4, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], f8, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], fb, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        carry[4 * g + tt] = __uint_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) * 4, __float_as_uint(y[tt])));
+                    if (is_last) {
+                        if (part) {
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) atomicAdd(arow + 8 * g + tt, y[tt]);
+                        } else {
+                            *reinterpret_cast<floatx4*>(arow + 8 * g) = floatx4{y[0], y[1], y[2], y[3]};
+                        }
+                    }
+                }
+                prev_last = cnt == BE ? __builtin_amdgcn_readlane(dnv, 31) : -3;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// node kernel
+// ------------------------------------------------------------------------------------------
+template <int H, int MODE>
+__global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
+    using C = Cfg<H>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uintx4* img = reinterpret_cast<uintx4*>(smem);
+    const half8* imgh = reinterpret_cast<const half8*>(smem);
+    float* ST = reinterpret_cast<float*>(smem + HM_IMG_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jb = wave % C::NJB, rg = wave / C::NJB;
+    const int n = lane & 31, hi = lane >> 5;
+    const int N = A.n_nodes;
+    if (N <= 0) return;
+    const int ntiles = (N + C::M - 1) / C::M;
+    constexpr int K0 = MODE == 0 ? 32 : 2 * H;
+    const size_t lin0 = hm_lin_floats(H, K0), linh = hm_lin_floats(H, H);
+
+    float* GB = reinterpret_cast<float*>(smem + HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES);   // gamma[H] | beta[H]
+    if (MODE != 2) {
+        for (int i = tid; i < H; i += HM_THREADS) { GB[i] = A.ln_g[i]; GB[H + i] = A.ln_b[i]; }
+    }
+    const float* gamp = GB + 32 * jb + 4 * hi;
+    const float* betp = GB + H + 32 * jb + 4 * hi;
+
+#pragma unroll 1
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int row0 = t * C::M;
+        auto row_of = [&](int rbg, int nn) -> long long {
+            const int r = row0 + 32 * rbg + nn;
+            return r < N ? r : N - 1;
+        };
+        __syncthreads();   // the previous tile's readers of the image are done
+        floatx16 acc[4];
+        Lin L;
+        if (MODE == 0) narrow_rows_to_image<H, 2>(A.x_in, A.k1, img, tid, row_of);
+        else rows_to_image<H, 8>(A.x_in, img, wave, lane, row_of, [](float*) {});
+        __syncthreads();
+        if (MODE != 2) {
+            const float* wp = A.w;
+            L = lin_at(wp, H);
+            init_bias(acc, L.bias, jb, hi);
+            if (MODE == 0) {
+                gemm(acc, L.frag + (size_t)jb * 2 * 128 + lane, imgh + (size_t)(4 * rg) * 2 * 128 + lane, 2, 2);
+            } else {
+                gemm(acc, L.frag + (size_t)jb * 2 * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                __syncthreads();
+                rows_to_image<H, 2>(A.agg, img, wave, lane, row_of, [](float*) {});
+                __syncthreads();
+                gemm(acc, L.frag + ((size_t)jb * 2 * C::KS + C::KS) * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+            }
+            wp += lin0;
+#pragma unroll 1
+            for (int l = 1; l <= A.nl; ++l) {
+                __syncthreads();
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc_to_img<true>(acc[rb], L.inv_t, img + (size_t)(4 * rg + rb) * C::KS * 128, jb, lane);
+                __syncthreads();
+                L = lin_at(wp, H);
+                init_bias(acc, L.bias, jb, hi);
+                gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                wp += linh;
+            }
+            ln_publish<H>(acc, ST, rg, jb, n, hi);
+            __syncthreads();
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const int rbg = 4 * rg + rb;
+                float k, m;
+                ln_merge<H>(ST, rbg, n, L.t, A.eps, k, m);
+                const int r = row0 + 32 * rbg + n;
+                const bool valid = r < N;
+                const size_t off = (size_t)(valid ? r : N - 1) * H + 32 * jb + 4 * hi;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 y;
+                    const floatx4 gm4 = *reinterpret_cast<const floatx4*>(gamp + 8 * g), bt4 = *reinterpret_cast<const floatx4*>(betp + 8 * g);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) y[tt] = fmaf(fmaf(acc[rb][4 * g + tt], k, m), gm4[tt], bt4[tt]);
+                    if (A.residual) {
+                        const floatx4 h0 = *reinterpret_cast<const floatx4*>(A.x_in + off + 8 * g);
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) y[tt] += h0[tt];
+                    }
+                    if (valid) *reinterpret_cast<floatx4*>(A.h_out + off + 8 * g) = y;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[rb][4 * g + tt] = y[tt];
+                }
+                if (A.agg_clear && valid) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<floatx4*>(A.agg_clear + off + 8 * g) = floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (A.tail == 0) continue;
+            // the new h becomes the tail's input image (every wave has passed the barrier after the last Linear)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc_to_img<false>(acc[rb], 1.0f, img + (size_t)(4 * rg + rb) * C::KS * 128, jb, lane);
+            __syncthreads();
+        }
+        if (A.tail == 1 || MODE == 2) {
+            const Lin LP = lin_at(A.w_tail, 2 * H);
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                const int jbv = jb + half * C::NJB;
+                init_bias(acc, LP.bias, jbv, hi);
+                gemm(acc, LP.frag + (size_t)jbv * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const int r = row0 + 32 * (4 * rg + rb) + n;
+                    if (r < N) {
+                        float* pp = A.P_out + (size_t)r * 2 * H + 32 * jbv + 4 * hi;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            floatx4 v;
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) v[tt] = acc[rb][4 * g + tt] * LP.inv_t;
+                            *reinterpret_cast<floatx4*>(pp + 8 * g) = v;
+                        }
+                    }
+                }
+            }
+        } else if (A.tail == 2) {
+            const float* wp = A.w_tail;
+#pragma unroll 1
+            for (int l = 0; l < A.nl; ++l) {
+                const Lin LD = lin_at(wp, H);
+                init_bias(acc, LD.bias, jb, hi);
+                gemm(acc, LD.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                __syncthreads();
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc_to_img<true>(acc[rb], LD.inv_t, img + (size_t)(4 * rg + rb) * C::KS * 128, jb, lane);
+                __syncthreads();
+                wp += linh;
+            }
+            if (jb == 0) {
+                const Lin LO = lin_at(wp, 32);
+                init_bias(acc, LO.bias, 0, hi);
+                gemm(acc, LO.frag + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                if (hi == 0) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        const int r = row0 + 32 * (4 * rg + rb) + n;
+                        if (r < N) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (c < A.out_dim) A.dec_out[(size_t)r * A.out_dim + c] = acc[rb][c] * LO.inv_t;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight images
+// ------------------------------------------------------------------------------------------
+struct PackHmJobs {
+    int n;
+    PackHmJob job[kPackHmMax];
+};
+
+__global__ void __launch_bounds__(256) pack_hm_kernel(PackHmJobs J) {
+    const PackHmJob& j = J.job[blockIdx.x];
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    auto value = [&](int o, int k) -> float {
+        const int os = o / j.out_seg, ro = o % j.out_seg, is = k / j.k_seg, rk = k % j.k_seg;
+        if (ro >= j.out_valid || rk >= j.k_valid) return 0.f;
+        return j.W[(size_t)ro * j.ld + j.col0[os + is] + rk];
+    };
+    float mx = 0.f;
+    for (int i = tid; i < j.out_pad * j.k_pad; i += 256) mx = fmaxf(mx, fabsf(value(i / j.k_pad, i % j.k_pad)));
+    red[tid] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    mx = red[0];
+    float t = 1.f;
+    if (mx > 0.f && mx < 3.0e38f) {
+        int ex;
+        (void)frexpf(mx, &ex);     // mx = f 2^ex, f in [0.5, 1)  ->  mx 2^(-ex - 1) in [0.25, 0.5)
+        int sh = -ex - 1;
+        sh = sh < -24 ? -24 : (sh > 24 ? 24 : sh);
+        t = ldexpf(1.f, sh);
+    }
+    if (tid == 0) { j.dst[0] = t; j.dst[1] = 1.f / t; j.dst[2] = 0.f; j.dst[3] = 0.f; }
+    for (int o = tid; o < j.out_pad; o += 256) j.dst[4 + o] = (j.bias && o < j.bias_n) ? j.bias[o] * t : 0.f;
+    _Float16* frag = reinterpret_cast<_Float16*>(j.dst + 4 + j.out_pad);
+    const int ksn = j.k_pad / 16;
+    const int entries = (j.out_pad / 32) * ksn * 64;   // (jb, ks, lane); two parts each
+    for (int e = tid; e < entries; e += 256) {
+        const int lane = e & 63, ks = (e >> 6) % ksn, jbv = (e >> 6) / ksn;
+        const int o = 32 * jbv + (lane & 31), kg = lane >> 5;
+        _Float16* hi_p = frag + ((size_t)((jbv * ksn + ks) * 2 + 0) * 64 + lane) * 8;
+        _Float16* lo_p = frag + ((size_t)((jbv * ksn + ks) * 2 + 1) * 64 + lane) * 8;
+        for (int q = 0; q < 8; ++q) {
+            const int k = 16 * ks + 8 * (q >> 2) + 4 * kg + (q & 3);
+            const float v = value(o, k) * t;
+            const _Float16 h = (_Float16)v;
+            hi_p[q] = h;
+            lo_p[q] = (_Float16)(v - (float)h);
+        }
+    }
+}
+
+int device_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+}
+
+template <class K>
+int set_lds_attr(K kernel) {
+    GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HM_LDS_BYTES));
+    return GM_OK;
+}
+
+template <int H>
+int launch_edge_h(bool enc, const HmEdgeArgs& a, hipStream_t s) {
+    static PerDeviceOnce once;
+    if (once.need()) {
+        int rc = set_lds_attr(hm_edge_kernel<H, true>);
+        if (rc == GM_OK) rc = set_lds_attr(hm_edge_kernel<H, false>);
+        if (rc != GM_OK) return rc;
+    }
+    ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
+    if (enc) hipLaunchKernelGGL((hm_edge_kernel<H, true>), dim3(device_cus()), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((hm_edge_kernel<H, false>), dim3(device_cus()), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+    return GM_OK;
+}
+
+template <int H>
+int launch_node_h(int mode, const HmNodeArgs& a, hipStream_t s) {
+    static PerDeviceOnce once;
+    if (once.need()) {
+        int rc = set_lds_attr(hm_node_kernel<H, 0>);
+        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 1>);
+        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 2>);
+        if (rc != GM_OK) return rc;
+    }
+    const int tiles = (int)cdiv(a.n_nodes, Cfg<H>::M);
+    int grid = device_cus();
+    if (tiles < grid) grid = tiles < 1 ? 1 : tiles;
+    ProfScope prof(mode == 0 ? PROF_ENC : PROF_NODE, s);
+    if (mode == 0) hipLaunchKernelGGL((hm_node_kernel<H, 0>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((hm_node_kernel<H, 1>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((hm_node_kernel<H, 2>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+    return GM_OK;
+}
+
+}  // namespace
+
+int pack_hm(const PackHmJob* jobs, int n, hipStream_t s) {
+    for (int off = 0; off < n; off += kPackHmMax) {
+        PackHmJobs J{};
+        J.n = n - off < kPackHmMax ? n - off : kPackHmMax;
+        for (int i = 0; i < J.n; ++i) J.job[i] = jobs[off + i];
+        hipLaunchKernelGGL(pack_hm_kernel, dim3(J.n), dim3(256), 0, s, J);
+        GM_LAUNCH_CHECK();
+    }
+    return GM_OK;
+}
+
+bool hm_supported(int H) { return H == 64 || H == 128 || H == 256; }
+
+int launch_edge_hm(int H, bool enc, const HmEdgeArgs& a, hipStream_t s) {
+    GM_REQUIRE(a.w && a.e_in && a.e_out && a.ln_g && a.ln_b, GM_ERR_INVALID_ARGUMENT, "launch_edge_hm: null pointer");
+    GM_REQUIRE(enc || (a.P && a.dst && a.src && a.blk && a.tab), GM_ERR_INVALID_ARGUMENT, "launch_edge_hm: processor step needs P, dst, src and the block table");
+    GM_REQUIRE(!enc || (a.k1 >= 1 && a.k1 <= 16), GM_ERR_UNSUPPORTED, "launch_edge_hm: edge_dim %d unsupported (1..16)", a.k1);
+    GM_REQUIRE(a.nl >= 2, GM_ERR_INVALID_ARGUMENT, "launch_edge_hm: num_layers %d", a.nl);
+    if (!a.hdr && a.n_edges_host <= 0) return GM_OK;
+    int rc;
+    switch (H) {
+    case 64: rc = launch_edge_h<64>(enc, a, s); break;
+    case 128: rc = launch_edge_h<128>(enc, a, s); break;
+    case 256: rc = launch_edge_h<256>(enc, a, s); break;
+    default: GM_REQUIRE(false, GM_ERR_UNSUPPORTED, "launch_edge_hm: hidden_size %d (64, 128, 256)", H);
+    }
+    if (rc != GM_OK) return rc;
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_node_hm(int H, int mode, const HmNodeArgs& a, hipStream_t s) {
+    GM_REQUIRE(a.x_in, GM_ERR_INVALID_ARGUMENT, "launch_node_hm: null input");
+    GM_REQUIRE(mode == 2 || (a.w && a.h_out && a.ln_g && a.ln_b), GM_ERR_INVALID_ARGUMENT, "launch_node_hm: null pointer");
+    GM_REQUIRE(mode != 1 || a.agg, GM_ERR_INVALID_ARGUMENT, "launch_node_hm: processor step needs agg");
+    GM_REQUIRE(mode != 0 || (a.k1 >= 1 && a.k1 <= 32), GM_ERR_UNSUPPORTED, "launch_node_hm: node_dim %d unsupported (1..32)", a.k1);
+    GM_REQUIRE((a.tail == 0 && mode != 2) || a.w_tail, GM_ERR_INVALID_ARGUMENT, "launch_node_hm: tail without weights");
+    GM_REQUIRE(!(a.tail == 1 || mode == 2) || a.P_out, GM_ERR_INVALID_ARGUMENT, "launch_node_hm: projection without P_out");
+    GM_REQUIRE(a.tail != 2 || (a.dec_out && a.out_dim >= 1 && a.out_dim <= 4), GM_ERR_INVALID_ARGUMENT, "launch_node_hm: decoder tail arguments");
+    if (a.n_nodes <= 0) return GM_OK;
+    int rc;
+    switch (H) {
+    case 64: rc = launch_node_h<64>(mode, a, s); break;
+    case 128: rc = launch_node_h<128>(mode, a, s); break;
+    case 256: rc = launch_node_h<256>(mode, a, s); break;
+    default: GM_REQUIRE(false, GM_ERR_UNSUPPORTED, "launch_node_hm: hidden_size %d (64, 128, 256)", H);
+    }
+    if (rc != GM_OK) return rc;
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+}  // namespace gm

@@ -1,0 +1,51 @@
+// Device helpers shared by the fp16-split matrix-pipe kernels (hedge.hip, hmlp.hip).
+//
+// Arithmetic.  Every fp32 operand is split into two fp16 parts, x = hi + lo (22 significant bits; the low parts may be
+// fp16 subnormals, which v_mfma_f32_32x32x16_f16 honours -- checked on gfx950).  A product of two fp16 values is exact in
+// fp32, so  lo*hi + hi*lo + hi*hi  accumulated in fp32 reproduces the fp32 product to 2^-22.
+//
+// Operand layout.  v_mfma_f32_32x32x16_f16 with A = 32 weight rows (output features) and B = 32 rows of the tile (edges or
+// nodes): lane (n, kg) = (lane & 31, lane >> 5) holds 8 halves of K.  K slot (kg, j) of k-group ks carries input feature
+//     16 ks + 8 (j >> 2) + 4 kg + (j & 3)
+// in BOTH operands, which makes the accumulator registers 8q..8q+7 of the wave that owns output block jb exactly the
+// 8 elements of the next Linear's B fragment ks = 2 jb + q on the same lane: activations go accumulator -> ReLU -> split
+// -> LDS image without any cross-lane movement.  Accumulator register r of lane (n, hi) is output feature
+//     32 jb + 8 (r >> 2) + 4 hi + (r & 3)   of row n.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) { unsigned u; asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b)); return u; }
+__device__ __forceinline__ float sub_lo(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
+__device__ __forceinline__ float sub_hi(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
+// compiler-visible on purpose: it is the first reader of MFMA results, and hipcc pads the MFMA -> VALU hazard only for
+// instructions it knows (an inline-asm reader sees stale accumulators)
+__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 65504.f); }
+
+// two-way fp16 split of 4 floats: hi / lo as two dwords each (elements in order)
+__device__ __forceinline__ void split4(float a, float b, float c, float d, uintx2& hi, uintx2& lo) {
+    hi[0] = cvt_pk(a, b);
+    hi[1] = cvt_pk(c, d);
+    lo[0] = cvt_pk(sub_lo(hi[0], a), sub_hi(hi[0], b));
+    lo[1] = cvt_pk(sub_lo(hi[1], c), sub_hi(hi[1], d));
+}
+
+// x += lanes(x shifted) * f.  The value is produced by compiler code just before: the VALU -> DPP hazard (2 wait states) of
+// the first reader is padded by hand, hipcc pads nothing inside asm.
+#define DPP_FMAC(x, f, ctrl) asm volatile("v_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(x) : "v"(f))
+#define DPP_FMAC_NOP(x, f, ctrl) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " ctrl : "+v"(x) : "v"(f))
+
+}  // namespace
+}  // namespace gm

@@ -35,6 +35,7 @@
 
 #include "mlp_dev.h"
 #include "hedge.h"
+#include "hmlp.h"
 
 namespace gm {
 
@@ -1878,7 +1879,7 @@ static int set_lds(K kernel, size_t bytes) {
     return GM_OK;
 }
 
-enum : int { EK_AUTO = 0, EK_16 = 1, EK_CLASSIC = 2, EK_B3 = 3, EK_B3P = 4, EK_SYS = 5 };
+enum : int { EK_AUTO = 0, EK_16 = 1, EK_CLASSIC = 2, EK_B3 = 3, EK_B3P = 4, EK_SYS = 5, EK_HM = 6 };
 
 template <int H>
 static int launch_edge_h(bool enc, const EdgeArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -1901,8 +1902,27 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     EdgeArgs a = a_in;
     a.debug = 0;   // timing ablations are a development build's business (the kernels keep the hooks)
     a.stamps = nullptr;
-    GM_REQUIRE((H == 128 || H == 256) && NL == 2, GM_ERR_UNSUPPORTED,
-               "edge kernel: hidden_size=%d num_layers=%d not instantiated (128 or 256, 2)", H, NL);
+    const int choice = a.kernel_choice;
+    const bool fp32_forms = choice >= EK_16 && choice <= EK_B3P;   // explicitly selected fp32 / bf16 x 6 kernels
+    // the systolic fp16 x 3 kernel (hedge.hip): processor step of the fused forward (rows in sorted order, device-side
+    // edge count, block tables present), hidden 128 / num_layers 2
+    const bool sys_ok = H == 128 && NL == 2 && !enc && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
+    if (sys_ok && (choice == EK_AUTO || choice == EK_SYS))
+        return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), s);
+    // the streamed fp16 x 3 kernels (hmlp.hip): every other case
+    if (!fp32_forms && a.wstream_hm && hm_supported(H) && (enc || a.edge_blocks)) {
+        HmEdgeArgs h{};
+        h.hdr = a.hdr; h.n_edges_host = a.n_edges_host; h.dst = a.dst; h.src = a.src; h.eid = a.eid; h.eid_out = a.eid_out;
+        h.P = a.P; h.e_in = a.e_in; h.e_out = a.e_out; h.agg = a.agg; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b;
+        h.eps = a.eps; h.residual = a.residual; h.k1 = a.k1; h.nl = NL;
+        if (!enc) {
+            const EdgeBlocks t = carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity);
+            h.blk = t.blk; h.tab = t.hdr;
+        }
+        return launch_edge_hm(H, enc, h, s);
+    }
+    GM_REQUIRE((H == 128 || H == 256) && NL == 2 && a.wstream, GM_ERR_UNSUPPORTED,
+               "edge kernel: hidden_size=%d num_layers=%d: the fp32 kernels are instantiated for 128 / 256 and 2", H, NL);
     const int grid = grid_for(cdiv(edge_capacity, TILE));
     const size_t lds = edge_lds_bytes();
     if (H == 256) {
@@ -1911,16 +1931,6 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         GM_LAUNCH_CHECK();
         return GM_OK;
     }
-    // Processor edge kernel choice (H = 128): "auto" = the bf16-pipe kernels (fp32-accurate six-product split) when the
-    // model carries their weight image -- 64-edge / two-workgroup form for small graphs, 128-edge form otherwise --
-    // else the fp32-MFMA 16x16x4 kernel.  GM_EDGE_KERNEL = 16 | classic | b3 | b3p, or gm_debug_set_edge_kernel().
-    const int choice = a.kernel_choice;
-    // the systolic fp16 x 3 kernel (hedge.hip): processor step of the fused forward (rows in sorted order, device-side
-    // edge count, block tables present)
-    const bool sys_ok = H == 128 && NL == 2 && !enc && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
-    if (sys_ok && (choice == EK_AUTO || choice == EK_SYS))
-        return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), s);
-    GM_REQUIRE(choice != EK_SYS, GM_ERR_UNSUPPORTED, "edge kernel 'sys' needs hidden 128, num_layers 2, device-resident weights and the fused forward path");
     int ncu = 256;
     {
         int dev = 0;
@@ -2011,8 +2021,15 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
 
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
     if (a.n_nodes <= 0) return GM_OK;
-    GM_REQUIRE((H == 128 || H == 256) && NL == 2, GM_ERR_UNSUPPORTED,
-               "node kernel: hidden_size=%d num_layers=%d not instantiated (128 or 256, 2)", H, NL);
+    if (!(a.kernel_choice >= EK_16 && a.kernel_choice <= EK_B3P) && hm_supported(H) && (mode == 2 ? a.tail_hm != nullptr : a.wstream_hm != nullptr)) {
+        HmNodeArgs h{};
+        h.n_nodes = a.n_nodes; h.x_in = a.x_in; h.k1 = a.k1; h.agg = a.agg; h.agg_clear = a.agg_clear; h.h_out = a.h_out;
+        h.residual = a.residual; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b; h.eps = a.eps; h.nl = NL;
+        h.tail = mode == 2 ? 1 : a.tail; h.w_tail = a.tail_hm; h.P_out = a.P_out; h.dec_out = a.dec_out; h.out_dim = a.out_dim;
+        return launch_node_hm(H, mode, h, s);
+    }
+    GM_REQUIRE((H == 128 || H == 256) && NL == 2 && a.wstream, GM_ERR_UNSUPPORTED,
+               "node kernel: hidden_size=%d num_layers=%d: the fp32 kernels are instantiated for 128 / 256 and 2", H, NL);
     const int grid = grid_for(cdiv(a.n_nodes, TILE));
     const size_t lds = node_lds_bytes();
     static const int wide_env = getenv("GM_NODE_WIDE") ? atoi(getenv("GM_NODE_WIDE")) : -1;

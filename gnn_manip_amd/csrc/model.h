@@ -13,6 +13,10 @@ struct gm_model {
     size_t packed16_floats = 0, s16_enc_edge = 0;
     float* packed_b3 = nullptr;  // bf16 x 3 operand image of the processor edge MLPs (hidden 128): [M][3 layers][4 stages]
     float* packed_h3 = nullptr;  // fp16 hi / lo image of the processor edge MLPs for the systolic kernel (hedge.h): [M][h3_image_floats]
+    float* packed_hm = nullptr;  // fp16 hi / lo image of every Linear (hmlp.h)
+    size_t hm_floats = 0, hm_enc_edge = 0, hm_enc_node = 0, hm_enc_node_tail = 0;
+    std::vector<size_t> hm_edge, hm_node, hm_node_tail;
+    bool legacy = false;         // hidden 128 / 256 with num_layers 2: the fp32 images (packed) exist
     int edge_kernel = 0;         // processor edge kernel of this model: 0 automatic, 1..5 see gm_model_set_edge_kernel
     std::vector<size_t> s16_edge;
     float* vec = nullptr;     // per-MLP contiguous [bias_0..bias_NL, ln_gamma, ln_beta]

@@ -5,6 +5,7 @@
 #include "mlp.h"
 #include "model.h"
 #include "hedge.h"
+#include "hmlp.h"
 #include <stdlib.h>
 
 using namespace gm;
@@ -17,9 +18,9 @@ int check_desc(const gm_model_desc* d, const char* who) {
     // the reference's two ctor asserts (epd_gnn.py:26-27)
     GM_REQUIRE(d->num_layers >= 2, GM_ERR_INVALID_ARGUMENT, "The number of layers num_layers must be at least 2");
     GM_REQUIRE(d->m_steps >= 1, GM_ERR_INVALID_ARGUMENT, "The number of m_steps message pasting steps must be at least 1");
-    GM_REQUIRE(d->hidden_size == 128 || d->hidden_size == 256, GM_ERR_UNSUPPORTED,
-               "%s: hidden_size=%d: kernels are instantiated for 128 and 256", who, d->hidden_size);
-    GM_REQUIRE(d->num_layers == 2, GM_ERR_UNSUPPORTED, "%s: num_layers=%d: kernels are instantiated for 2", who, d->num_layers);
+    GM_REQUIRE(hm_supported(d->hidden_size), GM_ERR_UNSUPPORTED, "%s: hidden_size=%d: kernels are instantiated for 64, 128 and 256", who,
+               d->hidden_size);
+    GM_REQUIRE(d->num_layers <= 16, GM_ERR_UNSUPPORTED, "%s: num_layers=%d: at most 16", who, d->num_layers);
     GM_REQUIRE(d->edge_dim >= 1 && d->edge_dim <= 8, GM_ERR_UNSUPPORTED, "%s: edge_dim=%d unsupported (1..8)", who, d->edge_dim);
     GM_REQUIRE(d->node_dim >= 1 && d->node_dim <= 32, GM_ERR_UNSUPPORTED, "%s: node_dim=%d unsupported (1..32)", who, d->node_dim);
     GM_REQUIRE(d->out_dim >= 1 && d->out_dim <= 4, GM_ERR_UNSUPPORTED, "%s: out_dim=%d unsupported (1..4)", who, d->out_dim);
@@ -49,97 +50,125 @@ FwdWs carve_fwd(void* ws, int H, int64_t n, int64_t cap) {
     return f;
 }
 
-int copy_vec(float* dst, const float* src, size_t count, bool on_device, hipStream_t s) {
-    GM_HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    return GM_OK;
-}
-
-// (re)build packed + vec from the caller's tensors
-int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hipStream_t s) {
+// element count of tensor ti in the state_dict order (epd_gnn.py:63-84: per MLP  W_0, b_0, .., W_NL, b_NL [, gamma, beta])
+size_t tensor_floats(const gm_model* m, int ti) {
     const int H = m->H, NL = m->NL, M = m->M;
     const int PM = tensors_per_normed_mlp(NL);
-    GM_REQUIRE(nt == gm_model_num_tensors(&m->d), GM_ERR_INVALID_ARGUMENT, "model: expected %d tensors, got %d",
-               gm_model_num_tensors(&m->d), nt);
-    for (int i = 0; i < nt; ++i) GM_REQUIRE(T[i] != nullptr, GM_ERR_INVALID_ARGUMENT, "model: tensor %d is null", i);
-    // device staging for host weights
-    float* stage = nullptr;
-    size_t stage_floats = (size_t)H * 3 * H;
-    if (!on_device) GM_HIP_CHECK(hipMalloc(&stage, stage_floats * sizeof(float)));
+    const int n_normed = 2 + 2 * M;
+    int mlp = ti / PM, r = ti % PM;
+    int in_dim, out_last = H;
+    if (mlp >= n_normed) { mlp = n_normed; r = ti - n_normed * PM; in_dim = H; out_last = m->d.out_dim; }
+    else if (mlp == 0) in_dim = m->d.edge_dim;
+    else if (mlp == 1) in_dim = m->d.node_dim;
+    else in_dim = (mlp % 2 == 0) ? 3 * H : 2 * H;
+    if (r >= 2 * (NL + 1)) return (size_t)H;   // LayerNorm gamma / beta
+    const int l = r / 2;
+    const int out = l == NL ? out_last : H, in = l == 0 ? in_dim : H;
+    return (r % 2) ? (size_t)out : (size_t)out * in;
+}
+
+// (re)build the operand images + vec from the caller's tensors (device pointers)
+int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
+    const int H = m->H, NL = m->NL, M = m->M;
+    const int PM = tensors_per_normed_mlp(NL);
     int rc = GM_OK;
-    auto weight = [&](int ti, size_t count) -> const float* {
-        if (on_device) return T[ti];
-        if (hipMemcpyAsync(stage, T[ti], count * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) rc = GM_ERR_HIP;
-        return stage;
-    };
-    // device-resident weights: everything is queued and done by a handful of batched launches
-    PackJobs pj;
-    pj.n = 0;
+    const int b_enc_edge = 0, b_enc_node = PM, b_dec = (2 + 2 * M) * PM;
+    auto b_edge = [&](int k) { return (2 + 2 * k) * PM; };
+    auto b_node = [&](int k) { return (3 + 2 * k) * PM; };
+
+    if (m->packed_hm) {   // fp16 hi / lo images of every Linear (hmlp.h)
+        std::vector<PackHmJob> jobs;
+        auto lin = [&](int ti, int ld, int col0a, int col0b, int out_valid, int out_pad, int out_seg, int k_valid, int k_pad, int k_seg,
+                       bool with_bias, int bias_n, size_t& off) {
+            PackHmJob j{};
+            j.W = T[ti]; j.ld = ld; j.bias = with_bias ? T[ti + 1] : nullptr; j.bias_n = bias_n;
+            j.out_valid = out_valid; j.out_pad = out_pad; j.out_seg = out_seg;
+            j.k_valid = k_valid; j.k_pad = k_pad; j.k_seg = k_seg; j.col0[0] = col0a; j.col0[1] = col0b;
+            j.dst = m->packed_hm + off;
+            off += hm_lin_floats(out_pad, k_pad);
+            jobs.push_back(j);
+        };
+        auto hh = [&](int ti, size_t& off) { lin(ti, H, 0, 0, H, H, H, H, H, H, true, H, off); };
+        auto hidden = [&](int base, size_t& off) { for (int l = 1; l <= NL; ++l) hh(base + 2 * l, off); };
+        auto proj = [&](int k, size_t& off) {   // P = h [W_i | W_j]^T + [b1 | 0] of processor step k
+            lin(b_edge(k), 3 * H, m->ci * H, m->cj * H, H, 2 * H, H, H, H, H, true, H, off);
+        };
+        size_t off = m->hm_enc_edge;
+        lin(b_enc_edge, m->d.edge_dim, 0, 0, H, H, H, m->d.edge_dim, 16, 16, true, H, off);
+        hidden(b_enc_edge, off);
+        off = m->hm_enc_node;
+        lin(b_enc_node, m->d.node_dim, 0, 0, H, H, H, m->d.node_dim, 32, 32, true, H, off);
+        hidden(b_enc_node, off);
+        proj(0, off);
+        for (int k = 0; k < M; ++k) {
+            off = m->hm_edge[k];
+            lin(b_edge(k), 3 * H, m->ce * H, 0, H, H, H, H, H, H, false, 0, off);   // the e block; b1 lives in P_i
+            hidden(b_edge(k), off);
+            off = m->hm_node[k];
+            lin(b_node(k), 2 * H, m->ch * H, m->ca * H, H, H, H, H, 2 * H, H, true, H, off);
+            hidden(b_node(k), off);
+            if (k + 1 < M) proj(k + 1, off);
+            else {
+                for (int l = 0; l < NL; ++l) hh(b_dec + 2 * l, off);
+                lin(b_dec + 2 * NL, H, 0, 0, m->d.out_dim, 32, 32, H, H, H, true, m->d.out_dim, off);
+            }
+        }
+        rc = pack_hm(jobs.data(), (int)jobs.size(), s);
+        if (rc != GM_OK) return rc;
+    }
+
+    // biases + LayerNorm vectors (fp32 kernels, training, LayerNorm of every kernel)
     VecJobs vj;
     vj.n = 0;
-    auto flush_pack = [&]() {
-        if (rc == GM_OK && pj.n > 0) rc = launch_pack_batch(pj, m->packed, m->packed16, s);
-        pj.n = 0;
-    };
     auto flush_vec = [&]() {
         if (rc == GM_OK && vj.n > 0) rc = launch_vec_batch(vj, m->vec, s);
         vj.n = 0;
-    };
-    auto queue_pack = [&](int ti, int out_rows, int ld, int col0, int k, size_t off, int layout) {
-        if (pj.n == kPackJobsMax) flush_pack();
-        PackJob& j = pj.job[pj.n++];
-        j.W = T[ti]; j.out_rows = out_rows; j.ld = ld; j.col0 = col0; j.kvalid = k; j.layout = layout; j.dst_off = off;
     };
     auto queue_vec = [&](const float* src, size_t off, int count, int zero_to) {
         if (vj.n == kVecJobsMax) flush_vec();
         VecJob& j = vj.job[vj.n++];
         j.src = src; j.dst_off = off; j.count = count; j.zero_to = zero_to;
     };
-    auto pack = [&](int ti, int out_rows, int ld, int col0, int k, size_t& off) {
-        if (rc != GM_OK) return;
-        if (on_device) {
-            queue_pack(ti, out_rows, ld, col0, k, off, 0);
-            off += (size_t)layer_stages(k, out_rows) * kStageFloats;
-            return;
-        }
-        const float* W = weight(ti, (size_t)out_rows * ld);
-        if (rc != GM_OK) return;
-        rc = pack_linear(W, out_rows, ld, col0, k, m->packed + off, s);
-        off += (size_t)layer_stages(k, out_rows) * kStageFloats;
-        // staging buffer is reused: serialise host copies behind the pack kernel
-        if (!on_device && rc == GM_OK && hipStreamSynchronize(s) != hipSuccess) rc = GM_ERR_HIP;
-    };
     auto vecs = [&](int base, bool normed, size_t voff) {  // biases (+ LN) of the MLP whose first tensor is `base`
-        if (on_device) {
-            for (int l = 0; l <= NL; ++l) {
-                const bool dec_out = !normed && l == NL;
-                if (dec_out) queue_vec(T[base + 2 * l + 1], voff + (size_t)NL * H, m->d.out_dim, 32);
-                else queue_vec(T[base + 2 * l + 1], voff + (size_t)l * H, H, 0);
-            }
-            if (normed) {
-                queue_vec(T[base + 2 * (NL + 1)], voff + (size_t)(NL + 1) * H, H, 0);
-                queue_vec(T[base + 2 * (NL + 1) + 1], voff + (size_t)(NL + 2) * H, H, 0);
-            }
-            return;
-        }
-        for (int l = 0; l <= NL && rc == GM_OK; ++l) {
+        for (int l = 0; l <= NL; ++l) {
             const bool dec_out = !normed && l == NL;
-            if (dec_out) {
-                if (hipMemsetAsync(m->vec + voff + (size_t)NL * H, 0, 32 * sizeof(float), s) != hipSuccess) rc = GM_ERR_HIP;
-                if (rc == GM_OK) rc = copy_vec(m->vec + voff + (size_t)NL * H, T[base + 2 * l + 1], m->d.out_dim, on_device, s);
-            } else {
-                rc = copy_vec(m->vec + voff + (size_t)l * H, T[base + 2 * l + 1], H, on_device, s);
-            }
+            if (dec_out) queue_vec(T[base + 2 * l + 1], voff + (size_t)NL * H, m->d.out_dim, 32);
+            else queue_vec(T[base + 2 * l + 1], voff + (size_t)l * H, H, 0);
         }
-        if (normed && rc == GM_OK) rc = copy_vec(m->vec + voff + (size_t)(NL + 1) * H, T[base + 2 * (NL + 1)], H, on_device, s);
-        if (normed && rc == GM_OK) rc = copy_vec(m->vec + voff + (size_t)(NL + 2) * H, T[base + 2 * (NL + 1) + 1], H, on_device, s);
+        if (normed) {
+            queue_vec(T[base + 2 * (NL + 1)], voff + (size_t)(NL + 1) * H, H, 0);
+            queue_vec(T[base + 2 * (NL + 1) + 1], voff + (size_t)(NL + 2) * H, H, 0);
+        }
+    };
+    vecs(b_enc_edge, true, m->v_enc_edge);
+    vecs(b_enc_node, true, m->v_enc_node);
+    for (int k = 0; k < M; ++k) {
+        vecs(b_edge(k), true, m->v_edge[k]);
+        vecs(b_node(k), true, m->v_node[k]);
+    }
+    vecs(b_dec, false, m->v_dec);
+    flush_vec();
+    if (rc != GM_OK || !m->packed) return rc;
+
+    // fp32 operand images (hidden 128 / 256, num_layers 2): training kernels and the selectable fp32 forward kernels
+    PackJobs pj;
+    pj.n = 0;
+    auto flush_pack = [&]() {
+        if (rc == GM_OK && pj.n > 0) rc = launch_pack_batch(pj, m->packed, m->packed16, s);
+        pj.n = 0;
+    };
+    auto queue_pack = [&](int ti, int out_rows, int ld, int col0, int k, size_t off, int layout) {
+        if (pj.n == kPackJobsMax) flush_pack();
+        PackJob& j = pj.job[pj.n++];
+        j.W = T[ti]; j.out_rows = out_rows; j.ld = ld; j.col0 = col0; j.kvalid = k; j.layout = layout; j.dst_off = off;
+    };
+    auto pack = [&](int ti, int out_rows, int ld, int col0, int k, size_t& off) {
+        queue_pack(ti, out_rows, ld, col0, k, off, 0);
+        off += (size_t)layer_stages(k, out_rows) * kStageFloats;
     };
     auto hidden = [&](int base, size_t& off) {  // Linear 1..NL of an MLP (HxH)
         for (int l = 1; l <= NL; ++l) pack(base + 2 * l, H, H, 0, H, off);
     };
-    const int b_enc_edge = 0, b_enc_node = PM, b_dec = (2 + 2 * M) * PM;
-    auto b_edge = [&](int k) { return (2 + 2 * k) * PM; };
-    auto b_node = [&](int k) { return (3 + 2 * k) * PM; };
-
     size_t off = m->s_enc_edge;
     pack(b_enc_edge, H, m->d.edge_dim, 0, m->d.edge_dim, off);
     hidden(b_enc_edge, off);
@@ -166,17 +195,8 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
     }
     if (m->packed16) {  // 16x16x4 image of the edge MLPs
         auto pack16 = [&](int ti, int out_rows, int ld, int col0, int k, size_t& o16) {
-            if (rc != GM_OK) return;
-            if (on_device) {
-                queue_pack(ti, out_rows, ld, col0, k, o16, 1);
-                o16 += (size_t)layer_stages16(k, out_rows) * kStageFloats;
-                return;
-            }
-            const float* W = weight(ti, (size_t)out_rows * ld);
-            if (rc != GM_OK) return;
-            rc = pack_linear16(W, out_rows, ld, col0, k, m->packed16 + o16, s);
+            queue_pack(ti, out_rows, ld, col0, k, o16, 1);
             o16 += (size_t)layer_stages16(k, out_rows) * kStageFloats;
-            if (!on_device && rc == GM_OK && hipStreamSynchronize(s) != hipSuccess) rc = GM_ERR_HIP;
         };
         size_t o16 = m->s16_enc_edge;
         pack16(b_enc_edge, H, m->d.edge_dim, 0, m->d.edge_dim, o16);
@@ -187,23 +207,14 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
             for (int l = 1; l <= NL; ++l) pack16(b_edge(k) + 2 * l, H, H, 0, H, o16);
         }
     }
-    if (m->packed_b3 && !on_device) {  // host-side weights: this image is not maintained, fall back to the fp32 kernels
-        hipFree(m->packed_b3);
-        m->packed_b3 = nullptr;
-    }
-    if (m->packed_b3) {  // three-part bf16 image of the processor edge MLPs (device-resident weights only)
+    flush_pack();
+    if (m->packed_b3) {  // three-part bf16 image of the processor edge MLPs
         for (int k = 0; k < M && rc == GM_OK; ++k) {
             float* base = m->packed_b3 + (size_t)k * 3 * 4 * kB3StageFloats;
-            if (on_device) {
-                rc = pack_linear_b3(T[b_edge(k)], 3 * H, m->ce * H, base, s);
-                for (int l = 1; l <= NL && rc == GM_OK; ++l)
-                    rc = pack_linear_b3(T[b_edge(k) + 2 * l], H, 0, base + (size_t)l * 4 * kB3StageFloats, s);
-            }
+            rc = pack_linear_b3(T[b_edge(k)], 3 * H, m->ce * H, base, s);
+            for (int l = 1; l <= NL && rc == GM_OK; ++l)
+                rc = pack_linear_b3(T[b_edge(k) + 2 * l], H, 0, base + (size_t)l * 4 * kB3StageFloats, s);
         }
-    }
-    if (m->packed_h3 && !on_device) {  // host-side weights: this image is not maintained either
-        hipFree(m->packed_h3);
-        m->packed_h3 = nullptr;
     }
     if (m->packed_h3 && rc == GM_OK) {  // fp16 hi / lo image of the systolic processor edge kernel
         std::vector<PackH3Job> jobs((size_t)M);
@@ -217,19 +228,33 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
         }
         rc = pack_h3(jobs.data(), M, s);
     }
-    vecs(b_enc_edge, true, m->v_enc_edge);
-    vecs(b_enc_node, true, m->v_enc_node);
-    for (int k = 0; k < M; ++k) {
-        vecs(b_edge(k), true, m->v_edge[k]);
-        vecs(b_node(k), true, m->v_node[k]);
+    return rc;
+}
+
+// Host-resident weights are first copied to the device as they are, so that both kinds of caller get every operand image
+// (and with it the same kernels).
+int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hipStream_t s) {
+    GM_REQUIRE(nt == gm_model_num_tensors(&m->d), GM_ERR_INVALID_ARGUMENT, "model: expected %d tensors, got %d",
+               gm_model_num_tensors(&m->d), nt);
+    for (int i = 0; i < nt; ++i) GM_REQUIRE(T[i] != nullptr, GM_ERR_INVALID_ARGUMENT, "model: tensor %d is null", i);
+    if (on_device) return load_weights_device(m, T, s);
+    size_t total = 0;
+    std::vector<size_t> offs((size_t)nt);
+    for (int i = 0; i < nt; ++i) { offs[(size_t)i] = total; total += (tensor_floats(m, i) + 3) & ~(size_t)3; }
+    float* stage = nullptr;
+    GM_HIP_CHECK(hipMalloc(&stage, total * sizeof(float)));
+    std::vector<const float*> D((size_t)nt);
+    int rc = GM_OK;
+    for (int i = 0; i < nt && rc == GM_OK; ++i) {
+        D[(size_t)i] = stage + offs[(size_t)i];
+        if (hipMemcpyAsync(stage + offs[(size_t)i], T[i], tensor_floats(m, i) * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) {
+            gm::set_error("model: copy of tensor %d to the device failed", i);
+            rc = GM_ERR_HIP;
+        }
     }
-    vecs(b_dec, false, m->v_dec);
-    flush_pack();
-    flush_vec();
-    if (stage) {
-        hipStreamSynchronize(s);
-        hipFree(stage);
-    }
+    if (rc == GM_OK) rc = load_weights_device(m, D.data(), s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(stage);
     return rc;
 }
 
@@ -253,6 +278,7 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
     const int H = m->H = desc->hidden_size, NL = m->NL = desc->num_layers, M = m->M = desc->m_steps;
     if (desc->col_i || desc->col_j || desc->col_e) { m->ci = desc->col_i; m->cj = desc->col_j; m->ce = desc->col_e; }
     if (desc->node_agg_first) { m->ch = 1; m->ca = 0; }
+    m->legacy = (H == 128 || H == 256) && NL == 2;   // sizes the fp32 kernels (selectable forward forms, training) exist for
     m->S_HH = layer_stages(H, H);
     m->S_e0 = layer_stages(desc->edge_dim, H);
     m->S_n0 = layer_stages(desc->node_dim, H);
@@ -279,7 +305,28 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
     }
     m->v_dec = v; v += (size_t)NL * H + 32;
     m->vec_floats = v;
-    if (H == 128 && desc->edge_dim <= 16) {
+    {   // fp16 hi / lo images (hmlp.h): every MLP, any supported size
+        const size_t hh = hm_lin_floats(H, H), pj = hm_lin_floats(2 * H, H);
+        size_t o = 0;
+        m->hm_enc_edge = o; o += hm_lin_floats(H, 16) + NL * hh;
+        m->hm_enc_node = o; o += hm_lin_floats(H, 32) + NL * hh;
+        m->hm_enc_node_tail = o; o += pj;
+        m->hm_edge.resize(M);
+        m->hm_node.resize(M);
+        m->hm_node_tail.resize(M);
+        for (int k = 0; k < M; ++k) {
+            m->hm_edge[k] = o; o += (NL + 1) * hh;
+            m->hm_node[k] = o; o += hm_lin_floats(H, 2 * H) + NL * hh;
+            m->hm_node_tail[k] = o; o += k + 1 < M ? pj : NL * hh + hm_lin_floats(32, H);
+        }
+        m->hm_floats = o;
+        if (hipMalloc(&m->packed_hm, m->hm_floats * sizeof(float)) != hipSuccess) {
+            gm::set_error("gm_model_create: hipMalloc failed");
+            gm_model_destroy(m);
+            return GM_ERR_HIP;
+        }
+    }
+    if (m->legacy && H == 128 && desc->edge_dim <= 16) {
         size_t st16 = 0;
         m->s16_enc_edge = 0;
         st16 += layer_stages16(desc->edge_dim, H) + NL * layer_stages16(H, H);
@@ -295,15 +342,9 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             return GM_ERR_HIP;
         }
     }
-    if (H == 128 && NL == 2 && on_device) {
-        if (hipMalloc(&m->packed_b3, (size_t)M * 3 * 4 * kB3StageFloats * sizeof(float)) != hipSuccess) {
-            gm::set_error("gm_model_create: hipMalloc failed");
-            gm_model_destroy(m);
-            return GM_ERR_HIP;
-        }
-    }
-    if (H == 128 && NL == 2 && on_device) {
-        if (hipMalloc(&m->packed_h3, (size_t)M * h3_image_floats() * sizeof(float)) != hipSuccess) {
+    if (m->legacy && H == 128) {
+        if (hipMalloc(&m->packed_b3, (size_t)M * 3 * 4 * kB3StageFloats * sizeof(float)) != hipSuccess ||
+            hipMalloc(&m->packed_h3, (size_t)M * h3_image_floats() * sizeof(float)) != hipSuccess) {
             gm::set_error("gm_model_create: hipMalloc failed");
             gm_model_destroy(m);
             return GM_ERR_HIP;
@@ -312,9 +353,9 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
     {
         const char* e = getenv("GM_EDGE_KERNEL");  // initial value of the per-model choice (diagnostics)
         m->edge_kernel = !e ? 0 : !strcmp(e, "16") ? 1 : !strcmp(e, "classic") ? 2 : !strcmp(e, "b3") ? 3 : !strcmp(e, "b3p") ? 4
-                         : !strcmp(e, "sys") ? 5 : 0;
+                         : !strcmp(e, "sys") ? 5 : !strcmp(e, "hm") ? 6 : 0;
     }
-    if (hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess ||
+    if ((m->legacy && hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess) ||
         hipMalloc(&m->vec, m->vec_floats * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
         gm_model_destroy(m);
@@ -341,6 +382,7 @@ void gm_model_destroy(gm_model* m) {
     if (m->packed16) hipFree(m->packed16);
     if (m->packed_b3) hipFree(m->packed_b3);
     if (m->packed_h3) hipFree(m->packed_h3);
+    if (m->packed_hm) hipFree(m->packed_hm);
     if (m->vec) hipFree(m->vec);
     delete m;
 }
@@ -358,8 +400,10 @@ EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid
     EdgeArgs a{};
     a.hdr = hdr; a.n_edges_host = e_host; a.eid = eid;
     a.e_in = edge_attr; a.e_out = e_out; a.k1 = m->d.edge_dim;
-    a.wstream = m->packed + m->s_enc_edge;
+    a.wstream = m->packed ? m->packed + m->s_enc_edge : nullptr;
     a.wstream16 = m->packed16 ? m->packed16 + m->s16_enc_edge : nullptr;
+    a.wstream_hm = m->packed_hm + m->hm_enc_edge;
+    a.kernel_choice = m->edge_kernel;
     const float* v = m->vec + m->v_enc_edge;
     a.bias = v; a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
     return a;
@@ -369,8 +413,9 @@ EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, int64_t n, con
     EdgeArgs a{};
     a.hdr = hdr; a.n_edges_host = e_host; a.dst = c.dst; a.src = c.src; a.eid = eid; a.eid_out = eid;
     a.P = P; a.e_in = e_in; a.e_out = e_out; a.agg = agg; a.residual = residual;
-    a.wstream = m->packed + m->s_edge[k];
+    a.wstream = m->packed ? m->packed + m->s_edge[k] : nullptr;
     a.wstream16 = m->packed16 ? m->packed16 + m->s16_edge[k] : nullptr;
+    a.wstream_hm = m->packed_hm + m->hm_edge[k];
     a.wstream_b3 = m->packed_b3 ? m->packed_b3 + (size_t)k * 3 * 4 * kB3StageFloats : nullptr;
     a.wstream_h3 = m->packed_h3 ? m->packed_h3 + (size_t)k * h3_image_floats() : nullptr;
     a.edge_blocks = c.blocks;
@@ -383,6 +428,7 @@ EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, int64_t n, con
 }
 void set_tail(const gm_model* m, NodeArgs& a, int next_edge_step /* -1: none, M: decoder */, float* P, float* out) {
     if (next_edge_step < 0) { a.tail = 0; return; }
+    a.tail_hm = m->packed_hm + (next_edge_step == 0 ? m->hm_enc_node_tail : m->hm_node_tail[next_edge_step - 1]);
     if (next_edge_step < m->M) {
         a.tail = 1;
         a.proj_bias = m->vec + m->v_edge[next_edge_step];
@@ -415,7 +461,8 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     if (rc != GM_OK) return rc;
     NodeArgs na{};
     na.n_nodes = (int)n; na.x_in = nodes; na.k1 = m->d.node_dim; na.h_out = f.h;
-    na.wstream = m->packed + m->s_enc_node;
+    na.wstream = m->packed ? m->packed + m->s_enc_node : nullptr;
+    na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel;
     const float* v = m->vec + m->v_enc_node;
     na.bias = v; na.ln_g = v + (size_t)(NL + 1) * H; na.ln_b = v + (size_t)(NL + 2) * H; na.eps = m->d.ln_eps;
     set_tail(m, na, 0, f.P, out);
@@ -428,7 +475,8 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
         if (rc != GM_OK) return rc;
         NodeArgs a{};
         a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.agg_clear = k + 1 < M ? f.agg : nullptr; a.h_out = f.h; a.residual = 1;
-        a.wstream = m->packed + m->s_node[k];
+        a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
+        a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel;
         const float* vn = m->vec + m->v_node[k];
         a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
         set_tail(m, a, k + 1, f.P, out);
@@ -449,7 +497,8 @@ int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n, c
     if (rc != GM_OK) return rc;
     NodeArgs na{};
     na.n_nodes = (int)n; na.x_in = x; na.k1 = m->d.node_dim; na.h_out = h_out;
-    na.wstream = m->packed + m->s_enc_node;
+    na.wstream = m->packed ? m->packed + m->s_enc_node : nullptr;
+    na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel;
     const float* v = m->vec + m->v_enc_node;
     na.bias = v; na.ln_g = v + (size_t)(m->NL + 1) * m->H; na.ln_b = v + (size_t)(m->NL + 2) * m->H; na.eps = m->d.ln_eps;
     na.tail = 0;
@@ -473,8 +522,10 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     // projection P = h [W_i | W_j]^T (+ b1): the tail section of the preceding node stream
     NodeArgs pa{};
     pa.n_nodes = (int)n; pa.x_in = h;
-    pa.wstream = k == 0 ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
-                        : m->packed + m->s_node[k - 1] + (size_t)((NL + 2) * m->S_HH) * kStageFloats;
+    pa.wstream = !m->packed ? nullptr
+                 : k == 0   ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
+                            : m->packed + m->s_node[k - 1] + (size_t)((NL + 2) * m->S_HH) * kStageFloats;
+    pa.kernel_choice = m->edge_kernel;
     set_tail(m, pa, k, f.P, nullptr);
     int rc = launch_node(H, NL, 2, pa, s);
     if (rc != GM_OK) return rc;
@@ -483,7 +534,8 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     if (rc != GM_OK) return rc;
     NodeArgs a{};
     a.n_nodes = (int)n; a.x_in = h; a.agg = f.agg; a.h_out = h_out; a.residual = 0;
-    a.wstream = m->packed + m->s_node[k];
+    a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
+    a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel;
     const float* vn = m->vec + m->v_node[k];
     a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
     a.tail = 0;
@@ -523,7 +575,9 @@ extern "C" {
 
 int gm_model_set_edge_kernel(gm_model* m, int choice) {
     GM_REQUIRE(m, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: null model");
-    GM_REQUIRE(choice >= 0 && choice <= 5, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: choice %d out of range", choice);
+    GM_REQUIRE(choice >= 0 && choice <= 6, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: choice %d out of range", choice);
+    GM_REQUIRE(m->legacy || choice == 0 || choice == 6, GM_ERR_UNSUPPORTED,
+               "gm_model_set_edge_kernel: hidden_size=%d num_layers=%d has the streamed fp16-split kernels only (0 / 6)", m->H, m->NL);
     m->edge_kernel = choice;
     return GM_OK;
 }

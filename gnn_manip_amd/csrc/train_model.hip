@@ -168,6 +168,7 @@ size_t gm_train_backward_workspace_bytes(const gm_model_desc* desc, int64_t n, i
 
 int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, const int64_t* edge_index,
                          int64_t e, float* out, void* tape, size_t tape_bytes, void* stream) {
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_epd_forward_train");
     gm::DevGuard dev_guard(nodes);
     int rc = check_sizes(m, n, e, "gm_epd_forward_train");
     if (rc != GM_OK) return rc;
@@ -253,6 +254,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
 int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, const float* nodes, const float* edge_attr, int64_t n,
                     int64_t e, const float* grad_out, float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
                     void* stream) {
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_epd_backward");
     gm::DevGuard dev_guard(nodes);
     int rc = check_sizes(m, n, e, "gm_epd_backward");
     if (rc != GM_OK) return rc;
@@ -422,6 +424,7 @@ size_t gm_block_backward_workspace_bytes(const gm_model_desc* desc, int64_t n, i
 
 int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_t n, const float* edge_attr, int64_t e, float* h_out,
                                        float* e_out, void* tape, size_t tape_bytes, void* stream) {
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_graph_independent_forward_train");
     gm::DevGuard dev_guard(x ? (const void*)x : (const void*)edge_attr);
     int rc = check_sizes(m, n, e, "gm_graph_independent_forward_train");
     if (rc != GM_OK) return rc;
@@ -452,6 +455,7 @@ int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_
 int gm_graph_independent_backward(const gm_model* m, const float* const* T, int n_tensors, const float* x, const float* edge_attr, int64_t n,
                                   int64_t e, const float* dh, const float* de, float* dx, float* dedge_attr, float* const* grads,
                                   void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_graph_independent_backward");
     gm::DevGuard dev_guard(x ? (const void*)x : (const void*)edge_attr);
     int rc = check_sizes(m, n, e, "gm_graph_independent_backward");
     if (rc != GM_OK) return rc;
@@ -507,6 +511,7 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
 
 int gm_interaction_network_forward_train(const gm_model* m, int k, const float* h, int64_t n, const float* e_in, const int64_t* edge_index,
                                          int64_t e, float* h_out, float* e_out, void* tape, size_t tape_bytes, void* stream) {
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_interaction_network_forward_train");
     gm::DevGuard dev_guard(h);
     int rc = check_sizes(m, n, e, "gm_interaction_network_forward_train");
     if (rc != GM_OK) return rc;
@@ -558,6 +563,7 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
 int gm_interaction_network_backward(const gm_model* m, int k, const float* const* T, int n_tensors, const float* h, const float* e_in,
                                     int64_t n, int64_t e, const float* dh_out, const float* de_out, float* dh_in, float* de_in,
                                     float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_interaction_network_backward");
     gm::DevGuard dev_guard(h);
     int rc = check_sizes(m, n, e, "gm_interaction_network_backward");
     if (rc != GM_OK) return rc;

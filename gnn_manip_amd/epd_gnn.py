@@ -423,7 +423,7 @@ class EncProcDecGNN(nn.Module):
         """gm_model* for the current parameters on `device` (packed once, re-packed on change)."""
         return self._handle.get(self.model_desc(), list(self.parameters()), device)
 
-    EDGE_KERNELS = {"auto": 0, "16": 1, "classic": 2, "b3": 3, "b3p": 4, "sys": 5}
+    EDGE_KERNELS = {"auto": 0, "16": 1, "classic": 2, "b3": 3, "b3p": 4, "sys": 5, "hm": 6}
 
     def set_edge_kernel(self, choice):
         """Processor edge kernel of this model (diagnostics / A-B measurements; no reference counterpart): 'auto',

@@ -250,8 +250,13 @@ def test_epd_forward_hidden_256_vs_oracle(dev, n, side, seed):
 def test_unsupported_sizes_fail_loudly(dev):
     from gnn_manip_amd import EncProcDecGNN
     from gnn_manip_amd._lib import GMError
-    m = EncProcDecGNN(25, 4, 3, 64, 2, 2).to(dev)
-    with pytest.raises(GMError), torch.no_grad():
+    m = EncProcDecGNN(25, 4, 3, 96, 2, 2).to(dev)   # kernels: hidden 64 / 128 / 256
+    with pytest.raises(GMError, match="hidden_size=96"), torch.no_grad():
+        m.forward(torch.zeros(4, 25, device=dev), torch.zeros(4, 4, device=dev),
+                  torch.zeros(2, 4, dtype=torch.long, device=dev))
+    m = EncProcDecGNN(25, 4, 3, 64, 3, 2).to(dev)   # runs, but has no fp32 kernels to select
+    with pytest.raises(GMError, match="streamed fp16-split kernels only"), torch.no_grad():
+        m.set_edge_kernel("classic")
         m.forward(torch.zeros(4, 25, device=dev), torch.zeros(4, 4, device=dev),
                   torch.zeros(2, 4, dtype=torch.long, device=dev))
 
@@ -346,29 +351,32 @@ def test_batched_radius_graph_is_block_diagonal(dev, golden):
 
 
 def test_candidate_batched_rollout_matches_independent_rollouts(dev):
+    """Candidate c of a batch == candidate c rolled out alone, bit for bit, with the raw (undamped) random decoder: every
+    per-row result is independent of its tile, and the scatter-add's blocks / chunks are laid out per graph
+    (build_edge_blocks), so the partial sums of a graph do not depend on what else shares the launch."""
     from gnn_manip_amd import RolloutEngine, scene
-    n, steps, b = 700, 3, 3
+    n, steps, b = 700, 4, 3
     obs = scene.make_scene(n, seed=95, side=0.075)
     trajs = np.stack([scene.rigid_drift_trajectory(obs, steps, seed=100 + c, step_size=3e-4) for c in range(b)])
     params = orc.init_params(25, 4, 3, 128, 2, 10, 96)
-    # damped decoder: with raw random weights the particles move ~1e-3 per step and a 1e-8 difference between the two
-    # runs (atomic order of tile-crossing segments) can flip an edge at the radius boundary in a later step
-    params["decoder.4.weight"] = params["decoder.4.weight"] * np.float32(0.05)
-    params["decoder.4.bias"] = params["decoder.4.bias"] * np.float32(0.05)
     m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    for kernel in ("auto", "hm"):
+        m.set_edge_kernel(kernel)
+        with torch.no_grad():
+            eng_b = RolloutEngine(m, _ga(), n, device=dev, candidates=b)
+            out = eng_b.rollout_candidates(_t(obs, dev), _t(trajs, dev)).cpu().numpy()
+            eng_1 = RolloutEngine(m, _ga(), n, device=dev)
+            for c in range(b):
+                one = eng_1.rollout(_t(obs, dev), _t(trajs[c], dev), horizon=steps).cpu().numpy()
+                assert np.array_equal(out[c], one), (kernel, c, np.abs(out[c] - one).max())
+    ref = orc.rollout(params, obs, trajs[1], 2, STATS, BOUNDS, 0.015, CART, MAT, CTRL)
     with torch.no_grad():
-        eng_b = RolloutEngine(m, _ga(), n, device=dev, candidates=b)
-        out = eng_b.rollout_candidates(_t(obs, dev), _t(trajs, dev)).cpu().numpy()
-        eng_1 = RolloutEngine(m, _ga(), n, device=dev)
-        for c in range(b):
-            one = eng_1.rollout(_t(obs, dev), _t(trajs[c], dev), horizon=steps).cpu().numpy()
-            np.testing.assert_allclose(out[c][:, :, 2:8], one[:, :, 2:8], rtol=0, atol=2e-6)
-    ref = orc.rollout(params, obs, trajs[1], steps, STATS, BOUNDS, 0.015, CART, MAT, CTRL)
-    np.testing.assert_allclose(out[1][:, :, 2:5], ref[:, :, 2:5], rtol=0, atol=5e-6)
+        two = eng_1.rollout(_t(obs, dev), _t(trajs[1], dev), horizon=2).cpu().numpy()
+    np.testing.assert_allclose(two[:, :, 2:5], ref[:, :, 2:5], rtol=0, atol=5e-6)
 
 
 @pytest.mark.parametrize("choice,name", [(1, "fp32 16x16x4"), (2, "fp32 32x32x2"), (3, "bf16 pipe, 128-edge tiles"), (4, "bf16 pipe, 64-edge tiles"),
-                                         (5, "systolic fp16 x 3")])
+                                         (5, "systolic fp16 x 3"), (6, "streamed fp16 x 3")])
 def test_every_processor_edge_kernel_form_vs_oracle(dev, choice, name):
     """Each selectable form of the processor edge kernel (EncProcDecGNN.set_edge_kernel, a per-model option) on a
     multi-tile graph, a ragged small one and a single node: same 1e-5 bar against the oracle."""
@@ -386,7 +394,7 @@ def test_every_processor_edge_kernel_form_vs_oracle(dev, choice, name):
         assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3), (name, n)
 
 
-@pytest.mark.parametrize("choice", [3, 4, 5])
+@pytest.mark.parametrize("choice", [3, 4, 5, 6])
 def test_split_operand_kernels_are_as_accurate_as_float32(dev, choice):
     """The matrix-pipe forms compute fp32 results (bf16: six exact partial products of three-way operand splits; fp16: three
     of two-way splits with pre-scaled weights; fp32 accumulation): against a float64 evaluation of the same model their
@@ -489,3 +497,98 @@ def test_block_convention_switch_trains(dev):
     for name, prm in m.named_parameters():
         g, gr = prm.grad.cpu().numpy(), p[name].grad.numpy()
         assert np.abs(g - gr).max() <= 2e-3 * max(np.abs(gr).max(), 1e-6), name
+
+
+# ------------------------------------------------------------------ a6: any hidden_size / num_layers the reference accepts
+def test_epd_h64_l3_golden(golden, dev):
+    """The reference's own wiring at hidden 64, num_layers 3, m_steps 2 (train_dyn.py:237-238 exposes both options;
+    epd_gnn.py:72-84 builds num_layers - 1 hidden Linears for any value): encoder, first processor block and the full
+    forward against the fixture the reference produced."""
+    g7 = golden("g7_epd_wiring.npz")
+    nd, ed, od, hid, nl, ms, seed = [int(v) for v in g7["h64_l3_m2.cfg"]]
+    assert (hid, nl, ms) == (64, 3, 2)
+    params = orc.init_params(nd, ed, od, hid, nl, ms, seed)
+    m = _model(params, (nd, ed, od, hid, nl, ms), dev)
+    nodes, ea, ei = _scene_graph(golden)
+    with torch.no_grad():
+        h0, e0, _ = m.encoder(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+        h1, e1, _ = m.processor[0](h0, e0, _t(ei, dev))
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    np.testing.assert_allclose(h0.cpu().numpy(), g7["h64_l3_m2.h0"], rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(e0.cpu().numpy()[:64], g7["h64_l3_m2.e0_head"], rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), g7["h64_l3_m2.h1"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(e1.cpu().numpy()[:64], g7["h64_l3_m2.e1_head"], rtol=1e-5, atol=5e-6)
+    ref = g7["h64_l3_m2.out"]
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("hid,nl,ms", [(64, 2, 3), (64, 5, 2), (128, 3, 3), (128, 2, 3), (256, 2, 3), (256, 4, 2)])
+def test_epd_any_size_vs_oracle(dev, hid, nl, ms):
+    """Streamed fp16-split kernels (hmlp.hip) at every hidden size they are instantiated for and several depths: forward on a
+    multi-tile graph and on ragged small ones, the standalone blocks, and a rollout step -- all against the oracle."""
+    from gnn_manip_amd import RolloutEngine, scene
+    params = orc.init_params(25, 4, 3, hid, nl, ms, 7 * hid + nl)
+    m = _model(params, (25, 4, 3, hid, nl, ms), dev)
+    m.set_edge_kernel("hm")
+    for n, side, seed in ((2500, 0.1, 81), (130, 0.3, 82), (1, 0.1, 83), (517, 0.06, 84)):
+        obs = scene.make_scene(n, seed=seed, side=side)
+        nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+        ei = np.stack((s, r))
+        with torch.no_grad():
+            out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+        ref = orc.epd_forward(params, nodes, ea, ei, nl, ms)
+        assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3), (n, np.abs(out - ref).max(), np.abs(ref).max())
+    # blocks on the last (517-node) graph
+    with torch.no_grad():
+        h0, e0, _ = m.encoder(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+        h1, e1, _ = m.processor[0](h0, e0, _t(ei, dev))
+    ho, eo = orc.graph_independent(params, "encoder", nodes, ea, nl)
+    np.testing.assert_allclose(h0.cpu().numpy(), ho, rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(e0.cpu().numpy(), eo, rtol=1e-5, atol=3e-6)
+    h1o, e1o = orc.interaction_network(params, "processor.0", ho, eo, ei, nl)
+    np.testing.assert_allclose(h1.cpu().numpy(), h1o, rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(e1.cpu().numpy(), e1o, rtol=1e-5, atol=5e-6)
+    # one device-resident rollout step
+    n = 600
+    obs = scene.make_scene(n, seed=85, side=0.07)
+    traj = scene.rigid_drift_trajectory(obs, 1)
+    eng = RolloutEngine(m, _ga(), n, device=dev)
+    with torch.no_grad():
+        final = eng.rollout(_t(obs, dev), _t(traj, dev), horizon=1).cpu().numpy()
+    fwd = lambda nn, ee, ii: orc.epd_forward(params, nn, ee, ii, nl, ms)
+    refs = orc.rollout(params, obs, traj, 1, STATS, BOUNDS, 0.015, CART, MAT, CTRL, forward_fn=fwd)
+    np.testing.assert_allclose(final[:, :, 2:5], refs[:, :, 2:5], rtol=0, atol=5e-6)
+
+
+def test_host_resident_weights_use_the_same_kernels(dev):
+    """A model whose parameters live in host memory is staged to the device whole, so it gets every operand image: same
+    kernels, bit-identical output to the model created from device tensors."""
+    from gnn_manip_amd import _lib, scene
+    n = 700
+    obs = scene.make_scene(n, seed=91, side=0.07)
+    params = orc.init_params(25, 4, 3, 128, 2, 4, 92)
+    m = _model(params, (25, 4, 3, 128, 2, 4), dev)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    ei = np.stack((s, r))
+    with torch.no_grad():
+        out_dev = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    import ctypes as C
+    from gnn_manip_amd.epd_gnn import DstCsr, _ws
+    L = _lib.lib()
+    host = [np.ascontiguousarray(p.detach().cpu().numpy()) for p in m.parameters()]   # state_dict order
+    arr = (C.c_void_p * len(host))(*[h.ctypes.data for h in host])
+    desc = _lib.ModelDesc(*m.model_desc())
+    handle = C.c_void_p()
+    xn, xe, xi = _t(nodes, dev), _t(ea, dev), _t(ei, dev)
+    csr = DstCsr(xi, n)
+    _lib.check(L.gm_model_create(C.byref(desc), arr, len(host), 0, _lib.current_stream(), C.byref(handle)))
+    try:
+        e = int(ei.shape[1])
+        out = torch.empty((n, 3), device=dev)
+        fwd = _ws(L.gm_forward_workspace_bytes(C.byref(desc), n, e), xn.device)
+        _lib.check(L.gm_epd_forward(handle, _lib.ptr(xn), n, _lib.ptr(xe), 0, _lib.ptr(csr.ws), e, _lib.ptr(out), _lib.ptr(fwd), fwd.numel(),
+                                    _lib.current_stream()))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), out_dev)
+    finally:
+        L.gm_model_destroy(handle)
