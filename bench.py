@@ -154,10 +154,8 @@ def build_engine(wl, dev, rank, candidates, edge_kernel, total_steps):
 
 def resolve_kernel(edge_kernel, hidden):
     ek = edge_kernel
-    if hidden != 128:
-        ek = "classic"
-    elif ek == "auto":
-        ek = "sys"
+    if ek == "auto":
+        ek = "sys" if hidden == 128 else "hm"
     return ek
 
 
@@ -170,22 +168,29 @@ def roofline_record(L, _lib, ek, hidden, edges, n_nodes, workload_key):
     # MFMA utilisation is priced on the flops the kernel ISSUES (3 HxH products per edge; SURVEY.md 8d "utilisation uses
     # F_issued"); the split-operand kernels issue 3 (fp16 two-way split) or 6 (bf16 three-way split) matrix-pipe product
     # blocks per fp32-equivalent block and are priced against the 16-bit pipe.
-    mult = {"sys": 3, "b3": 6, "b3p": 6}.get(ek, 1)
+    mult = {"sys": 3, "hm": 3, "b3": 6, "b3p": 6}.get(ek, 1)
     peak = MFMA_16BIT_PEAK_TFLOPS if mult > 1 else MFMA_F32_PEAK_TFLOPS
     achieved = issued * mult / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     kname = {"16": "edge_kernel16<2,1>", "classic": f"edge_kernel<{hidden},2,1>", "b3": "edge_kernel_b3<2,1>", "b3p": "edge_kernel_b3p<2,1>",
-             "sys": "sys_edge_kernel"}[ek]
+             "sys": "sys_edge_kernel", "hm": f"hm_edge_kernel<{hidden},false>"}[ek]
     alg_bytes = edge_kernel_alg_bytes(edges, n_nodes, hidden)
     hbm = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    rec = {"bound": "mfma", "kernel": kname + " (processor phi_e + scatter-add)",
-           "pipe": {"sys": "fp16 MFMA (2.5 PF dense)", "b3": "bf16 MFMA (2.5 PF dense)", "b3p": "bf16 MFMA (2.5 PF dense)"}.get(ek, "fp32 MFMA"),
-           "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+    pipe = {"sys": "fp16 MFMA (2.5 PF dense)", "hm": "fp16 MFMA (2.5 PF dense)", "b3": "bf16 MFMA (2.5 PF dense)",
+            "b3p": "bf16 MFMA (2.5 PF dense)"}.get(ek, "fp32 MFMA")
+    mfma = {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "pipe": pipe,
+            "floor_ms": issued * mult / (peak * 1e12) * 1e3}
+    hbmr = {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "floor_ms": alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3}
+    # the bound is the roof with the longer floor for this kernel and size: the fp16 x 3 scheme put the matrix-pipe floor of
+    # the hidden-128 kernel below its HBM floor
+    bound = "hbm" if hbmr["floor_ms"] >= mfma["floor_ms"] else "mfma"
+    top = hbmr if bound == "hbm" else mfma
+    rec = {"bound": bound, "kernel": kname + " (processor phi_e + scatter-add)",
+           "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"], "traffic": None,
            "avg_launch_ms": k_ms, "launches_timed": int(launches.value),
            "issued_flops_per_launch": issued * mult, "fp32_equivalent_flops_per_launch": issued,
            "fp32_equivalent_tflops": issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
            "alg_flops_per_launch": alg, "alg_tflops": alg / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
-           "alg_bytes_per_launch": alg_bytes,
-           "hbm": {"achieved_GBs": hbm, "peak_GBs": HBM_PEAK_GBS, "frac": hbm / HBM_PEAK_GBS}}
+           "alg_bytes_per_launch": alg_bytes, "mfma": mfma, "hbm": hbmr}
     # HBM traffic of the same kernel from rocprofv3 PMC passes of THIS round's build (collected separately with
     # tools/profile_round.sh, committed under profiles/); absent or of another kernel: null
     try:
@@ -323,7 +328,7 @@ def run_c5(dev, rank, world, dist, cdev, args):
     return {"metric": "rollout steps/sec (N particles, 10 MP steps, hidden=128)", "value": popsize * horizon / el, "unit": "rollout steps/s",
             "n_gpus": world, "steps": horizon, "warmup": 0, "ms_per_step": el / (per_rank * horizon) * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (fp16 two-way split operands on the matrix pipe, f32 accumulation)" if args.edge_kernel in ("auto", "sys") else "f32",
+            "dtype": "f32",
             "data": "synthetic (seeded dense scene; random-init weights; a candidate = an offset of the scripted cup drift)",
             "config": {"workload": wl["name"], "n_particles": wl["n"], "candidates": popsize, "candidates_per_rank": per_rank,
                        "block_diagonal_batch": batch, "horizon": horizon, "generation_s": el, "loss_mean": float(np.mean(losses)),
@@ -342,7 +347,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="c5: candidates per block-diagonal batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C3 / C4 sub-records")
-    ap.add_argument("--edge-kernel", default="auto", choices=["auto", "16", "classic", "b3", "b3p", "sys"],
+    ap.add_argument("--edge-kernel", default="auto", choices=["auto", "16", "classic", "b3", "b3p", "sys", "hm"],
                     help="processor edge kernel (per-model option): auto = systolic fp16 x 3 kernel for hidden 128 (DESIGN.md 5.1)")
     args = ap.parse_args()
 
@@ -380,10 +385,13 @@ def main():
             out = {"metric": f"rollout steps/sec (N particles, 10 MP steps, hidden={hidden})",
                    "value": rec["value"], "unit": "rollout steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
                    "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                   "dtype": {"sys": "f32 (products formed as three exact fp16 x fp16 partial products of two-way operand splits with power-of-two "
-                                    "pre-scaled weights on the fp16 MFMA pipe, f32 accumulation; 1e-6 vs float64 through the model, like plain f32)",
-                             "b3": "f32 (six exact bf16 x bf16 partial products of three-way operand splits, f32 accumulation)",
-                             "b3p": "f32 (six exact bf16 x bf16 partial products of three-way operand splits, f32 accumulation)"}.get(ek, "f32"),
+                   "dtype": "f32",
+                   "arithmetic": {"sys": "fp32 operands as two-way fp16 splits, three exact fp16 x fp16 partial products per multiply on the fp16 "
+                                         "MFMA pipe, fp32 accumulation (1e-6 vs float64 through the model, like plain fp32)",
+                                  "hm": "fp32 operands as two-way fp16 splits, three exact fp16 x fp16 partial products per multiply on the fp16 "
+                                        "MFMA pipe, fp32 accumulation (1e-6 vs float64 through the model, like plain fp32)",
+                                  "b3": "six exact bf16 x bf16 partial products of three-way operand splits, fp32 accumulation",
+                                  "b3p": "six exact bf16 x bf16 partial products of three-way operand splits, fp32 accumulation"}.get(ek, "fp32 MFMA"),
                    "data": "synthetic (seeded dense scene; random-init weights, decoder output layer scaled 1e-5 so the pile stays dense "
                            "over the rollout)",
                    "config": rec["config"], "roofline": rec["roofline"], "breakdown": rec["breakdown"]}

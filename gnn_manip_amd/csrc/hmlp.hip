@@ -41,12 +41,14 @@ constexpr size_t HM_ST_BYTES = 16384;    // [NRB][2 NJB partials][32 rows] float
 constexpr size_t HM_BLK_BYTES = 2 * 16 * sizeof(int2);
 constexpr size_t HM_LDS_BYTES = HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES + 2 * 256 * sizeof(float);   // + gamma | beta
 
-template <int H>
+// RBW: 32-row blocks per wave.  4 fills the LDS image (M * H = 32768); the node kernels also come with 1 for small
+// graphs (four times the tiles; per-row arithmetic is identical, so results do not depend on the choice).
+template <int H, int RBW = 4>
 struct Cfg {
     static constexpr int NJB = H / 32;           // output blocks = waves per row group
     static constexpr int KS = H / 16;            // k-groups of an H-wide input
     static constexpr int NRG = HM_WAVES / NJB;   // row groups
-    static constexpr int NRB = 4 * NRG;          // 32-row blocks per tile
+    static constexpr int NRB = RBW * NRG;        // 32-row blocks per tile
     static constexpr int M = 32 * NRB;           // rows per tile
 };
 
@@ -65,12 +67,13 @@ __device__ __forceinline__ Lin lin_at(const float* p, int out_pad) {
 }
 
 // accumulators of the wave's 4 row blocks <- bias (already scaled) of output block jbv
-__device__ __forceinline__ void init_bias(floatx16 (&acc)[4], const float* bias, int jbv, int hi) {
+template <int RBW>
+__device__ __forceinline__ void init_bias(floatx16 (&acc)[RBW], const float* bias, int jbv, int hi) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const floatx4 v = *reinterpret_cast<const floatx4*>(bias + 32 * jbv + 8 * g + 4 * hi);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) acc[rb][4 * g + tt] = v[tt];
     }
@@ -79,36 +82,37 @@ __device__ __forceinline__ void init_bias(floatx16 (&acc)[4], const float* bias,
 // acc[rb] += W[jb block, k-groups ks0 .. ks0 + nks) x image rows of row block rb.
 //   wf : this wave's fragments of the first k-group, + lane  (k-group stride 128 half8)
 //   im : image of the wave's first row block at k-group 0, + lane  (row-block stride img_ksn * 128, k-group stride 128)
-__device__ __forceinline__ void gemm(floatx16 (&acc)[4], const half8* __restrict__ wf, const half8* im, int img_ksn, int nks) {
+template <int RBW>
+__device__ __forceinline__ void gemm(floatx16 (&acc)[RBW], const half8* __restrict__ wf, const half8* im, int img_ksn, int nks) {
     half8 ah0 = wf[0], al0 = wf[64], ah1 = ah0, al1 = al0;
     if (nks > 1) { ah1 = wf[128]; al1 = wf[192]; }
-    half8 bh[4], bl[4], ch[4], cl[4];
+    half8 bh[RBW], bl[RBW], ch[RBW], cl[RBW];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) { bh[rb] = im[rb * img_ksn * 128]; bl[rb] = im[rb * img_ksn * 128 + 64]; }
+    for (int rb = 0; rb < RBW; ++rb) { bh[rb] = im[rb * img_ksn * 128]; bl[rb] = im[rb * img_ksn * 128 + 64]; }
 #pragma unroll 1
     for (int ks = 0; ks < nks; ks += 2) {
         if (ks + 1 < nks) {
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) { ch[rb] = im[(rb * img_ksn + ks + 1) * 128]; cl[rb] = im[(rb * img_ksn + ks + 1) * 128 + 64]; }
+            for (int rb = 0; rb < RBW; ++rb) { ch[rb] = im[(rb * img_ksn + ks + 1) * 128]; cl[rb] = im[(rb * img_ksn + ks + 1) * 128 + 64]; }
         }
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[rb], acc[rb], 0, 0, 0);
+        for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[rb], acc[rb], 0, 0, 0);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[rb], acc[rb], 0, 0, 0);
+        for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[rb], acc[rb], 0, 0, 0);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[rb], acc[rb], 0, 0, 0);
+        for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[rb], acc[rb], 0, 0, 0);
         if (ks + 2 < nks) { ah0 = wf[(ks + 2) * 128]; al0 = wf[(ks + 2) * 128 + 64]; }
         if (ks + 1 < nks) {
             if (ks + 2 < nks) {
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) { bh[rb] = im[(rb * img_ksn + ks + 2) * 128]; bl[rb] = im[(rb * img_ksn + ks + 2) * 128 + 64]; }
+                for (int rb = 0; rb < RBW; ++rb) { bh[rb] = im[(rb * img_ksn + ks + 2) * 128]; bl[rb] = im[(rb * img_ksn + ks + 2) * 128 + 64]; }
             }
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, ch[rb], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, ch[rb], acc[rb], 0, 0, 0);
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, cl[rb], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, cl[rb], acc[rb], 0, 0, 0);
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, ch[rb], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, ch[rb], acc[rb], 0, 0, 0);
             if (ks + 3 < nks) { ah1 = wf[(ks + 3) * 128]; al1 = wf[(ks + 3) * 128 + 64]; }
         }
     }
@@ -130,13 +134,13 @@ __device__ __forceinline__ void acc_to_img(const floatx16& a, float s, uintx4* i
     }
 }
 
-// rows of H floats -> image (k-group count KS).  64 units of (16 rows, 2 k-groups) per tile, 8 per wave; lane = (row, k-group
+// rows of H floats -> image (k-group count KS).  16 RBW units of (16 rows, 2 k-groups) per tile, 2 RBW per wave; lane = (row, k-group
 // parity, kg) reads the two 16-byte pieces that make its 8 K slots.  row_of(rbg, n) returns the source row (or -1: zeros).
-template <int H, int UNR, class R, class Z>
+template <int H, int RBW, int UNR, class R, class Z>
 __device__ __forceinline__ void rows_to_image(const float* __restrict__ src, uintx4* img, int wave, int lane, R&& row_of, Z&& after) {
-    using C = Cfg<H>;
+    using C = Cfg<H, RBW>;
 #pragma unroll UNR
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 2 * RBW; ++it) {
         const int u = it * 8 + wave;
         const int rowhalf = u % (2 * C::NRB), kspair = u / (2 * C::NRB);
         const int rbg = rowhalf >> 1, nn = 16 * (rowhalf & 1) + (lane & 15), c = lane >> 4, ks = 2 * kspair + (c >> 1), kg = c & 1;
@@ -154,9 +158,9 @@ __device__ __forceinline__ void rows_to_image(const float* __restrict__ src, uin
 }
 
 // rows of k1 <= 16 KSN floats -> image with KSN k-groups (zero-padded)
-template <int H, int KSN, class R>
+template <int H, int RBW, int KSN, class R>
 __device__ __forceinline__ void narrow_rows_to_image(const float* __restrict__ src, int k1, uintx4* img, int tid, R&& row_of) {
-    using C = Cfg<H>;
+    using C = Cfg<H, RBW>;
     for (int i = tid; i < C::NRB * KSN * 64; i += HM_THREADS) {
         const int rbg = i / (KSN * 64), rem = i % (KSN * 64), ks = rem >> 6, l = rem & 63, nn = l & 31, kg = l >> 5;
         const long long row = row_of(rbg, nn);
@@ -177,11 +181,11 @@ __device__ __forceinline__ void narrow_rows_to_image(const float* __restrict__ s
 
 // LayerNorm statistics of the wave's rows.  Each lane first publishes (mean, M2) of its 16 accumulator values per row
 // block; after the barrier every wave merges the 2 NJB partials of its rows: x_hat = acc * k + m.
-template <int H>
-__device__ __forceinline__ void ln_publish(const floatx16 (&acc)[4], float* ST, int rg, int jb, int n, int hi) {
+template <int H, int RBW>
+__device__ __forceinline__ void ln_publish(const floatx16 (&acc)[RBW], float* ST, int rg, int jb, int n, int hi) {
     using C = Cfg<H>;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = 0; rb < RBW; ++rb) {
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += acc[rb][r];
@@ -189,7 +193,7 @@ __device__ __forceinline__ void ln_publish(const floatx16 (&acc)[4], float* ST, 
         float q = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float d = acc[rb][r] - mh; q = fmaf(d, d, q); }
-        *reinterpret_cast<float2v*>(ST + ((((4 * rg + rb) * 2 * C::NJB) + 2 * jb + hi) * BE + n) * 2) = float2v{mh, q};
+        *reinterpret_cast<float2v*>(ST + ((((RBW * rg + rb) * 2 * C::NJB) + 2 * jb + hi) * BE + n) * 2) = float2v{mh, q};
     }
 }
 template <int H>
@@ -264,8 +268,8 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             const int p = pos_of(rbg, nn);
             return A.eid ? A.eid[p] : p;
         };
-        if (ENC) narrow_rows_to_image<H, 1>(A.e_in, A.k1, img, tid, in_row);
-        else rows_to_image<H, 8>(A.e_in, img, wave, lane, in_row, [](float*) {});
+        if (ENC) narrow_rows_to_image<H, 4, 1>(A.e_in, A.k1, img, tid, in_row);
+        else rows_to_image<H, 4, 8>(A.e_in, img, wave, lane, in_row, [](float*) {});
         __syncthreads();
 
         const float* wp = A.w;
@@ -309,7 +313,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             wp += linh;
         }
         // LayerNorm
-        ln_publish<H>(acc, ST, rg, jb, n, hi);
+        ln_publish<H, 4>(acc, ST, rg, jb, n, hi);
         __syncthreads();
         float carry[16];
 #pragma unroll
@@ -414,9 +418,9 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
 // ------------------------------------------------------------------------------------------
 // node kernel
 // ------------------------------------------------------------------------------------------
-template <int H, int MODE>
+template <int H, int MODE, int RBW>
 __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
-    using C = Cfg<H>;
+    using C = Cfg<H, RBW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uintx4* img = reinterpret_cast<uintx4*>(smem);
     const half8* imgh = reinterpret_cast<const half8*>(smem);
@@ -446,41 +450,41 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             return r < N ? r : N - 1;
         };
         __syncthreads();   // the previous tile's readers of the image are done
-        floatx16 acc[4];
+        floatx16 acc[RBW];
         Lin L;
-        if (MODE == 0) narrow_rows_to_image<H, 2>(A.x_in, A.k1, img, tid, row_of);
-        else rows_to_image<H, 8>(A.x_in, img, wave, lane, row_of, [](float*) {});
+        if (MODE == 0) narrow_rows_to_image<H, RBW, 2>(A.x_in, A.k1, img, tid, row_of);
+        else rows_to_image<H, RBW, 2 * RBW>(A.x_in, img, wave, lane, row_of, [](float*) {});
         __syncthreads();
         if (MODE != 2) {
             const float* wp = A.w;
             L = lin_at(wp, H);
             init_bias(acc, L.bias, jb, hi);
             if (MODE == 0) {
-                gemm(acc, L.frag + (size_t)jb * 2 * 128 + lane, imgh + (size_t)(4 * rg) * 2 * 128 + lane, 2, 2);
+                gemm(acc, L.frag + (size_t)jb * 2 * 128 + lane, imgh + (size_t)(RBW * rg) * 2 * 128 + lane, 2, 2);
             } else {
-                gemm(acc, L.frag + (size_t)jb * 2 * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, L.frag + (size_t)jb * 2 * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
                 __syncthreads();
-                rows_to_image<H, 2>(A.agg, img, wave, lane, row_of, [](float*) {});
+                rows_to_image<H, RBW, 2>(A.agg, img, wave, lane, row_of, [](float*) {});
                 __syncthreads();
-                gemm(acc, L.frag + ((size_t)jb * 2 * C::KS + C::KS) * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, L.frag + ((size_t)jb * 2 * C::KS + C::KS) * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
             }
             wp += lin0;
 #pragma unroll 1
             for (int l = 1; l <= A.nl; ++l) {
                 __syncthreads();
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) acc_to_img<true>(acc[rb], L.inv_t, img + (size_t)(4 * rg + rb) * C::KS * 128, jb, lane);
+                for (int rb = 0; rb < RBW; ++rb) acc_to_img<true>(acc[rb], L.inv_t, img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
                 __syncthreads();
                 L = lin_at(wp, H);
                 init_bias(acc, L.bias, jb, hi);
-                gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
                 wp += linh;
             }
-            ln_publish<H>(acc, ST, rg, jb, n, hi);
+            ln_publish<H, RBW>(acc, ST, rg, jb, n, hi);
             __syncthreads();
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const int rbg = 4 * rg + rb;
+            for (int rb = 0; rb < RBW; ++rb) {
+                const int rbg = RBW * rg + rb;
                 float k, m;
                 ln_merge<H>(ST, rbg, n, L.t, A.eps, k, m);
                 const int r = row0 + 32 * rbg + n;
@@ -509,7 +513,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             if (A.tail == 0) continue;
             // the new h becomes the tail's input image (every wave has passed the barrier after the last Linear)
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) acc_to_img<false>(acc[rb], 1.0f, img + (size_t)(4 * rg + rb) * C::KS * 128, jb, lane);
+            for (int rb = 0; rb < RBW; ++rb) acc_to_img<false>(acc[rb], 1.0f, img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
             __syncthreads();
         }
         if (A.tail == 1 || MODE == 2) {
@@ -518,10 +522,10 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             for (int half = 0; half < 2; ++half) {
                 const int jbv = jb + half * C::NJB;
                 init_bias(acc, LP.bias, jbv, hi);
-                gemm(acc, LP.frag + (size_t)jbv * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, LP.frag + (size_t)jbv * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    const int r = row0 + 32 * (4 * rg + rb) + n;
+                for (int rb = 0; rb < RBW; ++rb) {
+                    const int r = row0 + 32 * (RBW * rg + rb) + n;
                     if (r < N) {
                         float* pp = A.P_out + (size_t)r * 2 * H + 32 * jbv + 4 * hi;
 #pragma unroll
@@ -540,21 +544,21 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             for (int l = 0; l < A.nl; ++l) {
                 const Lin LD = lin_at(wp, H);
                 init_bias(acc, LD.bias, jb, hi);
-                gemm(acc, LD.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, LD.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
                 __syncthreads();
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) acc_to_img<true>(acc[rb], LD.inv_t, img + (size_t)(4 * rg + rb) * C::KS * 128, jb, lane);
+                for (int rb = 0; rb < RBW; ++rb) acc_to_img<true>(acc[rb], LD.inv_t, img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
                 __syncthreads();
                 wp += linh;
             }
             if (jb == 0) {
                 const Lin LO = lin_at(wp, 32);
                 init_bias(acc, LO.bias, 0, hi);
-                gemm(acc, LO.frag + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, LO.frag + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
                 if (hi == 0) {
 #pragma unroll
-                    for (int rb = 0; rb < 4; ++rb) {
-                        const int r = row0 + 32 * (4 * rg + rb) + n;
+                    for (int rb = 0; rb < RBW; ++rb) {
+                        const int r = row0 + 32 * (RBW * rg + rb) + n;
                         if (r < N) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
@@ -647,23 +651,29 @@ int launch_edge_h(bool enc, const HmEdgeArgs& a, hipStream_t s) {
     return GM_OK;
 }
 
-template <int H>
-int launch_node_h(int mode, const HmNodeArgs& a, hipStream_t s) {
+template <int H, int RBW>
+int launch_node_hr(int mode, const HmNodeArgs& a, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.need()) {
-        int rc = set_lds_attr(hm_node_kernel<H, 0>);
-        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 1>);
-        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 2>);
+        int rc = set_lds_attr(hm_node_kernel<H, 0, RBW>);
+        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 1, RBW>);
+        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 2, RBW>);
         if (rc != GM_OK) return rc;
     }
-    const int tiles = (int)cdiv(a.n_nodes, Cfg<H>::M);
+    const int tiles = (int)cdiv(a.n_nodes, Cfg<H, RBW>::M);
     int grid = device_cus();
     if (tiles < grid) grid = tiles < 1 ? 1 : tiles;
     ProfScope prof(mode == 0 ? PROF_ENC : PROF_NODE, s);
-    if (mode == 0) hipLaunchKernelGGL((hm_node_kernel<H, 0>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
-    else if (mode == 1) hipLaunchKernelGGL((hm_node_kernel<H, 1>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((hm_node_kernel<H, 2>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+    if (mode == 0) hipLaunchKernelGGL((hm_node_kernel<H, 0, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((hm_node_kernel<H, 1, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((hm_node_kernel<H, 2, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
     return GM_OK;
+}
+// small graphs: one 32-row block per wave, so that the tiles cover the CUs
+template <int H>
+int launch_node_h(int mode, const HmNodeArgs& a, hipStream_t s) {
+    if (cdiv(a.n_nodes, Cfg<H, 4>::M) < device_cus()) return launch_node_hr<H, 1>(mode, a, s);
+    return launch_node_hr<H, 4>(mode, a, s);
 }
 
 }  // namespace
