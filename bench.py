@@ -159,10 +159,9 @@ def resolve_kernel(edge_kernel, hidden):
     return ek
 
 
-def roofline_record(L, _lib, ek, hidden, edges, n_nodes, workload_key):
-    launches, ms = C.c_int64(0), C.c_double(0.0)
-    _lib.check(L.gm_profile_query(0, C.byref(launches), C.byref(ms)))
-    k_ms = ms.value / max(launches.value, 1)
+def roofline_record(model, ek, hidden, edges, n_nodes, workload_key):
+    n_launch, total_ms = model.profile_query(0)
+    k_ms = total_ms / max(n_launch, 1)
     alg = edge_kernel_alg_flops(edges, hidden)
     issued = edge_kernel_issued_flops(edges, hidden)
     # MFMA utilisation is priced on the flops the kernel ISSUES (3 HxH products per edge; SURVEY.md 8d "utilisation uses
@@ -186,7 +185,7 @@ def roofline_record(L, _lib, ek, hidden, edges, n_nodes, workload_key):
     top = hbmr if bound == "hbm" else mfma
     rec = {"bound": bound, "kernel": kname + " (processor phi_e + scatter-add)",
            "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"], "traffic": None,
-           "avg_launch_ms": k_ms, "launches_timed": int(launches.value),
+           "avg_launch_ms": k_ms, "launches_timed": n_launch,
            "issued_flops_per_launch": issued * mult, "fp32_equivalent_flops_per_launch": issued,
            "fp32_equivalent_tflops": issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
            "alg_flops_per_launch": alg, "alg_tflops": alg / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
@@ -224,7 +223,7 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
         eng.status()
         timed_traj = traj[warmup:].contiguous()
         barrier()
-        L.gm_profile_enable(1)  # HIP events around the dominant kernel only (kind 0: processor edge kernel)
+        model.profile(1)  # HIP events around the dominant kernel only (kind 0: processor edge kernel), this model's launches
         t0 = time.perf_counter()
         if dist:  # per-generation exchange of the candidate-parallel planner: scripted poses out ...
             first = timed_traj[0].to(cdev)
@@ -238,7 +237,7 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
             dist.all_gather(gathered, result)
         barrier()
         el = time.perf_counter() - t0
-    L.gm_profile_enable(0)
+    model.profile(0)
     edges = eng.status()  # edge count of the last timed step
     if dist:
         t = torch.tensor([el], dtype=torch.float64, device=cdev)
@@ -246,19 +245,18 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
         el = float(t.item())
     rec = None
     if rank == 0:
-        roof, k_ms = roofline_record(L, _lib, ek, wl["hidden"], edges, wl["n"] * candidates, wl_key)
+        roof, k_ms = roofline_record(model, ek, wl["hidden"], edges, wl["n"] * candidates, wl_key)
         # breakdown of the other kernels: a few extra, untimed steps with their events on
-        L.gm_profile_enable(14)
+        model.profile(14)
         with torch.no_grad():
             k2 = min(5, steps)
             eng.run(obs, timed_traj[:k2].contiguous(), k2)
         torch.cuda.synchronize()
-        L.gm_profile_enable(0)
-        launches, ms = C.c_int64(0), C.c_double(0.0)
         br = {"edge_kernel_ms_per_step": k_ms * 10}
         for name, (kind, calls) in {"node_kernel": (1, 10), "graph_build": (2, 1), "encoder_kernels": (3, 2)}.items():
-            _lib.check(L.gm_profile_query(kind, C.byref(launches), C.byref(ms)))
-            br[name + "_ms_per_step"] = ms.value / max(launches.value, 1) * calls
+            n_k, ms_k = model.profile_query(kind)
+            br[name + "_ms_per_step"] = ms_k / max(n_k, 1) * calls
+        model.profile(0)
         rec = {"value": world * candidates * steps / el, "unit": "rollout steps/s", "steps": steps, "warmup": warmup,
                "ms_per_step": el / steps * 1e3,
                "config": {"workload": wl["name"], "n_particles": wl["n"], "hidden": wl["hidden"], "edges_last_step": edges, "k_steps": 6,

@@ -87,9 +87,9 @@ PROTOTYPES = {
     "gm_rollout_step": (_i32, [_vp, _vp, _i64, _FD, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gm_rollout": (_i32, [_vp, _vp, _i64, _FD, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "gm_rollout_status": (_i32, [_vp, _MD, _i64, _i32, C.POINTER(_i64), _vp]),
-    "gm_profile_enable": (_i32, [_i32]),
+    "gm_model_profile": (_i32, [_vp, _i32]),
     "gm_model_set_edge_kernel": (_i32, [_vp, _i32]),
-    "gm_profile_query": (_i32, [_i32, C.POINTER(_i64), C.POINTER(_f64)]),
+    "gm_model_profile_query": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_f64)]),
 }
 
 _lib = None

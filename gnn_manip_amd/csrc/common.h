@@ -131,13 +131,22 @@ struct CsrWs {
 };
 CsrWs carve_csr(void* ws, int64_t n, int64_t cap);
 
-// ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
+// ---- optional per-kernel timing with HIP events on the launch stream, owned by a model handle (gm_model_profile)
 enum ProfKind : int { PROF_EDGE = 0, PROF_NODE = 1, PROF_GRAPH = 2, PROF_ENC = 3, PROF_KINDS = 4 };
+constexpr int PROF_MAX = 4096;
+struct ProfState {
+    int mask = 0;  // bit k: record kind k
+    int count[PROF_KINDS] = {0, 0, 0, 0};
+    hipEvent_t* start[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t* stop[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
+    ~ProfState();
+};
 struct ProfScope {
+    ProfState* p;
     int idx;
     int kind;
     hipStream_t s;
-    ProfScope(int kind, hipStream_t s);
+    ProfScope(ProfState* state, int kind, hipStream_t s);   // state may be null: nothing is recorded
     ~ProfScope();
 };
 

@@ -23,30 +23,29 @@ const char* last_error() { return g_err; }
 // ------------------------------------------------------------------------------------------
 // profiling hooks
 // ------------------------------------------------------------------------------------------
-namespace {
-constexpr int PROF_MAX = 4096;
-struct ProfState {
-    int mask = 0;  // bit k: record kind k
-    int count[PROF_KINDS] = {0, 0, 0, 0};
-    hipEvent_t* start[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t* stop[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
-} g_prof;
-}  // namespace
+ProfState::~ProfState() {
+    for (int k = 0; k < PROF_KINDS; ++k) {
+        if (!start[k]) continue;
+        for (int i = 0; i < PROF_MAX; ++i) { (void)hipEventDestroy(start[k][i]); (void)hipEventDestroy(stop[k][i]); }
+        delete[] start[k];
+        delete[] stop[k];
+    }
+}
 
-ProfScope::ProfScope(int k, hipStream_t st) : idx(-1), kind(k), s(st) {
-    if (!((g_prof.mask >> k) & 1) || g_prof.count[k] >= PROF_MAX) return;
-    if (!g_prof.start[k]) {
-        g_prof.start[k] = new hipEvent_t[PROF_MAX];
-        g_prof.stop[k] = new hipEvent_t[PROF_MAX];
+ProfScope::ProfScope(ProfState* state, int k, hipStream_t st) : p(state), idx(-1), kind(k), s(st) {
+    if (!p || !((p->mask >> k) & 1) || p->count[k] >= PROF_MAX) return;
+    if (!p->start[k]) {
+        p->start[k] = new hipEvent_t[PROF_MAX];
+        p->stop[k] = new hipEvent_t[PROF_MAX];
         for (int i = 0; i < PROF_MAX; ++i) {
-            if (hipEventCreate(&g_prof.start[k][i]) != hipSuccess || hipEventCreate(&g_prof.stop[k][i]) != hipSuccess) return;
+            if (hipEventCreate(&p->start[k][i]) != hipSuccess || hipEventCreate(&p->stop[k][i]) != hipSuccess) return;
         }
     }
-    idx = g_prof.count[k]++;
-    (void)hipEventRecord(g_prof.start[k][idx], s);
+    idx = p->count[k]++;
+    (void)hipEventRecord(p->start[k][idx], s);
 }
 ProfScope::~ProfScope() {
-    if (idx >= 0) (void)hipEventRecord(g_prof.stop[kind][idx], s);
+    if (idx >= 0) (void)hipEventRecord(p->stop[kind][idx], s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -743,26 +742,7 @@ extern "C" {
 
 const char* gm_last_error(void) { return gm::last_error(); }
 
-int gm_profile_enable(int kind_mask) {
-    for (int k = 0; k < PROF_KINDS; ++k)
-        if (((kind_mask & ~g_prof.mask) >> k) & 1) g_prof.count[k] = 0;  // newly enabled kinds start from zero
-    g_prof.mask = kind_mask;
-    return GM_OK;
-}
-
-int gm_profile_query(int kind, int64_t* launches, double* total_ms) {
-    GM_REQUIRE(kind >= 0 && kind < PROF_KINDS && launches && total_ms, GM_ERR_INVALID_ARGUMENT, "gm_profile_query: bad argument");
-    *launches = g_prof.count[kind];
-    *total_ms = 0.0;
-    for (int i = 0; i < g_prof.count[kind]; ++i) {
-        GM_HIP_CHECK(hipEventSynchronize(g_prof.stop[kind][i]));
-        float ms = 0.f;
-        GM_HIP_CHECK(hipEventElapsedTime(&ms, g_prof.start[kind][i], g_prof.stop[kind][i]));
-        *total_ms += ms;
-    }
-    return GM_OK;
-}
-int gm_abi_version(void) { return 2; }
+int gm_abi_version(void) { return 3; }
 
 size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours) {
     if (n_nodes < 0 || max_neighbours < 1) return 0;
@@ -788,7 +768,6 @@ int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t 
     GraphWs g = carve_graph(ws, n, K);
     GM_REQUIRE(ws_bytes >= g.bytes, GM_ERR_WORKSPACE, "gm_radius_graph_build: workspace %zu < %zu", ws_bytes, g.bytes);
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(PROF_GRAPH, s);
     {
         const int64_t work = (int64_t)g.max_cells + 1;
         int cb = (int)cdiv(work, 256);

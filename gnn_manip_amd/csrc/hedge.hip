@@ -661,7 +661,7 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
     A.hdr = a.hdr; A.dst = a.dst; A.src = a.src; A.P = a.P; A.e_in = a.e_in; A.e_out = a.e_out; A.agg = a.agg;
     A.hw = a.wstream_h3; A.blk = t.blk; A.chunk_first = t.chunk_first; A.tab = t.hdr; A.eps = a.eps; A.residual = a.residual;
     {
-        ProfScope prof(PROF_EDGE, s);
+        ProfScope prof(a.prof, PROF_EDGE, s);
         hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, A);
     }
     GM_LAUNCH_CHECK();

@@ -47,6 +47,7 @@ struct HmEdgeArgs {
     int nl;               // num_layers: nl + 1 Linears
     const int2* blk;      // processor: 32-edge block table (hedge.h)
     const EdgeBlockHeader* tab;
+    ProfState* prof;
 };
 
 struct HmNodeArgs {
@@ -67,6 +68,7 @@ struct HmNodeArgs {
     float* P_out;
     float* dec_out;
     int out_dim;
+    ProfState* prof;
 };
 
 bool hm_supported(int H);

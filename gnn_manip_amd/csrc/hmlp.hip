@@ -645,7 +645,7 @@ int launch_edge_h(bool enc, const HmEdgeArgs& a, hipStream_t s) {
         if (rc == GM_OK) rc = set_lds_attr(hm_edge_kernel<H, false>);
         if (rc != GM_OK) return rc;
     }
-    ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
+    ProfScope prof(a.prof, enc ? PROF_ENC : PROF_EDGE, s);
     if (enc) hipLaunchKernelGGL((hm_edge_kernel<H, true>), dim3(device_cus()), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
     else hipLaunchKernelGGL((hm_edge_kernel<H, false>), dim3(device_cus()), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
     return GM_OK;
@@ -663,7 +663,7 @@ int launch_node_hr(int mode, const HmNodeArgs& a, hipStream_t s) {
     const int tiles = (int)cdiv(a.n_nodes, Cfg<H, RBW>::M);
     int grid = device_cus();
     if (tiles < grid) grid = tiles < 1 ? 1 : tiles;
-    ProfScope prof(mode == 0 ? PROF_ENC : PROF_NODE, s);
+    ProfScope prof(a.prof, mode == 0 ? PROF_ENC : PROF_NODE, s);
     if (mode == 0) hipLaunchKernelGGL((hm_node_kernel<H, 0, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
     else if (mode == 1) hipLaunchKernelGGL((hm_node_kernel<H, 1, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
     else hipLaunchKernelGGL((hm_node_kernel<H, 2, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);

@@ -22,6 +22,7 @@ struct EdgeArgs {
     const float* wstream_hm; // fp16 hi / lo Linear images of this MLP for the streamed kernels (hmlp.h), or nullptr
     const int* edge_blocks;  // block / chunk tables of the edge list (carve_edge_blocks), or nullptr
     int64_t n_nodes_tab;     // n_nodes the tables were carved for
+    ProfState* prof;         // timing of this launch (gm_model_profile), or nullptr
     int kernel_choice;       // 0 automatic, 1 fp32 16x16x4, 2 fp32 32x32x2, 3 / 4 bf16 x 6, 5 systolic fp16 x 3, 6 streamed fp16 x 3
     const float* bias;     // processor: biases of layers 2..; encoder: biases of layers 1..
     const float* ln_g;
@@ -44,6 +45,7 @@ struct NodeArgs {
     const float* wstream;
     const float* wstream_hm;  // fp16 hi / lo Linear images of this MLP (hmlp.h), or nullptr
     const float* tail_hm;     // images of the tail
+    ProfState* prof;
     int kernel_choice;        // 1..4: the fp32 kernels; otherwise the streamed fp16 x 3 kernel when its images are present
     const float* bias;     // [NL+1][H]
     const float* ln_g;

@@ -1890,7 +1890,7 @@ static int launch_edge_h(bool enc, const EdgeArgs& a, int grid, size_t lds, hipS
         if (rc == GM_OK) rc = set_lds(edge_kernel<H, 2, 2>, lds);
         if (rc != GM_OK) return rc;
     }
-    ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
+    ProfScope prof(a.prof, enc ? PROF_ENC : PROF_EDGE, s);
     if (enc) hipLaunchKernelGGL((edge_kernel<H, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a);
     else if (a.residual) hipLaunchKernelGGL((edge_kernel<H, 2, 1>), dim3(grid), dim3(THREADS), lds, s, a);
     else hipLaunchKernelGGL((edge_kernel<H, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a);
@@ -1914,7 +1914,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         HmEdgeArgs h{};
         h.hdr = a.hdr; h.n_edges_host = a.n_edges_host; h.dst = a.dst; h.src = a.src; h.eid = a.eid; h.eid_out = a.eid_out;
         h.P = a.P; h.e_in = a.e_in; h.e_out = a.e_out; h.agg = a.agg; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b;
-        h.eps = a.eps; h.residual = a.residual; h.k1 = a.k1; h.nl = NL;
+        h.eps = a.eps; h.residual = a.residual; h.k1 = a.k1; h.nl = NL; h.prof = a.prof;
         if (!enc) {
             const EdgeBlocks t = carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity);
             h.blk = t.blk; h.tab = t.hdr;
@@ -1953,7 +1953,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         int gb = grid_for(cdiv(edge_capacity, T16));
         if (gb > 2 * cus) gb = 2 * cus;
         {
-            ProfScope prof(PROF_EDGE, s);
+            ProfScope prof(a.prof, PROF_EDGE, s);
             if (a.residual) hipLaunchKernelGGL((edge_kernel_b3p<2, 1>), dim3(gb), dim3(THREADS), lb, s, a);
             else hipLaunchKernelGGL((edge_kernel_b3p<2, 2>), dim3(gb), dim3(THREADS), lb, s, a);
         }
@@ -1973,7 +1973,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         int gb = grid_for(cdiv(edge_capacity, TE3));
         if (gb > cus) gb = cus;
         {
-            ProfScope prof(PROF_EDGE, s);
+            ProfScope prof(a.prof, PROF_EDGE, s);
             if (a.residual) hipLaunchKernelGGL((edge_kernel_b3<2, 1>), dim3(gb), dim3(B3_THREADS), lb, s, a);
             else hipLaunchKernelGGL((edge_kernel_b3<2, 2>), dim3(gb), dim3(B3_THREADS), lb, s, a);
         }
@@ -2003,7 +2003,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         int g16 = grid_for(cdiv(edge_capacity, T16));
         if (grid_cap > 0 && g16 > grid_cap) g16 = grid_cap;
         {
-            ProfScope prof(enc ? PROF_ENC : PROF_EDGE, s);
+            ProfScope prof(a.prof, enc ? PROF_ENC : PROF_EDGE, s);
             if (enc) hipLaunchKernelGGL((edge_kernel16<2, 0>), dim3(g16), dim3(THREADS), l16, s, a);
             else if (a.residual) hipLaunchKernelGGL((edge_kernel16<2, 1>), dim3(g16), dim3(THREADS), l16, s, a);
             else hipLaunchKernelGGL((edge_kernel16<2, 2>), dim3(g16), dim3(THREADS), l16, s, a);
@@ -2025,7 +2025,7 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
         HmNodeArgs h{};
         h.n_nodes = a.n_nodes; h.x_in = a.x_in; h.k1 = a.k1; h.agg = a.agg; h.agg_clear = a.agg_clear; h.h_out = a.h_out;
         h.residual = a.residual; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b; h.eps = a.eps; h.nl = NL;
-        h.tail = mode == 2 ? 1 : a.tail; h.w_tail = a.tail_hm; h.P_out = a.P_out; h.dec_out = a.dec_out; h.out_dim = a.out_dim;
+        h.tail = mode == 2 ? 1 : a.tail; h.w_tail = a.tail_hm; h.P_out = a.P_out; h.dec_out = a.dec_out; h.out_dim = a.out_dim; h.prof = a.prof;
         return launch_node_hm(H, mode, h, s);
     }
     GM_REQUIRE((H == 128 || H == 256) && NL == 2 && a.wstream, GM_ERR_UNSUPPORTED,
@@ -2044,14 +2044,14 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
             if (rc != GM_OK) return rc;
         }
         const int wg = grid_for(cdiv(a.n_nodes, WTILE));
-        ProfScope prof(mode == 1 ? PROF_NODE : PROF_ENC, s);
+        ProfScope prof(a.prof, mode == 1 ? PROF_NODE : PROF_ENC, s);
         switch (mode) {
             case 0: hipLaunchKernelGGL((node_kernel_wide<128, 2, 0>), dim3(wg), dim3(THREADS), wl, s, a); break;
             case 1: hipLaunchKernelGGL((node_kernel_wide<128, 2, 1>), dim3(wg), dim3(THREADS), wl, s, a); break;
             default: hipLaunchKernelGGL((node_kernel_wide<128, 2, 2>), dim3(wg), dim3(THREADS), wl, s, a); break;
         }
     } else {
-        ProfScope prof(mode == 1 ? PROF_NODE : PROF_ENC, s);
+        ProfScope prof(a.prof, mode == 1 ? PROF_NODE : PROF_ENC, s);
         if (H == 128) {
             switch (mode) {
                 case 0: hipLaunchKernelGGL((node_kernel<128, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a); break;

@@ -17,6 +17,7 @@ struct gm_model {
     size_t hm_floats = 0, hm_enc_edge = 0, hm_enc_node = 0, hm_enc_node_tail = 0;
     std::vector<size_t> hm_edge, hm_node, hm_node_tail;
     bool legacy = false;         // hidden 128 / 256 with num_layers 2: the fp32 images (packed) exist
+    gm::ProfState* prof = nullptr;  // gm_model_profile
     int edge_kernel = 0;         // processor edge kernel of this model: 0 automatic, 1..5 see gm_model_set_edge_kernel
     std::vector<size_t> s16_edge;
     float* vec = nullptr;     // per-MLP contiguous [bias_0..bias_NL, ln_gamma, ln_beta]

@@ -384,6 +384,7 @@ void gm_model_destroy(gm_model* m) {
     if (m->packed_h3) hipFree(m->packed_h3);
     if (m->packed_hm) hipFree(m->packed_hm);
     if (m->vec) hipFree(m->vec);
+    delete m->prof;
     delete m;
 }
 
@@ -403,7 +404,7 @@ EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid
     a.wstream = m->packed ? m->packed + m->s_enc_edge : nullptr;
     a.wstream16 = m->packed16 ? m->packed16 + m->s16_enc_edge : nullptr;
     a.wstream_hm = m->packed_hm + m->hm_enc_edge;
-    a.kernel_choice = m->edge_kernel;
+    a.kernel_choice = m->edge_kernel; a.prof = m->prof;
     const float* v = m->vec + m->v_enc_edge;
     a.bias = v; a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
     return a;
@@ -420,7 +421,7 @@ EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, int64_t n, con
     a.wstream_h3 = m->packed_h3 ? m->packed_h3 + (size_t)k * h3_image_floats() : nullptr;
     a.edge_blocks = c.blocks;
     a.n_nodes_tab = n;
-    a.kernel_choice = m->edge_kernel;
+    a.kernel_choice = m->edge_kernel; a.prof = m->prof;
     const float* v = m->vec + m->v_edge[k];
     a.bias = v + m->H;  // layer-1 bias lives in P_i
     a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
@@ -462,7 +463,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     NodeArgs na{};
     na.n_nodes = (int)n; na.x_in = nodes; na.k1 = m->d.node_dim; na.h_out = f.h;
     na.wstream = m->packed ? m->packed + m->s_enc_node : nullptr;
-    na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel;
+    na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel; na.prof = m->prof;
     const float* v = m->vec + m->v_enc_node;
     na.bias = v; na.ln_g = v + (size_t)(NL + 1) * H; na.ln_b = v + (size_t)(NL + 2) * H; na.eps = m->d.ln_eps;
     set_tail(m, na, 0, f.P, out);
@@ -476,7 +477,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
         NodeArgs a{};
         a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.agg_clear = k + 1 < M ? f.agg : nullptr; a.h_out = f.h; a.residual = 1;
         a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
-        a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel;
+        a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel; a.prof = m->prof;
         const float* vn = m->vec + m->v_node[k];
         a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
         set_tail(m, a, k + 1, f.P, out);
@@ -498,7 +499,7 @@ int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n, c
     NodeArgs na{};
     na.n_nodes = (int)n; na.x_in = x; na.k1 = m->d.node_dim; na.h_out = h_out;
     na.wstream = m->packed ? m->packed + m->s_enc_node : nullptr;
-    na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel;
+    na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel; na.prof = m->prof;
     const float* v = m->vec + m->v_enc_node;
     na.bias = v; na.ln_g = v + (size_t)(m->NL + 1) * m->H; na.ln_b = v + (size_t)(m->NL + 2) * m->H; na.eps = m->d.ln_eps;
     na.tail = 0;
@@ -525,7 +526,7 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     pa.wstream = !m->packed ? nullptr
                  : k == 0   ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
                             : m->packed + m->s_node[k - 1] + (size_t)((NL + 2) * m->S_HH) * kStageFloats;
-    pa.kernel_choice = m->edge_kernel;
+    pa.kernel_choice = m->edge_kernel; pa.prof = m->prof;
     set_tail(m, pa, k, f.P, nullptr);
     int rc = launch_node(H, NL, 2, pa, s);
     if (rc != GM_OK) return rc;
@@ -535,7 +536,7 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     NodeArgs a{};
     a.n_nodes = (int)n; a.x_in = h; a.agg = f.agg; a.h_out = h_out; a.residual = 0;
     a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
-    a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel;
+    a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel; a.prof = m->prof;
     const float* vn = m->vec + m->v_node[k];
     a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
     a.tail = 0;
@@ -582,6 +583,34 @@ int gm_model_set_edge_kernel(gm_model* m, int choice) {
     return GM_OK;
 }
 
+int gm_model_profile(gm_model* m, int kind_mask) {
+    GM_REQUIRE(m, GM_ERR_INVALID_ARGUMENT, "gm_model_profile: null model");
+    if (!m->prof) {
+        if (!kind_mask) return GM_OK;
+        m->prof = new ProfState();
+    }
+    for (int k = 0; k < PROF_KINDS; ++k)
+        if (((kind_mask & ~m->prof->mask) >> k) & 1) m->prof->count[k] = 0;  // newly enabled kinds start from zero
+    m->prof->mask = kind_mask;
+    return GM_OK;
+}
+
+int gm_model_profile_query(const gm_model* m, int kind, int64_t* launches, double* total_ms) {
+    GM_REQUIRE(m && kind >= 0 && kind < PROF_KINDS && launches && total_ms, GM_ERR_INVALID_ARGUMENT, "gm_model_profile_query: bad argument");
+    *launches = 0;
+    *total_ms = 0.0;
+    const ProfState* p = m->prof;
+    if (!p) return GM_OK;
+    *launches = p->count[kind];
+    for (int i = 0; i < p->count[kind]; ++i) {
+        GM_HIP_CHECK(hipEventSynchronize(p->stop[kind][i]));
+        float ms = 0.f;
+        GM_HIP_CHECK(hipEventElapsedTime(&ms, p->start[kind][i], p->stop[kind][i]));
+        *total_ms += ms;
+    }
+    return GM_OK;
+}
+
 size_t gm_rollout_workspace_bytes(const gm_model_desc* desc, int64_t n, int K) {
     if (!desc || n < 0 || K < 1) return 0;
     return carve_rollout(nullptr, desc, n, K).bytes;
@@ -605,8 +634,11 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
     rc = gm::rollout_pre_features(obs, n, fd, rigid_rank, rigid_target, r.x, hs);
     if (rc != GM_OK) return rc;
     const float* last_pos = obs + (size_t)(fd->k_steps - 1) * n * fd->data_dim + fd->cart_col;
-    rc = gm_radius_graph_build_batched(last_pos, fd->data_dim, n, fd->nodes_per_graph > 0 ? fd->nodes_per_graph : n, fd->conn_r, K,
+    {
+        ProfScope prof(m->prof, PROF_GRAPH, hs);
+        rc = gm_radius_graph_build_batched(last_pos, fd->data_dim, n, fd->nodes_per_graph > 0 ? fd->nodes_per_graph : n, fd->conn_r, K,
                                        r.graph, r.graph_bytes, stream);
+    }
     if (rc != GM_OK) return rc;
     // destination sort; the edge features are written by the same pass that fixes each segment's order
     rc = gm::csr_from_graph_with_features(r.graph, n, K, r.csr, r.csr_bytes, last_pos, fd->data_dim, (float)fd->conn_r,

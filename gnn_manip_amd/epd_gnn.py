@@ -59,6 +59,7 @@ class _Handle:
         self.key = None
         self.desc = None
         self.edge_kernel = 0
+        self.prof_mask = 0
 
     def get(self, desc_tuple, params, device):
         key = (desc_tuple, str(device), tuple((p.data_ptr(), p._version) for p in params))
@@ -77,7 +78,10 @@ class _Handle:
             self.h = out
             if self.edge_kernel:
                 check(L.gm_model_set_edge_kernel(self.h, self.edge_kernel))
-        torch.cuda.current_stream(device).synchronize()  # the temporaries above may be freed now
+            if self.prof_mask:
+                check(L.gm_model_profile(self.h, self.prof_mask))
+        # no synchronisation: the pack kernels are queued on torch's current stream, and the caching allocator hands the
+        # temporaries' memory out again only in that stream's order
         self.key = key
         self.desc = d
         return self.h
@@ -86,6 +90,22 @@ class _Handle:
         self.edge_kernel = int(choice)
         if self.h is not None:
             check(lib().gm_model_set_edge_kernel(self.h, self.edge_kernel))
+
+    def profile(self, kind_mask):
+        self.prof_mask = int(kind_mask)
+        if self.h is not None:
+            check(lib().gm_model_profile(self.h, self.prof_mask))
+
+    def profile_query(self, kind):
+        launches, ms = C.c_int64(0), C.c_double(0.0)
+        if self.h is not None:
+            check(lib().gm_model_profile_query(self.h, int(kind), C.byref(launches), C.byref(ms)))
+        return int(launches.value), float(ms.value)
+
+    def invalidate(self):
+        """Forget the packed state: the next use re-packs.  Needed only after writes that bypass autograd's version
+        counter (``p.data.copy_(..)``, raw pointers); in-place ops on the parameters themselves are noticed."""
+        self.key = None
 
     def close(self):
         if self.h is not None:
@@ -425,6 +445,20 @@ class EncProcDecGNN(nn.Module):
 
     EDGE_KERNELS = {"auto": 0, "16": 1, "classic": 2, "b3": 3, "b3p": 4, "sys": 5, "hm": 6}
 
+    def profile(self, kind_mask):
+        """HIP-event timing of this model's launches (gm_model_profile; bit 0 processor edge kernel, 1 processor node
+        kernel, 2 radius-graph build of the rollout step, 3 encoders).  0 switches it off."""
+        self._handle.profile(kind_mask)
+
+    def profile_query(self, kind):
+        """(launches, total milliseconds) recorded for `kind` since it was enabled; synchronises on the events."""
+        return self._handle.profile_query(kind)
+
+    def invalidate_packed_weights(self):
+        """Re-pack the device weight images on next use (after writes through ``.data`` / raw pointers, which the
+        version counters do not see)."""
+        self._handle.invalidate()
+
     def set_edge_kernel(self, choice):
         """Processor edge kernel of this model (diagnostics / A-B measurements; no reference counterpart): 'auto',
         'sys' (systolic fp16 x 3), 'b3' / 'b3p' (bf16 x 6), '16' / 'classic' (fp32 MFMA).  See include/gnn_manip_hip.h."""
@@ -456,8 +490,16 @@ class EncProcDecGNN(nn.Module):
         out = torch.empty((n, self.dims[2]), dtype=torch.float32, device=nodes.device)
         check(L.gm_epd_forward(h, ptr(nodes), n, ptr(edge_attr), 0, ptr(csr.ws), e, ptr(out), ptr(fwd),
                                fwd.numel(), current_stream()))
-        csr.validate()  # raises on an out-of-range edge_index entry
+        # no synchronisation here: an out-of-range edge_index entry is dropped by the destination sort and flagged in the
+        # CSR header; status() reports it
+        self._last_csr = csr
         return out
+
+    def status(self):
+        """Checks the last inference forward (synchronises): raises GMError if its edge_index held an entry outside
+        [0, n_nodes) -- such edges were left out --, else returns its edge count."""
+        csr = getattr(self, "_last_csr", None)
+        return csr.validate() if csr is not None else 0
 
     # the reference's per-step helper, kept for API parity (epd_gnn.py:100-105)
     def _process(self, in_module, prev_latent_node, prev_latent_edge, edge_index):

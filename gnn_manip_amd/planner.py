@@ -155,6 +155,7 @@ class TrajectoryCMAsolver:
         self.model, self.graph_attr = model, graph_attr
         self.horizon = total_steps
         self.device = torch.device(device)
+        self.collective_device = None   # where the broadcast / all-gather payloads live; None: self.device (RCCL).  "cpu" for gloo
         self.scale_rot, self.scale_ty = scale_rot, scale_ty
         self.nr_traj_points = traj_points
         self.traj_points = int(self.horizon / self.nr_traj_points)
@@ -257,7 +258,7 @@ class TrajectoryCMAsolver:
         X = [np.asarray(x, dtype=np.float64) for x in X]
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         if world > 1:
-            ev = CandidateEvaluator(None, result_dim=1, device=self.device)
+            ev = CandidateEvaluator(None, result_dim=1, device=self.collective_device or self.device)
             return ev.evaluate_blocks(X, self._local_losses).reshape(-1).tolist()
         return self._local_losses(X)
 

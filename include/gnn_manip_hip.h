@@ -278,14 +278,14 @@ int gm_rollout_status(const void* rollout_ws, const gm_model_desc* desc, int64_t
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart; the reference only wraps model.forward in
- * time.time(), examples/optimise_traj.py:99-103).  When enabled, the library brackets its dominant
- * kernel launches with HIP events on the launch stream.  kind: 0 processor edge kernel,
- * 1 processor node kernel, 2 radius-graph build (all its kernels), 3 encoder kernels; kind_mask has bit
- * `kind` set for every kind to record (0 disables; a newly enabled kind restarts its counters).
- * gm_profile_query synchronises on the recorded events.
+ * time.time(), examples/optimise_traj.py:99-103).  Per model handle: when enabled, launches made on behalf of THIS
+ * model are bracketed with HIP events on their launch stream; other handles and streams are unaffected.
+ * kind: 0 processor edge kernel, 1 processor node kernel, 2 radius-graph build of gm_rollout_step (all its kernels),
+ * 3 encoder kernels; kind_mask has bit `kind` set for every kind to record (0 disables; a newly enabled kind
+ * restarts its counters).  gm_model_profile_query synchronises on the recorded events.
  * ------------------------------------------------------------------------------------------ */
-int gm_profile_enable(int kind_mask);
-int gm_profile_query(int kind, int64_t* launches, double* total_ms);
+int gm_model_profile(gm_model* model, int kind_mask);
+int gm_model_profile_query(const gm_model* model, int kind, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

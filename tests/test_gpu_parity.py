@@ -161,6 +161,18 @@ def test_bad_edge_index_raises(dev):
     ei = torch.tensor([[0, 1, 2], [1, 2, 9]], dtype=torch.int64, device=dev)
     with pytest.raises(GMError):
         DstCsr(ei, 3).validate()
+    # the fused forward does not synchronise to check; the bad edge is left out and reported by status()
+    from gnn_manip_amd import EncProcDecGNN
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 2).to(dev)
+    with torch.no_grad():
+        out = m.forward(torch.randn(3, 25, device=dev), torch.randn(3, 4, device=dev), ei)
+        good = m.forward(torch.zeros(3, 25, device=dev), torch.zeros(2, 4, device=dev), ei[:, :2].contiguous())
+    assert torch.isfinite(out).all() and torch.isfinite(good).all()
+    assert m.status() == 2          # the second (valid) forward
+    with torch.no_grad():
+        m.forward(torch.zeros(3, 25, device=dev), torch.zeros(3, 4, device=dev), ei)
+    with pytest.raises(GMError, match="out of range"):
+        m.status()
 
 
 # ------------------------------------------------------------------ K4-K9 model
@@ -592,3 +604,23 @@ def test_host_resident_weights_use_the_same_kernels(dev):
         assert np.array_equal(out.cpu().numpy(), out_dev)
     finally:
         L.gm_model_destroy(handle)
+
+
+def test_profile_is_per_model(dev):
+    """gm_model_profile: HIP-event timing belongs to one model handle; a second model's launches are not recorded."""
+    from gnn_manip_amd import EncProcDecGNN
+    a = EncProcDecGNN(25, 4, 3, 128, 2, 2).to(dev)
+    b = EncProcDecGNN(25, 4, 3, 128, 2, 3).to(dev)
+    x, ea = torch.randn(50, 25, device=dev), torch.randn(200, 4, device=dev)
+    ei = torch.randint(0, 50, (2, 200), device=dev)
+    a.profile(0b11)
+    with torch.no_grad():
+        a.forward(x, ea, ei)
+        b.forward(x, ea, ei)
+    assert a.profile_query(0)[0] == 2 and a.profile_query(1)[0] == 2    # a's two processor steps
+    assert a.profile_query(0)[1] > 0.0
+    assert b.profile_query(0) == (0, 0.0)
+    a.profile(0)
+    with torch.no_grad():
+        a.forward(x, ea, ei)
+    assert a.profile_query(0)[0] == 2

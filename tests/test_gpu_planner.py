@@ -141,3 +141,41 @@ def test_interpolated_solver_runs_constrained_optimisation(dev):
     # the batched objective equals the one-by-one objective here as well
     X = [x0, x0 * 1.01, x0 * 0.99]
     np.testing.assert_allclose(s.population_losses(X), [s.cma_objective(x) for x in X], rtol=2e-5)
+
+
+def test_c5_two_ranks_on_one_gpu(dev, tmp_path):
+    """BASELINE C5's shape at rehearsal size: a CMA-ES generation sharded over two ranks (gloo, both on this GPU), each rank
+    rolling its candidates out in block-diagonal batches and taking one Sinkhorn loss per candidate -- the real
+    TrajectoryCMAsolver.population_losses -- must equal the single-process evaluation of the same population."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s, _, _ = _solver(dev, cands=2)
+    x0 = np.concatenate((s.sample_traj[:, 0], s.sample_traj[:, 1]))
+    rng = np.random.default_rng(6)
+    X = [x0 + 0.05 * rng.standard_normal(x0.shape) for _ in range(7)]
+    single = s.population_losses(X)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    out = tmp_path / "losses.json"
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_c5_rehearsal_worker.py")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, worker, str(out)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    sharded = json.load(open(out))
+    assert len(sharded) == 7
+    np.testing.assert_allclose(sharded, single, rtol=0, atol=0)   # same kernels, same per-graph tables: identical
