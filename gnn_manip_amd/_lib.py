@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnnmanip_hip.so")
+LIB_PATH = os.environ.get("GM_LIB_PATH") or os.path.join(_HERE, "libgnnmanip_hip.so")   # GM_LIB_PATH: A/B builds of the same library
 
 GM_OK = 0
 

@@ -39,6 +39,12 @@ namespace {
 constexpr int H = 128;
 constexpr int BE = 32;             // edges per block
 constexpr int SYS_THREADS = 768;
+#ifndef SIDE_STRIDE
+#define SIDE_STRIDE 6   // MFMA slots per row group of role 1's e_out epilogue (24 slots per tick)
+#endif
+#ifndef HEDGE_ABL
+#define HEDGE_ABL 0   // development builds: timing ablations (1 no residual read, 2 P_j from the P_i row, 4 no e_out store, 8 no agg store, 16 no e read, 32 e_out rows folded onto 1024 rows)
+#endif
 constexpr int HW_HEADER_FLOATS = 4;            // T1, 1/T3, pad, pad
 constexpr int HW_VEC_FLOATS = 4 * H;           // b2*T2 | b3*T3 | gamma | beta
 constexpr int HW_IMAGE_HALF8 = 3 * 4 * 8 * 2 * 64;   // [layer][jb][ks][part][lane]
@@ -219,7 +225,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
                     const int d = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, dl1);
                     const int s = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, sl1);
                     pi[j] = *reinterpret_cast<const floatx4*>(A.P + (unsigned)(d * (2 * H) + 32 * jb + 4 * cq));
-                    pj[j] = *reinterpret_cast<const floatx4*>(A.P + (unsigned)(s * (2 * H) + H + 32 * jb + 4 * cq));
+                    pj[j] = *reinterpret_cast<const floatx4*>(A.P + (unsigned)(((HEDGE_ABL & 2) ? d : s) * (2 * H) + H + 32 * jb + 4 * cq));
                 }
             }
             dl1 = dl2; sl1 = sl2;
@@ -265,21 +271,22 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             };
             float2v kmr;
             floatx4 zq, gm, bt;
-            auto side = [&](int slot) {   // LayerNorm + e_out of block x-3, row group slot / 6
-                const int j = slot / 6, r = 8 * j + rr;
-                if (slot % 6 == 0) {
+            auto side = [&](int slot) {   // LayerNorm + e_out of block x-3, row group slot / SIDE_STRIDE
+                if (slot >= 4 * SIDE_STRIDE) return;
+                const int j = slot / SIDE_STRIDE, r = 8 * j + rr;
+                if (slot % SIDE_STRIDE == 0) {
                     kmr = *reinterpret_cast<const float2v*>(km + r * 2);
                     zq = zt[tile_q(r, cq)];
                     gm = *reinterpret_cast<const floatx4*>(vgm);
                     bt = *reinterpret_cast<const floatx4*>(vgm + H);
-                } else if (slot % 6 == 2) {
+                } else if (slot % SIDE_STRIDE == 2) {
                     floatx4 o;
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
                         const float xh = fmaf(zq[tt], kmr[0], kmr[1]);
                         o[tt] = fmaf(xh, gm[tt], bt[tt]) + er[j][tt];
                     }
-                    if (epi && r < cnt_a) *reinterpret_cast<floatx4*>(A.e_out + (unsigned)((st_a + r) * H + 32 * jb + 4 * cq)) = o;
+                    if (!(HEDGE_ABL & 4) && epi && r < cnt_a) *reinterpret_cast<floatx4*>(A.e_out + (unsigned)((((HEDGE_ABL & 32) ? (st_a & 1023) : st_a) + r) * H + 32 * jb + 4 * cq)) = o;
                 }
             };
             {
@@ -297,7 +304,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             acc_to_image(acc, reinterpret_cast<uintx4*>(X2 + ((x - 1) & 1) * 1024), jb, lane);
             st_a = st_b; cnt_a = cnt_b;
             st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
-            if (ok(x - 2) && A.residual) {  // rows of block x-2: consumed next tick
+            if (!(HEDGE_ABL & 1) && ok(x - 2) && A.residual) {  // rows of block x-2: consumed next tick
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int row = st_a + 8 * j + rr;
@@ -306,7 +313,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
                 }
             }
             if (ok(x)) bi_c = A.blk[x];
-            if (ok(x + 2)) {
+            if (!(HEDGE_ABL & 16) && ok(x + 2)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int row = be.x + 8 * j + rr;
@@ -410,7 +417,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
                         carry[4 * g + tt] = __uint_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) * 4, __float_as_uint(y[tt])));
                     break;
                 default:
-                    if (is_last) {
+                    if (!(HEDGE_ABL & 8) && is_last) {
                         if (part) {
 #pragma unroll
                             for (int tt = 0; tt < 4; ++tt) atomicAdd(arow + 8 * g + tt, y[tt]);
