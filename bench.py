@@ -74,14 +74,13 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(obs, model, stats, scene, hidden, budget_s=25.0):
+def cpu_baseline(obs, model, stats, scene, hidden):
     """The CPU restatement of the reference step: oracle graph build + featurisation (numpy, the
     KD-tree query of the reference is single-threaded too) and the plain-torch forward of oracle/torch_epd.py with all host
     threads, on the same scene and weights; bounded sample."""
     from oracle import epd_oracle as orc
     from oracle import torch_epd
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
+    cores = os.cpu_count() or 1
     params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     t0 = time.perf_counter()
     last = np.asarray(obs[-1][:, scene.CART], np.float32)
@@ -93,21 +92,24 @@ def cpu_baseline(obs, model, stats, scene, hidden, budget_s=25.0):
     t_feat = time.perf_counter() - t0
     tn, te, ti = torch.from_numpy(nodes), torch.from_numpy(ea), torch.from_numpy(np.stack((s, r)))
     # bounded sample of the forward: encoder + decoder alone (m_steps = 0) and with ONE of the ten identical message-passing
-    # steps, each timed on its second pass; forward = t0 + 10 (t1 - t0).  (All ten steps take ~90 s on this host at N = 100k.)
+    # steps; forward = t0 + 10 (t1 - t0).  PyTorch's CPU ops stop scaling (and then slow down) well before a big host's
+    # core count, so two thread counts are tried and the faster one is reported.
     def timed_forward(ms):
-        best = None
-        for _ in range(2):
-            t0 = time.perf_counter()
-            o = torch_epd.epd_forward(params, tn, te, ti, 2, ms)
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-            if dt > budget_s / 3:
-                break
-        return best, o
+        t0 = time.perf_counter()
+        o = torch_epd.epd_forward(params, tn, te, ti, 2, ms)
+        return time.perf_counter() - t0, o
+    best = None
     with torch.no_grad():
-        t_encdec, out = timed_forward(0)
-        t_one, _ = timed_forward(1)
-    t_forward = t_encdec + 10.0 * max(t_one - t_encdec, 0.0)
+        for th in sorted({min(32, cores), cores}):
+            torch.set_num_threads(th)
+            if best is None:
+                timed_forward(0)   # first touch of the weights / allocator warm-up
+            t_encdec, out = timed_forward(0)
+            t_one, _ = timed_forward(1)
+            fwd = t_encdec + 10.0 * max(t_one - t_encdec, 0.0)
+            if best is None or fwd < best[0]:
+                best = (fwd, t_encdec, t_one, th, out)
+    t_forward, t_encdec, t_one, threads, out = best
     t0 = time.perf_counter()
     orc.get_position_from_prediction(stats, scene.CART, out.numpy(), obs)
     t_int = time.perf_counter() - t0
@@ -118,8 +120,8 @@ def cpu_baseline(obs, model, stats, scene, hidden, budget_s=25.0):
                 forward_encoder_decoder_ms=t_encdec * 1e3, forward_one_mp_step_ms=max(t_one - t_encdec, 0.0) * 1e3,
                 sample=f"one rollout step of the same scene and weights (N={obs.shape[1]}, E={len(s)}, hidden={hidden}): oracle graph "
                        f"build + features (numpy, single thread) once; oracle/torch_epd.py forward with torch.set_num_threads({threads}): "
-                       f"encoder + decoder and ONE of the 10 identical message-passing steps timed (best of 2 passes), forward = "
-                       f"enc/dec + 10 x one MP step")
+                       f"encoder + decoder and ONE of the 10 identical message-passing steps timed, forward = enc/dec + 10 x one MP step; "
+                       f"the faster of 32 and {cores} threads is reported")
 
 
 def build_engine(wl, dev, rank, candidates, edge_kernel, total_steps):
