@@ -126,6 +126,8 @@ struct CsrWs {
     int* src;      // [cap]
     int* eid;      // [cap] original edge id (row in the caller's edge order)
     int* scan_tmp;
+    int* sort_tmp;  // [2 * cap] copies of long segments during the destination sort
+    int64_t cap;
     int* blocks;   // block / chunk tables for the systolic edge kernel (hedge.h: carve_edge_blocks)
     size_t bytes;
 };

@@ -246,6 +246,8 @@ CsrWs carve_csr(void* ws, int64_t n, int64_t cap) {
     w.src = c.take<int>(cap);
     w.eid = c.take<int>(cap);
     w.scan_tmp = c.take<int>(scan_tmp_ints(n + 1));
+    w.sort_tmp = c.take<int>(2 * (size_t)cap);   // copies of long segments (in-degree > 96) while they are rank-sorted
+    w.cap = cap;
     w.blocks = c.take<int>(edge_blocks_ints(n, cap));
     w.bytes = c.used();
     return w;
@@ -663,16 +665,18 @@ __global__ void __launch_bounds__(256) fill_ei_kernel(const int64_t* __restrict_
 
 // Make the order inside each destination segment deterministic: ascending original edge id.
 // 8 lanes per segment: the segment is staged in LDS, every element is ranked against the others
-// (ids are unique) and written back in place.  Segments longer than SEG_CAP (in-degree > 96) are
-// sorted by one lane with an insertion sort in global memory.
+// (ids are unique) and written back in place.  Segments longer than SEG_CAP (in-degree > 96) are rank-sorted by the
+// whole workgroup through a copy in the workspace.
 constexpr int SEG_CAP = 96;
 constexpr int SEG_STRIDE = SEG_CAP + 1;
 __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict__ in_ptr, int64_t n,
                                                             int* __restrict__ src, int* __restrict__ eid,
                                                             CsrHeader* hdr, const float* __restrict__ pos,
-                                                            int64_t pos_stride, float conn_r, float* __restrict__ edge_attr, int flow) {
+                                                            int64_t pos_stride, float conn_r, float* __restrict__ edge_attr, int flow,
+                                                            int* __restrict__ tmp_eid, int* __restrict__ tmp_src) {
     __shared__ int se[32 * SEG_STRIDE];
     __shared__ int ss[32 * SEG_STRIDE];
+    __shared__ int s_long[32];
     const int tid = threadIdx.x, sub = tid & 7, sl = tid >> 3;
     const int64_t i = (int64_t)blockIdx.x * 32 + sl;
     if (i == 0 && sub == 0) hdr->n_edges = in_ptr[n];
@@ -687,50 +691,46 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
             le[a] = eid[b + a];
             ls[a] = src[b + a];
         }
+    if (sub == 0) s_long[sl] = (active && !small) ? 1 : 0;
     __syncthreads();
-    if (!active) return;
-    if (small) {
+    auto write_attr = [&](int64_t node, int srcv, int64_t at) {  // [(p_s - p_r)/r, |.|] of the edge at sorted position `at` (utils.py:43-61)
+        float d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            d[c] = flow ? __fdiv_rn(__fsub_rn(pos[node * pos_stride + c], pos[(int64_t)srcv * pos_stride + c]), conn_r)
+                        : __fdiv_rn(__fsub_rn(pos[(int64_t)srcv * pos_stride + c], pos[node * pos_stride + c]), conn_r);
+        float q = __fmul_rn(d[0], d[0]);
+        q = __fadd_rn(q, __fmul_rn(d[1], d[1]));
+        q = __fadd_rn(q, __fmul_rn(d[2], d[2]));
+        *reinterpret_cast<float4*>(edge_attr + at * 4) = make_float4(d[0], d[1], d[2], __fsqrt_rn(q));
+    };
+    if (active && small) {
         for (int a = sub; a < len; a += 8) {
             const int ka = le[a];
             int rank = 0;
             for (int f = 0; f < len; ++f) rank += le[f] < ka ? 1 : 0;
             eid[b + rank] = ka;
             src[b + rank] = ls[a];
-            if (edge_attr) {  // [(p_s - p_r)/r, |.|] of the edge now at sorted position b + rank (utils.py:43-61)
-                float d[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    d[c] = flow ? __fdiv_rn(__fsub_rn(pos[i * pos_stride + c], pos[(int64_t)ls[a] * pos_stride + c]), conn_r)
-                                : __fdiv_rn(__fsub_rn(pos[(int64_t)ls[a] * pos_stride + c], pos[i * pos_stride + c]), conn_r);
-                float q = __fmul_rn(d[0], d[0]);
-                q = __fadd_rn(q, __fmul_rn(d[1], d[1]));
-                q = __fadd_rn(q, __fmul_rn(d[2], d[2]));
-                *reinterpret_cast<float4*>(edge_attr + (int64_t)(b + rank) * 4) = make_float4(d[0], d[1], d[2], __fsqrt_rn(q));
-            }
+            if (edge_attr) write_attr(i, ls[a], (int64_t)b + rank);
         }
-    } else if (sub == 0) {
-        for (int a = b + 1; a < e; ++a) {
-            const int ke = eid[a], ks = src[a];
-            int p = a;
-            while (p > b && eid[p - 1] > ke) {
-                eid[p] = eid[p - 1];
-                src[p] = src[p - 1];
-                --p;
-            }
-            eid[p] = ke;
-            src[p] = ks;
+    }
+    // long segments (hub nodes of a caller's edge_index): the whole workgroup rank-sorts one at a time through a copy in
+    // the workspace, len^2 / 256 comparisons per thread instead of a single lane's insertion sort
+    for (int q = 0; q < 32; ++q) {
+        if (!s_long[q]) continue;   // uniform
+        const int64_t node = (int64_t)blockIdx.x * 32 + q;
+        const int lb = in_ptr[node], ll = in_ptr[node + 1] - lb;
+        for (int a = tid; a < ll; a += 256) { tmp_eid[lb + a] = eid[lb + a]; tmp_src[lb + a] = src[lb + a]; }
+        __syncthreads();   // the copy is complete (this workgroup is the only writer of the segment)
+        for (int a = tid; a < ll; a += 256) {
+            const int ka = tmp_eid[lb + a];
+            int rank = 0;
+            for (int f = 0; f < ll; ++f) rank += tmp_eid[lb + f] < ka ? 1 : 0;
+            eid[lb + rank] = ka;
+            src[lb + rank] = tmp_src[lb + a];
+            if (edge_attr) write_attr(node, tmp_src[lb + a], (int64_t)lb + rank);
         }
-        if (edge_attr)
-            for (int a = b; a < e; ++a) {
-                float d[3];
-                for (int c = 0; c < 3; ++c)
-                    d[c] = flow ? __fdiv_rn(__fsub_rn(pos[i * pos_stride + c], pos[(int64_t)src[a] * pos_stride + c]), conn_r)
-                                : __fdiv_rn(__fsub_rn(pos[(int64_t)src[a] * pos_stride + c], pos[i * pos_stride + c]), conn_r);
-                float q = __fmul_rn(d[0], d[0]);
-                q = __fadd_rn(q, __fmul_rn(d[1], d[1]));
-                q = __fadd_rn(q, __fmul_rn(d[2], d[2]));
-                *reinterpret_cast<float4*>(edge_attr + (int64_t)a * 4) = make_float4(d[0], d[1], d[2], __fsqrt_rn(q));
-            }
+        __syncthreads();
     }
 }
 
@@ -876,7 +876,7 @@ int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* c
         if (rc != GM_OK) return rc;
         hipLaunchKernelGGL(fill_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.out_ptr, g.nbr, n, K, c.in_ptr,
                            c.cursor, cap, flow, c.dst, c.src, c.eid, c.hdr);
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, pos, pos_stride, conn_r, edge_attr, flow);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, pos, pos_stride, conn_r, edge_attr, flow, c.sort_tmp, c.sort_tmp + c.cap);
         GM_LAUNCH_CHECK();
     }
     // 32-edge blocks aligned to every graph's first edge (the systolic processor edge kernel walks them)
@@ -911,7 +911,7 @@ int gm_csr_from_edge_index_flow(const int64_t* ei, int64_t n, int64_t e, int flo
         hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, flow, c.in_ptr, c.cursor, c.dst, c.src, c.eid);
     }
     if (n > 0)
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0, c.sort_tmp, c.sort_tmp + c.cap);
     GM_LAUNCH_CHECK();
     return build_edge_blocks(c.in_ptr, n, e, nullptr, (int)n, carve_edge_blocks(c.blocks, n, e), s);
 }

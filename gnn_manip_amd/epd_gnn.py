@@ -51,6 +51,20 @@ def _mlp_dims(seq):
     return lin, norm
 
 
+class _Model:
+    """A gm_model* that lives as long as anything refers to it (the owning _Handle, or the ctx of a pending backward):
+    ctypes passes `_as_parameter_`; the library object is destroyed when the last reference goes."""
+
+    def __init__(self, pointer):
+        self._as_parameter_ = pointer
+
+    def __del__(self):
+        try:
+            lib().gm_model_destroy(self._as_parameter_)
+        except Exception:
+            pass
+
+
 class _Handle:
     """Owns a gm_model built from a list of parameter tensors; re-packs when they change."""
 
@@ -75,7 +89,7 @@ class _Handle:
             self.close()
             out = C.c_void_p()
             check(L.gm_model_create(C.byref(d), arr, len(tensors), 1, current_stream(), C.byref(out)))
-            self.h = out
+            self.h = _Model(out)
             if self.edge_kernel:
                 check(L.gm_model_set_edge_kernel(self.h, self.edge_kernel))
             if self.prof_mask:
@@ -108,9 +122,7 @@ class _Handle:
         self.key = None
 
     def close(self):
-        if self.h is not None:
-            lib().gm_model_destroy(self.h)
-            self.h = None
+        self.h = None   # destroyed once no autograd ctx holds it either
 
     def __del__(self):
         try:

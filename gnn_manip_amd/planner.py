@@ -268,12 +268,14 @@ class TrajectoryCMAsolver:
             out += self._block_losses(X[b:b + self.candidates_per_gpu])
         return out
 
+    def _start_point(self):
+        """The search starts at the sample trajectory: all rotation variables, then all translation variables."""
+        return np.ascontiguousarray(self.sample_traj.T, dtype=np.float64).reshape(-1)
+
     def optimize_trajectory(self, desired_position):
         """traj_utils.py:247-259."""
         from . import cmaes
-        initial_traj = np.zeros(int(self.sample_traj.shape[0] * 2))
-        initial_traj[:self.sample_traj.shape[0]] = self.sample_traj[:, 0]
-        initial_traj[self.sample_traj.shape[0]:] = self.sample_traj[:, 1]
+        initial_traj = self._start_point()
         self.desired_pos = desired_position.clone()
         return cmaes.fmin2(self.cma_objective, initial_traj.tolist(), self.cma_initial_var, options=self.cma_options,
                            parallel_objective=self.population_losses)
@@ -286,12 +288,12 @@ class InterpolatedCMAsolver(TrajectoryCMAsolver):
     rotation is box-bounded.  Objective evaluation (batched rollouts, device loss) is inherited."""
 
     def set_sample_traj(self, sample_traj):
-        sample_traj = np.asarray(sample_traj)
-        index_points = [i for i in range(self.nr_traj_points, sample_traj.shape[0], self.nr_traj_points)]
-        traj_points = sample_traj[index_points, :]
-        rotation_scaled = (np.deg2rad(traj_points[:, 0]) - self.rx_init) / self.scale_rot
-        translation_scaled = (traj_points[:, 1] - self.ty_init[0]) / self.scale_ty
-        self.sample_traj = np.stack((rotation_scaled, translation_scaled)).T
+        """traj_utils.py:296-304: the key points are every ``traj_points``-th pose after the first, as offsets from the
+        initial pose in search-variable units (column 0 rotation [deg in the file], column 1 translation)."""
+        keys = np.asarray(sample_traj, dtype=np.float64)[self.nr_traj_points::self.nr_traj_points]
+        offset = np.array([self.rx_init, self.ty_init[0]])
+        scale = np.array([self.scale_rot, self.scale_ty])
+        self.sample_traj = (np.column_stack((np.deg2rad(keys[:, 0]), keys[:, 1])) - offset) / scale
 
     def interpolate_trajectory(self, x, type_interp='pchip'):
         from scipy.interpolate import interp1d, pchip_interpolate
@@ -347,9 +349,7 @@ class InterpolatedCMAsolver(TrajectoryCMAsolver):
         """traj_utils.py:324-337."""
         from . import cmaes
         self.cma_options['bounds'] = [-self.rotation_limit / self.scale_rot, self.rotation_limit / self.scale_rot]
-        initial_traj = np.zeros(int(self.sample_traj.shape[0] * 2))
-        initial_traj[:self.sample_traj.shape[0]] = self.sample_traj[:, 0]
-        initial_traj[self.sample_traj.shape[0]:] = self.sample_traj[:, 1]
+        initial_traj = self._start_point()
         self.desired_pos = desired_position.clone()
         return cmaes.fmin_con(self.cma_objective, initial_traj.tolist(), self.cma_initial_var, g=self.ineq_constraint,
                               options=self.cma_options, parallel_objective=self.population_losses)
