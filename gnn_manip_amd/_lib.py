@@ -68,6 +68,7 @@ PROTOTYPES = {
     "gm_model_update": (_i32, [_vp, C.POINTER(_vp), _i32, _i32, _vp]),
     "gm_model_destroy": (None, [_vp]),
     "gm_forward_workspace_bytes": (_sz, [_MD, _i64, _i64]),
+    "gm_block_workspace_bytes": (_sz, [_MD, _i64, _i64]),
     "gm_epd_forward": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "gm_graph_independent_forward": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "gm_interaction_network_forward": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),

@@ -880,7 +880,7 @@ int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* c
         GM_LAUNCH_CHECK();
     }
     // 32-edge blocks aligned to every graph's first edge (the systolic processor edge kernel walks them)
-    return build_edge_blocks(c.in_ptr, n, cap, &g.hdr->n_per_graph, 0, carve_edge_blocks(c.blocks, n, cap), s);
+    return build_edge_blocks(c.in_ptr, c.dst, n, cap, &g.hdr->n_per_graph, 0, carve_edge_blocks(c.blocks, n, cap), s);
 }
 }  // namespace gm
 
@@ -913,7 +913,7 @@ int gm_csr_from_edge_index_flow(const int64_t* ei, int64_t n, int64_t e, int flo
     if (n > 0)
         hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0, c.sort_tmp, c.sort_tmp + c.cap);
     GM_LAUNCH_CHECK();
-    return build_edge_blocks(c.in_ptr, n, e, nullptr, (int)n, carve_edge_blocks(c.blocks, n, e), s);
+    return build_edge_blocks(c.in_ptr, c.dst, n, e, nullptr, (int)n, carve_edge_blocks(c.blocks, n, e), s);
 }
 
 int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream) {

@@ -5,30 +5,32 @@
 
 namespace gm {
 
-// ---- tables of 32-edge blocks over a destination-sorted edge list (one or more equal-sized graphs back to back)
+// ---- tables of 32-edge blocks over a destination-sorted edge list (one or more equal-sized graphs back to back).
+// The scatter-add keeps a running sum over a GROUP of 4 blocks.  A segment that begins in a group is stored to agg by
+// that group (whole, or its first piece); the pieces that later groups hold of it ("head partials") go to a side
+// buffer [n_groups][H] and are added in group order by the node kernel: no atomics, one summation order.
 struct EdgeBlockHeader {
     int n_blocks;
-    int n_chunks;
-    int chunk_blocks;   // unused (chunk sizes are per graph: edge_chunk_blocks)
+    int n_groups;       // n_blocks / 4
     int n_graphs;
     int n_per_graph;
-    int n_cus;          // CU count the chunk sizes were derived with
-    int pad[2];
+    int pad[4];
 };
 struct EdgeBlocks {
     EdgeBlockHeader* hdr;
     int* gblk;          // [n_graphs + 1] first block of a graph
-    int* gch;           // [n_graphs + 1] first chunk of a graph
-    int* chunk_first;   // [n_chunks + 1] first block of a chunk
-    int2* blk;          // [n_blocks] (first edge, count | flags << 8); flags: 1 first block of its chunk, 2 last
+    int2* blk;          // [n_blocks] (first edge, count | flags << 8); flags: 1 first block of its group of 4, 2 last
+    int* head;          // [n_groups] destination whose segment continues from the previous group into this one, or -1
+    int* stitch;        // [n_nodes] first group of the run of head partials of a destination, or -1
     int64_t max_blocks;
 };
 size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity);
+size_t edge_groups_max(int64_t n_nodes, int64_t edge_capacity);   // rows of the side buffer of head partials
 EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity);
-// n_per_graph: device pointer (GraphHeader::n_per_graph of the radius-graph build) or, if null, the host value
-// (<= 0: one graph)
-int build_edge_blocks(const int* in_ptr, int64_t n_nodes, int64_t edge_capacity, const int* n_per_graph_dev, int n_per_graph_host,
-                      const EdgeBlocks& t, hipStream_t s);
+// in_ptr / dst: the destination-sorted edge structure; n_per_graph: device pointer (GraphHeader::n_per_graph of the
+// radius-graph build) or, if null, the host value (<= 0: one graph)
+int build_edge_blocks(const int* in_ptr, const int* dst, int64_t n_nodes, int64_t edge_capacity, const int* n_per_graph_dev,
+                      int n_per_graph_host, const EdgeBlocks& t, hipStream_t s);
 
 // ---- weight image of one processor step's phi_e for the systolic kernel
 constexpr int kPackH3Max = 16;

@@ -17,13 +17,14 @@
 //   role 1: e of block x+1 -> image E; Linear 2 of block x-1 (X1 -> X2); LayerNorm + e_out = e + e' of block x-3;
 //   role 2: Linear 3 of block x-2 (X2 -> Z + LayerNorm partial statistics); aggregation of block x-3: segmented DPP scan
 //           over the destination-sorted edges with the carry of an open segment kept in registers, one row store per
-//           finished segment; only segments cut by a chunk boundary use atomics (two partials: order-independent).
+//           finished segment -- to its agg row, or, for the piece of a segment that began in an earlier group of 4 blocks,
+//           to that group's row of the side buffer, which the node kernel adds in group order: no atomics.
 // A wave's MFMAs form one dependent chain, so its other work of the tick is placed BETWEEN them with the order pinned
 // (one MFMA shadows about three vector instructions of the same wave).  Global rows move as whole 128-byte lines
 // (8 lanes per row); the register <-> MFMA-fragment re-layouts go through XOR-swizzled, conflict-free LDS images.
 //
-// Blocks are aligned to each graph's first edge and grouped into chunks (the aggregation's carry resets there), both
-// listed by build_edge_blocks(): results do not depend on how many graphs share a launch.
+// Blocks are aligned to each graph's first edge and grouped in fours (the aggregation's carry resets there), both
+// listed by build_edge_blocks(): results do not depend on how many graphs share a launch, nor on the run.
 //
 // Built with -fno-slp-vectorize: packed fp32 VALU beside MFMAs is slow (guide) and hipcc's v_pk_fma_f32 form of the
 // LayerNorm epilogue returned wrong low lanes on gfx950 in this kernel.
@@ -59,7 +60,8 @@ struct SysArgs {
     float* agg;
     const float* hw;       // header | vec | weight image of this processor step
     const int2* blk;
-    const int* chunk_first;
+    const int* head;       // [n_groups] (hedge.h)
+    float* side;           // [n_groups][H] head partials of the scatter-add
     const EdgeBlockHeader* tab;
     float eps;
     int residual;
@@ -156,11 +158,11 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2, jb = wave & 3;
     const int E = A.hdr->n_edges;
-    const int nchunks = A.tab->n_chunks;
+    const int nchunks = A.tab->n_groups;   // the workgroup takes a contiguous range of whole groups (4 blocks each)
     const int c0 = (int)((long long)blockIdx.x * nchunks / gridDim.x);
     const int c1 = (int)((long long)(blockIdx.x + 1) * nchunks / gridDim.x);
     if (c1 <= c0) return;
-    const int b0 = A.chunk_first[c0], b1 = A.chunk_first[c1];
+    const int b0 = 4 * c0, b1 = 4 * c1;
     const int nb = b1 - b0;
     if (nb <= 0) return;
     const float T1 = A.hw[0], inv_T = A.hw[1];
@@ -330,7 +332,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) carry[r] = 0.f;
         int dn_a = -1, nx_a = -2, fl_a = 0, cnt_a = 0, dn_b = -1, nx_b = -2, fl_b = 0, cnt_b = 0;  // blocks x-3, x-2
-        int head_a = -1, head_b = -1;   // destination whose segment began in an earlier chunk (its pieces are added atomically)
+        int head_a = -1, head_b = -1;   // destination whose segment began in an earlier group (its sum over this group goes to the side buffer)
         int prev_last_dst = -3;         // destination of lane 31 of the previous block while its segment is open, else -3
         const float* vgam = vecs + 2 * H + 32 * jb;
         const float* vbet = vecs + 3 * H + 32 * jb;
@@ -343,10 +345,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             const int p = bi.x + n;
             dn = n < cnt ? A.dst[p] : -1 - n;
             nx = (n < cnt && p + 1 < E) ? A.dst[p + 1] : -2;
-            if (fl & 1) {
-                const int first = A.dst[bi.x];
-                head = (bi.x > 0 && A.dst[bi.x - 1] == first) ? first : -1;
-            }
+            if (fl & 1) head = A.head[x >> 2];
         };
 #pragma unroll 1
         for (int t = -2; t <= nb + 2; ++t) {
@@ -370,13 +369,14 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
                 // the carry of the segment the previous block of this chunk left open enters at lane 0
                 fc = (n == 0 && !(fl_a & 1) && dn == prev_last_dst) ? 1.f : 0.f;
             }
-            bool is_last = false, part = false;
+            bool is_last = false;
             if (agg_on) {
                 const bool lastf = (fl_a & 2) != 0;
                 is_last = n < cnt_a && (nx_a != dn || (lastf && n == cnt_a - 1));
-                part = dn == head_a || (lastf && n == cnt_a - 1 && nx_a == dn);
             }
-            float* arow = A.agg + (unsigned)((dn < 0 ? 0 : dn) * H + 32 * jb + 4 * hi);
+            // a finished (or group-final) sum is stored exactly once: to its agg row, or -- for the piece of a segment that
+            // began in an earlier group -- to this group's row of the side buffer (added in group order by the node kernel)
+            float* arow = (dn == head_a ? A.side + (unsigned)(((x - 3) >> 2) * H) : A.agg + (unsigned)((dn < 0 ? 0 : dn) * H)) + 32 * jb + 4 * hi;
             const floatx4* zt3 = Z + (((x - 3) & 1) * 4 + jb) * 256;
             floatx4 zq, gmv, btv;
             float y[4];
@@ -417,14 +417,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
                         carry[4 * g + tt] = __uint_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) * 4, __float_as_uint(y[tt])));
                     break;
                 default:
-                    if (!(HEDGE_ABL & 8) && is_last) {
-                        if (part) {
-#pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) atomicAdd(arow + 8 * g + tt, y[tt]);
-                        } else {
-                            *reinterpret_cast<floatx4*>(arow + 8 * g) = floatx4{y[0], y[1], y[2], y[3]};
-                        }
-                    }
+                    if (!(HEDGE_ABL & 8) && is_last) *reinterpret_cast<floatx4*>(arow + 8 * g) = floatx4{y[0], y[1], y[2], y[3]};
                     break;
                 }
             };
@@ -543,46 +536,36 @@ __global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
 // block / chunk tables of a destination-sorted edge list that holds one or more equal-sized graphs back to back
 // ------------------------------------------------------------------------------------------
 __host__ __device__ inline int edge_blocks_padded(int n_edges) { return ((n_edges + BE - 1) / BE + 3) & ~3; }
-// blocks per chunk of a graph with nbk blocks: about 4 chunks per CU for one big graph, between 4 and 32 blocks, multiple of 4
-__host__ __device__ inline int edge_chunk_blocks(int nbk, int n_cus) {
-    int cb = (nbk + 4 * n_cus - 1) / (4 * n_cus);
-    cb = (cb + 3) & ~3;
-    return cb < 4 ? 4 : (cb > 32 ? 32 : cb);
-}
 
 __global__ void __launch_bounds__(256) edge_blocks_plan_kernel(const int* __restrict__ in_ptr, int n_nodes, const int* n_per_dev, int n_per_host,
-                                                               int n_cus, EdgeBlockHeader* tab, int* gblk, int* gch, int max_graphs) {
-    // one thread: per-graph block / chunk counts and their prefixes.  Every graph is padded to a multiple of 4 blocks (the
-    // row group of a wave in hmlp.hip) and its chunk size depends on ITS block count only: the partial sums of a graph do
-    // not depend on what else shares the launch.
+                                                               EdgeBlockHeader* tab, int* gblk, int max_graphs) {
+    // one thread: per-graph block counts and their prefix.  Every graph is padded to a multiple of 4 blocks = one group
+    // (the unit over which the scatter-add carries a running sum: a wave's rows in hmlp.hip, 4 ticks in the systolic kernel),
+    // so groups never straddle graphs and the partial sums of a graph do not depend on what else shares the launch.
     if (threadIdx.x != 0) return;
     int n_per = n_per_dev ? *n_per_dev : n_per_host;
     if (n_per <= 0) n_per = n_nodes > 0 ? n_nodes : 1;
     int G = (n_nodes + n_per - 1) / n_per;
-    if (G > max_graphs) G = max_graphs;   // capacity of the prefix arrays (never hit: they hold n_nodes + 2 entries)
-    int pb = 0, pc = 0;
+    if (G > max_graphs) G = max_graphs;   // capacity of the prefix array (never hit: it holds n_nodes + 2 entries)
+    int pb = 0;
     for (int g = 0; g < G; ++g) {
         const int lo = g * n_per, hi = min(n_nodes, (g + 1) * n_per);
-        const int nbk = edge_blocks_padded(in_ptr[hi] - in_ptr[lo]);
-        const int cb = edge_chunk_blocks(nbk, n_cus);
         gblk[g] = pb;
-        gch[g] = pc;
-        pb += nbk;
-        pc += (nbk + cb - 1) / cb;
+        pb += edge_blocks_padded(in_ptr[hi] - in_ptr[lo]);
     }
     gblk[G] = pb;
-    gch[G] = pc;
     tab->n_blocks = pb;
-    tab->n_chunks = pc;
-    tab->chunk_blocks = 0;
+    tab->n_groups = pb / 4;
     tab->n_graphs = G;
     tab->n_per_graph = n_per;
-    tab->n_cus = n_cus;
 }
 
-__global__ void __launch_bounds__(256) edge_blocks_fill_kernel(const int* __restrict__ in_ptr, int n_nodes, const EdgeBlockHeader* tab,
-                                                               const int* __restrict__ gblk, const int* __restrict__ gch, int2* blk,
-                                                               int* chunk_first) {
+// blk[b] = (first edge, count | flags << 8) with flags 1 = first block of its group, 2 = last;
+// head[g] = the destination whose segment continues from group g - 1 into group g (its sum over group g is a "head
+// partial", stored to the side buffer), or -1;  stitch[v] = first group of the run of head partials of destination v.
+__global__ void __launch_bounds__(256) edge_blocks_fill_kernel(const int* __restrict__ in_ptr, const int* __restrict__ dst, int n_nodes,
+                                                               const EdgeBlockHeader* tab, const int* __restrict__ gblk, int2* blk,
+                                                               int* __restrict__ head, int* __restrict__ stitch) {
     const int nblk = tab->n_blocks, G = tab->n_graphs, n_per = tab->n_per_graph;
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
         int lo = 0, hi = G;   // graph g with gblk[g] <= b < gblk[g + 1]
@@ -592,16 +575,22 @@ __global__ void __launch_bounds__(256) edge_blocks_fill_kernel(const int* __rest
         }
         const int g = lo, j = b - gblk[g];
         const int e0 = in_ptr[g * n_per], e1 = in_ptr[min(n_nodes, (g + 1) * n_per)];
-        const int nbk = gblk[g + 1] - gblk[g];
-        const int cb = edge_chunk_blocks(nbk, tab->n_cus);
         const int start = min(e0 + j * BE, e1);          // padding blocks: (end of the graph, 0 edges)
         const int cnt = min(BE, e1 - start);
-        int fl = 0;
-        if (j % cb == 0) { fl |= 1; chunk_first[gch[g] + j / cb] = b; }
-        if (j % cb == cb - 1 || j == nbk - 1) fl |= 2;
+        const int fl = ((j & 3) == 0 ? 1 : 0) | ((j & 3) == 3 ? 2 : 0);
         blk[b] = make_int2(start, cnt | (fl << 8));
+        if ((j & 3) == 0) {
+            int h = -1;
+            if (cnt > 0 && start > e0 && dst[start - 1] == dst[start]) h = dst[start];
+            head[b >> 2] = h;
+            if (h >= 0) {
+                // the run of head partials of h starts here unless the previous group (then entirely h's) is one too
+                const int ps = start - 4 * BE;
+                const bool prev_is_head = j >= 4 && dst[ps] == h && ps > e0 && dst[ps - 1] == h;
+                if (!prev_is_head) stitch[h] = b >> 2;
+            }
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) chunk_first[tab->n_chunks] = nblk;
 }
 
 }  // namespace
@@ -623,20 +612,27 @@ int pack_h3(const PackH3Job* jobs, int n, hipStream_t s) {
     return GM_OK;
 }
 
+static size_t max_blocks_of(int64_t n_nodes, int64_t edge_capacity) {
+    return (size_t)cdiv(edge_capacity, BE) + 4 * (size_t)n_nodes + 4;   // each graph: up to 3 padding blocks + 1 partial
+}
+size_t edge_groups_max(int64_t n_nodes, int64_t edge_capacity) { return max_blocks_of(n_nodes, edge_capacity) / 4 + 1; }
+
 size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity) {
-    const size_t nblk = (size_t)cdiv(edge_capacity, BE) + 4 * (size_t)n_nodes + 4;   // each graph: up to 3 padding blocks + 1 partial
-    // header | gblk[n+2] | gch[n+2] | chunk_first[nblk + 2] | blk[nblk] (int2)
-    return 8 + 2 * ((size_t)n_nodes + 2) + (nblk + 2) + 2 * nblk;
+    const size_t nblk = max_blocks_of(n_nodes, edge_capacity);
+    // header | gblk[n+2] | blk[nblk] (int2) | head[nblk/4 + 2] | stitch[n]
+    return 8 + ((size_t)n_nodes + 2) + 1 + 2 * nblk + (nblk / 4 + 2) + (size_t)n_nodes;
 }
 
 EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity) {
     EdgeBlocks t;
-    const size_t nblk = (size_t)cdiv(edge_capacity, BE) + 4 * (size_t)n_nodes + 4;   // each graph: up to 3 padding blocks + 1 partial
+    const size_t nblk = max_blocks_of(n_nodes, edge_capacity);
     t.hdr = reinterpret_cast<EdgeBlockHeader*>(base);
     t.gblk = base + 8;
-    t.gch = t.gblk + n_nodes + 2;
-    t.chunk_first = t.gch + n_nodes + 2;
-    t.blk = reinterpret_cast<int2*>(t.chunk_first + nblk + 2);
+    int* p = t.gblk + n_nodes + 2;
+    p += (reinterpret_cast<uintptr_t>(p) & 4) ? 1 : 0;   // int2 alignment
+    t.blk = reinterpret_cast<int2*>(p);
+    t.head = p + 2 * nblk;
+    t.stitch = t.head + nblk / 4 + 2;
     t.max_blocks = (int64_t)nblk;
     return t;
 }
@@ -647,26 +643,27 @@ static int device_cus() {
     return cus;
 }
 
-int build_edge_blocks(const int* in_ptr, int64_t n_nodes, int64_t edge_capacity, const int* n_per_graph_dev, int n_per_graph_host,
-                      const EdgeBlocks& t, hipStream_t s) {
-    hipLaunchKernelGGL(edge_blocks_plan_kernel, dim3(1), dim3(256), 0, s, in_ptr, (int)n_nodes, n_per_graph_dev, n_per_graph_host,
-                       device_cus(), t.hdr, t.gblk, t.gch, (int)n_nodes + 1);
+int build_edge_blocks(const int* in_ptr, const int* dst, int64_t n_nodes, int64_t edge_capacity, const int* n_per_graph_dev,
+                      int n_per_graph_host, const EdgeBlocks& t, hipStream_t s) {
+    GM_HIP_CHECK(hipMemsetAsync(t.stitch, 0xff, (size_t)n_nodes * sizeof(int), s));
+    hipLaunchKernelGGL(edge_blocks_plan_kernel, dim3(1), dim3(64), 0, s, in_ptr, (int)n_nodes, n_per_graph_dev, n_per_graph_host,
+                       t.hdr, t.gblk, (int)n_nodes + 1);
     int gb = (int)cdiv(t.max_blocks, 256);
     gb = gb < 1 ? 1 : (gb > 1024 ? 1024 : gb);
-    hipLaunchKernelGGL(edge_blocks_fill_kernel, dim3(gb), dim3(256), 0, s, in_ptr, (int)n_nodes, t.hdr, t.gblk, t.gch, t.blk, t.chunk_first);
+    hipLaunchKernelGGL(edge_blocks_fill_kernel, dim3(gb), dim3(256), 0, s, in_ptr, dst, (int)n_nodes, t.hdr, t.gblk, t.blk, t.head, t.stitch);
     GM_LAUNCH_CHECK();
     (void)edge_capacity;
     return GM_OK;
 }
 
 int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
-    GM_REQUIRE(a.hdr && a.wstream_h3 && a.agg && !a.eid && !a.eid_out, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: unsupported argument combination");
+    GM_REQUIRE(a.hdr && a.wstream_h3 && a.agg && a.side && !a.eid && !a.eid_out, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: unsupported argument combination");
     static PerDeviceOnce attr_done;
     if (attr_done.need())
         GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
     SysArgs A{};
     A.hdr = a.hdr; A.dst = a.dst; A.src = a.src; A.P = a.P; A.e_in = a.e_in; A.e_out = a.e_out; A.agg = a.agg;
-    A.hw = a.wstream_h3; A.blk = t.blk; A.chunk_first = t.chunk_first; A.tab = t.hdr; A.eps = a.eps; A.residual = a.residual;
+    A.hw = a.wstream_h3; A.blk = t.blk; A.head = t.head; A.side = a.side; A.tab = t.hdr; A.eps = a.eps; A.residual = a.residual;
     {
         ProfScope prof(a.prof, PROF_EDGE, s);
         hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, A);

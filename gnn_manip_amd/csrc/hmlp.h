@@ -46,6 +46,8 @@ struct HmEdgeArgs {
     int k1;
     int nl;               // num_layers: nl + 1 Linears
     const int2* blk;      // processor: 32-edge block table (hedge.h)
+    const int* head;      // processor: head list of the groups
+    float* side;          // processor: [n_groups][H] head partials
     const EdgeBlockHeader* tab;
     ProfState* prof;
 };
@@ -68,6 +70,10 @@ struct HmNodeArgs {
     float* P_out;
     float* dec_out;
     int out_dim;
+    const int* stitch;    // mode 1: stitch / head lists + side buffer of the edge kernel's head partials (hedge.h), or nullptr
+    const int* head;
+    const float* side;
+    const EdgeBlockHeader* tab;
     ProfState* prof;
 };
 

@@ -17,10 +17,10 @@
 // barrier.  LayerNorm statistics are merged across the waves of a row through LDS (parallel-variance merge); outputs,
 // the residual and the scatter-add work directly on the accumulator layout (16-byte pieces of the rows).
 //
-// The scatter-add is the one of hedge.hip: segmented DPP scan over the destination-sorted rows, one row store per finished
-// segment, atomics only for the (at most two) partial segments at the ends of a wave's 4-block group; groups are aligned
-// to each graph's first block (build_edge_blocks pads every graph to a multiple of 4 blocks), so a graph gives the same
-// sums alone or inside a batch.
+// The scatter-add is the one of hedge.hip: segmented DPP scan over the destination-sorted rows of a wave's 4-block group, one
+// row store per finished segment -- to agg, or, for the piece of a segment that began in an earlier group, to the group's
+// row of the side buffer; the node kernel adds those pieces in group order when it reads agg (hedge.h: head / stitch
+// lists).  No atomics: one summation order, the same alone or inside a batch (groups are aligned to each graph's first block).
 //
 // Built with -fno-slp-vectorize like hedge.hip.
 #include "common.h"
@@ -137,7 +137,7 @@ __device__ __forceinline__ void acc_to_img(const floatx16& a, float s, uintx4* i
 // rows of H floats -> image (k-group count KS).  16 RBW units of (16 rows, 2 k-groups) per tile, 2 RBW per wave; lane = (row, k-group
 // parity, kg) reads the two 16-byte pieces that make its 8 K slots.  row_of(rbg, n) returns the source row (or -1: zeros).
 template <int H, int RBW, int UNR, class R, class Z>
-__device__ __forceinline__ void rows_to_image(const float* __restrict__ src, uintx4* img, int wave, int lane, R&& row_of, Z&& after) {
+__device__ __forceinline__ void rows_to_image(const float* __restrict__ src, uintx4* img, int wave, int lane, R&& row_of, Z&& adjust) {
     using C = Cfg<H, RBW>;
 #pragma unroll UNR
     for (int it = 0; it < 2 * RBW; ++it) {
@@ -146,9 +146,9 @@ __device__ __forceinline__ void rows_to_image(const float* __restrict__ src, uin
         const int rbg = rowhalf >> 1, nn = 16 * (rowhalf & 1) + (lane & 15), c = lane >> 4, ks = 2 * kspair + (c >> 1), kg = c & 1;
         const long long row = row_of(rbg, nn);
         const float* p = src + row * H + 16 * ks + 4 * kg;
-        const floatx4 v0 = *reinterpret_cast<const floatx4*>(p);
-        const floatx4 v1 = *reinterpret_cast<const floatx4*>(p + 8);
-        after(const_cast<float*>(p));
+        floatx4 v0 = *reinterpret_cast<const floatx4*>(p);
+        floatx4 v1 = *reinterpret_cast<const floatx4*>(p + 8);
+        adjust(row, 16 * ks + 4 * kg, v0, v1);
         uintx2 h0, l0, h1, l1;
         split4(v0[0], v0[1], v0[2], v0[3], h0, l0);
         split4(v1[0], v1[1], v1[2], v1[3], h1, l1);
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             return A.eid ? A.eid[p] : p;
         };
         if (ENC) narrow_rows_to_image<H, 4, 1>(A.e_in, A.k1, img, tid, in_row);
-        else rows_to_image<H, 4, 8>(A.e_in, img, wave, lane, in_row, [](float*) {});
+        else rows_to_image<H, 4, 8>(A.e_in, img, wave, lane, in_row, [](long long, int, floatx4&, floatx4&) {});
         __syncthreads();
 
         const float* wp = A.w;
@@ -319,13 +319,8 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) carry[r] = 0.f;
         int prev_last = -3, head = -1;
-        if (!ENC && A.agg) {
-            const int2 b0 = sb[4 * rg];
-            if (b0.y > 0 && b0.x > 0) {
-                const int first = A.dst[b0.x];
-                if (A.dst[b0.x - 1] == first) head = first;
-            }
-        }
+        const int grp = t * C::NRG + rg;   // this wave's group of 4 blocks
+        if (!ENC && A.agg && grp < A.tab->n_groups) head = A.head[grp];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             const int rbg = 4 * rg + rb;
@@ -368,8 +363,9 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                 }
                 const bool lastblk = rb == 3;
                 const bool is_last = valid && (nxv != dnv || (lastblk && n == cnt - 1));
-                const bool part = dnv == head || (lastblk && n == cnt - 1 && nxv == dnv);
-                float* arow = A.agg + (size_t)(dnv < 0 ? 0 : dnv) * H + 32 * jb + 4 * hi;
+                // stored exactly once: to its agg row, or -- the piece of a segment that began in an earlier group -- to this
+                // group's row of the side buffer
+                float* arow = (dnv == head ? A.side + (size_t)grp * H : A.agg + (size_t)(dnv < 0 ? 0 : dnv) * H) + 32 * jb + 4 * hi;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float y[4];
@@ -400,14 +396,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt)
                         carry[4 * g + tt] = __uint_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) * 4, __float_as_uint(y[tt])));
-                    if (is_last) {
-                        if (part) {
-#pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) atomicAdd(arow + 8 * g + tt, y[tt]);
-                        } else {
-                            *reinterpret_cast<floatx4*>(arow + 8 * g) = floatx4{y[0], y[1], y[2], y[3]};
-                        }
-                    }
+                    if (is_last) *reinterpret_cast<floatx4*>(arow + 8 * g) = floatx4{y[0], y[1], y[2], y[3]};
                 }
                 prev_last = cnt == BE ? __builtin_amdgcn_readlane(dnv, 31) : -3;
             }
@@ -453,7 +442,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
         floatx16 acc[RBW];
         Lin L;
         if (MODE == 0) narrow_rows_to_image<H, RBW, 2>(A.x_in, A.k1, img, tid, row_of);
-        else rows_to_image<H, RBW, 2 * RBW>(A.x_in, img, wave, lane, row_of, [](float*) {});
+        else rows_to_image<H, RBW, 2 * RBW>(A.x_in, img, wave, lane, row_of, [](long long, int, floatx4&, floatx4&) {});
         __syncthreads();
         if (MODE != 2) {
             const float* wp = A.w;
@@ -464,7 +453,19 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             } else {
                 gemm(acc, L.frag + (size_t)jb * 2 * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
                 __syncthreads();
-                rows_to_image<H, RBW, 2>(A.agg, img, wave, lane, row_of, [](float*) {});
+                // agg row + the head partials other groups hold of its segment, in group order (hedge.h)
+                rows_to_image<H, RBW, 2>(A.agg, img, wave, lane, row_of, [&](long long row, int f0, floatx4& v0, floatx4& v1) {
+                    if (!A.stitch) return;
+                    int c = A.stitch[row];
+                    const int ng = A.tab->n_groups;
+                    while (c >= 0 && c < ng && A.head[c] == (int)row) {
+                        const float* sp = A.side + (size_t)c * H + f0;
+                        const floatx4 s0 = *reinterpret_cast<const floatx4*>(sp), s1 = *reinterpret_cast<const floatx4*>(sp + 8);
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) { v0[tt] += s0[tt]; v1[tt] += s1[tt]; }
+                        ++c;
+                    }
+                });
                 __syncthreads();
                 gemm(acc, L.frag + ((size_t)jb * 2 * C::KS + C::KS) * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
             }
@@ -693,7 +694,8 @@ bool hm_supported(int H) { return H == 64 || H == 128 || H == 256; }
 
 int launch_edge_hm(int H, bool enc, const HmEdgeArgs& a, hipStream_t s) {
     GM_REQUIRE(a.w && a.e_in && a.e_out && a.ln_g && a.ln_b, GM_ERR_INVALID_ARGUMENT, "launch_edge_hm: null pointer");
-    GM_REQUIRE(enc || (a.P && a.dst && a.src && a.blk && a.tab), GM_ERR_INVALID_ARGUMENT, "launch_edge_hm: processor step needs P, dst, src and the block table");
+    GM_REQUIRE(enc || (a.P && a.dst && a.src && a.blk && a.tab && a.head && (a.side || !a.agg)), GM_ERR_INVALID_ARGUMENT,
+               "launch_edge_hm: processor step needs P, dst, src, the block tables and the side buffer");
     GM_REQUIRE(!enc || (a.k1 >= 1 && a.k1 <= 16), GM_ERR_UNSUPPORTED, "launch_edge_hm: edge_dim %d unsupported (1..16)", a.k1);
     GM_REQUIRE(a.nl >= 2, GM_ERR_INVALID_ARGUMENT, "launch_edge_hm: num_layers %d", a.nl);
     if (!a.hdr && a.n_edges_host <= 0) return GM_OK;

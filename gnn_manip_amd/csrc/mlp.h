@@ -15,6 +15,7 @@ struct EdgeArgs {
     const float* e_in;     // processor: [E][H]; encoder: raw edge_attr [E][k1]
     float* e_out;          // [E][H]
     float* agg;            // [N][H] pre-zeroed, or nullptr
+    float* side;           // [n_groups][H] head partials of the scatter-add (hedge.h), sys / hm kernels
     const float* wstream;  // packed weights (32x32x2 operand image), stage 0
     const float* wstream16;  // same layers in the 16x16x4 operand image, or nullptr
     const float* wstream_b3; // same layers as three bf16 parts for v_mfma_f32_32x32x16_bf16 (H = 128), or nullptr
@@ -39,7 +40,10 @@ struct NodeArgs {
     const float* x_in;     // mode 0: raw node features [N][k1]; mode 1/2: h [N][H]
     int k1;
     const float* agg;      // mode 1: [N][H]
-    float* agg_clear;      // mode 1: same buffer, zeroed row by row after it is read (next step's scatter-add target), or nullptr
+    float* agg_clear;      // mode 1: same buffer, zeroed row by row after it is read (the fp32 edge kernels add into it atomically), or nullptr
+    const int* edge_blocks;  // mode 1: block tables whose stitch / head lists say which side-buffer rows to add to agg (hedge.h), or nullptr
+    int64_t n_nodes_tab, edge_capacity_tab;
+    const float* side;
     float* h_out;          // [N][H] (may alias x_in)
     int residual;
     const float* wstream;

@@ -1910,14 +1910,14 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     if (sys_ok && (choice == EK_AUTO || choice == EK_SYS))
         return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), s);
     // the streamed fp16 x 3 kernels (hmlp.hip): every other case
-    if (!fp32_forms && a.wstream_hm && hm_supported(H) && (enc || a.edge_blocks)) {
+    if (!fp32_forms && a.wstream_hm && hm_supported(H) && (enc || (a.edge_blocks && (a.side || !a.agg)))) {
         HmEdgeArgs h{};
         h.hdr = a.hdr; h.n_edges_host = a.n_edges_host; h.dst = a.dst; h.src = a.src; h.eid = a.eid; h.eid_out = a.eid_out;
         h.P = a.P; h.e_in = a.e_in; h.e_out = a.e_out; h.agg = a.agg; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b;
         h.eps = a.eps; h.residual = a.residual; h.k1 = a.k1; h.nl = NL; h.prof = a.prof;
         if (!enc) {
             const EdgeBlocks t = carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity);
-            h.blk = t.blk; h.tab = t.hdr;
+            h.blk = t.blk; h.tab = t.hdr; h.head = t.head; h.side = a.side;
         }
         return launch_edge_hm(H, enc, h, s);
     }
@@ -2026,6 +2026,10 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
         h.n_nodes = a.n_nodes; h.x_in = a.x_in; h.k1 = a.k1; h.agg = a.agg; h.agg_clear = a.agg_clear; h.h_out = a.h_out;
         h.residual = a.residual; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b; h.eps = a.eps; h.nl = NL;
         h.tail = mode == 2 ? 1 : a.tail; h.w_tail = a.tail_hm; h.P_out = a.P_out; h.dec_out = a.dec_out; h.out_dim = a.out_dim; h.prof = a.prof;
+        if (mode == 1 && a.edge_blocks && a.side) {   // lists + side buffer of the edge kernel's head partials (hedge.h)
+            const EdgeBlocks t = carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, a.edge_capacity_tab);
+            h.stitch = t.stitch; h.head = t.head; h.side = a.side; h.tab = t.hdr;
+        }
         return launch_node_hm(H, mode, h, s);
     }
     GM_REQUIRE((H == 128 || H == 256) && NL == 2 && a.wstream, GM_ERR_UNSUPPORTED,

@@ -36,16 +36,19 @@ int check_desc(const gm_model_desc* d, const char* who) {
 }
 
 struct FwdWs {
-    float *h, *P, *agg, *e;
+    float *h, *P, *agg, *side, *e;
     size_t bytes;
 };
-FwdWs carve_fwd(void* ws, int H, int64_t n, int64_t cap) {
+// cap_e: rows of the latent edge array held here (0: the caller's); cap_side: edge capacity the side buffer of the
+// scatter-add's head partials is sized for (hedge.h)
+FwdWs carve_fwd(void* ws, int H, int64_t n, int64_t cap_e, int64_t cap_side) {
     FwdWs f;
     Carver c(ws);
     f.h = c.take<float>((size_t)n * H);
     f.P = c.take<float>((size_t)n * 2 * H);
     f.agg = c.take<float>((size_t)n * H);
-    f.e = c.take<float>((size_t)cap * H);
+    f.side = c.take<float>(edge_groups_max(n, cap_side) * H);
+    f.e = c.take<float>((size_t)cap_e * H);
     f.bytes = c.used();
     return f;
 }
@@ -390,7 +393,12 @@ void gm_model_destroy(gm_model* m) {
 
 size_t gm_forward_workspace_bytes(const gm_model_desc* desc, int64_t n, int64_t cap) {
     if (!desc || n < 0 || cap < 0) return 0;
-    return carve_fwd(nullptr, desc->hidden_size, n, cap).bytes;
+    return carve_fwd(nullptr, desc->hidden_size, n, cap, cap).bytes;
+}
+
+size_t gm_block_workspace_bytes(const gm_model_desc* desc, int64_t n, int64_t cap) {
+    if (!desc || n < 0 || cap < 0) return 0;
+    return carve_fwd(nullptr, desc->hidden_size, n, 0, cap).bytes;
 }
 
 }  // extern "C"
@@ -410,10 +418,10 @@ EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid
     return a;
 }
 EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, int64_t n, const CsrHeader* hdr, int e_host, const int* eid,
-                        const float* P, const float* e_in, float* e_out, float* agg, int residual) {
+                        const float* P, const float* e_in, float* e_out, float* agg, float* side, int residual) {
     EdgeArgs a{};
     a.hdr = hdr; a.n_edges_host = e_host; a.dst = c.dst; a.src = c.src; a.eid = eid; a.eid_out = eid;
-    a.P = P; a.e_in = e_in; a.e_out = e_out; a.agg = agg; a.residual = residual;
+    a.P = P; a.e_in = e_in; a.e_out = e_out; a.agg = agg; a.side = side; a.residual = residual;
     a.wstream = m->packed ? m->packed + m->s_edge[k] : nullptr;
     a.wstream16 = m->packed16 ? m->packed16 + m->s16_edge[k] : nullptr;
     a.wstream_hm = m->packed_hm + m->hm_edge[k];
@@ -454,7 +462,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     if (n == 0) return GM_OK;
     GM_REQUIRE(nodes && out && (edge_attr || cap == 0), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: null tensor");
     const int H = m->H, NL = m->NL, M = m->M;
-    FwdWs f = carve_fwd(fwd_ws, H, n, cap);
+    FwdWs f = carve_fwd(fwd_ws, H, n, cap, cap);
     GM_REQUIRE(fwd_ws_bytes >= f.bytes, GM_ERR_WORKSPACE, "gm_epd_forward: workspace %zu < %zu", fwd_ws_bytes, f.bytes);
     CsrWs c = carve_csr(const_cast<void*>(csr_ws), n, cap);
     hipStream_t s = (hipStream_t)stream;
@@ -469,13 +477,18 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     set_tail(m, na, 0, f.P, out);
     rc = launch_node(H, NL, 0, na, s);
     if (rc != GM_OK) return rc;
-    // agg is zeroed once; afterwards every node kernel clears the rows it has consumed
+    const bool legacy_kernels = m->edge_kernel >= 1 && m->edge_kernel <= 4;
+    // agg is zeroed once (nodes without in-edges read zeros)
     GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
     for (int k = 0; k < M; ++k) {
-        rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, 1), cap, s);
+        rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, f.side, 1), cap, s);
         if (rc != GM_OK) return rc;
         NodeArgs a{};
-        a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.agg_clear = k + 1 < M ? f.agg : nullptr; a.h_out = f.h; a.residual = 1;
+        a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.h_out = f.h; a.residual = 1;
+        // the fp32 edge kernels add into agg atomically, so the rows consumed here are cleared for the next step; the
+        // sys / hm kernels store every row with in-edges whole (rows without keep the zeros of the memset above)
+        a.agg_clear = (legacy_kernels && k + 1 < M) ? f.agg : nullptr;
+        a.edge_blocks = c.blocks; a.n_nodes_tab = n; a.edge_capacity_tab = cap; a.side = f.side;
         a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
         a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel; a.prof = m->prof;
         const float* vn = m->vec + m->v_node[k];
@@ -516,7 +529,7 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     if (n == 0) return GM_OK;
     GM_REQUIRE(h && h_out && (cap == 0 || (e && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward: null tensor");
     const int H = m->H, NL = m->NL;
-    FwdWs f = carve_fwd(fwd_ws, H, n, 0);  // only P and agg are used
+    FwdWs f = carve_fwd(fwd_ws, H, n, 0, cap);  // P, agg and the side buffer are used
     GM_REQUIRE(fwd_ws_bytes >= f.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_forward: workspace %zu < %zu", fwd_ws_bytes, f.bytes);
     CsrWs c = carve_csr(const_cast<void*>(csr_ws), n, cap);
     hipStream_t s = (hipStream_t)stream;
@@ -531,10 +544,11 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     int rc = launch_node(H, NL, 2, pa, s);
     if (rc != GM_OK) return rc;
     GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
-    rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, c.eid, f.P, e, e_out, f.agg, 0), cap, s);
+    rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, c.eid, f.P, e, e_out, f.agg, f.side, 0), cap, s);
     if (rc != GM_OK) return rc;
     NodeArgs a{};
     a.n_nodes = (int)n; a.x_in = h; a.agg = f.agg; a.h_out = h_out; a.residual = 0;
+    a.edge_blocks = c.blocks; a.n_nodes_tab = n; a.edge_capacity_tab = cap; a.side = f.side;
     a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
     a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel; a.prof = m->prof;
     const float* vn = m->vec + m->v_node[k];

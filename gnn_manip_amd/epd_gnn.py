@@ -357,7 +357,7 @@ def _run_block(handle, desc, k, x, edge_attr, edge_index, csr=None):
         csr = DstCsr(edge_index, n, flow=desc[7] if len(desc) > 7 else 0)
     L = lib()
     d = ModelDesc(*desc)
-    fwd = _ws(L.gm_forward_workspace_bytes(C.byref(d), n, 0), x.device)
+    fwd = _ws(L.gm_block_workspace_bytes(C.byref(d), n, e), x.device)
     h_out = torch.empty_like(x)
     e_out = torch.empty_like(edge_attr)
     check(L.gm_interaction_network_forward(handle, k, ptr(x), n, ptr(edge_attr), ptr(csr.ws), e, ptr(h_out),

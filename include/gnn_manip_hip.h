@@ -172,11 +172,14 @@ void gm_model_destroy(gm_model* m);
 /* Processor edge kernel of THIS model (no reference counterpart; diagnostics / A-B measurements).  0 = automatic
  * (the systolic fp16 x 3 kernel for hidden 128 / num_layers 2 in the fused forward, else the
  * kernels below); 1 = fp32 MFMA 16x16x4; 2 = fp32 MFMA 32x32x2; 3 / 4 = bf16 matrix pipe, six partial products,
- * 128- / 64-edge tiles; 5 = systolic fp16 x 3 (fails where it does not apply).  The environment variable
- * GM_EDGE_KERNEL=16|classic|b3|b3p|sys sets the initial value of models created afterwards. */
+ * 128- / 64-edge tiles; 5 = systolic fp16 x 3 where it applies, else 6; 6 = streamed fp16 x 3 (hmlp.hip; every MLP of
+ * the model, any supported size).  1..4 exist for hidden 128 / 256 with num_layers 2 only.  The environment variable
+ * GM_EDGE_KERNEL=16|classic|b3|b3p|sys|hm sets the initial value of models created afterwards. */
 int gm_model_set_edge_kernel(gm_model* m, int choice);
 
 size_t gm_forward_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t edge_capacity);
+/* workspace of gm_interaction_network_forward (the latent edge arrays are the caller's) */
+size_t gm_block_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t edge_capacity);
 
 /* EncProcDecGNN.forward(nodes, edge_attr, edge_index)   epd_gnn.py:86-105.
  * edge_attr is in the CALLER's edge order; the csr workspace (built from the same edge_index or

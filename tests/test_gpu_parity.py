@@ -624,3 +624,32 @@ def test_profile_is_per_model(dev):
     with torch.no_grad():
         a.forward(x, ea, ei)
     assert a.profile_query(0)[0] == 2
+
+
+@pytest.mark.parametrize("kernel", ["auto", "hm"])
+def test_scatter_add_is_deterministic_with_hub_nodes(dev, kernel):
+    """Destinations whose segments span many 4-block groups (in-degree 700 and 300, i.e. > 5 and > 2 groups of 128 edges):
+    their head partials go to the side buffer and are added in group order by the node kernel -- no atomics -- so two
+    runs agree bit for bit, and the result is the oracle's."""
+    rng = np.random.Generator(np.random.PCG64(73))
+    n, e = 500, 9000
+    ei = rng.integers(0, n, size=(2, e)).astype(np.int64)
+    ei[1, :700] = 17
+    ei[1, 700:1000] = 401
+    nodes = rng.standard_normal((n, 25)).astype(np.float32)
+    ea = rng.standard_normal((e, 4)).astype(np.float32)
+    params = orc.init_params(25, 4, 3, 128, 2, 3, 74)
+    m = _model(params, (25, 4, 3, 128, 2, 3), dev)
+    m.set_edge_kernel(kernel)
+    with torch.no_grad():
+        outs = [m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy() for _ in range(4)]
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    ref = orc.epd_forward(params, nodes, ea, ei, 2, 3)
+    assert np.abs(outs[0] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
+    # the standalone block (edges in the caller's order, eid indirection) goes through the same lists
+    h0, e0 = orc.graph_independent(params, "encoder", nodes, ea, 2)
+    with torch.no_grad():
+        h1, e1, _ = m.processor[0](_t(h0, dev), _t(e0, dev), _t(ei, dev))
+    h1o, e1o = orc.interaction_network(params, "processor.0", h0, e0, ei, 2)
+    np.testing.assert_allclose(h1.cpu().numpy(), h1o, rtol=1e-5, atol=2e-5)
