@@ -18,7 +18,9 @@
 //   role 2: Linear 3 of block x-2 (X2 -> Z + LayerNorm partial statistics); aggregation of block x-3: segmented DPP scan
 //           over the destination-sorted edges with the carry of an open segment kept in registers, one row store per
 //           finished segment -- to its agg row, or, for the piece of a segment that began in an earlier group of 4 blocks,
-//           to that group's row of the side buffer, which the node kernel adds in group order: no atomics.
+//           to that group's row of the side buffer, which the node kernel adds in group order: no atomics.  The rows'
+//           destinations come from a small LDS ring that role 0 fills from the indices it loads anyway (role 2 issues no
+//           global loads per tick); roles run at different s_setprio levels (role 2 first, then role 0).
 // A wave's MFMAs form one dependent chain, so its other work of the tick is placed BETWEEN them with the order pinned
 // (one MFMA shadows about three vector instructions of the same wave).  Global rows move as whole 128-byte lines
 // (8 lanes per row); the register <-> MFMA-fragment re-layouts go through XOR-swizzled, conflict-free LDS images.
@@ -42,6 +44,18 @@ constexpr int BE = 32;             // edges per block
 constexpr int SYS_THREADS = 768;
 #ifndef SIDE_STRIDE
 #define SIDE_STRIDE 6   // MFMA slots per row group of role 1's e_out epilogue (24 slots per tick)
+#endif
+#ifdef HEDGE_STAMPS
+// development build only: s_memtime stamps of role 2 (workgroup 0, wave jb = 0, lane 0) at the phase boundaries of ticks
+// 16..47; read back with gm_debug_sys_stamps (tools/sys_stamps.py)
+__device__ unsigned long long g_sys_stamps[32 * 8];
+#define SYS_STAMP(tick, slot)                                                                                         \
+    do {                                                                                                              \
+        if (blockIdx.x == 0 && jb == 0 && lane0 == 0 && (tick) >= 16 && (tick) < 48)                                  \
+            g_sys_stamps[((tick) - 16) * 8 + (slot)] = __builtin_readcyclecounter();                                  \
+    } while (0)
+#else
+#define SYS_STAMP(tick, slot) do { } while (0)
 #endif
 #ifndef HEDGE_ABL
 #define HEDGE_ABL 0   // development builds: timing ablations (1 no residual read, 2 P_j from the P_i row, 4 no e_out store, 8 no agg store, 16 no e read, 32 e_out rows folded onto 1024 rows)
@@ -142,7 +156,8 @@ __device__ __forceinline__ void ln_merge(const float* st, int n, float inv_T, fl
 // accumulator-layout accesses.  Returns the float4 index inside the 4 KiB tile.
 __device__ __forceinline__ int tile_q(int row, int quad) { return row * 8 + (quad ^ (row & 7)); }
 
-constexpr size_t SYS_LDS_BYTES = 3 * 2 * 16384 + 2 * 16384 + 16384 + 2 * 8 * BE * 2 * 4 + 4 * BE * 2 * 4 + 4 * H * 4;
+constexpr int DR_SLOTS = 8;   // ring of per-block destination ids handed from role 0 to role 2 (written 2 ticks before it is read)
+constexpr size_t SYS_LDS_BYTES = 3 * 2 * 16384 + 2 * 16384 + 16384 + 2 * 8 * BE * 2 * 4 + 4 * BE * 2 * 4 + 4 * H * 4 + DR_SLOTS * BE * 4;
 
 __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -154,6 +169,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
     float* ST = reinterpret_cast<float*>(PS + 1024);          // [2][4 jb][2 halves][32][2]: LayerNorm partials
     float* KM = ST + 2 * 8 * BE * 2;                          // [4 jb][32][2]: role-1 merged statistics
     float* vecs = KM + 4 * BE * 2;                            // 4 x 128: b2 T2 | b3 T3 | gamma | beta
+    int* DR = reinterpret_cast<int*>(vecs + 4 * H);           // [DR_SLOTS][32]: destination of every row of a block (role 0 -> role 2)
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2, jb = wave & 3;
@@ -227,6 +243,10 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             acc_to_image(acc, reinterpret_cast<uintx4*>(X1 + (x & 1) * 1024), jb, lane);
             // requests: P rows of block x+1 (whole 128-byte lines: 8 lanes per row)
             if (ok(x + 1)) {
+                // the destinations of block x+1 are here (loaded two ticks ago): hand them to role 2, which needs them in
+                // two ticks, so that its waves issue no index loads of their own (the CU's vector-memory issue is what
+                // every role queues on: tools/sys_stamps.py)
+                if (jb == 0 && hi == 0) DR[((x + 1) & (DR_SLOTS - 1)) * BE + n] = dl1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int d = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, dl1);
@@ -336,20 +356,21 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
         floatx16 acc, carry;
 #pragma unroll
         for (int r = 0; r < 16; ++r) carry[r] = 0.f;
-        int dn_a = -1, nx_a = -2, fl_a = 0, cnt_a = 0, dn_b = -1, nx_b = -2, fl_b = 0, cnt_b = 0;  // blocks x-3, x-2
+        int dn_a = -1, fl_a = 0, cnt_a = 0, dn_b = -1, fl_b = 0, cnt_b = 0;  // blocks x-3, x-2 (cnt_b = 0 while there is none)
         int head_a = -1, head_b = -1;   // destination whose segment began in an earlier group (its sum over this group goes to the side buffer)
         int prev_last_dst = -3;         // destination of lane 31 of the previous block while its segment is open, else -3
         const float* vgam = vecs + 2 * H + 32 * jb;
         const float* vbet = vecs + 3 * H + 32 * jb;
         int2 bn = make_int2(0, 0);      // table entry of the block the next fetch() handles
-        auto fetch = [&](int x, int2 bi, int& dn, int& nx, int& fl, int& cnt, int& head) {
-            if (!ok(x)) return;
+        // destinations of block x: from the ring role 0 filled two ticks ago (no global load); rows past the block's end
+        // get unique negative ids.  Past the workgroup's range there is no block: cnt = 0.
+        auto fetch = [&](int x, int2 bi, int& dn, int& fl, int& cnt, int& head) {
             const int n = lane0 & 31;
+            if (!ok(x)) { cnt = 0; dn = -1 - n; return; }
             cnt = bi.y & 0xff;
             fl = bi.y >> 8;
-            const int p = bi.x + n;
-            dn = n < cnt ? A.dst[p] : -1 - n;
-            nx = (n < cnt && p + 1 < E) ? A.dst[p + 1] : -2;
+            const int v = DR[(x & (DR_SLOTS - 1)) * BE + n];
+            dn = n < cnt ? v : -1 - n;
             if (fl & 1) head = A.head[x >> 2];
         };
 #pragma unroll 1
@@ -361,6 +382,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             const bool agg_on = ok(x - 3);
             float k, m, f1, f2, f4, f8, fb, fc;
             const int dn = dn_a;
+            SYS_STAMP(t, 0);
             {
                 ln_merge(ST + ((x - 3) & 1) * 8 * BE * 2, n, inv_T, A.eps, k, m);
                 // same-destination flags of the scan steps (lanes past the block's end hold unique negative ids)
@@ -374,10 +396,17 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
                 // the carry of the segment the previous block of this chunk left open enters at lane 0
                 fc = (n == 0 && !(fl_a & 1) && dn == prev_last_dst) ? 1.f : 0.f;
             }
+            SYS_STAMP(t, 1);   // merged statistics + scan flags
             bool is_last = false;
             if (agg_on) {
                 const bool lastf = (fl_a & 2) != 0;
-                is_last = n < cnt_a && (nx_a != dn || (lastf && n == cnt_a - 1));
+                // destination of the next edge: the next row of this block; for the block's last row the first row of the
+                // following block (blocks of a graph are contiguous; a short block ends its graph, and other graphs,
+                // padding blocks and the end of the workgroup's range never match: -2)
+                const int nrow = __builtin_amdgcn_ds_bpermute(((lane & 32) | ((n + 1) & 31)) * 4, dn);
+                const int nblk0 = __builtin_amdgcn_readlane(dn_b, 0);
+                const int nx = n + 1 < cnt_a ? nrow : ((cnt_a == BE && cnt_b > 0) ? nblk0 : -2);
+                is_last = n < cnt_a && (nx != dn || (lastf && n == cnt_a - 1));
             }
             // a finished (or group-final) sum is stored exactly once: to its agg row, or -- for the piece of a segment that
             // began in an earlier group -- to this group's row of the side buffer (added in group order by the node kernel)
@@ -437,7 +466,9 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
                     for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
                 }
             }
+            SYS_STAMP(t, 2);   // accumulators initialised
             mlp_layer<false>(acc, wh, wl, X2 + par2 * 1024, lane, side);
+            SYS_STAMP(t, 3);   // 24 MFMAs with the scatter-add's scan between them
             if (agg_on) prev_last_dst = (cnt_a == BE && !(fl_a & 2)) ? __builtin_amdgcn_readlane(dn, 31) : -3;
             {
                 // LayerNorm partial statistics of the scaled accumulators (16 features per lane); raw accumulators to Z
@@ -458,11 +489,14 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
                     zt[tile_q(n, 2 * g + hi)] = z;
                 }
             }
-            dn_a = dn_b; nx_a = nx_b; fl_a = fl_b; cnt_a = cnt_b;
+            SYS_STAMP(t, 4);   // partial statistics + Z written
+            dn_a = dn_b; fl_a = fl_b; cnt_a = cnt_b;
             if (fl_b & 1) head_a = head_b;
-            fetch(x - 1, bn, dn_b, nx_b, fl_b, cnt_b, head_b);
+            fetch(x - 1, bn, dn_b, fl_b, cnt_b, head_b);
             if (ok(x)) bn = A.blk[x];
+            SYS_STAMP(t, 5);   // destinations of the next block read from the ring (+ the table entry / head loads)
             lds_barrier();
+            SYS_STAMP(t, 6);   // every wave of the workgroup has finished the tick
         }
     }
 }
@@ -676,5 +710,11 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
+
+#ifdef HEDGE_STAMPS
+extern "C" int gm_debug_sys_stamps(unsigned long long* out) {   // 32 ticks x 8 slots, development builds only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sys_stamps), sizeof(unsigned long long) * 32 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace gm
