@@ -670,10 +670,16 @@ int launch_node_hr(int mode, const HmNodeArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((hm_node_kernel<H, 2, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
     return GM_OK;
 }
-// small graphs: one 32-row block per wave, so that the tiles cover the CUs
+// small graphs: one 32-row block per wave, so that the tiles cover the CUs.  HM_NODE_SMALL_ROUNDS: the 4-block form is used
+// once its tiles fill the CUs that many times over.  1 is the measured choice: at N = 100k / hidden 128 (391 tiles of 256
+// rows on 256 CUs, a half-empty second round) the small form is still 16 % slower (1.80 vs 1.55 ms of node kernels per
+// step, A/B on one box) -- it streams the weights four times as often.
+#ifndef HM_NODE_SMALL_ROUNDS
+#define HM_NODE_SMALL_ROUNDS 1
+#endif
 template <int H>
 int launch_node_h(int mode, const HmNodeArgs& a, hipStream_t s) {
-    if (cdiv(a.n_nodes, Cfg<H, 4>::M) < device_cus()) return launch_node_hr<H, 1>(mode, a, s);
+    if (cdiv(a.n_nodes, Cfg<H, 4>::M) < (int64_t)HM_NODE_SMALL_ROUNDS * device_cus()) return launch_node_hr<H, 1>(mode, a, s);
     return launch_node_hr<H, 4>(mode, a, s);
 }
 
