@@ -31,7 +31,7 @@ struct EdgeArgs {
     float eps;
     int residual;          // e_out = e' + e_in
     int k1;                // encoder: edge_dim
-    int debug;             // timing ablations (GM_DEBUG_SKIP), 0 in production
+    int debug;             // timing-ablation bits of the fp32 kernels; launch_edge always passes 0 (no run-time switch)
     unsigned long long* stamps;  // diagnostic build only: per-tile s_memrealtime stamps, or nullptr
 };
 

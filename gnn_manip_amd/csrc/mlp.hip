@@ -169,8 +169,8 @@ int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // EDGE kernel
 // ------------------------------------------------------------------------------------------
-// Diagnostic stamps (tools/stamps.py): 100 MHz s_memrealtime per tile phase, written to a buffer that no
-// other code reads.  Never enabled in a timed run.
+// Diagnostic stamps: 100 MHz s_memrealtime per tile phase, written to a buffer that no other code reads.  The
+// library always passes a null buffer (launch_edge); round 1's reader script went with the stamp setter of the ABI.
 #define GM_STAMP(k)                                                                          \
     do {                                                                                     \
         if (A.stamps && tid == 0) A.stamps[(size_t)tile * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) edge_kernel(EdgeArg
 // registers of state), which leaves no room to prefetch, and the measured cost of that is large --
 // the two workgroups of a CU run in phase, so their gather / epilogue phases (bound by the CU's own
 // ~24 GB/s memory path) serialise with their MFMA phases instead of hiding under them
-// (tools/stamps.py).  16x16x4 runs at the same FLOP rate with HALF the state per wave (16 edges:
+// (in-kernel stamps, round 1).  16x16x4 runs at the same FLOP rate with HALF the state per wave (16 edges:
 // 32 + 32 registers), and the same register-chaining trick holds:
 //     D block jb, lane (n = lane & 15, g = lane >> 4), register r  <->  feature 16 jb + 4 g + r
 // is exactly the k this lane must supply as B operand in step r of k-block jb of the next layer.
