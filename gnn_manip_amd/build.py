@@ -18,9 +18,14 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, tag=None):
+    """tag: development A/B builds -- objects in build_<tag>/, library in <repo>/variants/lib_<tag>.so (GM_LIB_PATH selects it)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if not tag else "build_" + tag)
+    lib = LIB
+    if tag:
+        os.makedirs(os.path.join(os.path.dirname(HERE), "variants"), exist_ok=True)
+        lib = os.path.join(os.path.dirname(HERE), "variants", f"lib_{tag}.so")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "gnn_manip_hip.h"))
@@ -41,10 +46,11 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if jobs or force or not os.path.exists(lib):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), None)
+    print(build(force="--force" in sys.argv, verbose=True, tag=tag))

@@ -46,16 +46,19 @@ constexpr int SYS_THREADS = 768;
 #define SIDE_STRIDE 6   // MFMA slots per row group of role 1's e_out epilogue (24 slots per tick)
 #endif
 #ifdef HEDGE_STAMPS
-// development build only: s_memtime stamps of role 2 (workgroup 0, wave jb = 0, lane 0) at the phase boundaries of ticks
-// 16..47; read back with gm_debug_sys_stamps (tools/sys_stamps.py)
-__device__ unsigned long long g_sys_stamps[32 * 8];
+// development build only: s_memtime stamps of the three roles (workgroup 0, waves jb = 0, lane 0) at the phase boundaries of
+// ticks 16..47; read back with gm_debug_sys_stamps (tools/sys_stamps.py)
+__device__ unsigned long long g_sys_stamps[3 * 32 * 8];
 #define SYS_STAMP(tick, slot)                                                                                         \
     do {                                                                                                              \
         if (blockIdx.x == 0 && jb == 0 && lane0 == 0 && (tick) >= 16 && (tick) < 48)                                  \
-            g_sys_stamps[((tick) - 16) * 8 + (slot)] = __builtin_readcyclecounter();                                  \
+            g_sys_stamps[(role * 32 + (tick) - 16) * 8 + (slot)] = __builtin_readcyclecounter();                     \
     } while (0)
 #else
 #define SYS_STAMP(tick, slot) do { } while (0)
+#endif
+#ifndef HEDGE_VAR
+#define HEDGE_VAR 0   // development builds: structural variants under A/B test (bit meanings at their use)
 #endif
 #ifndef HEDGE_ABL
 #define HEDGE_ABL 0   // development builds: timing ablations (1 no residual read, 2 P_j from the P_i row, 4 no e_out store, 8 no agg store, 16 no e read, 32 e_out rows folded onto 1024 rows)
@@ -64,22 +67,6 @@ constexpr int HW_HEADER_FLOATS = 4;            // T1, 1/T3, pad, pad
 constexpr int HW_VEC_FLOATS = 4 * H;           // b2*T2 | b3*T3 | gamma | beta
 constexpr int HW_IMAGE_HALF8 = 3 * 4 * 8 * 2 * 64;   // [layer][jb][ks][part][lane]
 
-struct SysArgs {
-    const CsrHeader* hdr;
-    const int* dst;
-    const int* src;
-    const float* P;        // [N][2H]  P_i (+ b1) | P_j, unscaled
-    const float* e_in;
-    float* e_out;
-    float* agg;
-    const float* hw;       // header | vec | weight image of this processor step
-    const int2* blk;
-    const int* head;       // [n_groups] (hedge.h)
-    float* side;           // [n_groups][H] head partials of the scatter-add
-    const EdgeBlockHeader* tab;
-    float eps;
-    int residual;
-};
 
 // accumulator registers 8q..8q+7 of a wave's 32-feature block are the elements of B fragment ks = 2 jb + q (same lane):
 // K slot (lane >> 5, j) of k-group ks carries feature 16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) in both operands
@@ -148,7 +135,11 @@ __device__ __forceinline__ void ln_merge(const float* st, int n, float inv_T, fl
 #pragma unroll
     for (int w = 0; w < 8; ++w) { const float d = mw[w] - mean; m2 = fmaf(16.0f * d, d, m2); }
     const float var = m2 * (1.0f / 128.0f) * inv_T * inv_T;
-    k = inv_T / sqrtf(var + eps);
+    // 1 / sqrt(var + eps): v_rsq_f32 (1 ulp) + one Newton step instead of the ~25 instructions of an IEEE sqrt and divide
+    const float v = var + eps;
+    float r = __builtin_amdgcn_rsqf(v);
+    r = r * fmaf(-0.5f * v * r, r, 1.5f);
+    k = inv_T * r;
     m = -mean * k;
 }
 
@@ -159,7 +150,10 @@ __device__ __forceinline__ int tile_q(int row, int quad) { return row * 8 + (qua
 constexpr int DR_SLOTS = 8;   // ring of per-block destination ids handed from role 0 to role 2 (written 2 ticks before it is read)
 constexpr size_t SYS_LDS_BYTES = 3 * 2 * 16384 + 2 * 16384 + 16384 + 2 * 8 * BE * 2 * 4 + 4 * BE * 2 * 4 + 4 * H * 4 + DR_SLOTS * BE * 4;
 
-__global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
+__global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeader* __restrict__ a_hdr, const int* __restrict__ a_dst, const int* __restrict__ a_src, const float* __restrict__ a_P,
+                                                                       const float* a_e_in, float* a_e_out, float* __restrict__ a_agg, const float* __restrict__ a_hw,
+                                                                       const int2* __restrict__ a_blk, const int* __restrict__ a_head, float* __restrict__ a_side,
+                                                                       const EdgeBlockHeader* __restrict__ a_tab, float a_eps, int a_residual) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* Eimg = reinterpret_cast<half8*>(smem);            // [2][8 ks][2 parts][64]  2 x 16 KiB, eslot() order
     half8* X1 = Eimg + 2 * 1024;
@@ -173,17 +167,17 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2, jb = wave & 3;
-    const int E = A.hdr->n_edges;
-    const int nchunks = A.tab->n_groups;   // the workgroup takes a contiguous range of whole groups (4 blocks each)
+    const int E = a_hdr->n_edges;
+    const int nchunks = a_tab->n_groups;   // the workgroup takes a contiguous range of whole groups (4 blocks each)
     const int c0 = (int)((long long)blockIdx.x * nchunks / gridDim.x);
     const int c1 = (int)((long long)(blockIdx.x + 1) * nchunks / gridDim.x);
     if (c1 <= c0) return;
     const int b0 = 4 * c0, b1 = 4 * c1;
     const int nb = b1 - b0;
     if (nb <= 0) return;
-    const float T1 = A.hw[0], inv_T = A.hw[1];
-    const float* hvec = A.hw + HW_HEADER_FLOATS;
-    const half8* wimg = reinterpret_cast<const half8*>(A.hw + HW_HEADER_FLOATS + HW_VEC_FLOATS);
+    const float T1 = a_hw[0], inv_T = a_hw[1];
+    const float* hvec = a_hw + HW_HEADER_FLOATS;
+    const half8* wimg = reinterpret_cast<const half8*>(a_hw + HW_HEADER_FLOATS + HW_VEC_FLOATS);
 
     half8 wh[8], wl[8];
 #pragma unroll
@@ -195,8 +189,13 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
     // flag-multiplied scan
     for (int i = tid; i < (int)((reinterpret_cast<char*>(vecs) - smem) / 16); i += SYS_THREADS) reinterpret_cast<uintx4*>(smem)[i] = uintx4{0u, 0u, 0u, 0u};
     for (int i = tid; i < 4 * H; i += SYS_THREADS) vecs[i] = hvec[i];
+    // The weight registers must have ARRIVED before the tick loops: otherwise hipcc places their counted vmcnt waits at the first
+    // uses inside the loop, where (loads and stores share the counter, in issue order) they wait for the tick's own row stores
+    // and index loads every tick.
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), a form the compiler's wait-count bookkeeping sees
     __syncthreads();
     auto ok = [&](int x) { return x >= b0 && x < b1; };
+    auto clampb = [&](int x) { return x < b0 ? b0 : (x < b1 ? x : b1 - 1); };
     auto nothing = [](int) {};
 
     // Instruction arbitration: role 2 (Linear 3 + statistics + the scatter-add's scan) is the longest instruction stream of
@@ -211,15 +210,18 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
         for (int j = 0; j < 4; ++j) { pi[j] = floatx4{0.f, 0.f, 0.f, 0.f}; pj[j] = pi[j]; }
         floatx16 acc;
         int dl1 = 0, sl1 = 0, dl2 = 0, sl2 = 0;   // destination / source of row (lane & 31): blocks x+1 and x+2
-        int2 bn = ok(b0 + 1) ? A.blk[b0 + 1] : make_int2(0, 0);   // table entry of the block the next fetch() handles
-        auto fetch = [&](int x, int2 bi, int& dl, int& sl) {
-            if (!ok(x)) return;
+        // Every global load of the tick loops is issued unconditionally with a clamped index (blocks past the workgroup's range
+        // repeat its last block): hipcc's counted vmcnt waits assume the path with the fewest younger operations, so a load
+        // or store inside a branch turns the waits for older loads into waits for (almost) everything.
+        int2 bn = a_blk[clampb(b0 + 1)];   // table entry of the block the next fetch() handles
+        auto fetch = [&](int2 bi, int& dl, int& sl) {
             const int cnt = bi.y & 0xff, n = lane0 & 31;
-            const int p = bi.x + (n < cnt ? n : cnt - 1);
-            dl = A.dst[p];
-            sl = A.src[p];
+            int p = bi.x + (n < cnt ? n : cnt - 1);
+            p = p < 0 ? 0 : (p < E ? p : E - 1);
+            dl = a_dst[p];
+            sl = a_src[p];
         };
-        fetch(b0, A.blk[b0], dl2, sl2);
+        fetch(a_blk[b0], dl2, sl2);
         floatx4* ps = PS + jb * 256;
 #pragma unroll 1
         for (int t = -2; t <= nb + 2; ++t) {
@@ -229,9 +231,26 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             int lane_t = lane0;
             asm volatile("" : "+v"(lane_t));
             const int lane = lane_t, n = lane & 31, hi = lane >> 5, rr = lane >> 3, cq = lane & 7;
+            SYS_STAMP(t, 0);
             // accumulator = (P_i[dst] + P_j[src]) * T1: row-major sum -> tile -> accumulator layout
 #pragma unroll
             for (int j = 0; j < 4; ++j) ps[tile_q(8 * j + rr, cq)] = (pi[j] + pj[j]) * T1;
+            SYS_STAMP(t, 1);   // P rows of this block have arrived
+            // Requests, all at the top of the tick so that they have a whole tick to arrive (loads and stores complete in issue
+            // order on one counter: whatever is requested last is what the next tick's first wait waits for).
+            // P rows of block x+1 (whole 128-byte lines: 8 lanes per row).  Its destinations (loaded two ticks ago) also go to
+            // role 2, which needs them in two ticks: its waves issue no vector loads at all.
+            if (jb == 0 && hi == 0) DR[((x + 1) & (DR_SLOTS - 1)) * BE + n] = dl1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, dl1);
+                const int s = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, sl1);
+                pi[j] = *reinterpret_cast<const floatx4*>(a_P + (unsigned)(d * (2 * H) + 32 * jb + 4 * cq));
+                pj[j] = *reinterpret_cast<const floatx4*>(a_P + (unsigned)(((HEDGE_ABL & 2) ? d : s) * (2 * H) + H + 32 * jb + 4 * cq));
+            }
+            dl1 = dl2; sl1 = sl2;
+            fetch(bn, dl2, sl2);          // indices of block x+3
+            bn = a_blk[clampb(x + 4)];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -239,26 +258,14 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
             }
+            SYS_STAMP(t, 2);
             mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, nothing);
+            SYS_STAMP(t, 3);
             acc_to_image(acc, reinterpret_cast<uintx4*>(X1 + (x & 1) * 1024), jb, lane);
-            // requests: P rows of block x+1 (whole 128-byte lines: 8 lanes per row)
-            if (ok(x + 1)) {
-                // the destinations of block x+1 are here (loaded two ticks ago): hand them to role 2, which needs them in
-                // two ticks, so that its waves issue no index loads of their own (the CU's vector-memory issue is what
-                // every role queues on: tools/sys_stamps.py)
-                if (jb == 0 && hi == 0) DR[((x + 1) & (DR_SLOTS - 1)) * BE + n] = dl1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int d = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, dl1);
-                    const int s = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, sl1);
-                    pi[j] = *reinterpret_cast<const floatx4*>(A.P + (unsigned)(d * (2 * H) + 32 * jb + 4 * cq));
-                    pj[j] = *reinterpret_cast<const floatx4*>(A.P + (unsigned)(((HEDGE_ABL & 2) ? d : s) * (2 * H) + H + 32 * jb + 4 * cq));
-                }
-            }
-            dl1 = dl2; sl1 = sl2;
-            fetch(x + 3, bn, dl2, sl2);
-            if (ok(x + 4)) bn = A.blk[x + 4];
+            SYS_STAMP(t, 4);
+            SYS_STAMP(t, 5);
             lds_barrier();
+            SYS_STAMP(t, 6);
         }
     } else if (role == 1) {
         // ------------------------------------------------------------------ role 1
@@ -267,7 +274,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
         floatx4 eq[4];                      // e rows of block x+1 on their way into the operand image E
         int st_a = 0, cnt_a = 0, st_b = 0, cnt_b = 0;  // blocks x-3, x-2
         int2 bi_c = make_int2(0, 0);                    // raw table entry of block x-1 (decoded a tick after its load)
-        int2 be = A.blk[b0];                            // raw table entry of block x+2 (its .x = first edge)
+        int2 be = a_blk[b0];                            // raw table entry of block x+2 (its .x = first edge)
+        const float res_w = a_residual ? 1.f : 0.f;
         const float* vgm = vecs + 2 * H + 32 * jb + 4 * (lane0 & 7);
         float* km = KM + jb * BE * 2;
 #pragma unroll
@@ -280,9 +288,10 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             const int lane = lane_t, n = lane & 31, hi = lane >> 5, rr = lane >> 3, cq = lane & 7;
             const bool epi = ok(x - 3);
             const int par3 = (x - 3) & 1;
+            SYS_STAMP(t, 0);
             {  // merged statistics of block x-3: lane n (both halves) -> km[n]
                 float k, m;
-                ln_merge(ST + par3 * 8 * BE * 2, n, inv_T, A.eps, k, m);
+                ln_merge(ST + par3 * 8 * BE * 2, n, inv_T, a_eps, k, m);
                 if (hi == 0) *reinterpret_cast<float2v*>(km + n * 2) = float2v{k, m};
             }
             const floatx4* zt = Z + (par3 * 4 + jb) * 256;
@@ -311,9 +320,9 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
                         const float xh = fmaf(zq[tt], kmr[0], kmr[1]);
-                        o[tt] = fmaf(xh, gm[tt], bt[tt]) + er[j][tt];
+                        o[tt] = fmaf(er[j][tt], res_w, fmaf(xh, gm[tt], bt[tt]));
                     }
-                    if (!(HEDGE_ABL & 4) && epi && r < cnt_a) *reinterpret_cast<floatx4*>(A.e_out + (unsigned)((((HEDGE_ABL & 32) ? (st_a & 1023) : st_a) + r) * H + 32 * jb + 4 * cq)) = o;
+                    if (!(HEDGE_ABL & 4) && epi && r < cnt_a) *reinterpret_cast<floatx4*>(a_e_out + (unsigned)((((HEDGE_ABL & 32) ? (st_a & 1023) : st_a) + r) * H + 32 * jb + 4 * cq)) = o;
                 }
             };
             {
@@ -325,31 +334,40 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
                     for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
                 }
             }
+            SYS_STAMP(t, 1);
             conv_e(0); conv_e(1); conv_e(2); conv_e(3);
+            SYS_STAMP(t, 2);   // e rows of block x+1 have arrived and are in the image
+            auto request_e = [&]() {
+                if (!(HEDGE_ABL & 16)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int row = be.x + 8 * j + rr;
+                        row = row < E ? row : E - 1;
+                        eq[j] = *reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
+                    }
+                }
+                be = a_blk[clampb(x + 3)];
+            };
+            request_e();   // right after their registers are free: a whole tick in flight
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // km visible to this wave's own reads
             mlp_layer<false>(acc, wh, wl, X1 + ((x - 1) & 1) * 1024, lane, side);
+            SYS_STAMP(t, 3);
             acc_to_image(acc, reinterpret_cast<uintx4*>(X2 + ((x - 1) & 1) * 1024), jb, lane);
+            SYS_STAMP(t, 4);
             st_a = st_b; cnt_a = cnt_b;
             st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
-            if (!(HEDGE_ABL & 1) && ok(x - 2) && A.residual) {  // rows of block x-2: consumed next tick
+            if (!(HEDGE_ABL & 1)) {  // rows of block x-2: consumed next tick (scaled by 0 when there is no residual)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int row = st_a + 8 * j + rr;
                     row = row < E ? row : E - 1;
-                    er[j] = *reinterpret_cast<const floatx4*>(A.e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
+                    er[j] = *reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
                 }
             }
-            if (ok(x)) bi_c = A.blk[x];
-            if (!(HEDGE_ABL & 16) && ok(x + 2)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int row = be.x + 8 * j + rr;
-                    row = row < E ? row : E - 1;
-                    eq[j] = *reinterpret_cast<const floatx4*>(A.e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
-                }
-            }
-            if (ok(x + 3)) be = A.blk[x + 3];
+            bi_c = a_blk[clampb(x)];
+            SYS_STAMP(t, 5);
             lds_barrier();
+            SYS_STAMP(t, 6);
         }
     } else {
         // ------------------------------------------------------------------ role 2
@@ -371,7 +389,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             fl = bi.y >> 8;
             const int v = DR[(x & (DR_SLOTS - 1)) * BE + n];
             dn = n < cnt ? v : -1 - n;
-            if (fl & 1) head = A.head[x >> 2];
+            if (fl & 1) head = a_head[x >> 2];
         };
 #pragma unroll 1
         for (int t = -2; t <= nb + 2; ++t) {
@@ -384,7 +402,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             const int dn = dn_a;
             SYS_STAMP(t, 0);
             {
-                ln_merge(ST + ((x - 3) & 1) * 8 * BE * 2, n, inv_T, A.eps, k, m);
+                ln_merge(ST + ((x - 3) & 1) * 8 * BE * 2, n, inv_T, a_eps, k, m);
                 // same-destination flags of the scan steps (lanes past the block's end hold unique negative ids)
                 const int p1 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x111, 0xf, 0xf, false);
                 const int p2 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x112, 0xf, 0xf, false);
@@ -410,7 +428,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             }
             // a finished (or group-final) sum is stored exactly once: to its agg row, or -- for the piece of a segment that
             // began in an earlier group -- to this group's row of the side buffer (added in group order by the node kernel)
-            float* arow = (dn == head_a ? A.side + (unsigned)(((x - 3) >> 2) * H) : A.agg + (unsigned)((dn < 0 ? 0 : dn) * H)) + 32 * jb + 4 * hi;
+            float* arow = (dn == head_a ? a_side + (unsigned)(((x - 3) >> 2) * H) : a_agg + (unsigned)((dn < 0 ? 0 : dn) * H)) + 32 * jb + 4 * hi;
             const floatx4* zt3 = Z + (((x - 3) & 1) * 4 + jb) * 256;
             floatx4 zq, gmv, btv;
             float y[4];
@@ -493,7 +511,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(SysArgs A) {
             dn_a = dn_b; fl_a = fl_b; cnt_a = cnt_b;
             if (fl_b & 1) head_a = head_b;
             fetch(x - 1, bn, dn_b, fl_b, cnt_b, head_b);
-            if (ok(x)) bn = A.blk[x];
+            if (ok(x)) bn = a_blk[x];
             SYS_STAMP(t, 5);   // destinations of the next block read from the ring (+ the table entry / head loads)
             lds_barrier();
             SYS_STAMP(t, 6);   // every wave of the workgroup has finished the tick
@@ -700,20 +718,20 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
     static PerDeviceOnce attr_done;
     if (attr_done.need())
         GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
-    SysArgs A{};
-    A.hdr = a.hdr; A.dst = a.dst; A.src = a.src; A.P = a.P; A.e_in = a.e_in; A.e_out = a.e_out; A.agg = a.agg;
-    A.hw = a.wstream_h3; A.blk = t.blk; A.head = t.head; A.side = a.side; A.tab = t.hdr; A.eps = a.eps; A.residual = a.residual;
     {
         ProfScope prof(a.prof, PROF_EDGE, s);
-        hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, A);
+        // pointers as separate __restrict__ parameters (e_in / e_out may be the same array): the table and index reads are
+        // then provably unclobbered and become scalar loads where their address is wave-uniform
+        hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
+                           a.agg, a.wstream_h3, t.blk, t.head, a.side, t.hdr, a.eps, a.residual);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
 
 #ifdef HEDGE_STAMPS
-extern "C" int gm_debug_sys_stamps(unsigned long long* out) {   // 32 ticks x 8 slots, development builds only
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sys_stamps), sizeof(unsigned long long) * 32 * 8) == hipSuccess ? 0 : -1;
+extern "C" int gm_debug_sys_stamps(unsigned long long* out) {   // 3 roles x 32 ticks x 8 slots, development builds only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sys_stamps), sizeof(unsigned long long) * 3 * 32 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 

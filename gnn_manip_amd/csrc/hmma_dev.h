@@ -28,18 +28,25 @@ namespace {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) { unsigned u; asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b)); return u; }
-__device__ __forceinline__ float sub_lo(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
-__device__ __forceinline__ float sub_hi(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
 // compiler-visible on purpose: it is the first reader of MFMA results, and hipcc pads the MFMA -> VALU hazard only for
 // instructions it knows (an inline-asm reader sees stale accumulators)
 __device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 65504.f); }
+
+// low part of a pair straight to fp16: x - hi is exact in fp32, so one rounding either way (v_fma_mixlo / mixhi write one half
+// of the destination and keep the other)
+__device__ __forceinline__ unsigned lo_pair(unsigned h, float a, float b) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(r) : "v"(h), "v"(a), "v"(b));
+    return r;
+}
 
 // two-way fp16 split of 4 floats: hi / lo as two dwords each (elements in order)
 __device__ __forceinline__ void split4(float a, float b, float c, float d, uintx2& hi, uintx2& lo) {
     hi[0] = cvt_pk(a, b);
     hi[1] = cvt_pk(c, d);
-    lo[0] = cvt_pk(sub_lo(hi[0], a), sub_hi(hi[0], b));
-    lo[1] = cvt_pk(sub_lo(hi[1], c), sub_hi(hi[1], d));
+    lo[0] = lo_pair(hi[0], a, b);
+    lo[1] = lo_pair(hi[1], c, d);
 }
 
 // x += lanes(x shifted) * f.  The value is produced by compiler code just before: the VALU -> DPP hazard (2 wait states) of

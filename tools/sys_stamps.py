@@ -1,10 +1,10 @@
-"""Development tool: per-tick timeline of role 2 of sys_edge_kernel (workgroup 0, wave jb = 0) from a -DHEDGE_STAMPS build.
+"""Development tool: per-tick timeline of the three roles of sys_edge_kernel (workgroup 0, waves jb = 0) from a -DHEDGE_STAMPS build.
 
-    GM_HEDGE_FLAGS="-DHEDGE_STAMPS" python -m gnn_manip_amd.build      # a stamps build of the library
-    python tools/sys_stamps.py [n_particles]
+    GM_HEDGE_FLAGS="-DHEDGE_STAMPS" python -m gnn_manip_amd.build --tag=stamps
+    GM_LIB_PATH=variants/lib_stamps.so python tools/sys_stamps.py [n_particles]
 
-Ticks are s_memtime counts (about one per shader clock).  Role 2 = Linear 3 + LayerNorm partial statistics + the
-scatter-add's segmented scan; DESIGN.md section 6 explains why it is the long pole of a tick.
+Ticks are s_memtime counts (about one per shader clock; the stamps themselves drain the scalar-memory counter, so the
+figures are inflated).  DESIGN.md section 6 reads them.
 """
 import ctypes as C
 import os
@@ -35,14 +35,30 @@ L = _lib.lib()
 if not hasattr(L, "gm_debug_sys_stamps"):
     raise SystemExit("this library was not built with -DHEDGE_STAMPS")
 L.gm_debug_sys_stamps.restype = C.c_int
-buf = (C.c_ulonglong * 256)()
+buf = (C.c_ulonglong * (3 * 256))()
 assert L.gm_debug_sys_stamps(buf) == 0
-st = np.array(buf, dtype=np.int64).reshape(32, 8)
-ticks = [t for t in range(31) if st[t, 6] > st[t, 0] > 0 and st[t + 1, 0] > 0]
-names = ["merge statistics + scan flags", "accumulator init (bias)", "24 MFMAs + scan between them", "partial statistics + Z writes",
-         "index loads of the next block", "wait at the tick barrier"]
-print(f"N = {n}, E = {e}; role 2, {len(ticks)} ticks averaged")
-for a in range(6):
-    d = [st[t, a + 1] - st[t, a] for t in ticks]
-    print(f"  {names[a]:34s} {np.mean(d):8.0f}")
-print(f"  {'tick (start to start)':34s} {np.mean([st[t + 1, 0] - st[t, 0] for t in ticks]):8.0f}")
+st_all = np.array(buf, dtype=np.int64).reshape(3, 32, 8)
+NAMES = [
+    ["wait for the P rows + sum -> staging tile", "requests (P rows, indices) + tile -> accumulators", "24 MFMAs (Linear 1)",
+     "ReLU + split -> image X1", "-", "wait at the tick barrier"],
+    ["merge statistics", "e rows -> image E (waits for them)", "requests + 24 MFMAs (Linear 2) + LayerNorm / e_out between them",
+     "ReLU + split -> image X2", "residual requests", "wait at the tick barrier"],
+    ["merge statistics + scan flags", "accumulator init (bias)", "24 MFMAs (Linear 3) + scatter-add scan between them",
+     "partial statistics + Z writes", "destinations of the next block", "wait at the tick barrier"],
+]
+print(f"N = {n}, E = {e}")
+t0 = st_all[:, :, 0]
+for role in range(3):
+    st = st_all[role]
+    ticks = [t for t in range(31) if st[t, 6] > st[t, 0] > 0 and st[t + 1, 0] > 0]
+    print(f"role {role}: {len(ticks)} ticks averaged")
+    for a in range(6):
+        d = [st[t, a + 1] - st[t, a] for t in ticks]
+        print(f"  {NAMES[role][a]:64s} {np.mean(d):8.0f}")
+    print(f"  {'tick (start to start)':64s} {np.mean([st[t + 1, 0] - st[t, 0] for t in ticks]):8.0f}")
+# arrival order at the barrier: stamp 5 (arrival) of each role relative to role 2's, and release (stamp 6)
+ticks = [t for t in range(31) if all(st_all[r, t, 6] > st_all[r, t, 0] > 0 for r in range(3))]
+if ticks:
+    arr = np.array([[st_all[r, t, 5] - st_all[2, t, 0] for r in range(3)] for t in ticks])
+    rel = np.array([[st_all[r, t, 6] - st_all[2, t, 0] for r in range(3)] for t in ticks])
+    print("barrier arrival after role 2's tick start (roles 0, 1, 2):", arr.mean(axis=0).round(0), " release:", rel.mean(axis=0).round(0))
