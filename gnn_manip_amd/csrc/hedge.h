@@ -25,7 +25,8 @@ struct EdgeBlocks {
     int64_t max_blocks;
 };
 size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity);
-size_t edge_groups_max(int64_t n_nodes, int64_t edge_capacity);   // rows of the side buffer of head partials
+constexpr int kSinkRows = 1024;   // power of two >= workgroups of a launch
+size_t edge_groups_max(int64_t n_nodes, int64_t edge_capacity);   // rows of the side buffer: head partials + kSinkRows sink rows
 EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity);
 // in_ptr / dst: the destination-sorted edge structure; n_per_graph: device pointer (GraphHeader::n_per_graph of the
 // radius-graph build) or, if null, the host value (<= 0: one graph)

@@ -57,6 +57,11 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8];
 #else
 #define SYS_STAMP(tick, slot) do { } while (0)
 #endif
+#ifndef HEDGE_PRIO0
+#define HEDGE_PRIO0 1
+#define HEDGE_PRIO1 1
+#define HEDGE_PRIO2 3
+#endif
 #ifndef HEDGE_VAR
 #define HEDGE_VAR 0   // development builds: structural variants under A/B test (bit meanings at their use)
 #endif
@@ -153,7 +158,7 @@ constexpr size_t SYS_LDS_BYTES = 3 * 2 * 16384 + 2 * 16384 + 16384 + 2 * 8 * BE 
 __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeader* __restrict__ a_hdr, const int* __restrict__ a_dst, const int* __restrict__ a_src, const float* __restrict__ a_P,
                                                                        const float* a_e_in, float* a_e_out, float* __restrict__ a_agg, const float* __restrict__ a_hw,
                                                                        const int2* __restrict__ a_blk, const int* __restrict__ a_head, float* __restrict__ a_side,
-                                                                       const EdgeBlockHeader* __restrict__ a_tab, float a_eps, int a_residual) {
+                                                                       const EdgeBlockHeader* __restrict__ a_tab, float* a_sink, float a_eps, int a_residual) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* Eimg = reinterpret_cast<half8*>(smem);            // [2][8 ks][2 parts][64]  2 x 16 KiB, eslot() order
     half8* X1 = Eimg + 2 * 1024;
@@ -201,15 +206,20 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
     // Instruction arbitration: role 2 (Linear 3 + statistics + the scatter-add's scan) is the longest instruction stream of
     // a tick and role 0 feeds the pipeline; measured at the target: 0.943 ms with equal priorities, 0.897 with these
     // (role 1 above role 0 loses the gain).
-    if (role == 2) __builtin_amdgcn_s_setprio(3);        // the builtin takes an immediate
-    else if (role == 0) __builtin_amdgcn_s_setprio(1);
+    if (role == 2) __builtin_amdgcn_s_setprio(HEDGE_PRIO2);        // the builtin takes an immediate
+    else if (role == 0) __builtin_amdgcn_s_setprio(HEDGE_PRIO0);
+    else __builtin_amdgcn_s_setprio(HEDGE_PRIO1);
     if (role == 0) {
         // ------------------------------------------------------------------ role 0
         floatx4 pi[4], pj[4];   // row-major quads of rows 8 j + rr: P_i / P_j of block x
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pi[j] = floatx4{0.f, 0.f, 0.f, 0.f}; pj[j] = pi[j]; }
+        floatx4 eq[4];          // e rows of block x+1 on their way into the operand image E
+#pragma unroll
+        for (int j = 0; j < 4; ++j) eq[j] = floatx4{0.f, 0.f, 0.f, 0.f};
         floatx16 acc;
         int dl1 = 0, sl1 = 0, dl2 = 0, sl2 = 0;   // destination / source of row (lane & 31): blocks x+1 and x+2
+        int2 be = a_blk[b0];    // table entry of block x+2 (its .x = first edge): the rows requested this tick
         // Every global load of the tick loops is issued unconditionally with a clamped index (blocks past the workgroup's range
         // repeat its last block): hipcc's counted vmcnt waits assume the path with the fewest younger operations, so a load
         // or store inside a branch turns the waits for older loads into waits for (almost) everything.
@@ -250,7 +260,32 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             }
             dl1 = dl2; sl1 = sl2;
             fetch(bn, dl2, sl2);          // indices of block x+3
+            const int2 be_next = bn;      // entry of block x+3 = next tick's x+2
             bn = a_blk[clampb(x + 4)];
+            // e of block x+1 -> operand image E (this role reads it next tick), one row group per call, between the MFMAs;
+            // then the rows of block x+2 are requested into the same registers
+            uintx2* ew = reinterpret_cast<uintx2*>(Eimg + ((x + 1) & 1) * 1024);
+            auto side = [&](int slot) {
+                if (slot < 8 && !(slot & 1)) {
+                    const int j = slot >> 1, r = 8 * j + rr;
+                    uintx2 h, l;
+                    split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
+                    const int kks = 2 * jb + (cq >> 2), kg = cq & 1, half = (cq >> 1) & 1;
+                    const int slot_e = eslot(r, kg, cq >> 2);
+                    ew[((kks * 2 + 0) * 64 + slot_e) * 2 + half] = h;
+                    ew[((kks * 2 + 1) * 64 + slot_e) * 2 + half] = l;
+                } else if (slot == 8) {
+                    if (!(HEDGE_ABL & 16)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int row = be.x + 8 * j + rr;
+                            row = row < E ? row : E - 1;
+                            eq[j] = *reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
+                        }
+                    }
+                    be = be_next;
+                }
+            };
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -259,7 +294,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
             }
             SYS_STAMP(t, 2);
-            mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, nothing);
+            mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, side);
             SYS_STAMP(t, 3);
             acc_to_image(acc, reinterpret_cast<uintx4*>(X1 + (x & 1) * 1024), jb, lane);
             SYS_STAMP(t, 4);
@@ -271,15 +306,14 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         // ------------------------------------------------------------------ role 1
         floatx16 acc;
         floatx4 er[4];                      // e rows (row-major quads) of block x-3 for the residual
-        floatx4 eq[4];                      // e rows of block x+1 on their way into the operand image E
         int st_a = 0, cnt_a = 0, st_b = 0, cnt_b = 0;  // blocks x-3, x-2
         int2 bi_c = make_int2(0, 0);                    // raw table entry of block x-1 (decoded a tick after its load)
-        int2 be = a_blk[b0];                            // raw table entry of block x+2 (its .x = first edge)
         const float res_w = a_residual ? 1.f : 0.f;
+        float* const sink = a_sink + (blockIdx.x & (kSinkRows - 1)) * H;
         const float* vgm = vecs + 2 * H + 32 * jb + 4 * (lane0 & 7);
         float* km = KM + jb * BE * 2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { er[j] = floatx4{0.f, 0.f, 0.f, 0.f}; eq[j] = er[j]; }
+        for (int j = 0; j < 4; ++j) er[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int t = -2; t <= nb + 2; ++t) {
             const int x = b0 + t;
@@ -295,16 +329,6 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 if (hi == 0) *reinterpret_cast<float2v*>(km + n * 2) = float2v{k, m};
             }
             const floatx4* zt = Z + (par3 * 4 + jb) * 256;
-            uintx2* ew = reinterpret_cast<uintx2*>(Eimg + ((x + 1) & 1) * 1024);
-            auto conv_e = [&](int j) {   // e of block x+1 -> operand image E (row group j)
-                const int r = 8 * j + rr;
-                uintx2 h, l;
-                split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
-                const int kks = 2 * jb + (cq >> 2), kg = cq & 1, half = (cq >> 1) & 1;
-                const int slot = eslot(r, kg, cq >> 2);
-                ew[((kks * 2 + 0) * 64 + slot) * 2 + half] = h;
-                ew[((kks * 2 + 1) * 64 + slot) * 2 + half] = l;
-            };
             float2v kmr;
             floatx4 zq, gm, bt;
             auto side = [&](int slot) {   // LayerNorm + e_out of block x-3, row group slot / SIDE_STRIDE
@@ -322,7 +346,10 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                         const float xh = fmaf(zq[tt], kmr[0], kmr[1]);
                         o[tt] = fmaf(er[j][tt], res_w, fmaf(xh, gm[tt], bt[tt]));
                     }
-                    if (!(HEDGE_ABL & 4) && epi && r < cnt_a) *reinterpret_cast<floatx4*>(a_e_out + (unsigned)((((HEDGE_ABL & 32) ? (st_a & 1023) : st_a) + r) * H + 32 * jb + 4 * cq)) = o;
+                    // unconditional store (a branch around it would turn this wave's counted waits for its loads into
+                    // waits for everything): rows past the block's end and the fill / drain ticks go to the workgroup's sink row
+                    float* orow = (epi && r < cnt_a) ? a_e_out + (unsigned)((((HEDGE_ABL & 32) ? (st_a & 1023) : st_a) + r) * H) : sink;
+                    if (!(HEDGE_ABL & 4)) *reinterpret_cast<floatx4*>(orow + 32 * jb + 4 * cq) = o;
                 }
             };
             {
@@ -335,20 +362,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 }
             }
             SYS_STAMP(t, 1);
-            conv_e(0); conv_e(1); conv_e(2); conv_e(3);
-            SYS_STAMP(t, 2);   // e rows of block x+1 have arrived and are in the image
-            auto request_e = [&]() {
-                if (!(HEDGE_ABL & 16)) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        int row = be.x + 8 * j + rr;
-                        row = row < E ? row : E - 1;
-                        eq[j] = *reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
-                    }
-                }
-                be = a_blk[clampb(x + 3)];
-            };
-            request_e();   // right after their registers are free: a whole tick in flight
+            SYS_STAMP(t, 2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // km visible to this wave's own reads
             mlp_layer<false>(acc, wh, wl, X1 + ((x - 1) & 1) * 1024, lane, side);
             SYS_STAMP(t, 3);
@@ -672,7 +686,9 @@ int pack_h3(const PackH3Job* jobs, int n, hipStream_t s) {
 static size_t max_blocks_of(int64_t n_nodes, int64_t edge_capacity) {
     return (size_t)cdiv(edge_capacity, BE) + 4 * (size_t)n_nodes + 4;   // each graph: up to 3 padding blocks + 1 partial
 }
-size_t edge_groups_max(int64_t n_nodes, int64_t edge_capacity) { return max_blocks_of(n_nodes, edge_capacity) / 4 + 1; }
+// rows of the side buffer: one per group, then kSinkRows rows that take the masked-off lanes of the systolic kernel's
+// (unconditional) row stores, one per workgroup
+size_t edge_groups_max(int64_t n_nodes, int64_t edge_capacity) { return max_blocks_of(n_nodes, edge_capacity) / 4 + 1 + kSinkRows; }
 
 size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity) {
     const size_t nblk = max_blocks_of(n_nodes, edge_capacity);
@@ -723,7 +739,7 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
         // pointers as separate __restrict__ parameters (e_in / e_out may be the same array): the table and index reads are
         // then provably unclobbered and become scalar loads where their address is wave-uniform
         hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
-                           a.agg, a.wstream_h3, t.blk, t.head, a.side, t.hdr, a.eps, a.residual);
+                           a.agg, a.wstream_h3, t.blk, t.head, a.side, t.hdr, a.side + (size_t)(t.max_blocks / 4 + 1) * H, a.eps, a.residual);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;
