@@ -114,7 +114,7 @@ def cpu_baseline(obs, model, stats, scene, hidden):
     orc.get_position_from_prediction(stats, scene.CART, out.numpy(), obs)
     t_int = time.perf_counter() - t0
     step = t_graph + t_feat + t_forward + t_int
-    return dict(value=1.0 / step, unit="rollout steps/s", cores=threads, kind="port", cpu=cpu_model_name(),
+    return dict(value=1.0 / step, unit="rollout steps/s", cores=threads, host_logical_cpus=cores, kind="port", cpu=cpu_model_name(),
                 graph_build_ms_single_thread=t_graph * 1e3, features_ms=t_feat * 1e3, forward_ms=t_forward * 1e3,
                 integrate_ms=t_int * 1e3,
                 forward_encoder_decoder_ms=t_encdec * 1e3, forward_one_mp_step_ms=max(t_one - t_encdec, 0.0) * 1e3,
@@ -195,11 +195,11 @@ def roofline_record(model, ek, hidden, edges, n_nodes, workload_key):
     # HBM traffic of the same kernel from rocprofv3 PMC passes of THIS round's build (collected separately with
     # tools/profile_round.sh, committed under profiles/); absent or of another kernel: null
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
         ent = tr.get(workload_key)
         if ent and ent.get("kernel") == kname:
             rec["traffic"] = ent["traffic_bytes_per_launch"]
-            rec["traffic_source"] = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this "
+            rec["traffic_source"] = ("profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this "
                                      "round's build, FETCH doubled per the guide)")
     except (OSError, ValueError, KeyError):
         pass
@@ -225,21 +225,26 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
         eng.status()
         timed_traj = traj[warmup:].contiguous()
         barrier()
-        model.profile(1)  # HIP events around the dominant kernel only (kind 0: processor edge kernel), this model's launches
+        coll = 0.0   # the timed region below carries no instrumentation: kernel timings come from a separate pass after it
         t0 = time.perf_counter()
         if dist:  # per-generation exchange of the candidate-parallel planner: scripted poses out ...
             first = timed_traj[0].to(cdev)
             dist.broadcast(first, src=0)
             timed_traj[0].copy_(first)
+            torch.cuda.synchronize()
+            coll += time.perf_counter() - t0
         eng.run(obs, timed_traj, steps)  # K steps, one library call
         result = obs[-1, :, 2:5].mean(dim=0)
         if dist:  # ... per-candidate results back
             result = result.to(cdev)
+            torch.cuda.synchronize()   # this rank's rollout is done: what follows is exchange + waiting for the other ranks
+            t1 = time.perf_counter()
             gathered = [torch.empty_like(result) for _ in range(world)]
             dist.all_gather(gathered, result)
+            torch.cuda.synchronize()
+            coll += time.perf_counter() - t1
         barrier()
         el = time.perf_counter() - t0
-    model.profile(0)
     edges = eng.status()  # edge count of the last timed step
     if dist:
         t = torch.tensor([el], dtype=torch.float64, device=cdev)
@@ -247,23 +252,23 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
         el = float(t.item())
     rec = None
     if rank == 0:
-        roof, k_ms = roofline_record(model, ek, wl["hidden"], edges, wl["n"] * candidates, wl_key)
-        # breakdown of the other kernels: a few extra, untimed steps with their events on
-        model.profile(14)
+        # Kernel timings: the same K steps once more, untimed, with HIP events (on the launch stream) around every model kernel
+        # of this handle -- the dominant kernel's average launch duration for the roofline, the others for the breakdown.
+        model.profile(15)
         with torch.no_grad():
-            k2 = min(5, steps)
-            eng.run(obs, timed_traj[:k2].contiguous(), k2)
+            eng.run(obs, timed_traj, steps)
         torch.cuda.synchronize()
+        model.profile(0)
+        roof, k_ms = roofline_record(model, ek, wl["hidden"], edges, wl["n"] * candidates, wl_key)
         br = {"edge_kernel_ms_per_step": k_ms * 10}
         for name, (kind, calls) in {"node_kernel": (1, 10), "graph_build": (2, 1), "encoder_kernels": (3, 2)}.items():
             n_k, ms_k = model.profile_query(kind)
             br[name + "_ms_per_step"] = ms_k / max(n_k, 1) * calls
-        model.profile(0)
         rec = {"value": world * candidates * steps / el, "unit": "rollout steps/s", "steps": steps, "warmup": warmup,
                "ms_per_step": el / steps * 1e3,
                "config": {"workload": wl["name"], "n_particles": wl["n"], "hidden": wl["hidden"], "edges_last_step": edges, "k_steps": 6,
                           "candidates_per_gpu": candidates, "parallelism": f"candidate-parallel x{world}"},
-               "roofline": roof, "breakdown": br}
+               "roofline": roof, "breakdown": br, "collective_ms": coll * 1e3}
     return rec, (model, obs_np, stats, scene, ek)
 
 
@@ -313,6 +318,7 @@ def run_c5(dev, rank, world, dist, cdev, args):
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    ev.collective_s = 0.0
     t0 = time.perf_counter()
     losses = generation(X)
     if dist:
@@ -332,7 +338,59 @@ def run_c5(dev, rank, world, dist, cdev, args):
             "data": "synthetic (seeded dense scene; random-init weights; a candidate = an offset of the scripted cup drift)",
             "config": {"workload": wl["name"], "n_particles": wl["n"], "candidates": popsize, "candidates_per_rank": per_rank,
                        "block_diagonal_batch": batch, "horizon": horizon, "generation_s": el, "loss_mean": float(np.mean(losses)),
-                       "parallelism": f"candidate-parallel x{world}"}}
+                       "parallelism": f"candidate-parallel x{world}"},
+            # rank 0's wall time inside the generation's broadcast + all-gather calls (the all-gather includes the wait for the
+            # slowest rank): what is not rollout or loss work when the 1 -> N curve falls short
+            "collective_ms": ev.collective_s * 1e3}
+
+
+def extra_c5_1gpu(dev, args):
+    """A reduced CMA-ES generation on this GPU (BASELINE C5's path at a size that takes a few seconds): 16 candidates x 50
+    rollout steps at N = 5k in block-diagonal batches of 8 + one device Sinkhorn loss per candidate (run_c5, one rank)."""
+    import copy
+    a = copy.copy(args)
+    a.candidates_total, a.batch, a.steps = 16, 8, 50
+    r = run_c5(dev, 0, 1, None, dev, a)
+    return {"value": r["value"], "unit": r["unit"], "ms": r["config"]["generation_s"] * 1e3, "config": r["config"],
+            "note": "the full C5 shape (64 x 200, one GPU) is `--workload c5`"}
+
+
+def extra_train(dev, steps=5, warmup=2):
+    """A few training steps of the reference's configuration (examples/train_dyn.py:49-72 defaults: batch of 2 graphs, hidden
+    128, 10 message-passing steps, L1 loss, Adam) on synthetic N = 5k scenes: forward with tape + HIP backward + optimiser."""
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, scene
+    n, bsz, H, M = 5000, 2, 128, 10
+    ga = GraphBoundedMultimaterialControl(0.015, scene.STATS, scene.CART, scene.MAT, scene.CTRL, scene.BOUNDS)
+    batch = []
+    for b in range(bsz):
+        o = torch.from_numpy(scene.make_scene(n, seed=100 + b, side=0.152 * 0.8)).to(dev)
+        batch.append((o, o[-1][:, 2:5] + 1e-4))
+    with torch.no_grad():
+        nodes, edge_attr, edge_index, tgt = ga.process_collate(batch)
+    torch.manual_seed(0)
+    model = EncProcDecGNN(25, 4, 3, H, 2, M).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    crit = torch.nn.L1Loss(reduction="sum")
+
+    def step():
+        pred = model.forward(nodes, edge_attr, edge_index)
+        loss = crit(pred, tgt) / pred.shape[0]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": 1.0 / dt, "unit": "training steps/s", "ms": dt * 1e3, "loss": float(loss.detach()),
+            "config": {"workload": f"batch of {bsz} synthetic scenes x N={n} (collated), hidden={H}, {M} MP steps, L1 loss, Adam",
+                       "nodes": int(nodes.shape[0]), "edges": int(edge_attr.shape[0]), "steps": steps, "warmup": warmup}}
 
 
 def main():
@@ -395,6 +453,8 @@ def main():
                    "data": "synthetic (seeded dense scene; random-init weights, decoder output layer scaled 1e-5 so the pile stays dense "
                            "over the rollout)",
                    "config": rec["config"], "roofline": rec["roofline"], "breakdown": rec["breakdown"]}
+            if world > 1:
+                out["collective_ms"] = rec["collective_ms"]   # rank 0: broadcast + all-gather (incl. waiting for the slowest rank)
             if world == 1 and not args.no_extra and args.workload == "target" and args.candidates == 1:
                 extra = {}
                 for key in ("c2", "c3", "c4"):
@@ -402,6 +462,10 @@ def main():
                     r2, _ = measure(key, dev, rank, world, None, cdev, args, w2["steps"], w2["warmup"], 1)
                     extra[key] = r2
                     torch.cuda.empty_cache()
+                extra["c5_1gpu"] = extra_c5_1gpu(dev, args)
+                torch.cuda.empty_cache()
+                extra["train"] = extra_train(dev)
+                torch.cuda.empty_cache()
                 out["extra"] = extra
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(obs_np, model, stats, scene, hidden)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include "../../include/gnn_manip_hip.h"
 
 namespace gm {
@@ -48,15 +49,21 @@ struct DevGuard {
     DevGuard& operator=(const DevGuard&) = delete;
 };
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembers, per call site, the devices it was done for
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: runs `setup` once per device and call site, under a lock
+// (entry points may be called from several host threads), and remembers the device only when the setup succeeded -- a
+// failed attempt is retried by the next launch instead of leaving the attribute unset behind an opaque launch error.
 struct PerDeviceOnce {
+    std::mutex mu;
     bool done[64] = {};
-    bool need() {
+    template <class F>
+    int run(F&& setup) {
         int d = 0;
-        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
-        if (done[d]) return false;
-        done[d] = true;
-        return true;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return setup();
+        std::lock_guard<std::mutex> lock(mu);
+        if (done[d]) return GM_OK;
+        const int rc = setup();
+        if (rc == GM_OK) done[d] = true;
+        return rc;
     }
 };
 

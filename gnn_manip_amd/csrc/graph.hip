@@ -35,11 +35,23 @@ ProfState::~ProfState() {
 ProfScope::ProfScope(ProfState* state, int k, hipStream_t st) : p(state), idx(-1), kind(k), s(st) {
     if (!p || !((p->mask >> k) & 1) || p->count[k] >= PROF_MAX) return;
     if (!p->start[k]) {
-        p->start[k] = new hipEvent_t[PROF_MAX];
-        p->stop[k] = new hipEvent_t[PROF_MAX];
-        for (int i = 0; i < PROF_MAX; ++i) {
-            if (hipEventCreate(&p->start[k][i]) != hipSuccess || hipEventCreate(&p->stop[k][i]) != hipSuccess) return;
+        hipEvent_t* a = new hipEvent_t[PROF_MAX];
+        hipEvent_t* b = new hipEvent_t[PROF_MAX];
+        int made = 0;
+        bool ok = true;
+        for (; made < PROF_MAX && ok; ++made) {
+            if (hipEventCreate(&a[made]) != hipSuccess) { ok = false; break; }
+            if (hipEventCreate(&b[made]) != hipSuccess) { (void)hipEventDestroy(a[made]); ok = false; break; }
         }
+        if (!ok) {   // all or nothing: a partly created set is released and this kind stays unrecorded
+            for (int i = 0; i < made; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
+            delete[] a;
+            delete[] b;
+            (void)hipGetLastError();
+            return;
+        }
+        p->start[k] = a;
+        p->stop[k] = b;
     }
     idx = p->count[k]++;
     (void)hipEventRecord(p->start[k][idx], s);
@@ -791,8 +803,11 @@ int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t 
             size_t lds = (size_t)K * BS * 12;
             if (lds > 64 * 1024) {
                 static PerDeviceOnce big_lds;
-                if (big_lds.need())
+                const int rc_attr = big_lds.run([]() -> int {
                     GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbor_kernel<BS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    return GM_OK;
+                });
+                if (rc_attr != GM_OK) return rc_attr;
             }
             hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
                                g.hdr, n, r2, K, g.cnt, g.nbr);
@@ -802,8 +817,11 @@ int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t 
             GM_REQUIRE(lds <= 160 * 1024, GM_ERR_UNSUPPORTED, "gm_radius_graph_build: max_neighbours=%d needs %zu bytes of LDS", K, lds);
             if (lds > 64 * 1024) {
                 static PerDeviceOnce big_lds64;
-                if (big_lds64.need())
+                const int rc_attr = big_lds64.run([]() -> int {
                     GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbor_kernel<BS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    return GM_OK;
+                });
+                if (rc_attr != GM_OK) return rc_attr;
             }
             hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
                                g.hdr, n, r2, K, g.cnt, g.nbr);

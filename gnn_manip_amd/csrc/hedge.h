@@ -20,6 +20,9 @@ struct EdgeBlocks {
     EdgeBlockHeader* hdr;
     int* gblk;          // [n_graphs + 1] first block of a graph
     int2* blk;          // [n_blocks] (first edge, count | flags << 8); flags: 1 first block of its group of 4, 2 last
+    int2* seg;          // [n_blocks] (continuation bits, last-row bits) of the block's rows for the systolic kernel's scatter-add:
+                        // bit n of .x: row n continues the segment of the row before it (bit 0: of the previous block's last
+                        // row, inside a group); bit n of .y: row n is the last one of its segment's piece in this group
     int* head;          // [n_groups] destination whose segment continues from the previous group into this one, or -1
     int* stitch;        // [n_nodes] first group of the run of head partials of a destination, or -1
     int64_t max_blocks;

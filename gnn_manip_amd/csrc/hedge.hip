@@ -152,13 +152,23 @@ __device__ __forceinline__ void ln_merge(const float* st, int n, float inv_T, fl
 // accumulator-layout accesses.  Returns the float4 index inside the 4 KiB tile.
 __device__ __forceinline__ int tile_q(int row, int quad) { return row * 8 + (quad ^ (row & 7)); }
 
+// v_permlane32_swap: the upper half of the first operand and the lower half of the second change places
+__device__ __forceinline__ float lower_half_to_both(float v) {   // every lane l gets the value of lane l & 31
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]);
+}
+__device__ __forceinline__ float upper_half_to_both(float v) {   // every lane l gets the value of lane 32 | l
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[1]);
+}
+
 constexpr int DR_SLOTS = 8;   // ring of per-block destination ids handed from role 0 to role 2 (written 2 ticks before it is read)
-constexpr size_t SYS_LDS_BYTES = 3 * 2 * 16384 + 2 * 16384 + 16384 + 2 * 8 * BE * 2 * 4 + 4 * BE * 2 * 4 + 4 * H * 4 + DR_SLOTS * BE * 4;
+constexpr size_t SYS_LDS_BYTES = 3 * 2 * 16384 + 2 * 16384 + 16384 + 2 * 8 * BE * 2 * 4 + 4 * BE * 2 * 4 + 4 * H * 4 + DR_SLOTS * BE * 4 + 4 * BE * 2 * 4;
 
 __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeader* __restrict__ a_hdr, const int* __restrict__ a_dst, const int* __restrict__ a_src, const float* __restrict__ a_P,
                                                                        const float* a_e_in, float* a_e_out, float* __restrict__ a_agg, const float* __restrict__ a_hw,
-                                                                       const int2* __restrict__ a_blk, const int* __restrict__ a_head, float* __restrict__ a_side,
-                                                                       const EdgeBlockHeader* __restrict__ a_tab, float* a_sink, float a_eps, int a_residual) {
+                                                                       const int2* __restrict__ a_blk, const int2* __restrict__ a_seg, const int* __restrict__ a_head,
+                                                                       const EdgeBlockHeader* __restrict__ a_tab, float* a_sink, unsigned a_side_off, float a_eps, int a_residual) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* Eimg = reinterpret_cast<half8*>(smem);            // [2][8 ks][2 parts][64]  2 x 16 KiB, eslot() order
     half8* X1 = Eimg + 2 * 1024;
@@ -169,6 +179,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
     float* KM = ST + 2 * 8 * BE * 2;                          // [4 jb][32][2]: role-1 merged statistics
     float* vecs = KM + 4 * BE * 2;                            // 4 x 128: b2 T2 | b3 T3 | gamma | beta
     int* DR = reinterpret_cast<int*>(vecs + 4 * H);           // [DR_SLOTS][32]: destination of every row of a block (role 0 -> role 2)
+    float* KM2 = reinterpret_cast<float*>(DR + DR_SLOTS * BE); // [4 jb][32][2]: role-2 merged statistics
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2, jb = wave & 3;
@@ -294,10 +305,15 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
             }
             SYS_STAMP(t, 2);
-            mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, side);
+            if (HEDGE_VAR & 1) mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, nothing);
+            else mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, side);
             SYS_STAMP(t, 3);
             acc_to_image(acc, reinterpret_cast<uintx4*>(X1 + (x & 1) * 1024), jb, lane);
             SYS_STAMP(t, 4);
+            if (HEDGE_VAR & 1) {
+#pragma unroll
+                for (int sl = 0; sl < 24; ++sl) side(sl);
+            }
             SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);
@@ -310,7 +326,20 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         int2 bi_c = make_int2(0, 0);                    // raw table entry of block x-1 (decoded a tick after its load)
         const float res_w = a_residual ? 1.f : 0.f;
         float* const sink = a_sink + (blockIdx.x & (kSinkRows - 1)) * H;
-        const float* vgm = vecs + 2 * H + 32 * jb + 4 * (lane0 & 7);
+        // LayerNorm gamma / beta of this lane's feature quad: constant over the launch (8 registers instead of 8 LDS reads per tick)
+        const floatx4 gm = *reinterpret_cast<const floatx4*>(vecs + 2 * H + 32 * jb + 4 * (lane0 & 7));
+        const floatx4 bt = *reinterpret_cast<const floatx4*>(vecs + 3 * H + 32 * jb + 4 * (lane0 & 7));
+        // accumulators <- b2 T2: read at the end of a tick for the next one (behind the barrier's LDS wait, off the critical path)
+        auto init_acc = [&]() {
+            const float* vb2 = vecs + 32 * jb + 4 * (lane0 >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 v = *reinterpret_cast<const floatx4*>(vb2 + 8 * g);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
+            }
+        };
+        init_acc();
         float* km = KM + jb * BE * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) er[j] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -330,15 +359,13 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             }
             const floatx4* zt = Z + (par3 * 4 + jb) * 256;
             float2v kmr;
-            floatx4 zq, gm, bt;
+            floatx4 zq;
             auto side = [&](int slot) {   // LayerNorm + e_out of block x-3, row group slot / SIDE_STRIDE
                 if (slot >= 4 * SIDE_STRIDE) return;
                 const int j = slot / SIDE_STRIDE, r = 8 * j + rr;
                 if (slot % SIDE_STRIDE == 0) {
                     kmr = *reinterpret_cast<const float2v*>(km + r * 2);
                     zq = zt[tile_q(r, cq)];
-                    gm = *reinterpret_cast<const floatx4*>(vgm);
-                    bt = *reinterpret_cast<const floatx4*>(vgm + H);
                 } else if (slot % SIDE_STRIDE == 2) {
                     floatx4 o;
 #pragma unroll
@@ -352,57 +379,70 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     if (!(HEDGE_ABL & 4)) *reinterpret_cast<floatx4*>(orow + 32 * jb + 4 * cq) = o;
                 }
             };
-            {
-                const float* vb2 = vecs + 32 * jb;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const floatx4 v = *reinterpret_cast<const floatx4*>(vb2 + 8 * g + 4 * hi);
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
-                }
-            }
             SYS_STAMP(t, 1);
             SYS_STAMP(t, 2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // km visible to this wave's own reads
-            mlp_layer<false>(acc, wh, wl, X1 + ((x - 1) & 1) * 1024, lane, side);
+            auto request_er = [&]() {
+                st_a = st_b; cnt_a = cnt_b;
+                st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
+                if (!(HEDGE_ABL & 1)) {  // rows of block x-2: consumed next tick (scaled by 0 when there is no residual)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int row = st_a + 8 * j + rr;
+                        row = row < E ? row : E - 1;
+                        er[j] = *reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
+                    }
+                }
+                bi_c = a_blk[clampb(x)];
+            };
+            if (HEDGE_VAR & 1) {
+#pragma unroll
+                for (int sl = 0; sl < 24; ++sl) side(sl);
+                request_er();   // a whole tick in flight
+                mlp_layer<false>(acc, wh, wl, X1 + ((x - 1) & 1) * 1024, lane, nothing);
+            } else {
+                mlp_layer<false>(acc, wh, wl, X1 + ((x - 1) & 1) * 1024, lane, side);
+            }
             SYS_STAMP(t, 3);
             acc_to_image(acc, reinterpret_cast<uintx4*>(X2 + ((x - 1) & 1) * 1024), jb, lane);
             SYS_STAMP(t, 4);
-            st_a = st_b; cnt_a = cnt_b;
-            st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
-            if (!(HEDGE_ABL & 1)) {  // rows of block x-2: consumed next tick (scaled by 0 when there is no residual)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int row = st_a + 8 * j + rr;
-                    row = row < E ? row : E - 1;
-                    er[j] = *reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
-                }
-            }
-            bi_c = a_blk[clampb(x)];
+            if (!(HEDGE_VAR & 1)) request_er();
+            init_acc();
             SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);
         }
     } else {
         // ------------------------------------------------------------------ role 2
-        floatx16 acc, carry;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) carry[r] = 0.f;
-        int dn_a = -1, fl_a = 0, cnt_a = 0, dn_b = -1, fl_b = 0, cnt_b = 0;  // blocks x-3, x-2 (cnt_b = 0 while there is none)
+        // Aggregation of block x-3 on a TRANSPOSED view of its LayerNorm input: lane (f, h) = feature 32 jb + f, rows 16 h ..
+        // 16 h + 15 in 16 registers.  The segment structure of the destination-sorted rows is the same for every feature, so it
+        // lives in scalar registers (continuation / last-row bits from the block tables): the segmented scan is 15 masked
+        // adds down the registers, a finished segment is one 128-byte store per half-wave.  The sum of a segment that is
+        // still open at the end of a half (or block) travels on in `carry` and joins the first row stored afterwards.
+        floatx16 acc;
+        float carry = 0.f;              // open segment's sum from the previous block (this lane's feature; both halves hold it)
+        int cnt_a = 0, fl_a = 0, cnt_b = 0, fl_b = 0;    // blocks x-3, x-2 (cnt = 0 while there is none)
+        unsigned cont_a = 0, last_a = 0, cont_b = 0, last_b = 0;
         int head_a = -1, head_b = -1;   // destination whose segment began in an earlier group (its sum over this group goes to the side buffer)
-        int prev_last_dst = -3;         // destination of lane 31 of the previous block while its segment is open, else -3
-        const float* vgam = vecs + 2 * H + 32 * jb;
-        const float* vbet = vecs + 3 * H + 32 * jb;
-        int2 bn = make_int2(0, 0);      // table entry of the block the next fetch() handles
-        // destinations of block x: from the ring role 0 filled two ticks ago (no global load); rows past the block's end
-        // get unique negative ids.  Past the workgroup's range there is no block: cnt = 0.
-        auto fetch = [&](int x, int2 bi, int& dn, int& fl, int& cnt, int& head) {
-            const int n = lane0 & 31;
-            if (!ok(x)) { cnt = 0; dn = -1 - n; return; }
+        int2 bn = make_int2(0, 0), sn = make_int2(0, 0);      // table entries of the block the next fetch() handles
+        const float gam = vecs[2 * H + 32 * jb + (lane0 & 31)], bet = vecs[3 * H + 32 * jb + (lane0 & 31)];
+        float* km2 = KM2 + jb * BE * 2;
+        auto init_acc = [&]() {   // accumulators <- b3 T3, read at the end of a tick for the next one
+            const float* vb3 = vecs + H + 32 * jb + 4 * (lane0 >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 v = *reinterpret_cast<const floatx4*>(vb3 + 8 * g);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
+            }
+        };
+        init_acc();
+        auto fetch = [&](int x, int2 bi, int2 si, int& cnt, int& fl, unsigned& cont, unsigned& last, int& head) {
+            if (!ok(x)) { cnt = 0; fl = 0; cont = 0; last = 0; return; }
             cnt = bi.y & 0xff;
             fl = bi.y >> 8;
-            const int v = DR[(x & (DR_SLOTS - 1)) * BE + n];
-            dn = n < cnt ? v : -1 - n;
+            cont = (unsigned)si.x;
+            last = (unsigned)si.y;
             if (fl & 1) head = a_head[x >> 2];
         };
 #pragma unroll 1
@@ -412,102 +452,84 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             asm volatile("" : "+v"(lane_t));
             const int lane = lane_t, n = lane & 31, hi = lane >> 5;
             const bool agg_on = ok(x - 3);
-            float k, m, f1, f2, f4, f8, fb, fc;
-            const int dn = dn_a;
+            const int par3 = (x - 3) & 1;
             SYS_STAMP(t, 0);
-            {
-                ln_merge(ST + ((x - 3) & 1) * 8 * BE * 2, n, inv_T, a_eps, k, m);
-                // same-destination flags of the scan steps (lanes past the block's end hold unique negative ids)
-                const int p1 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x111, 0xf, 0xf, false);
-                const int p2 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x112, 0xf, 0xf, false);
-                const int p4 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x114, 0xf, 0xf, false);
-                const int p8 = __builtin_amdgcn_update_dpp(-1000000, dn, 0x118, 0xf, 0xf, false);
-                const int pb = __builtin_amdgcn_update_dpp(-1000000, dn, 0x142, 0xa, 0xf, false);
-                f1 = p1 == dn ? 1.f : 0.f; f2 = p2 == dn ? 1.f : 0.f; f4 = p4 == dn ? 1.f : 0.f; f8 = p8 == dn ? 1.f : 0.f;
-                fb = pb == dn ? 1.f : 0.f;
-                // the carry of the segment the previous block of this chunk left open enters at lane 0
-                fc = (n == 0 && !(fl_a & 1) && dn == prev_last_dst) ? 1.f : 0.f;
+            {   // merged statistics of block x-3 (lane = row) -> this wave's table, read back per register row below
+                float k, m;
+                ln_merge(ST + par3 * 8 * BE * 2, n, inv_T, a_eps, k, m);
+                if (hi == 0) *reinterpret_cast<float2v*>(km2 + n * 2) = float2v{k, m};
             }
-            SYS_STAMP(t, 1);   // merged statistics + scan flags
-            bool is_last = false;
-            if (agg_on) {
-                const bool lastf = (fl_a & 2) != 0;
-                // destination of the next edge: the next row of this block; for the block's last row the first row of the
-                // following block (blocks of a graph are contiguous; a short block ends its graph, and other graphs,
-                // padding blocks and the end of the workgroup's range never match: -2)
-                const int nrow = __builtin_amdgcn_ds_bpermute(((lane & 32) | ((n + 1) & 31)) * 4, dn);
-                const int nblk0 = __builtin_amdgcn_readlane(dn_b, 0);
-                const int nx = n + 1 < cnt_a ? nrow : ((cnt_a == BE && cnt_b > 0) ? nblk0 : -2);
-                is_last = n < cnt_a && (nx != dn || (lastf && n == cnt_a - 1));
-            }
-            // a finished (or group-final) sum is stored exactly once: to its agg row, or -- for the piece of a segment that
-            // began in an earlier group -- to this group's row of the side buffer (added in group order by the node kernel)
-            float* arow = (dn == head_a ? a_side + (unsigned)(((x - 3) >> 2) * H) : a_agg + (unsigned)((dn < 0 ? 0 : dn) * H)) + 32 * jb + 4 * hi;
-            const floatx4* zt3 = Z + (((x - 3) & 1) * 4 + jb) * 256;
-            floatx4 zq, gmv, btv;
-            float y[4];
-            // aggregation of block x-3: chunk g = slot / 6 handles accumulator registers 4g..4g+3 = one 16-byte piece of
-            // the destination rows
+            SYS_STAMP(t, 1);
+            const unsigned cont = agg_on ? cont_a : 0u, last = agg_on ? last_a : 0u;
+            // destinations of this lane's 16 rows: from the ring role 0 filled (no global load)
+            const intx4* drp = reinterpret_cast<const intx4*>(DR + ((x - 3) & (DR_SLOTS - 1)) * BE + 16 * hi);
+            const char* zb = reinterpret_cast<const char*>(Z + (par3 * 4 + jb) * 256) + 2048 * hi;   // row 16 hi of the tile (tile_q order)
+            const floatx4* kmp = reinterpret_cast<const floatx4*>(km2 + 32 * hi);
+            floatx16 y;     // vectors: the store loop below indexes them with a (wave-uniform) run-time row
+            intx16 dq;
+            floatx4 kq0, kq1;
+            float zz[4];
+            float cpend = 0.f;
+            // value of an open segment handed to the next half: half 0 -> half 1 inside the tick, half 1 -> half 0 of the next block
             auto side = [&](int slot) {
-                const int g = slot / 6;
-                switch (slot % 6) {
-                case 0:
-                    zq = zt3[tile_q(n, 2 * g + hi)];
-                    gmv = *reinterpret_cast<const floatx4*>(vgam + 8 * g + 4 * hi);
-                    btv = *reinterpret_cast<const floatx4*>(vbet + 8 * g + 4 * hi);
-                    break;
-                case 1:
+                if (slot < 8) {
+                    const int c = slot >> 1;
+                    if (!(slot & 1)) {   // requests of rows 4c .. 4c+3: (k, m) pairs, z values (quad index XORed with the row)
+                        kq0 = kmp[2 * c];
+                        kq1 = kmp[2 * c + 1];
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const float xh = fmaf(zq[tt], k, m);
-                        y[tt] = fmaf(carry[4 * g + tt], fc, fmaf(xh, gmv[tt], btv[tt]));
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = 4 * c + i;
+                            zz[i] = *reinterpret_cast<const float*>(zb + 128 * r + ((4 * n) ^ (16 * (r & 7))));
+                        }
+                        {
+                            const intx4 dv = drp[c];
+                            dq[4 * c + 0] = dv[0]; dq[4 * c + 1] = dv[1]; dq[4 * c + 2] = dv[2]; dq[4 * c + 3] = dv[3];
+                        }
+                    } else {
+                        y[4 * c + 0] = fmaf(fmaf(zz[0], kq0[0], kq0[1]), gam, bet);
+                        y[4 * c + 1] = fmaf(fmaf(zz[1], kq0[2], kq0[3]), gam, bet);
+                        y[4 * c + 2] = fmaf(fmaf(zz[2], kq1[0], kq1[1]), gam, bet);
+                        y[4 * c + 3] = fmaf(fmaf(zz[3], kq1[2], kq1[3]), gam, bet);
                     }
-                    break;
-                case 2:
+                } else if (slot < 13) {
+                    // segmented scan down the registers: y[r] += y[r-1] where row r continues row r-1's segment (lane mask from the
+                    // two halves' bits: scalar work)
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], f1, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC(y[tt], f2, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-                    break;
-                case 3:
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], f4, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC(y[tt], f8, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-                    break;
-                case 4:
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) DPP_FMAC_NOP(y[tt], fb, "row_bcast:15 row_mask:0xa bank_mask:0xf");
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
-                        carry[4 * g + tt] = __uint_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) * 4, __float_as_uint(y[tt])));
-                    break;
-                default:
-                    if (!(HEDGE_ABL & 8) && is_last) *reinterpret_cast<floatx4*>(arow + 8 * g) = floatx4{y[0], y[1], y[2], y[3]};
-                    break;
+                    for (int r = 3 * (slot - 8) + 1; r <= 3 * (slot - 8) + 3; ++r) {
+                        const unsigned long long mk = (unsigned long long)(unsigned)__builtin_amdgcn_sbfe((int)cont, r, 1) |
+                                                      ((unsigned long long)(unsigned)__builtin_amdgcn_sbfe((int)cont, 16 + r, 1) << 32);
+                        float tq;
+                        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(tq) : "v"(y[r - 1]), "s"(mk));
+                        y[r] += tq;
+                    }
+                } else if (slot == 13) {
+                    // what enters each half at its first row: half 0 the previous block's open sum, half 1 the sum half 0 leaves open
+                    const float c0v = (cont & 1u) ? carry : 0.f;
+                    const float open0 = y[15] + ((last & 0xffffu) ? 0.f : c0v);        // meaningful in half 0
+                    const float from0 = lower_half_to_both(open0);
+                    const float c1v = (cont & 0x10000u) ? from0 : 0.f;
+                    cpend = hi ? c1v : c0v;
                 }
             };
             const bool l3 = ok(x - 2);
             const int par2 = (x - 2) & 1;
-            {
-                const float* vb3 = vecs + H + 32 * jb;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const floatx4 v = *reinterpret_cast<const floatx4*>(vb3 + 8 * g + 4 * hi);
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
-                }
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // km2 visible to this wave's own reads
             SYS_STAMP(t, 2);   // accumulators initialised
-            mlp_layer<false>(acc, wh, wl, X2 + par2 * 1024, lane, side);
-            SYS_STAMP(t, 3);   // 24 MFMAs with the scatter-add's scan between them
-            if (agg_on) prev_last_dst = (cnt_a == BE && !(fl_a & 2)) ? __builtin_amdgcn_readlane(dn, 31) : -3;
+            if (HEDGE_VAR & 1) {
+#pragma unroll
+                for (int sl = 0; sl < 24; ++sl) side(sl);
+                mlp_layer<false>(acc, wh, wl, X2 + par2 * 1024, lane, nothing);
+            } else {
+                mlp_layer<false>(acc, wh, wl, X2 + par2 * 1024, lane, side);
+            }
+            SYS_STAMP(t, 3);   // 24 MFMAs with the scatter-add between them
             {
                 // LayerNorm partial statistics of the scaled accumulators (16 features per lane); raw accumulators to Z
-                float s = 0.f;
+                float sacc = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[r];
-                const float mh = s * (1.0f / 16.0f);
+                for (int r = 0; r < 16; ++r) sacc += acc[r];
+                const float mh = sacc * (1.0f / 16.0f);
                 float q = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { const float d = acc[r] - mh; q = fmaf(d, d, q); }
@@ -522,11 +544,35 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 }
             }
             SYS_STAMP(t, 4);   // partial statistics + Z written
-            dn_a = dn_b; fl_a = fl_b; cnt_a = cnt_b;
+            {
+                // Stores of the finished segments: one iteration per row index r that ends a segment in either half (about two
+                // per tick on a dense graph), ascending, so that the first store of a half takes its pending carry.  A segment's
+                // sum goes to its agg row, or -- the piece of a segment that began in an earlier group -- to this group's row of
+                // the side buffer (one allocation with agg: 32-bit element offsets from a_agg).
+                unsigned pend = (last | (last >> 16)) & 0xffffu;
+                const unsigned side_row = a_side_off + (unsigned)(((x - 3) >> 2) * H);
+                while (pend) {
+                    const int r = __builtin_ctz(pend);
+                    pend &= pend - 1;
+                    const unsigned long long mk = (unsigned long long)(0u - ((last >> r) & 1u)) | ((unsigned long long)(0u - ((last >> (16 + r)) & 1u)) << 32);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mk)) {
+                        const int d = dq[r];
+                        const unsigned off = (d == head_a ? side_row : (unsigned)(d * H)) + 32 * jb + n;
+                        if (!(HEDGE_ABL & 8)) a_agg[off] = y[r] + cpend;
+                        cpend = 0.f;
+                    }
+                }
+                // the sum left open at the end of the block (half 1's last row) becomes the next block's carry, in both halves
+                const float nc = upper_half_to_both(y[15] + cpend);
+                carry = (((last >> 31) & 1u) || !agg_on || cnt_a < BE) ? 0.f : nc;
+            }
+            cnt_a = cnt_b; fl_a = fl_b; cont_a = cont_b; last_a = last_b;
             if (fl_b & 1) head_a = head_b;
-            fetch(x - 1, bn, dn_b, fl_b, cnt_b, head_b);
-            if (ok(x)) bn = a_blk[x];
-            SYS_STAMP(t, 5);   // destinations of the next block read from the ring (+ the table entry / head loads)
+            fetch(x - 1, bn, sn, cnt_b, fl_b, cont_b, last_b, head_b);
+            bn = a_blk[clampb(x)];
+            sn = a_seg[clampb(x)];
+            init_acc();
+            SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);   // every wave of the workgroup has finished the tick
         }
@@ -635,7 +681,7 @@ __global__ void __launch_bounds__(256) edge_blocks_plan_kernel(const int* __rest
 // head[g] = the destination whose segment continues from group g - 1 into group g (its sum over group g is a "head
 // partial", stored to the side buffer), or -1;  stitch[v] = first group of the run of head partials of destination v.
 __global__ void __launch_bounds__(256) edge_blocks_fill_kernel(const int* __restrict__ in_ptr, const int* __restrict__ dst, int n_nodes,
-                                                               const EdgeBlockHeader* tab, const int* __restrict__ gblk, int2* blk,
+                                                               const EdgeBlockHeader* tab, const int* __restrict__ gblk, int2* blk, int2* seg,
                                                                int* __restrict__ head, int* __restrict__ stitch) {
     const int nblk = tab->n_blocks, G = tab->n_graphs, n_per = tab->n_per_graph;
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
@@ -650,6 +696,22 @@ __global__ void __launch_bounds__(256) edge_blocks_fill_kernel(const int* __rest
         const int cnt = min(BE, e1 - start);
         const int fl = ((j & 3) == 0 ? 1 : 0) | ((j & 3) == 3 ? 2 : 0);
         blk[b] = make_int2(start, cnt | (fl << 8));
+        {
+            // Segment structure of the block's rows (destination-sorted): same reasoning as the kernels' scans.  A block shorter
+            // than 32 rows ends its graph; the group's last block ends every open piece.
+            unsigned cont = 0, last = 0;
+            int prev = (cnt > 0 && (j & 3) != 0 && start > e0) ? dst[start - 1] : -1;   // a full block precedes it in the group
+            for (int n = 0; n < cnt; ++n) {
+                const int d = dst[start + n];
+                if (d == prev) cont |= 1u << n;
+                prev = d;
+                bool is_last;
+                if (n + 1 < cnt) is_last = dst[start + n + 1] != d;
+                else is_last = (j & 3) == 3 || cnt < BE || start + cnt >= e1 || dst[start + cnt] != d;
+                if (is_last) last |= 1u << n;
+            }
+            seg[b] = make_int2((int)cont, (int)last);
+        }
         if ((j & 3) == 0) {
             int h = -1;
             if (cnt > 0 && start > e0 && dst[start - 1] == dst[start]) h = dst[start];
@@ -692,8 +754,8 @@ size_t edge_groups_max(int64_t n_nodes, int64_t edge_capacity) { return max_bloc
 
 size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity) {
     const size_t nblk = max_blocks_of(n_nodes, edge_capacity);
-    // header | gblk[n+2] | blk[nblk] (int2) | head[nblk/4 + 2] | stitch[n]
-    return 8 + ((size_t)n_nodes + 2) + 1 + 2 * nblk + (nblk / 4 + 2) + (size_t)n_nodes;
+    // header | gblk[n+2] | blk[nblk] (int2) | seg[nblk] (int2) | head[nblk/4 + 2] | stitch[n]
+    return 8 + ((size_t)n_nodes + 2) + 1 + 4 * nblk + (nblk / 4 + 2) + (size_t)n_nodes;
 }
 
 EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity) {
@@ -704,7 +766,8 @@ EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity) 
     int* p = t.gblk + n_nodes + 2;
     p += (reinterpret_cast<uintptr_t>(p) & 4) ? 1 : 0;   // int2 alignment
     t.blk = reinterpret_cast<int2*>(p);
-    t.head = p + 2 * nblk;
+    t.seg = reinterpret_cast<int2*>(p + 2 * nblk);
+    t.head = p + 4 * nblk;
     t.stitch = t.head + nblk / 4 + 2;
     t.max_blocks = (int64_t)nblk;
     return t;
@@ -723,7 +786,7 @@ int build_edge_blocks(const int* in_ptr, const int* dst, int64_t n_nodes, int64_
                        t.hdr, t.gblk, (int)n_nodes + 1);
     int gb = (int)cdiv(t.max_blocks, 256);
     gb = gb < 1 ? 1 : (gb > 1024 ? 1024 : gb);
-    hipLaunchKernelGGL(edge_blocks_fill_kernel, dim3(gb), dim3(256), 0, s, in_ptr, dst, (int)n_nodes, t.hdr, t.gblk, t.blk, t.head, t.stitch);
+    hipLaunchKernelGGL(edge_blocks_fill_kernel, dim3(gb), dim3(256), 0, s, in_ptr, dst, (int)n_nodes, t.hdr, t.gblk, t.blk, t.seg, t.head, t.stitch);
     GM_LAUNCH_CHECK();
     (void)edge_capacity;
     return GM_OK;
@@ -731,15 +794,21 @@ int build_edge_blocks(const int* in_ptr, const int* dst, int64_t n_nodes, int64_
 
 int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
     GM_REQUIRE(a.hdr && a.wstream_h3 && a.agg && a.side && !a.eid && !a.eid_out, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: unsupported argument combination");
+    // the scatter-add addresses agg rows and side rows with 32-bit element offsets from agg (carve_fwd puts them in one workspace)
+    GM_REQUIRE(a.side >= a.agg && (uint64_t)(a.side - a.agg) + (uint64_t)(t.max_blocks / 4 + 1 + kSinkRows) * H < (1ull << 32), GM_ERR_INVALID_ARGUMENT,
+               "launch_edge_sys: the side buffer must follow agg within 2^32 floats");
     static PerDeviceOnce attr_done;
-    if (attr_done.need())
+    const int rc_attr = attr_done.run([]() -> int {
         GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
+        return GM_OK;
+    });
+    if (rc_attr != GM_OK) return rc_attr;
     {
         ProfScope prof(a.prof, PROF_EDGE, s);
         // pointers as separate __restrict__ parameters (e_in / e_out may be the same array): the table and index reads are
         // then provably unclobbered and become scalar loads where their address is wave-uniform
         hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
-                           a.agg, a.wstream_h3, t.blk, t.head, a.side, t.hdr, a.side + (size_t)(t.max_blocks / 4 + 1) * H, a.eps, a.residual);
+                           a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, a.side + (size_t)(t.max_blocks / 4 + 1) * H, (unsigned)(a.side - a.agg), a.eps, a.residual);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;

@@ -641,11 +641,12 @@ int set_lds_attr(K kernel) {
 template <int H>
 int launch_edge_h(bool enc, const HmEdgeArgs& a, hipStream_t s) {
     static PerDeviceOnce once;
-    if (once.need()) {
+    const int rc_attr = once.run([]() -> int {
         int rc = set_lds_attr(hm_edge_kernel<H, true>);
         if (rc == GM_OK) rc = set_lds_attr(hm_edge_kernel<H, false>);
-        if (rc != GM_OK) return rc;
-    }
+        return rc;
+    });
+    if (rc_attr != GM_OK) return rc_attr;
     ProfScope prof(a.prof, enc ? PROF_ENC : PROF_EDGE, s);
     if (enc) hipLaunchKernelGGL((hm_edge_kernel<H, true>), dim3(device_cus()), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
     else hipLaunchKernelGGL((hm_edge_kernel<H, false>), dim3(device_cus()), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
@@ -655,12 +656,13 @@ int launch_edge_h(bool enc, const HmEdgeArgs& a, hipStream_t s) {
 template <int H, int RBW>
 int launch_node_hr(int mode, const HmNodeArgs& a, hipStream_t s) {
     static PerDeviceOnce once;
-    if (once.need()) {
+    const int rc_attr = once.run([]() -> int {
         int rc = set_lds_attr(hm_node_kernel<H, 0, RBW>);
         if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 1, RBW>);
         if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 2, RBW>);
-        if (rc != GM_OK) return rc;
-    }
+        return rc;
+    });
+    if (rc_attr != GM_OK) return rc_attr;
     const int tiles = (int)cdiv(a.n_nodes, Cfg<H, RBW>::M);
     int grid = device_cus();
     if (tiles < grid) grid = tiles < 1 ? 1 : tiles;

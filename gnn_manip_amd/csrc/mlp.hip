@@ -28,7 +28,6 @@
 //
 // Reference semantics: EncProcDecGNN.forward / _process / _build_mlp,
 // gnn_manip/models/epd_gnn.py:72-105; block semantics per BASELINE.json north_star.
-#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 #include "mlp.h"
@@ -166,6 +165,9 @@ int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s) {
     return GM_OK;
 }
 
+#ifdef GM_DEV_KERNELS
+// Round-1 inference kernels (fp32 MFMA chains and the six-product bf16 forms): A/B and accuracy references of DEVELOPMENT builds
+// (GM_DEV_KERNELS=1 python -m gnn_manip_amd.build --tag=dev); the product library does not contain them.
 // ------------------------------------------------------------------------------------------
 // EDGE kernel
 // ------------------------------------------------------------------------------------------
@@ -1860,9 +1862,11 @@ __global__ void __launch_bounds__(THREADS, 2) node_kernel_wide(NodeArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#endif  // GM_DEV_KERNELS
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+#ifdef GM_DEV_KERNELS
 size_t edge_lds_bytes() { return (size_t)(2 * STAGE_FLOATS + TILE * TS + 2 * (TILE + 4) + 2 * 2 * 4 * 64 + 8 * 128) * 4; }
 size_t edge16_lds_bytes() { return (size_t)(2 * STAGE_FLOATS + T16 * TS16 + 2 * (T16 + 4) + 2 * 1024 + 6 * 128) * 4; }
 size_t node_lds_bytes() { return (size_t)(2 * STAGE_FLOATS) * 4; }
@@ -1879,16 +1883,22 @@ static int set_lds(K kernel, size_t bytes) {
     return GM_OK;
 }
 
+#endif  // GM_DEV_KERNELS
+
 enum : int { EK_AUTO = 0, EK_16 = 1, EK_CLASSIC = 2, EK_B3 = 3, EK_B3P = 4, EK_SYS = 5, EK_HM = 6 };
 
+#ifdef GM_DEV_KERNELS
 template <int H>
 static int launch_edge_h(bool enc, const EdgeArgs& a, int grid, size_t lds, hipStream_t s) {
     static PerDeviceOnce attr_done_dev;
-    if (attr_done_dev.need()) {
+    {
+        const int rc_attr = attr_done_dev.run([&]() -> int {
         int rc = set_lds(edge_kernel<H, 2, 0>, lds);
         if (rc == GM_OK) rc = set_lds(edge_kernel<H, 2, 1>, lds);
         if (rc == GM_OK) rc = set_lds(edge_kernel<H, 2, 2>, lds);
-        if (rc != GM_OK) return rc;
+            return rc;
+        });
+        if (rc_attr != GM_OK) return rc_attr;
     }
     ProfScope prof(a.prof, enc ? PROF_ENC : PROF_EDGE, s);
     if (enc) hipLaunchKernelGGL((edge_kernel<H, 2, 0>), dim3(grid), dim3(THREADS), lds, s, a);
@@ -1896,6 +1906,8 @@ static int launch_edge_h(bool enc, const EdgeArgs& a, int grid, size_t lds, hipS
     else hipLaunchKernelGGL((edge_kernel<H, 2, 2>), dim3(grid), dim3(THREADS), lds, s, a);
     return GM_OK;
 }
+
+#endif  // GM_DEV_KERNELS
 
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capacity, hipStream_t s) {
     if (edge_capacity <= 0) return GM_OK;
@@ -1921,6 +1933,10 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         }
         return launch_edge_hm(H, enc, h, s);
     }
+#ifndef GM_DEV_KERNELS
+    (void)fp32_forms;
+    GM_REQUIRE(false, GM_ERR_UNSUPPORTED, "edge kernel: hidden_size=%d, kernel choice %d: no kernel of this library build takes this launch", H, choice);
+#else
     GM_REQUIRE((H == 128 || H == 256) && NL == 2 && a.wstream, GM_ERR_UNSUPPORTED,
                "edge kernel: hidden_size=%d num_layers=%d: the fp32 kernels are instantiated for 128 / 256 and 2", H, NL);
     const int grid = grid_for(cdiv(edge_capacity, TILE));
@@ -1943,10 +1959,13 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     if (use_b3p) {
         const size_t lb = (size_t)(2 * B3P_STAGE_FLOATS + T16 * TSP + 2 * (T16 + 4) + 2 * 1024 + 4 * 128 + 4 * 32 * 2) * 4;
         static PerDeviceOnce donebp_dev;
-        if (donebp_dev.need()) {
+        {
+            const int rc_attr = donebp_dev.run([&]() -> int {
             int rc = set_lds(edge_kernel_b3p<2, 1>, lb);
             if (rc == GM_OK) rc = set_lds(edge_kernel_b3p<2, 2>, lb);
-            if (rc != GM_OK) return rc;
+                return rc;
+            });
+            if (rc_attr != GM_OK) return rc_attr;
         }
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1963,10 +1982,13 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     if (use_b3) {
         const size_t lb = (size_t)(2 * B3_STAGE_FLOATS + TE3 * TSP + 2 * (TE3 + 4) + 2 * 2048 + 4 * 128 + 8 * 32 * 2) * 4;
         static PerDeviceOnce doneb_dev;
-        if (doneb_dev.need()) {
+        {
+            const int rc_attr = doneb_dev.run([&]() -> int {
             int rc = set_lds(edge_kernel_b3<2, 1>, lb);
             if (rc == GM_OK) rc = set_lds(edge_kernel_b3<2, 2>, lb);
-            if (rc != GM_OK) return rc;
+                return rc;
+            });
+            if (rc_attr != GM_OK) return rc_attr;
         }
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1984,18 +2006,20 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     if (H == 128 && use16 && a.wstream16) {
         const size_t l16 = edge16_lds_bytes();
         static PerDeviceOnce done16_dev;
-        if (done16_dev.need()) {
+        {
+            const int rc_attr = done16_dev.run([&]() -> int {
             int rc = set_lds(edge_kernel16<2, 0>, l16);
             if (rc == GM_OK) rc = set_lds(edge_kernel16<2, 1>, l16);
             if (rc == GM_OK) rc = set_lds(edge_kernel16<2, 2>, l16);
-            if (rc != GM_OK) return rc;
+                return rc;
+            });
+            if (rc_attr != GM_OK) return rc_attr;
         }
         a.wstream = a.wstream16;
         // persistent grid: one workgroup per resident slot (2 per CU), so that every workgroup walks several tiles and
         // the next tile's gathers / first weight stage are always in flight (at N = 5k a one-tile-per-workgroup grid
-        // costs 6 % per launch: no prefetch, 3x the prologues); GM_EDGE_GRID_CAP overrides
+        // costs 6 % per launch: no prefetch, 3x the prologues)
         static const int grid_cap = [] {
-            if (getenv("GM_EDGE_GRID_CAP")) return atoi(getenv("GM_EDGE_GRID_CAP"));
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             return 2 * cus;
@@ -2017,6 +2041,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     }
     GM_LAUNCH_CHECK();
     return GM_OK;
+#endif  // GM_DEV_KERNELS
 }
 
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
@@ -2032,20 +2057,25 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
         }
         return launch_node_hm(H, mode, h, s);
     }
+#ifndef GM_DEV_KERNELS
+    GM_REQUIRE(false, GM_ERR_UNSUPPORTED, "node kernel: hidden_size=%d, kernel choice %d: no kernel of this library build takes this launch", H, a.kernel_choice);
+#else
     GM_REQUIRE((H == 128 || H == 256) && NL == 2 && a.wstream, GM_ERR_UNSUPPORTED,
                "node kernel: hidden_size=%d num_layers=%d: the fp32 kernels are instantiated for 128 / 256 and 2", H, NL);
     const int grid = grid_for(cdiv(a.n_nodes, TILE));
     const size_t lds = node_lds_bytes();
-    static const int wide_env = getenv("GM_NODE_WIDE") ? atoi(getenv("GM_NODE_WIDE")) : -1;
-    const bool wide = H == 128 && (wide_env == 1 || (wide_env != 0 && cdiv(a.n_nodes, TILE) <= 64));
+    const bool wide = H == 128 && cdiv(a.n_nodes, TILE) <= 64;
     if (wide) {
         const size_t wl = node_wide_lds_bytes();
         static PerDeviceOnce attr_done_dev;
-        if (attr_done_dev.need()) {
+        {
+            const int rc_attr = attr_done_dev.run([&]() -> int {
             int rc = set_lds(node_kernel_wide<128, 2, 0>, wl);
             if (rc == GM_OK) rc = set_lds(node_kernel_wide<128, 2, 1>, wl);
             if (rc == GM_OK) rc = set_lds(node_kernel_wide<128, 2, 2>, wl);
-            if (rc != GM_OK) return rc;
+                return rc;
+            });
+            if (rc_attr != GM_OK) return rc_attr;
         }
         const int wg = grid_for(cdiv(a.n_nodes, WTILE));
         ProfScope prof(a.prof, mode == 1 ? PROF_NODE : PROF_ENC, s);
@@ -2072,6 +2102,7 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
     }
     GM_LAUNCH_CHECK();
     return GM_OK;
+#endif  // GM_DEV_KERNELS
 }
 
 }  // namespace gm

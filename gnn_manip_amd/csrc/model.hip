@@ -6,7 +6,6 @@
 #include "model.h"
 #include "hedge.h"
 #include "hmlp.h"
-#include <stdlib.h>
 
 using namespace gm;
 
@@ -211,6 +210,7 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
         }
     }
     flush_pack();
+#ifdef GM_DEV_KERNELS
     if (m->packed_b3) {  // three-part bf16 image of the processor edge MLPs
         for (int k = 0; k < M && rc == GM_OK; ++k) {
             float* base = m->packed_b3 + (size_t)k * 3 * 4 * kB3StageFloats;
@@ -219,6 +219,7 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
                 rc = pack_linear_b3(T[b_edge(k) + 2 * l], H, 0, base + (size_t)l * 4 * kB3StageFloats, s);
         }
     }
+#endif
     if (m->packed_h3 && rc == GM_OK) {  // fp16 hi / lo image of the systolic processor edge kernel
         std::vector<PackH3Job> jobs((size_t)M);
         for (int k = 0; k < M; ++k) {
@@ -329,6 +330,7 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             return GM_ERR_HIP;
         }
     }
+#ifdef GM_DEV_KERNELS   // operand images of the round-1 inference kernels (development builds)
     if (m->legacy && H == 128 && desc->edge_dim <= 16) {
         size_t st16 = 0;
         m->s16_enc_edge = 0;
@@ -345,19 +347,18 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             return GM_ERR_HIP;
         }
     }
-    if (m->legacy && H == 128) {
-        if (hipMalloc(&m->packed_b3, (size_t)M * 3 * 4 * kB3StageFloats * sizeof(float)) != hipSuccess ||
-            hipMalloc(&m->packed_h3, (size_t)M * h3_image_floats() * sizeof(float)) != hipSuccess) {
-            gm::set_error("gm_model_create: hipMalloc failed");
-            gm_model_destroy(m);
-            return GM_ERR_HIP;
-        }
+    if (m->legacy && H == 128 && hipMalloc(&m->packed_b3, (size_t)M * 3 * 4 * kB3StageFloats * sizeof(float)) != hipSuccess) {
+        gm::set_error("gm_model_create: hipMalloc failed");
+        gm_model_destroy(m);
+        return GM_ERR_HIP;
     }
-    {
-        const char* e = getenv("GM_EDGE_KERNEL");  // initial value of the per-model choice (diagnostics)
-        m->edge_kernel = !e ? 0 : !strcmp(e, "16") ? 1 : !strcmp(e, "classic") ? 2 : !strcmp(e, "b3") ? 3 : !strcmp(e, "b3p") ? 4
-                         : !strcmp(e, "sys") ? 5 : !strcmp(e, "hm") ? 6 : 0;
+#endif
+    if (H == 128 && NL == 2 && hipMalloc(&m->packed_h3, (size_t)M * h3_image_floats() * sizeof(float)) != hipSuccess) {
+        gm::set_error("gm_model_create: hipMalloc failed");
+        gm_model_destroy(m);
+        return GM_ERR_HIP;
     }
+    m->edge_kernel = 0;   // automatic; gm_model_set_edge_kernel changes it per handle (no process-wide switch)
     if ((m->legacy && hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess) ||
         hipMalloc(&m->vec, m->vec_floats * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
@@ -591,6 +592,11 @@ extern "C" {
 int gm_model_set_edge_kernel(gm_model* m, int choice) {
     GM_REQUIRE(m, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: null model");
     GM_REQUIRE(choice >= 0 && choice <= 6, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: choice %d out of range", choice);
+#ifndef GM_DEV_KERNELS
+    GM_REQUIRE(choice == 0 || choice >= 5, GM_ERR_UNSUPPORTED,
+               "gm_model_set_edge_kernel: choices 1..4 (the round-1 fp32 / bf16 x 6 kernels) exist in development builds of the library only");
+#endif
+    GM_REQUIRE(choice != 5 || m->packed_h3, GM_ERR_UNSUPPORTED, "gm_model_set_edge_kernel: the systolic kernel is for hidden_size 128, num_layers 2");
     GM_REQUIRE(m->legacy || choice == 0 || choice == 6, GM_ERR_UNSUPPORTED,
                "gm_model_set_edge_kernel: hidden_size=%d num_layers=%d has the streamed fp16-split kernels only (0 / 6)", m->H, m->NL);
     m->edge_kernel = choice;

@@ -710,7 +710,7 @@ int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_
 
 int train_kernels_init() {
     static PerDeviceOnce done_dev;
-    if (!done_dev.need()) return GM_OK;
+    return done_dev.run([]() -> int {
     const size_t lds = (size_t)2 * STAGE_FLOATS * 4;
     int rc = GM_OK;
 #define GM_SET(k) if (rc == GM_OK) rc = set_dyn_lds(k, lds)
@@ -723,6 +723,7 @@ int train_kernels_init() {
     GM_SET((train_bwd_kernel<256, TB_ENC>)); GM_SET((train_bwd_kernel<256, TB_EDGE>)); GM_SET((train_bwd_kernel<256, TB_NODE>)); GM_SET((train_bwd_kernel<256, TB_DEC>));
 #undef GM_SET
     return rc;
+    });
 }
 
 }  // namespace gm

@@ -472,8 +472,10 @@ class EncProcDecGNN(nn.Module):
         self._handle.invalidate()
 
     def set_edge_kernel(self, choice):
-        """Processor edge kernel of this model (diagnostics / A-B measurements; no reference counterpart): 'auto',
-        'sys' (systolic fp16 x 3), 'b3' / 'b3p' (bf16 x 6), '16' / 'classic' (fp32 MFMA).  See include/gnn_manip_hip.h."""
+        """Processor edge kernel of this model (diagnostics / A-B measurements; no reference counterpart): 'auto', 'sys'
+        (systolic fp16 x 3, hidden 128 / num_layers 2), 'hm' (streamed fp16 x 3).  'b3' / 'b3p' (bf16 x 6) and '16' /
+        'classic' (fp32 MFMA) exist in development builds of the library only (GM_DEV_KERNELS=1) and raise otherwise.
+        See include/gnn_manip_hip.h."""
         self._handle.set_edge_kernel(self.EDGE_KERNELS.get(choice, choice))
 
     def forward(self, nodes, edge_attr, edge_index):

@@ -72,6 +72,7 @@ class CandidateEvaluator:
         self.result_dim = int(result_dim)
         self.group = group
         self.device = device
+        self.collective_s = 0.0   # wall time spent in the broadcast / all-gather calls so far (host clock around each call)
 
     def _dist(self):
         import torch.distributed as dist
@@ -93,7 +94,9 @@ class CandidateEvaluator:
         world = dist.get_world_size(self.group) if dist else 1
         rank = dist.get_rank(self.group) if dist else 0
         dev = self.device if self.device is not None else torch.device("cpu")
+        import time
         if dist:
+            t_c = time.perf_counter()
             shape = torch.zeros(2, dtype=torch.int64, device=dev)
             if rank == 0:
                 pop = torch.as_tensor(np.asarray(population, dtype=np.float64), device=dev)
@@ -103,6 +106,7 @@ class CandidateEvaluator:
                 pop = torch.empty((int(shape[0]), int(shape[1])), dtype=torch.float64, device=dev)
             dist.broadcast(pop, src=0, group=self.group)
             pop_np = pop.cpu().numpy()
+            self.collective_s += time.perf_counter() - t_c
         else:
             pop_np = np.asarray(population, dtype=np.float64)
         n = pop_np.shape[0]
@@ -119,12 +123,14 @@ class CandidateEvaluator:
                 local[j] = torch.as_tensor(r, dtype=torch.float64).reshape(-1).to(dev)
         if not dist:
             return local[:n].cpu().numpy()
+        t_c = time.perf_counter()   # includes the wait for the slowest rank: load imbalance shows up here
         gathered = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(gathered, local, group=self.group)
         out = np.zeros((n, self.result_dim))
         for r in range(world):
             a, b = shard_range(n, world, r)
             out[a:b] = gathered[r][:b - a].cpu().numpy()
+        self.collective_s += time.perf_counter() - t_c
         return out
 
 

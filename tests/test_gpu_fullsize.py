@@ -70,8 +70,9 @@ def test_csr_full_size_is_a_stable_sort(dev, scene100k):
 
 
 def test_forward_full_size_two_kernel_sets_agree(dev, scene100k):
-    """Fused inference kernels (16x16x4 edge kernel, in-kernel scatter-add with LDS stitching and atomics) against the
-    tape-recording training forward (32x32x2 chain, separate deterministic segment sums) on the target scene: E = 1.96 M."""
+    """Fused inference kernels (systolic fp16 x 3 edge kernel with its in-register segmented scatter-add, streamed fp16 x 3 node
+    kernels) against the tape-recording training forward (fp32 MFMA chains, separate deterministic segment sums) on the
+    target scene: E = 1.96 M."""
     from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl
     ga = GraphBoundedMultimaterialControl(0.015, STATS, CART, MAT, CTRL, BOUNDS)
     params = orc.init_params(25, 4, 3, 128, 2, 10, 77)
@@ -109,6 +110,62 @@ def test_forward_c3_size_against_the_oracle(dev):
     ref = orc.epd_forward(params, nodes, ea, ei, 2, 2)
     assert np.isfinite(out).all()
     assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def _forward_vs_oracle(dev, obs, hidden, seed, m_steps=1):
+    from gnn_manip_amd import EncProcDecGNN
+    params = orc.init_params(25, 4, 3, hidden, 2, m_steps, seed)
+    m = EncProcDecGNN(25, 4, 3, hidden, 2, m_steps)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev)
+    nodes, ea, s, r, _ = orc.process(obs, None, STATS, BOUNDS, 0.015, CART, MAT, CTRL)
+    ei = np.stack((s, r))
+    with torch.no_grad():
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    assert m.status() == ei.shape[1]
+    ref = orc.epd_forward(params, nodes, ea, ei, 2, m_steps)
+    assert np.isfinite(out).all()
+    return np.abs(out - ref).max() / np.abs(ref).max(), ei.shape[1]
+
+
+def test_forward_target_size_against_the_oracle(dev, scene100k):
+    """The north_star target scene (N = 100k, E ~ 1.97 M, hidden 128) through encoder, one processor step and decoder --
+    the systolic edge kernel at its full size -- against the numpy oracle on the same graph and weights: 1e-5 relative."""
+    err, e = _forward_vs_oracle(dev, scene100k, 128, 80)
+    assert e > 1900000
+    assert err <= 1e-5, err
+
+
+def test_forward_c4_size_against_the_oracle(dev, scene100k):
+    """BASELINE config C4 (N = 100k, hidden 256) through encoder, one processor step and decoder -- the streamed `hm`
+    kernels at their full size -- against the numpy oracle: 1e-5 relative."""
+    err, e = _forward_vs_oracle(dev, scene100k, 256, 81)
+    assert e > 1900000
+    assert err <= 1e-5, err
+
+
+def test_rollout_c2_size_against_the_oracle(dev):
+    """BASELINE config C2's scene (N = 5k dense, hidden 128, 10 message-passing steps): a 10-step device-resident rollout
+    (graph rebuilt every step) against oracle.rollout, the restatement of the reference's cma_objective loop
+    (rollout_utils.py:38-61): positions to 5e-6 absolute (positions are O(0.5); one float32 ulp there is 6e-8)."""
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, RolloutEngine, scene
+    n, steps = 5000, 10
+    obs = scene.make_scene(n, seed=11)
+    traj = scene.rigid_drift_trajectory(obs, steps, seed=12)
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 82)
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 10)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev)
+    ga = GraphBoundedMultimaterialControl(0.015, STATS, CART, MAT, CTRL, BOUNDS)
+    eng = RolloutEngine(m, ga, n, device=dev)
+    with torch.no_grad():
+        final = eng.rollout(_t(obs, dev), _t(traj, dev), horizon=steps).cpu().numpy()
+    ref = orc.rollout(params, obs, traj, steps, STATS, BOUNDS, 0.015, CART, MAT, CTRL, 2, 10)
+    assert np.isfinite(final).all() and eng.status() > 90000
+    # the whole final window [k, N, D]: positions and control columns of the last k frames, ids / material untouched
+    np.testing.assert_allclose(final[:, :, 2:5], ref[:, :, 2:5], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(final[:, :, 5:8], ref[:, :, 5:8], rtol=0, atol=5e-6)
+    np.testing.assert_array_equal(final[:, :, :2], ref[:, :, :2])
 
 
 def test_rollout_full_size_state_properties(dev, scene100k):

@@ -259,6 +259,20 @@ def test_epd_forward_hidden_256_vs_oracle(dev, n, side, seed):
     assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
 
 
+def _dev_kernels(m, dev):
+    """True when the loaded library is a development build that contains the round-1 kernels (choices 1..4)."""
+    from gnn_manip_amd._lib import GMError
+    try:
+        m.set_edge_kernel(2)
+        with torch.no_grad():
+            m.forward(torch.zeros(2, m.dims[0], device=dev), torch.zeros(1, m.dims[1], device=dev), torch.zeros(2, 1, dtype=torch.long, device=dev))
+        ok = True
+    except GMError:
+        ok = False
+    m.set_edge_kernel(0)
+    return ok
+
+
 def test_unsupported_sizes_fail_loudly(dev):
     from gnn_manip_amd import EncProcDecGNN
     from gnn_manip_amd._lib import GMError
@@ -266,11 +280,18 @@ def test_unsupported_sizes_fail_loudly(dev):
     with pytest.raises(GMError, match="hidden_size=96"), torch.no_grad():
         m.forward(torch.zeros(4, 25, device=dev), torch.zeros(4, 4, device=dev),
                   torch.zeros(2, 4, dtype=torch.long, device=dev))
-    m = EncProcDecGNN(25, 4, 3, 64, 3, 2).to(dev)   # runs, but has no fp32 kernels to select
-    with pytest.raises(GMError, match="streamed fp16-split kernels only"), torch.no_grad():
-        m.set_edge_kernel("classic")
+    m = EncProcDecGNN(25, 4, 3, 64, 3, 2).to(dev)   # runs on the streamed kernels; the systolic one is for hidden 128 / num_layers 2
+    with pytest.raises(GMError, match="systolic kernel is for hidden_size 128"), torch.no_grad():
+        m.set_edge_kernel("sys")
         m.forward(torch.zeros(4, 25, device=dev), torch.zeros(4, 4, device=dev),
                   torch.zeros(2, 4, dtype=torch.long, device=dev))
+    # the round-1 fp32 / bf16 x 6 kernels are not part of the product library (development builds: GM_DEV_KERNELS=1)
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 2).to(dev)
+    if not _dev_kernels(m, dev):
+        with pytest.raises(GMError, match="development builds"), torch.no_grad():
+            m.set_edge_kernel("classic")
+            m.forward(torch.zeros(4, 25, device=dev), torch.zeros(4, 4, device=dev),
+                      torch.zeros(2, 4, dtype=torch.long, device=dev))
 
 
 def test_epd_forward_permutation_of_edges_is_immaterial(dev):
@@ -397,6 +418,8 @@ def test_every_processor_edge_kernel_form_vs_oracle(dev, choice, name):
         obs = scene.make_scene(n, seed=seed, side=side)
         params = orc.init_params(25, 4, 3, 128, 2, 10, seed)
         m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+        if choice <= 4 and not _dev_kernels(m, dev):
+            pytest.skip("round-1 kernels: development builds of the library only")
         m.set_edge_kernel(choice)
         nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
         ei = np.stack((s, r))
@@ -416,6 +439,8 @@ def test_split_operand_kernels_are_as_accurate_as_float32(dev, choice):
     obs = scene.make_scene(2500, seed=71, side=0.1)
     params = orc.init_params(25, 4, 3, 128, 2, 10, 71)
     m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    if choice <= 4 and not _dev_kernels(m, dev):
+        pytest.skip("round-1 kernels: development builds of the library only")
     nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
     ei = np.stack((s, r))
     p64 = {k: torch.tensor(v, dtype=torch.float64) for k, v in params.items()}

@@ -179,3 +179,43 @@ def test_c5_two_ranks_on_one_gpu(dev, tmp_path):
     sharded = json.load(open(out))
     assert len(sharded) == 7
     np.testing.assert_allclose(sharded, single, rtol=0, atol=0)   # same kernels, same per-graph tables: identical
+
+
+def test_bench_c5_two_rank_rehearsal(dev):
+    """The driver's multi-GPU launch of bench.py, rehearsed on one card: `bench.py --gpus 2 --workload c5` as two fresh rank
+    processes (env rendezvous on 127.0.0.1, GM_BENCH_REHEARSE=1: gloo, both ranks on cuda:0, reduced sizes).  Checks the JSON
+    line rank 0 prints: rank count, contiguous candidate blocks (SURVEY 8e / traj_utils.py:247-259), finite losses, and the
+    separately timed broadcast + all-gather share."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c5", "--candidates-total", "6", "--batch", "2",
+           "--steps", "4"]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", GM_BENCH_REHEARSE="1")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, e = p.communicate()
+        outs.append((o.decode(errors="replace"), e.decode(errors="replace")))
+    assert all(p.returncode == 0 for p in procs), "\n".join(o + e for o, e in outs)
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # ONE line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["unit"] == "rollout steps/s"
+    cfg = rec["config"]
+    assert cfg["candidates"] == 6 and cfg["candidates_per_rank"] == 3 and cfg["block_diagonal_batch"] == 2 and cfg["horizon"] == 4
+    assert np.isfinite(cfg["loss_mean"]) and rec["value"] > 0
+    assert rec["collective_ms"] >= 0.0 and rec["collective_ms"] < cfg["generation_s"] * 1e3
