@@ -216,6 +216,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
         pa.wstream = k == 0 ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
                             : m->packed + m->s_node[k - 1] + (size_t)(NL + 2) * U;
         pa.tail = 1; pa.proj_bias = m->vec + m->v_edge[k]; pa.P_out = t.P;
+        pa.tail_hm = m->packed_hm + (k == 0 ? m->hm_enc_node_tail : m->hm_node_tail[k - 1]);   // the streamed fp16 x 3 projection kernel
         rc = launch_node(H, NL, 2, pa, s);
         if (rc != GM_OK) return rc;
         const float* ve = mlp_vec(m, m->v_edge[k]);
@@ -536,6 +537,7 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
     pa.wstream = k == 0 ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
                         : m->packed + m->s_node[k - 1] + (size_t)(NL + 2) * U;
     pa.tail = 1; pa.proj_bias = m->vec + m->v_edge[k]; pa.P_out = t.P;
+    pa.tail_hm = m->packed_hm + (k == 0 ? m->hm_enc_node_tail : m->hm_node_tail[k - 1]);   // the streamed fp16 x 3 projection kernel
     rc = launch_node(H, NL, 2, pa, s);
     if (rc != GM_OK) return rc;
     auto normed = [&](TrainFwdArgs& a, size_t voff) {
