@@ -86,7 +86,7 @@ struct Carver {
 };
 
 // ---- error flags written by device code into workspace headers
-enum : int { ERRF_NONFINITE_POS = 1, ERRF_BAD_EDGE_INDEX = 2, ERRF_CAPACITY = 4 };
+enum : int { ERRF_NONFINITE_POS = 1, ERRF_BAD_EDGE_INDEX = 2, ERRF_CAPACITY = 4, ERRF_SPLIT_RANGE = 8 };
 
 // ---- graph workspace (graph.hip) ---------------------------------------------------------
 struct GraphHeader {  // lives at the start of the graph workspace (device memory)

@@ -943,6 +943,9 @@ int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream) {
     *n_edges_host = h.n_edges;
     GM_REQUIRE(!(h.error_flags & ERRF_BAD_EDGE_INDEX), GM_ERR_DATA, "edge_index entry out of range [0, n_nodes)");
     GM_REQUIRE(!(h.error_flags & ERRF_CAPACITY), GM_ERR_DATA, "edge capacity exceeded");
+    GM_REQUIRE(!(h.error_flags & ERRF_SPLIT_RANGE), GM_ERR_DATA,
+               "fp16 split range exceeded: a feature, latent or hidden activation of the last forward over this edge structure reached "
+               "|x| >= 65504 in a matrix-pipe operand image (include/gnn_manip_hip.h, numeric domain); its results are not valid");
     return GM_OK;
 }
 

@@ -43,6 +43,7 @@ struct PackH3Job {
     int W1_col0;       // first column of that block (2H with the default concat order)
     const float* W2;   // [H][H]
     const float* W3;   // [H][H]
+    const float* b1;   // Linear 1 bias (applied through P; here only for the scale estimate)
     const float* b2;
     const float* b3;
     const float* gamma;

@@ -33,6 +33,7 @@
 #include "common.h"
 #include "mlp.h"
 #include "hedge.h"
+#include "hmlp.h"
 #include "hmma_dev.h"
 
 namespace gm {
@@ -165,10 +166,10 @@ __device__ __forceinline__ float upper_half_to_both(float v) {   // every lane l
 constexpr int DR_SLOTS = 8;   // ring of per-block destination ids handed from role 0 to role 2 (written 2 ticks before it is read)
 constexpr size_t SYS_LDS_BYTES = 3 * 2 * 16384 + 2 * 16384 + 16384 + 2 * 8 * BE * 2 * 4 + 4 * BE * 2 * 4 + 4 * H * 4 + DR_SLOTS * BE * 4 + 4 * BE * 2 * 4;
 
-__global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeader* __restrict__ a_hdr, const int* __restrict__ a_dst, const int* __restrict__ a_src, const float* __restrict__ a_P,
+__global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeader* a_hdr, const int* __restrict__ a_dst, const int* __restrict__ a_src, const float* __restrict__ a_P,
                                                                        const float* a_e_in, float* a_e_out, float* __restrict__ a_agg, const float* __restrict__ a_hw,
                                                                        const int2* __restrict__ a_blk, const int2* __restrict__ a_seg, const int* __restrict__ a_head,
-                                                                       const EdgeBlockHeader* __restrict__ a_tab, float* a_sink, unsigned a_side_off, float a_eps, int a_residual) {
+                                                                       const EdgeBlockHeader* __restrict__ a_tab, float* a_sink, unsigned a_side_off, int* a_flags, float a_eps, int a_residual) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* Eimg = reinterpret_cast<half8*>(smem);            // [2][8 ks][2 parts][64]  2 x 16 KiB, eslot() order
     half8* X1 = Eimg + 2 * 1024;
@@ -225,6 +226,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         floatx4 pi[4], pj[4];   // row-major quads of rows 8 j + rr: P_i / P_j of block x
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pi[j] = floatx4{0.f, 0.f, 0.f, 0.f}; pj[j] = pi[j]; }
+        int rng = 0;            // range check of the fp16 split: set once an accumulator row turns NaN
         floatx4 eq[4];          // e rows of block x+1 on their way into the operand image E
 #pragma unroll
         for (int j = 0; j < 4; ++j) eq[j] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -308,6 +310,9 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             if (HEDGE_VAR & 1) mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, nothing);
             else mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, side);
             SYS_STAMP(t, 3);
+            // range check of the fp16 split: a value that does not fit an operand image is (inf, -inf) as a pair and turns every
+            // accumulator of its row into NaN (hmlp.hip: check_rows) -- one comparison per tick, wave-uniform verdict
+            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
             acc_to_image(acc, reinterpret_cast<uintx4*>(X1 + (x & 1) * 1024), jb, lane);
             SYS_STAMP(t, 4);
             if (HEDGE_VAR & 1) {
@@ -318,9 +323,11 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             lds_barrier();
             SYS_STAMP(t, 6);
         }
+        if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else if (role == 1) {
         // ------------------------------------------------------------------ role 1
         floatx16 acc;
+        int rng = 0;
         floatx4 er[4];                      // e rows (row-major quads) of block x-3 for the residual
         int st_a = 0, cnt_a = 0, st_b = 0, cnt_b = 0;  // blocks x-3, x-2
         int2 bi_c = make_int2(0, 0);                    // raw table entry of block x-1 (decoded a tick after its load)
@@ -404,6 +411,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 mlp_layer<false>(acc, wh, wl, X1 + ((x - 1) & 1) * 1024, lane, side);
             }
             SYS_STAMP(t, 3);
+            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
             acc_to_image(acc, reinterpret_cast<uintx4*>(X2 + ((x - 1) & 1) * 1024), jb, lane);
             SYS_STAMP(t, 4);
             if (!(HEDGE_VAR & 1)) request_er();
@@ -412,6 +420,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             lds_barrier();
             SYS_STAMP(t, 6);
         }
+        if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else {
         // ------------------------------------------------------------------ role 2
         // Aggregation of block x-3 on a TRANSPOSED view of its LayerNorm input: lane (f, h) = feature 32 jb + f, rows 16 h ..
@@ -420,6 +429,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         // adds down the registers, a finished segment is one 128-byte store per half-wave.  The sum of a segment that is
         // still open at the end of a half (or block) travels on in `carry` and joins the first row stored afterwards.
         floatx16 acc;
+        int rng = 0;
         float carry = 0.f;              // open segment's sum from the previous block (this lane's feature; both halves hold it)
         int cnt_a = 0, fl_a = 0, cnt_b = 0, fl_b = 0;    // blocks x-3, x-2 (cnt = 0 while there is none)
         unsigned cont_a = 0, last_a = 0, cont_b = 0, last_b = 0;
@@ -524,6 +534,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 mlp_layer<false>(acc, wh, wl, X2 + par2 * 1024, lane, side);
             }
             SYS_STAMP(t, 3);   // 24 MFMAs with the scatter-add between them
+            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
             {
                 // LayerNorm partial statistics of the scaled accumulators (16 features per lane); raw accumulators to Z
                 float sacc = 0.f;
@@ -576,12 +587,13 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             lds_barrier();
             SYS_STAMP(t, 6);   // every wave of the workgroup has finished the tick
         }
+        if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // weight image: [T1, 1/T3, 0, 0 | b2 T2, b3 T3, gamma, beta | fp16 hi / lo fragments of t_l W_l]
-// One workgroup per processor step.  t_l = 2^k with max |W_l| t_l in [0.25, 0.5).
+// One workgroup per processor step.  t_l: power of two from the Linear's gain (hmlp.h).
 // ------------------------------------------------------------------------------------------
 struct PackH3Jobs {
     int n;
@@ -589,6 +601,7 @@ struct PackH3Jobs {
     int c1[kPackH3Max];
     const float* W2[kPackH3Max];
     const float* W3[kPackH3Max];
+    const float* b1[kPackH3Max];
     const float* b2[kPackH3Max];
     const float* b3[kPackH3Max];
     const float* gamma[kPackH3Max];
@@ -598,30 +611,65 @@ struct PackH3Jobs {
 
 __global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
     __shared__ float red[256];
-    __shared__ float tsc[3];
+    __shared__ float tsc[4];
     const int job = blockIdx.x, tid = threadIdx.x;
     const float* Wl[3] = {J.W1[job], J.W2[job], J.W3[job]};
     const int ld[3] = {3 * H, H, H}, c0[3] = {J.c1[job], 0, 0};
+    // Scales as in the streamed kernels (hmlp.h / pack_hm_kernel): m = estimated rms of the activations, a ReLU layer maps
+    // m^2 -> gain^2 m^2 + rms(b)^2 / 2 with gain = ||W_l||_F / sqrt(out) / sqrt(2); U_l = power of two nearest kHmTargetRms / m_l,
+    // t_l = U_l / U_(l-1).  Linear 1's pre-activation takes h_i and h_j too: its gain is that of the whole [H x 3H] matrix; its
+    // inputs (h, e) are at their natural magnitude (m_0 = 1).
+    const float* bl[3] = {J.b1[job], J.b2[job], J.b3[job]};
+    float m_est = 1.f, U_prev = 1.f;
     for (int l = 0; l < 3; ++l) {
-        float mx = 0.f;
-        for (int i = tid; i < H * H; i += 256) mx = fmaxf(mx, fabsf(Wl[l][(size_t)(i / H) * ld[l] + c0[l] + (i % H)]));
-        red[tid] = mx;
+        float ss = 0.f, wm = 0.f;
+        const int cols = l == 0 ? 3 * H : H;
+        for (int i = tid; i < H * cols; i += 256) {
+            const int col = i % cols;
+            const float v = Wl[l][(size_t)(i / cols) * ld[l] + (l == 0 ? 0 : c0[l]) + col];
+            ss = fmaf(v, v, ss);
+            if (l != 0 || (col >= c0[0] && col < c0[0] + H)) wm = fmaxf(wm, fabsf(v));   // the packed block
+        }
+        red[tid] = ss;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const float ss_all = red[0];
+        __syncthreads();
+        red[tid] = wm;
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1) {
             if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
             __syncthreads();
         }
         if (tid == 0) {
-            const float m = red[0];
-            int ex = 0;
-            float t = 1.f;
-            if (m > 0.f && m < 3.0e38f) {
-                frexpf(m, &ex);
-                ex = ex < -20 ? -20 : (ex > 20 ? 20 : ex);
-                t = ldexpf(1.f, -ex - 1);
+            const float wmax = red[0];
+            float bs = 0.f;
+            for (int o = 0; o < H; ++o) bs = fmaf(bl[l][o], bl[l][o], bs);
+            const float g2 = ss_all / (float)H * 0.5f;
+            float m = sqrtf(fmaf(0.5f, bs / (float)H, g2 * m_est * m_est));
+            if (!(m > 1.0e-30f) || !(m < 1.0e30f)) m = 1.f;
+            auto pow2 = [](float want, bool nearest) {
+                if (!(want > 0.f) || !(want < 3.0e38f)) return 1.f;
+                int ex;
+                const float f = frexpf(want, &ex);
+                int sh = (nearest && f >= 0.70710678f) ? ex : ex - 1;
+                sh = sh < -100 ? -100 : (sh > 100 ? 100 : sh);
+                return ldexpf(1.f, sh);
+            };
+            float t = pow2(kHmTargetRms / m, true) / U_prev;
+            if (wmax > 0.f && wmax < 3.0e38f) {   // packed weights where both halves of the split are normal
+                if (wmax * t > 8192.0f) t = pow2(8192.0f / wmax, false);
+                if (wmax * t < 0.0625f) t = 2.f * pow2(0.0625f / wmax, false);
             }
             tsc[l] = t;
+            tsc[3] = m;
         }
+        __syncthreads();
+        m_est = tsc[3];
+        U_prev *= tsc[l];
         __syncthreads();
     }
     const float T1 = tsc[0], T2 = T1 * tsc[1], T3 = T2 * tsc[2];
@@ -736,7 +784,7 @@ int pack_h3(const PackH3Job* jobs, int n, hipStream_t s) {
         J.n = n - off < kPackH3Max ? n - off : kPackH3Max;
         for (int i = 0; i < J.n; ++i) {
             const PackH3Job& j = jobs[off + i];
-            J.W1[i] = j.W1; J.c1[i] = j.W1_col0; J.W2[i] = j.W2; J.W3[i] = j.W3; J.b2[i] = j.b2; J.b3[i] = j.b3; J.gamma[i] = j.gamma; J.beta[i] = j.beta;
+            J.W1[i] = j.W1; J.c1[i] = j.W1_col0; J.W2[i] = j.W2; J.W3[i] = j.W3; J.b1[i] = j.b1; J.b2[i] = j.b2; J.b3[i] = j.b3; J.gamma[i] = j.gamma; J.beta[i] = j.beta;
             J.dst[i] = j.dst;
         }
         hipLaunchKernelGGL(pack_h3_kernel, dim3(J.n), dim3(256), 0, s, J);
@@ -808,7 +856,7 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
         // pointers as separate __restrict__ parameters (e_in / e_out may be the same array): the table and index reads are
         // then provably unclobbered and become scalar loads where their address is wave-uniform
         hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
-                           a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, a.side + (size_t)(t.max_blocks / 4 + 1) * H, (unsigned)(a.side - a.agg), a.eps, a.residual);
+                           a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, a.side + (size_t)(t.max_blocks / 4 + 1) * H, (unsigned)(a.side - a.agg), const_cast<int*>(&a.hdr->error_flags), a.eps, a.residual);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;

@@ -6,8 +6,18 @@
 
 namespace gm {
 
-// ---- image of one Linear: [t, 1/t, 0, 0] | bias * t (out_pad floats) | fp16 hi / lo A-operand fragments
-//      [out_pad / 32][k_pad / 16][2 parts][64 lanes][8 halves]   (t: power of two with max|W| t in [0.25, 0.5))
+// ---- image of one Linear:  [t, 1/U, U, 0] | bias * U (out_pad floats) | fp16 hi / lo A-operand fragments of t W
+//      [out_pad / 32][k_pad / 16][2 parts][64 lanes][8 halves]
+// Scales (all powers of two, so nothing is rounded).  The Linears of an MLP form a chain; the activations are never brought
+// back to their natural magnitude between them: the accumulators of Linear l are  U_l z_l  with  U_l = t_1 .. t_l  (times the
+// scale of the chain's input image, 1 for h / e / agg, a per-row power of two for the encoders' raw features), ReLU passes
+// them on, the bias comes pre-multiplied by U_l, and the scale leaves where results are read (LayerNorm: eps U^2; outputs:
+// 1 / U).  U_l is chosen from an estimate of the activations' rms m_l -- a ReLU layer maps the second moment
+// m^2 -> gain^2 m^2 + rms(b)^2 / 2  with  gain = ||W_l||_F / sqrt(out) / sqrt(2) -- so that the operand image of the next Linear
+// has an rms near 2^4 (and the packed weights t W stay where both halves of their split are normal): elements down to 2^-7 of that keep all
+// 22 bits of the two-way fp16 split, values up to 2^12 times it fit (a hub node's aggregate, an outlier activation), and scaling (W_l, b_l) by s and W_l+1 by 1/s -- which
+// leaves the function unchanged -- leaves every operand image unchanged bit for bit.  A value that does not fit
+// (|x| >= 65504 in an operand image) raises ERRF_SPLIT_RANGE in the forward's CSR header (status() reports it).
 __host__ __device__ static inline size_t hm_lin_floats(int out_pad, int k_pad) { return 4 + (size_t)out_pad + (size_t)out_pad * k_pad; }
 
 struct PackHmJob {
@@ -22,10 +32,18 @@ struct PackHmJob {
     int k_pad;          // total padded inputs (multiple of 16)
     int k_seg;          // inputs per segment (= k_pad when there is one)
     int col0[2];        // first column of W for segment 0 / 1 (output segments OR input segments)
+    int pred;           // job (index in the whole list handed to pack_hm) whose output is this Linear's input, or -1: chain head
+    float in_rms;       // chain heads: assumed rms of the input operand image (1 for natural-magnitude inputs)
+    int gain_cols;      // columns [gain_col0, gain_col0 + gain_cols) of W that make this Linear's pre-activation (0: the packed ones;
+    int gain_col0;      //   phi_e's first Linear is packed as its e block, but h_i and h_j feed the same pre-activation)
     float* dst;
 };
-constexpr int kPackHmMax = 24;
-int pack_hm(const PackHmJob* jobs, int n, hipStream_t s);
+constexpr int kPackHmMax = 20;
+// jobs: host list that stays alive until the stream has run the copy; jobs_dev: device room for n jobs; stats: device scratch of
+// 4 * n floats (phase 1 fills it with every job's gain / bias rms / bias max / weight max, phase 2 walks the chains)
+int pack_hm(const PackHmJob* jobs, int n, PackHmJob* jobs_dev, float* stats, hipStream_t s);
+constexpr float kHmTargetRms = 16.0f;       // rms the operand images aim at: full 22 bits from rms / 128 up, values up to 4096 x rms fit
+constexpr float kHmRawInputRms = 32.0f;     // encoders: raw feature rows are scaled so that their maximum is in [2^6, 2^7)
 
 struct HmEdgeArgs {
     const CsrHeader* hdr;
@@ -49,6 +67,7 @@ struct HmEdgeArgs {
     const int* head;      // processor: head list of the groups
     float* side;          // processor: [n_groups][H] head partials
     const EdgeBlockHeader* tab;
+    int* flags;           // error flags of the forward (CsrHeader::error_flags), or nullptr
     ProfState* prof;
 };
 
@@ -74,6 +93,7 @@ struct HmNodeArgs {
     const int* head;
     const float* side;
     const EdgeBlockHeader* tab;
+    int* flags;           // error flags of the forward (CsrHeader::error_flags), or nullptr
     ProfState* prof;
 };
 

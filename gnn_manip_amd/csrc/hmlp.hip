@@ -6,8 +6,10 @@
 //                            P = h [W_i | W_j]^T + b1, or the decoder MLP (epd_gnn.py:47-48,107)
 //
 // Arithmetic: hmma_dev.h (two-way fp16 operand split, three exact partial products per multiply, fp32 accumulation).
-// Every Linear is pre-scaled by a power of two t (hmlp.h); the scale is removed where the accumulators are read
-// (ReLU / LayerNorm statistics / outputs), so activations keep their natural magnitude whatever the depth.
+// Power-of-two scales ride through an MLP's chain of Linears (hmlp.h): accumulators of Linear l are U_l z_l, ReLU passes them on
+// as the next operand image, the scale leaves in the LayerNorm statistics / at the outputs.  The encoders scale every raw
+// feature row by its own power of two (row maximum to [2^6, 2^7)), which rides along the same way.  Every value written
+// to an operand image is range-checked (|x| < 65504): a violation sets ERRF_SPLIT_RANGE in the forward's CSR header.
 //
 // Structure.  One 8-wave workgroup per CU walks over tiles of M rows with M * H = 32768: the fp16 hi / lo operand image of
 // a tile's activations is exactly 128 KiB of LDS.  Wave (rg, jb) owns output block jb (32 features) of the 128 rows of row
@@ -39,7 +41,9 @@ constexpr int BE = 32;
 constexpr size_t HM_IMG_BYTES = 131072;
 constexpr size_t HM_ST_BYTES = 16384;    // [NRB][2 NJB partials][32 rows] float2  (NRB * 2 NJB = 64)
 constexpr size_t HM_BLK_BYTES = 2 * 16 * sizeof(int2);
-constexpr size_t HM_LDS_BYTES = HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES + 2 * 256 * sizeof(float);   // + gamma | beta
+constexpr size_t HM_GB_BYTES = 2 * 256 * sizeof(float);    // gamma | beta
+constexpr size_t HM_RS_BYTES = 32 * 32 * sizeof(float);    // encoders: power-of-two scale of every row of the tile
+constexpr size_t HM_LDS_BYTES = HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES + HM_GB_BYTES + HM_RS_BYTES;
 
 // RBW: 32-row blocks per wave.  4 fills the LDS image (M * H = 32768); the node kernels also come with 1 for small
 // graphs (four times the tiles; per-row arithmetic is identical, so results do not depend on the choice).
@@ -53,14 +57,17 @@ struct Cfg {
 };
 
 struct Lin {
-    float t, inv_t;
-    const float* bias;
+    float t, inv_u, u;   // this Linear's weight scale; 1 / U and U, the scale its accumulators carry (hmlp.h)
+    float cap;           // encoders' first Linear: largest per-row input scale
+    const float* bias;   // pre-multiplied by U
     const half8* frag;
 };
 __device__ __forceinline__ Lin lin_at(const float* p, int out_pad) {
     Lin L;
     L.t = p[0];
-    L.inv_t = p[1];
+    L.inv_u = p[1];
+    L.u = p[2];
+    L.cap = p[3];
     L.bias = p + 4;
     L.frag = reinterpret_cast<const half8*>(p + 4 + out_pad);
     return L;
@@ -77,6 +84,33 @@ __device__ __forceinline__ void init_bias(floatx16 (&acc)[RBW], const float* bia
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) acc[rb][4 * g + tt] = v[tt];
     }
+}
+// the same with the per-row power of two of the encoders' raw features (rs[rb]: this lane's row of row block rb)
+template <int RBW>
+__device__ __forceinline__ void init_bias_rows(floatx16 (&acc)[RBW], const float* bias, int jbv, int hi, const float (&rs)[RBW]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const floatx4 v = *reinterpret_cast<const floatx4*>(bias + 32 * jbv + 8 * g + 4 * hi);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[rb][4 * g + tt] = v[tt] * rs[rb];
+    }
+}
+
+// Range check of the fp16 split (hmma_dev.h).  A value of magnitude >= 65520 becomes (inf, -inf) as a pair, and every accumulator of
+// its row that sums over it becomes NaN (inf - inf) -- the whole row, all output features.  So one accumulator per row and
+// Linear tells: a comparison per row block instead of a maximum over every value written.  The verdict is wave-uniform and
+// lives in a scalar register.  (A non-finite input of the caller's raises the same flag.)
+template <int RBW>
+__device__ __forceinline__ void check_rows(int& bad, const floatx16 (&acc)[RBW]) {
+    bool nan = false;
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) nan |= acc[rb][0] != acc[rb][0];
+    bad |= __any(nan) ? 1 : 0;
+}
+__device__ __forceinline__ void report_range(int bad, int* flags) {
+    if (flags && bad && (threadIdx.x & 63) == 0) atomicOr(flags, ERRF_SPLIT_RANGE);
 }
 
 // acc[rb] += W[jb block, k-groups ks0 .. ks0 + nks) x image rows of row block rb.
@@ -118,14 +152,15 @@ __device__ __forceinline__ void gemm(floatx16 (&acc)[RBW], const half8* __restri
     }
 }
 
-// accumulators (scaled by 1/s) -> [ReLU] -> fp16 hi / lo -> the wave's two k-groups of the image of row block rb
+// accumulators -> [ReLU] -> fp16 hi / lo -> the wave's two k-groups of the image of row block rb.  The ReLU form passes the
+// accumulators' scale on (no multiply); the other form (a LayerNorm output entering a tail) writes the values as they are.
 template <bool RELU>
-__device__ __forceinline__ void acc_to_img(const floatx16& a, float s, uintx4* img_rb, int jb, int lane) {
+__device__ __forceinline__ void acc_to_img(const floatx16& a, uintx4* img_rb, int jb, int lane) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (RELU ? relu(a[8 * q + j]) : a[8 * q + j]) * s;
+        for (int j = 0; j < 8; ++j) v[j] = RELU ? relu(a[8 * q + j]) : a[8 * q + j];
         uintx2 h0, l0, h1, l1;
         split4(v[0], v[1], v[2], v[3], h0, l0);
         split4(v[4], v[5], v[6], v[7], h1, l1);
@@ -157,19 +192,30 @@ __device__ __forceinline__ void rows_to_image(const float* __restrict__ src, uin
     }
 }
 
-// rows of k1 <= 16 KSN floats -> image with KSN k-groups (zero-padded)
+// rows of k1 <= 16 KSN raw features -> image with KSN k-groups (zero-padded), every row scaled by its own power of two so that
+// its largest magnitude lands in [2^6, 2^7), but by no more than `cap` (pack_hm_kernel: what keeps the bias in range; an
+// all-zero row takes the cap).  RS[rbg * 32 + n] receives the scale.
 template <int H, int RBW, int KSN, class R>
-__device__ __forceinline__ void narrow_rows_to_image(const float* __restrict__ src, int k1, uintx4* img, int tid, R&& row_of) {
+__device__ __forceinline__ void narrow_rows_to_image(const float* __restrict__ src, int k1, uintx4* img, float* RS, float cap, int tid, R&& row_of) {
     using C = Cfg<H, RBW>;
     for (int i = tid; i < C::NRB * KSN * 64; i += HM_THREADS) {
         const int rbg = i / (KSN * 64), rem = i % (KSN * 64), ks = rem >> 6, l = rem & 63, nn = l & 31, kg = l >> 5;
         const long long row = row_of(rbg, nn);
         const float* p = src + row * k1;
+        float mx = 0.f;
+        for (int f = 0; f < k1; ++f) mx = fmaxf(mx, fabsf(p[f]));   // the whole row (L1-resident): every lane of the row agrees
+        float sc = cap;                       // zero (or non-finite) row: bias only
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);            // mx = f 2^ex, f in [0.5, 1)  ->  mx 2^(7 - ex) in [2^6, 2^7)
+            sc = fminf(ldexpf(1.f, min(7 - ex, 100)), cap);
+        }
+        if (ks == 0 && kg == 0) RS[rbg * 32 + nn] = sc;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int f = 16 * ks + 8 * (j >> 2) + 4 * kg + (j & 3);
-            v[j] = f < k1 ? p[f] : 0.f;
+            v[j] = f < k1 ? p[f] * sc : 0.f;
         }
         uintx2 h0, l0, h1, l1;
         split4(v[0], v[1], v[2], v[3], h0, l0);
@@ -212,7 +258,8 @@ __device__ __forceinline__ void ln_merge(const float* ST, int rbg, int n, float 
     mean *= 1.0f / NP;
 #pragma unroll
     for (int w = 0; w < NP; ++w) { const float d = mw[w] - mean; m2 = fmaf(16.0f * d, d, m2); }
-    // accumulators carry the Linear's scale t: (acc - mean) / sqrt(var_acc + eps t^2) is the normalised value
+    // accumulators carry the scale t (= U of the chain, times the row's own scale in the encoders):
+    // (acc - mean) / sqrt(var_acc + eps t^2) is the normalised value
     k = 1.0f / sqrtf(m2 * (1.0f / H) + eps * t * t);
     m = -mean * k;
 }
@@ -240,9 +287,11 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
     const size_t lin0 = hm_lin_floats(H, 16 * KS0), linh = hm_lin_floats(H, H);
 
     float* GB = reinterpret_cast<float*>(smem + HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES);   // gamma[H] | beta[H]
+    float* RS = reinterpret_cast<float*>(smem + HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES + HM_GB_BYTES);   // encoder: row scales
     for (int i = tid; i < H; i += HM_THREADS) { GB[i] = A.ln_g[i]; GB[H + i] = A.ln_b[i]; }
     const float* gamp = GB + 32 * jb + 4 * hi;
     const float* betp = GB + H + 32 * jb + 4 * hi;
+    int rng = 0;   // range check of the fp16 split: set once a value written to an operand image does not fit
 
     int iter = 0;
 #pragma unroll 1
@@ -268,7 +317,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             const int p = pos_of(rbg, nn);
             return A.eid ? A.eid[p] : p;
         };
-        if (ENC) narrow_rows_to_image<H, 4, 1>(A.e_in, A.k1, img, tid, in_row);
+        if (ENC) narrow_rows_to_image<H, 4, 1>(A.e_in, A.k1, img, RS, A.w[3], tid, in_row);
         else rows_to_image<H, 4, 8>(A.e_in, img, wave, lane, in_row, [](long long, int, floatx4&, floatx4&) {});
         __syncthreads();
 
@@ -276,8 +325,11 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
         Lin L = lin_at(wp, H);
         floatx16 acc[4];
         int pe[4], dn[4];
+        float rs[4] = {1.f, 1.f, 1.f, 1.f};   // encoder: scale of this lane's row of every row block (rides through the chain)
         if (ENC) {
-            init_bias(acc, L.bias, jb, hi);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) rs[rb] = RS[(4 * rg + rb) * 32 + n];
+            init_bias_rows(acc, L.bias, jb, hi, rs);
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) { pe[rb] = pos_of(4 * rg + rb, n); dn[rb] = 0; }
         } else {
@@ -295,21 +347,24 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                     const floatx4 a = *reinterpret_cast<const floatx4*>(pi + 8 * g);
                     const floatx4 b = *reinterpret_cast<const floatx4*>(pj + 8 * g);
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) acc[rb][4 * g + tt] = (a[tt] + b[tt]) * L.t;
+                    for (int tt = 0; tt < 4; ++tt) acc[rb][4 * g + tt] = (a[tt] + b[tt]) * L.u;
                 }
             }
         }
         gemm(acc, L.frag + (size_t)jb * KS0 * 128 + lane, imgh + (size_t)(4 * rg) * KS0 * 128 + lane, KS0, KS0);
+        check_rows(rng, acc);
         wp += lin0;
 #pragma unroll 1
         for (int l = 1; l <= A.nl; ++l) {
             __syncthreads();
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) acc_to_img<true>(acc[rb], L.inv_t, img + (size_t)(4 * rg + rb) * C::KS * 128, jb, lane);
+            for (int rb = 0; rb < 4; ++rb) acc_to_img<true>(acc[rb], img + (size_t)(4 * rg + rb) * C::KS * 128, jb, lane);
             __syncthreads();
             L = lin_at(wp, H);
-            init_bias(acc, L.bias, jb, hi);
+            if (ENC) init_bias_rows(acc, L.bias, jb, hi, rs);
+            else init_bias(acc, L.bias, jb, hi);
             gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
+            check_rows(rng, acc);
             wp += linh;
         }
         // LayerNorm
@@ -326,7 +381,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             const int rbg = 4 * rg + rb;
             const int cnt = sb[rbg].y;
             float k, m;
-            ln_merge<H>(ST, rbg, n, L.t, A.eps, k, m);
+            ln_merge<H>(ST, rbg, n, L.u * rs[rb], A.eps, k, m);
             const bool valid = n < cnt;
             const int p = pe[rb];
             const long long orow = A.eid_out ? A.eid_out[p] : p;
@@ -402,6 +457,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             }
         }
     }
+    report_range(rng, A.flags);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -425,6 +481,11 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
     const size_t lin0 = hm_lin_floats(H, K0), linh = hm_lin_floats(H, H);
 
     float* GB = reinterpret_cast<float*>(smem + HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES);   // gamma[H] | beta[H]
+    float* RS = reinterpret_cast<float*>(smem + HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES + HM_GB_BYTES);   // encoder: row scales
+    int rng = 0;
+    // decoder tail: a range violation anywhere earlier in this forward (its kernels have finished: stream order) makes the
+    // prediction NaN instead of a plausible wrong number -- a rollout then stops at its next graph build (non-finite position)
+    const bool poisoned = A.tail == 2 && A.flags && (*A.flags & ERRF_SPLIT_RANGE) != 0;
     if (MODE != 2) {
         for (int i = tid; i < H; i += HM_THREADS) { GB[i] = A.ln_g[i]; GB[H + i] = A.ln_b[i]; }
     }
@@ -441,17 +502,28 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
         __syncthreads();   // the previous tile's readers of the image are done
         floatx16 acc[RBW];
         Lin L;
-        if (MODE == 0) narrow_rows_to_image<H, RBW, 2>(A.x_in, A.k1, img, tid, row_of);
+        float rs[RBW];
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) rs[rb] = 1.f;
+        if (MODE == 0) narrow_rows_to_image<H, RBW, 2>(A.x_in, A.k1, img, RS, A.w[3], tid, row_of);
         else rows_to_image<H, RBW, 2 * RBW>(A.x_in, img, wave, lane, row_of, [](long long, int, floatx4&, floatx4&) {});
         __syncthreads();
         if (MODE != 2) {
             const float* wp = A.w;
             L = lin_at(wp, H);
-            init_bias(acc, L.bias, jb, hi);
+            if (MODE == 0) {
+#pragma unroll
+                for (int rb = 0; rb < RBW; ++rb) rs[rb] = RS[(RBW * rg + rb) * 32 + n];
+                init_bias_rows(acc, L.bias, jb, hi, rs);
+            } else {
+                init_bias(acc, L.bias, jb, hi);
+            }
             if (MODE == 0) {
                 gemm(acc, L.frag + (size_t)jb * 2 * 128 + lane, imgh + (size_t)(RBW * rg) * 2 * 128 + lane, 2, 2);
+                check_rows(rng, acc);
             } else {
                 gemm(acc, L.frag + (size_t)jb * 2 * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                check_rows(rng, acc);
                 __syncthreads();
                 // agg row + the head partials other groups hold of its segment, in group order (hedge.h)
                 rows_to_image<H, RBW, 2>(A.agg, img, wave, lane, row_of, [&](long long row, int f0, floatx4& v0, floatx4& v1) {
@@ -468,17 +540,20 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                 });
                 __syncthreads();
                 gemm(acc, L.frag + ((size_t)jb * 2 * C::KS + C::KS) * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                check_rows(rng, acc);
             }
             wp += lin0;
 #pragma unroll 1
             for (int l = 1; l <= A.nl; ++l) {
                 __syncthreads();
 #pragma unroll
-                for (int rb = 0; rb < RBW; ++rb) acc_to_img<true>(acc[rb], L.inv_t, img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
+                for (int rb = 0; rb < RBW; ++rb) acc_to_img<true>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
                 __syncthreads();
                 L = lin_at(wp, H);
-                init_bias(acc, L.bias, jb, hi);
+                if (MODE == 0) init_bias_rows(acc, L.bias, jb, hi, rs);
+                else init_bias(acc, L.bias, jb, hi);
                 gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                check_rows(rng, acc);
                 wp += linh;
             }
             ln_publish<H, RBW>(acc, ST, rg, jb, n, hi);
@@ -487,7 +562,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             for (int rb = 0; rb < RBW; ++rb) {
                 const int rbg = RBW * rg + rb;
                 float k, m;
-                ln_merge<H>(ST, rbg, n, L.t, A.eps, k, m);
+                ln_merge<H>(ST, rbg, n, L.u * rs[rb], A.eps, k, m);
                 const int r = row0 + 32 * rbg + n;
                 const bool valid = r < N;
                 const size_t off = (size_t)(valid ? r : N - 1) * H + 32 * jb + 4 * hi;
@@ -514,7 +589,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             if (A.tail == 0) continue;
             // the new h becomes the tail's input image (every wave has passed the barrier after the last Linear)
 #pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) acc_to_img<false>(acc[rb], 1.0f, img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
+            for (int rb = 0; rb < RBW; ++rb) acc_to_img<false>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
             __syncthreads();
         }
         if (A.tail == 1 || MODE == 2) {
@@ -524,6 +599,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                 const int jbv = jb + half * C::NJB;
                 init_bias(acc, LP.bias, jbv, hi);
                 gemm(acc, LP.frag + (size_t)jbv * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                check_rows(rng, acc);
 #pragma unroll
                 for (int rb = 0; rb < RBW; ++rb) {
                     const int r = row0 + 32 * (RBW * rg + rb) + n;
@@ -533,7 +609,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                         for (int g = 0; g < 4; ++g) {
                             floatx4 v;
 #pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) v[tt] = acc[rb][4 * g + tt] * LP.inv_t;
+                            for (int tt = 0; tt < 4; ++tt) v[tt] = acc[rb][4 * g + tt] * LP.inv_u;
                             *reinterpret_cast<floatx4*>(pp + 8 * g) = v;
                         }
                     }
@@ -546,9 +622,10 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                 const Lin LD = lin_at(wp, H);
                 init_bias(acc, LD.bias, jb, hi);
                 gemm(acc, LD.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                check_rows(rng, acc);
                 __syncthreads();
 #pragma unroll
-                for (int rb = 0; rb < RBW; ++rb) acc_to_img<true>(acc[rb], LD.inv_t, img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
+                for (int rb = 0; rb < RBW; ++rb) acc_to_img<true>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
                 __syncthreads();
                 wp += linh;
             }
@@ -556,6 +633,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                 const Lin LO = lin_at(wp, 32);
                 init_bias(acc, LO.bias, 0, hi);
                 gemm(acc, LO.frag + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                check_rows(rng, acc);
                 if (hi == 0) {
 #pragma unroll
                     for (int rb = 0; rb < RBW; ++rb) {
@@ -563,51 +641,135 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                         if (r < N) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
-                                if (c < A.out_dim) A.dec_out[(size_t)r * A.out_dim + c] = acc[rb][c] * LO.inv_t;
+                                if (c < A.out_dim) A.dec_out[(size_t)r * A.out_dim + c] = (poisoned || rng) ? __builtin_nanf("") : acc[rb][c] * LO.inv_u;
                         }
                     }
                 }
             }
         }
     }
+    report_range(rng, A.flags);
 }
 
 // ------------------------------------------------------------------------------------------
 // weight images
 // ------------------------------------------------------------------------------------------
 struct PackHmJobs {
-    int n;
+    int n, first;   // first: index of job[0] in the whole list (stats rows)
     PackHmJob job[kPackHmMax];
 };
 
-__global__ void __launch_bounds__(256) pack_hm_kernel(PackHmJobs J) {
+__device__ __forceinline__ float hm_value(const PackHmJob& j, int o, int k) {
+    const int os = o / j.out_seg, ro = o % j.out_seg, is = k / j.k_seg, rk = k % j.k_seg;
+    if (ro >= j.out_valid || rk >= j.k_valid) return 0.f;
+    return j.W[(size_t)ro * j.ld + j.col0[os + is] + rk];
+}
+
+// phase 1: statistics of every Linear -> stats[4 job ..]: gain ||W||_F / sqrt(out) / sqrt(2) over the columns that make its
+// pre-activation, rms and maximum of the bias, maximum |W| of the packed block.  Also resets the job's row-scale cap slot.
+__global__ void __launch_bounds__(256) pack_hm_stats_kernel(PackHmJobs J, float* __restrict__ stats) {
     const PackHmJob& j = J.job[blockIdx.x];
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    auto value = [&](int o, int k) -> float {
-        const int os = o / j.out_seg, ro = o % j.out_seg, is = k / j.k_seg, rk = k % j.k_seg;
-        if (ro >= j.out_valid || rk >= j.k_valid) return 0.f;
-        return j.W[(size_t)ro * j.ld + j.col0[os + is] + rk];
-    };
-    float mx = 0.f;
-    for (int i = tid; i < j.out_pad * j.k_pad; i += 256) mx = fmaxf(mx, fabsf(value(i / j.k_pad, i % j.k_pad)));
-    red[tid] = mx;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+    float ss = 0.f, wm = 0.f;
+    if (j.gain_cols > 0) {
+        for (int i = tid; i < j.out_valid * j.gain_cols; i += 256) {
+            const float v = j.W[(size_t)(i / j.gain_cols) * j.ld + j.gain_col0 + (i % j.gain_cols)];
+            ss = fmaf(v, v, ss);
+        }
+    }
+    for (int i = tid; i < j.out_pad * j.k_pad; i += 256) {
+        const float v = hm_value(j, i / j.k_pad, i % j.k_pad);
+        if (j.gain_cols <= 0) ss = fmaf(v, v, ss);
+        wm = fmaxf(wm, fabsf(v));
+    }
+    auto reduce = [&](float v, bool is_max) {
+        red[tid] = v;
         __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] = is_max ? fmaxf(red[tid], red[tid + s]) : red[tid] + red[tid + s];
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        return r;
+    };
+    ss = reduce(ss, false);
+    wm = reduce(wm, true);
+    if (tid == 0) {
+        float bs = 0.f, bm = 0.f;
+        if (j.bias) for (int o = 0; o < j.bias_n; ++o) { bs = fmaf(j.bias[o], j.bias[o], bs); bm = fmaxf(bm, fabsf(j.bias[o])); }
+        const int outs = j.out_valid * (j.out_pad / j.out_seg);
+        float* st = stats + 4 * (J.first + blockIdx.x);
+        st[0] = sqrtf(ss / (float)(outs > 0 ? outs : 1) * 0.5f);
+        st[1] = j.bias_n > 0 ? sqrtf(bs / (float)j.bias_n) : 0.f;
+        st[2] = bm;
+        st[3] = wm;
+        j.dst[3] = 1.0e18f;   // row-scale cap (chain heads on raw features): phase 2 takes the minimum over the chain
     }
-    mx = red[0];
-    float t = 1.f;
-    if (mx > 0.f && mx < 3.0e38f) {
-        int ex;
-        (void)frexpf(mx, &ex);     // mx = f 2^ex, f in [0.5, 1)  ->  mx 2^(-ex - 1) in [0.25, 0.5)
-        int sh = -ex - 1;
-        sh = sh < -24 ? -24 : (sh > 24 ? 24 : sh);
-        t = ldexpf(1.f, sh);
+}
+
+__device__ __forceinline__ float hm_pow2_near(float want) {
+    if (!(want > 0.f) || !(want < 3.0e38f)) return 1.f;
+    int ex;
+    const float f = frexpf(want, &ex);          // want = f 2^ex, f in [0.5, 1): nearest power of two
+    int sh = f >= 0.70710678f ? ex : ex - 1;
+    sh = sh < -100 ? -100 : (sh > 100 ? 100 : sh);
+    return ldexpf(1.f, sh);
+}
+__device__ __forceinline__ float hm_pow2_floor(float want) {
+    if (!(want > 0.f) || !(want < 3.0e38f)) return 1.f;
+    int ex;
+    (void)frexpf(want, &ex);
+    int sh = ex - 1;
+    sh = sh < -100 ? -100 : (sh > 100 ? 100 : sh);
+    return ldexpf(1.f, sh);
+}
+
+// phase 2: walk the chain from its head to this Linear (scales of every predecessor from the phase-1 statistics), then pack.
+// m = estimated rms of the activations in the chain's units: a ReLU layer maps the second moment  m^2 -> gain^2 m^2 + b_rms^2 / 2
+// (zero-mean weights; the bias term is what deep chains settle on).  U_l = power of two nearest kHmTargetRms / m_l.
+__global__ void __launch_bounds__(256) pack_hm_kernel(PackHmJobs J, const PackHmJob* __restrict__ all, const float* __restrict__ stats) {
+    const PackHmJob& j = J.job[blockIdx.x];
+    __shared__ float sc[2];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int chain[24], nc = 0;
+        for (int q = J.first + blockIdx.x; q >= 0 && nc < 24; q = all[q].pred) chain[nc++] = q;
+        const int head = chain[nc - 1];
+        const bool raw = all[head].in_rms != 1.f;   // rows scaled by their own power of two (encoders): biases are the cap's business
+        float m = all[head].in_rms, U = 1.f, t = 1.f;
+        if (!(m > 0.f)) m = 1.f;
+        for (int c = nc - 1; c >= 0; --c) {
+            const float* st = stats + 4 * chain[c];
+            float m2 = st[0] * st[0] * m * m;
+            if (!raw) m2 = fmaf(0.5f * st[1], st[1], m2);
+            m = sqrtf(m2);
+            if (!(m > 1.0e-30f) || !(m < 1.0e30f)) m = 1.f;
+            float Un = hm_pow2_near(kHmTargetRms / m);
+            t = Un / U;
+            // keep the packed weights inside the window where both halves of the split are normal: max |W t| in [2^-4, 2^13]
+            const float wm = st[3];
+            if (wm > 0.f && wm < 3.0e38f) {
+                if (wm * t > 8192.0f) t = hm_pow2_floor(8192.0f / wm);
+                if (wm * t < 0.0625f) t = 2.f * hm_pow2_floor(0.0625f / wm);
+            }
+            U = U * t;
+            if (!(U > 7.9e-31f)) U = 7.9e-31f;   // float range whatever the depth
+            if (!(U < 1.2e30f)) U = 1.2e30f;
+            if (raw && st[2] > 0.f) {
+                // no row of this chain may be scaled so far that this Linear's bias leaves the range (accumulator units: U rs b)
+                const float cap = hm_pow2_floor(4096.0f / (U * st[2]));
+                atomicMin(reinterpret_cast<unsigned*>(all[head].dst + 3), __float_as_uint(cap));   // positive floats order like their bits
+            }
+        }
+        sc[0] = t;
+        sc[1] = U;
     }
-    if (tid == 0) { j.dst[0] = t; j.dst[1] = 1.f / t; j.dst[2] = 0.f; j.dst[3] = 0.f; }
-    for (int o = tid; o < j.out_pad; o += 256) j.dst[4 + o] = (j.bias && o < j.bias_n) ? j.bias[o] * t : 0.f;
+    __syncthreads();
+    const float t = sc[0], U = sc[1];
+    if (tid == 0) { j.dst[0] = t; j.dst[1] = 1.f / U; j.dst[2] = U; }
+    for (int o = tid; o < j.out_pad; o += 256) j.dst[4 + o] = (j.bias && o < j.bias_n) ? j.bias[o] * U : 0.f;
     _Float16* frag = reinterpret_cast<_Float16*>(j.dst + 4 + j.out_pad);
     const int ksn = j.k_pad / 16;
     const int entries = (j.out_pad / 32) * ksn * 64;   // (jb, ks, lane); two parts each
@@ -618,7 +780,7 @@ __global__ void __launch_bounds__(256) pack_hm_kernel(PackHmJobs J) {
         _Float16* lo_p = frag + ((size_t)((jbv * ksn + ks) * 2 + 1) * 64 + lane) * 8;
         for (int q = 0; q < 8; ++q) {
             const int k = 16 * ks + 8 * (q >> 2) + 4 * kg + (q & 3);
-            const float v = value(o, k) * t;
+            const float v = hm_value(j, o, k) * t;
             const _Float16 h = (_Float16)v;
             hi_p[q] = h;
             lo_p[q] = (_Float16)(v - (float)h);
@@ -687,13 +849,21 @@ int launch_node_h(int mode, const HmNodeArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int pack_hm(const PackHmJob* jobs, int n, hipStream_t s) {
-    for (int off = 0; off < n; off += kPackHmMax) {
-        PackHmJobs J{};
-        J.n = n - off < kPackHmMax ? n - off : kPackHmMax;
-        for (int i = 0; i < J.n; ++i) J.job[i] = jobs[off + i];
-        hipLaunchKernelGGL(pack_hm_kernel, dim3(J.n), dim3(256), 0, s, J);
-        GM_LAUNCH_CHECK();
+int pack_hm(const PackHmJob* jobs, int n, PackHmJob* jobs_dev, float* stats, hipStream_t s) {
+    if (n <= 0) return GM_OK;
+    GM_REQUIRE(stats && jobs_dev, GM_ERR_INVALID_ARGUMENT, "pack_hm: no scratch");
+    // the whole job list on the device: phase 2 walks chains across launch batches
+    GM_HIP_CHECK(hipMemcpyAsync(jobs_dev, jobs, (size_t)n * sizeof(PackHmJob), hipMemcpyHostToDevice, s));
+    for (int phase = 0; phase < 2; ++phase) {
+        for (int off = 0; off < n; off += kPackHmMax) {
+            PackHmJobs J{};
+            J.n = n - off < kPackHmMax ? n - off : kPackHmMax;
+            J.first = off;
+            for (int i = 0; i < J.n; ++i) J.job[i] = jobs[off + i];
+            if (phase == 0) hipLaunchKernelGGL(pack_hm_stats_kernel, dim3(J.n), dim3(256), 0, s, J, stats);
+            else hipLaunchKernelGGL(pack_hm_kernel, dim3(J.n), dim3(256), 0, s, J, jobs_dev, stats);
+            GM_LAUNCH_CHECK();
+        }
     }
     return GM_OK;
 }

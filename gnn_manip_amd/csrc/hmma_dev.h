@@ -4,6 +4,13 @@
 // fp16 subnormals, which v_mfma_f32_32x32x16_f16 honours -- checked on gfx950).  A product of two fp16 values is exact in
 // fp32, so  lo*hi + hi*lo + hi*hi  accumulated in fp32 reproduces the fp32 product to 2^-22.
 //
+// Domain.  hi is a normal fp16 number for 2^-14 <= |x| < 65504 and lo keeps all of its 11 bits for |x| >= 2^-3; below that
+// the pair carries an absolute error of 2^-25 (lo's subnormal spacing).  The kernels therefore keep the operand images at
+// power-of-two scales chosen from the weights (hmlp.h: rms near 2^4, so everything within 2^-7 .. 2^12 of the rms is exact to
+// 22 bits) and scale raw feature rows by their own maximum; |x| >= 65504 in an image is reported (ERRF_SPLIT_RANGE), never
+// clamped.  What is NOT covered: a row whose h / e / agg entries (LayerNorm outputs and their sums, written at their natural
+// magnitude) are all below ~2^-8 in magnitude loses relative precision, where the fp32 reference would not.
+//
 // Operand layout.  v_mfma_f32_32x32x16_f16 with A = 32 weight rows (output features) and B = 32 rows of the tile (edges or
 // nodes): lane (n, kg) = (lane & 31, lane >> 5) holds 8 halves of K.  K slot (kg, j) of k-group ks carries input feature
 //     16 ks + 8 (j >> 2) + 4 kg + (j & 3)
@@ -32,7 +39,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) { unsigned u; asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b)); return u; }
 // compiler-visible on purpose: it is the first reader of MFMA results, and hipcc pads the MFMA -> VALU hazard only for
 // instructions it knows (an inline-asm reader sees stale accumulators)
-__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 65504.f); }
+// No clamp: a value beyond the fp16 range is not saturated silently.  Every value written to an operand image is range-checked
+// by its kernel instead (ERRF_SPLIT_RANGE, common.h).
+__device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 
 // low part of a pair straight to fp16: x - hi is exact in fp32, so one rounding either way (v_fma_mixlo / mixhi write one half
 // of the destination and keep the other)

@@ -44,6 +44,7 @@ struct NodeArgs {
     const int* edge_blocks;  // mode 1: block tables whose stitch / head lists say which side-buffer rows to add to agg (hedge.h), or nullptr
     int64_t n_nodes_tab, edge_capacity_tab;
     const float* side;
+    int* err_flags;        // error flags of the forward (CsrHeader::error_flags: ERRF_SPLIT_RANGE), or nullptr
     float* h_out;          // [N][H] (may alias x_in)
     int residual;
     const float* wstream;

@@ -2,6 +2,7 @@
 #pragma once
 #include <vector>
 #include "common.h"
+#include "hmlp.h"
 
 struct gm_model {
     gm_model_desc d;
@@ -14,6 +15,10 @@ struct gm_model {
     float* packed_b3 = nullptr;  // bf16 x 3 operand image of the processor edge MLPs (hidden 128): [M][3 layers][4 stages]
     float* packed_h3 = nullptr;  // fp16 hi / lo image of the processor edge MLPs for the systolic kernel (hedge.h): [M][h3_image_floats]
     float* packed_hm = nullptr;  // fp16 hi / lo image of every Linear (hmlp.h)
+    std::vector<gm::PackHmJob> hm_jobs;   // the pack job list of the last weight load (host copy of hm_jobs_dev)
+    void* hm_jobs_dev = nullptr;
+    float* hm_stats = nullptr;
+    size_t hm_jobs_cap = 0;
     size_t hm_floats = 0, hm_enc_edge = 0, hm_enc_node = 0, hm_enc_node_tail = 0;
     std::vector<size_t> hm_edge, hm_node, hm_node_tail;
     bool legacy = false;         // hidden 128 / 256 with num_layers 2: the fp32 images (packed) exist

@@ -78,44 +78,58 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
     auto b_edge = [&](int k) { return (2 + 2 * k) * PM; };
     auto b_node = [&](int k) { return (3 + 2 * k) * PM; };
 
-    if (m->packed_hm) {   // fp16 hi / lo images of every Linear (hmlp.h)
-        std::vector<PackHmJob> jobs;
+    if (m->packed_hm) {   // fp16 hi / lo images of every Linear (hmlp.h); consecutive Linears of an MLP form a scale chain
+        std::vector<PackHmJob>& jobs = m->hm_jobs;
+        jobs.clear();
+        int prev = -1;   // job whose output feeds the next lin() (-1: the next one heads a chain)
+        float head_rms = 1.f;
         auto lin = [&](int ti, int ld, int col0a, int col0b, int out_valid, int out_pad, int out_seg, int k_valid, int k_pad, int k_seg,
-                       bool with_bias, int bias_n, size_t& off) {
+                       bool with_bias, int bias_n, size_t& off, int gain_col0 = 0, int gain_cols = 0) {
             PackHmJob j{};
             j.W = T[ti]; j.ld = ld; j.bias = with_bias ? T[ti + 1] : nullptr; j.bias_n = bias_n;
             j.out_valid = out_valid; j.out_pad = out_pad; j.out_seg = out_seg;
             j.k_valid = k_valid; j.k_pad = k_pad; j.k_seg = k_seg; j.col0[0] = col0a; j.col0[1] = col0b;
+            j.pred = prev; j.in_rms = head_rms; j.gain_col0 = gain_col0; j.gain_cols = gain_cols;
             j.dst = m->packed_hm + off;
             off += hm_lin_floats(out_pad, k_pad);
+            prev = (int)jobs.size();
             jobs.push_back(j);
         };
+        auto head = [&](float rms) { prev = -1; head_rms = rms; };
         auto hh = [&](int ti, size_t& off) { lin(ti, H, 0, 0, H, H, H, H, H, H, true, H, off); };
         auto hidden = [&](int base, size_t& off) { for (int l = 1; l <= NL; ++l) hh(base + 2 * l, off); };
-        auto proj = [&](int k, size_t& off) {   // P = h [W_i | W_j]^T + [b1 | 0] of processor step k
+        auto proj = [&](int k, size_t& off) {   // P = h [W_i | W_j]^T + [b1 | 0] of processor step k: a chain of its own (input h)
+            head(1.f);
             lin(b_edge(k), 3 * H, m->ci * H, m->cj * H, H, 2 * H, H, H, H, H, true, H, off);
         };
         size_t off = m->hm_enc_edge;
+        head(kHmRawInputRms);   // raw edge features: per-row power-of-two scale in the kernel
         lin(b_enc_edge, m->d.edge_dim, 0, 0, H, H, H, m->d.edge_dim, 16, 16, true, H, off);
         hidden(b_enc_edge, off);
         off = m->hm_enc_node;
+        head(kHmRawInputRms);
         lin(b_enc_node, m->d.node_dim, 0, 0, H, H, H, m->d.node_dim, 32, 32, true, H, off);
         hidden(b_enc_node, off);
         proj(0, off);
         for (int k = 0; k < M; ++k) {
             off = m->hm_edge[k];
-            lin(b_edge(k), 3 * H, m->ce * H, 0, H, H, H, H, H, H, false, 0, off);   // the e block; b1 lives in P_i
+            head(1.f);
+            // the e block; b1 lives in P_i.  Its pre-activation also takes h_i and h_j: the gain is that of the whole [H x 3H] Linear
+            lin(b_edge(k), 3 * H, m->ce * H, 0, H, H, H, H, H, H, false, 0, off, 0, 3 * H);
             hidden(b_edge(k), off);
             off = m->hm_node[k];
+            head(1.f);
             lin(b_node(k), 2 * H, m->ch * H, m->ca * H, H, H, H, H, 2 * H, H, true, H, off);
             hidden(b_node(k), off);
             if (k + 1 < M) proj(k + 1, off);
             else {
+                head(1.f);
                 for (int l = 0; l < NL; ++l) hh(b_dec + 2 * l, off);
                 lin(b_dec + 2 * NL, H, 0, 0, m->d.out_dim, 32, 32, H, H, H, true, m->d.out_dim, off);
             }
         }
-        rc = pack_hm(jobs.data(), (int)jobs.size(), s);
+        GM_REQUIRE(jobs.size() <= m->hm_jobs_cap, GM_ERR_INVALID_ARGUMENT, "model: %zu pack jobs, room for %zu", jobs.size(), m->hm_jobs_cap);
+        rc = pack_hm(jobs.data(), (int)jobs.size(), static_cast<PackHmJob*>(m->hm_jobs_dev), m->hm_stats, s);
         if (rc != GM_OK) return rc;
     }
 
@@ -226,7 +240,7 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
             PackH3Job& j = jobs[(size_t)k];
             const int b = b_edge(k);
             j.W1 = T[b]; j.W1_col0 = m->ce * H; j.W2 = T[b + 2]; j.W3 = T[b + 4];
-            j.b2 = T[b + 3]; j.b3 = T[b + 5];
+            j.b1 = T[b + 1]; j.b2 = T[b + 3]; j.b3 = T[b + 5];
             j.gamma = T[b + 6]; j.beta = T[b + 7];
             j.dst = m->packed_h3 + (size_t)k * h3_image_floats();
         }
@@ -324,7 +338,10 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             m->hm_node_tail[k] = o; o += k + 1 < M ? pj : NL * hh + hm_lin_floats(32, H);
         }
         m->hm_floats = o;
-        if (hipMalloc(&m->packed_hm, m->hm_floats * sizeof(float)) != hipSuccess) {
+        m->hm_jobs_cap = (size_t)(2 + 2 * M) * (NL + 1) + M + NL + 1 + 4;
+        if (hipMalloc(&m->packed_hm, m->hm_floats * sizeof(float)) != hipSuccess ||
+            hipMalloc(&m->hm_jobs_dev, m->hm_jobs_cap * sizeof(PackHmJob)) != hipSuccess ||
+            hipMalloc(&m->hm_stats, m->hm_jobs_cap * 4 * sizeof(float)) != hipSuccess) {
             gm::set_error("gm_model_create: hipMalloc failed");
             gm_model_destroy(m);
             return GM_ERR_HIP;
@@ -387,6 +404,8 @@ void gm_model_destroy(gm_model* m) {
     if (m->packed_b3) hipFree(m->packed_b3);
     if (m->packed_h3) hipFree(m->packed_h3);
     if (m->packed_hm) hipFree(m->packed_hm);
+    if (m->hm_jobs_dev) hipFree(m->hm_jobs_dev);
+    if (m->hm_stats) hipFree(m->hm_stats);
     if (m->vec) hipFree(m->vec);
     delete m->prof;
     delete m;
@@ -473,6 +492,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     na.n_nodes = (int)n; na.x_in = nodes; na.k1 = m->d.node_dim; na.h_out = f.h;
     na.wstream = m->packed ? m->packed + m->s_enc_node : nullptr;
     na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel; na.prof = m->prof;
+    na.err_flags = &c.hdr->error_flags;
     const float* v = m->vec + m->v_enc_node;
     na.bias = v; na.ln_g = v + (size_t)(NL + 1) * H; na.ln_b = v + (size_t)(NL + 2) * H; na.eps = m->d.ln_eps;
     set_tail(m, na, 0, f.P, out);
@@ -490,6 +510,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
         // sys / hm kernels store every row with in-edges whole (rows without keep the zeros of the memset above)
         a.agg_clear = (legacy_kernels && k + 1 < M) ? f.agg : nullptr;
         a.edge_blocks = c.blocks; a.n_nodes_tab = n; a.edge_capacity_tab = cap; a.side = f.side;
+        a.err_flags = &c.hdr->error_flags;
         a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
         a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel; a.prof = m->prof;
         const float* vn = m->vec + m->v_node[k];
@@ -541,6 +562,7 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
                  : k == 0   ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
                             : m->packed + m->s_node[k - 1] + (size_t)((NL + 2) * m->S_HH) * kStageFloats;
     pa.kernel_choice = m->edge_kernel; pa.prof = m->prof;
+    pa.err_flags = &c.hdr->error_flags;
     set_tail(m, pa, k, f.P, nullptr);
     int rc = launch_node(H, NL, 2, pa, s);
     if (rc != GM_OK) return rc;
@@ -550,6 +572,7 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     NodeArgs a{};
     a.n_nodes = (int)n; a.x_in = h; a.agg = f.agg; a.h_out = h_out; a.residual = 0;
     a.edge_blocks = c.blocks; a.n_nodes_tab = n; a.edge_capacity_tab = cap; a.side = f.side;
+    a.err_flags = &c.hdr->error_flags;
     a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
     a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel; a.prof = m->prof;
     const float* vn = m->vec + m->v_node[k];

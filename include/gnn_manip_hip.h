@@ -147,6 +147,18 @@ int gm_rigid_transform(const float* rigid_init /*[Nr,3]*/, int64_t n_rigid, cons
  * encoder.phi_node.*, processor.k.phi_edge.*, processor.k.phi_node.*, decoder.*; inside an MLP:
  * Linear weight [out,in] row-major, bias, ..., LayerNorm weight, bias).  They are copied and
  * repacked into the MFMA operand image; the caller's tensors are not referenced afterwards.
+ *
+ * Numeric domain.  The reference computes every Linear in float32.  The inference kernels form the same float32 products
+ * on the fp16 matrix pipe: each operand is a pair of fp16 numbers (22 significant bits), three exact partial products per
+ * multiply, float32 accumulation.  An fp16 pair represents |x| < 65504 and keeps full precision down to 2^-3, so the
+ * kernels hold every operand at a power-of-two scale chosen from the weights (nothing is rounded by it): hidden
+ * activations ride at an rms near 2^4 (4096-fold headroom) whatever the scale of the weights -- scaling (W_l, b_l) by s and W_(l+1) by 1/s
+ * changes no operand bit -- and each raw node / edge feature row is scaled by its own maximum, so features of any
+ * magnitude (1e-30 .. 1e30) are as accurate as in float32.  Latents (h, e, agg: LayerNorm outputs and their sums) enter at
+ * their natural magnitude: fine from ~2^-8 to 65504.  A value outside the representable range is never clamped: the
+ * kernel that meets it sets a flag in the CSR header of that forward and gm_csr_num_edges / gm_rollout_status return
+ * GM_ERR_DATA ("fp16 split range exceeded"); the outputs of that forward are then invalid.  A float32 evaluation would
+ * also stay finite for magnitudes up to 3.4e38: that part of its domain is not covered.
  * ------------------------------------------------------------------------------------------ */
 typedef struct gm_model_desc {
     int32_t node_dim, edge_dim, out_dim;

@@ -1,0 +1,151 @@
+"""Numeric domain of the fp16-split matrix-pipe kernels (include/gnn_manip_hip.h, "Numeric domain"): the reference computes in
+plain float32 (epd_gnn.py:72-84), so a function-preserving rescaling of the weights, or features of very different magnitude,
+must not change the 1e-5 parity bar.  What cannot be represented is reported (status() raises, predictions are NaN), never
+clamped."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import BOUNDS, CART, CTRL, MAT, STATS
+from oracle import epd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(stats=STATS, bounds=BOUNDS, conn_r=0.015, cartesian_idx=CART, material_idx=MAT)
+MLPS = ["encoder.phi_edge", "encoder.phi_node", "processor.0.phi_edge", "processor.1.phi_node", "decoder"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _model(params, dims, dev, kernel):
+    from gnn_manip_amd import EncProcDecGNN
+    m = EncProcDecGNN(*dims)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.to(dev)
+    m.set_edge_kernel(kernel)
+    return m
+
+
+@pytest.fixture(scope="module")
+def graph():
+    from gnn_manip_amd import scene
+    obs = scene.make_scene(600, seed=31, side=0.07)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    return nodes, ea, np.stack((s, r))
+
+
+def _rel(out, ref):
+    return np.abs(out - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.mark.parametrize("hidden,kernel", [(128, "sys"), (128, "hm"), (64, "hm"), (256, "hm")])
+@pytest.mark.parametrize("log2s", [-12, -6, 6, 12])
+def test_weight_rescaling_between_linears_is_immaterial(dev, graph, hidden, kernel, log2s):
+    """A ReLU MLP is positively homogeneous: (W_l, b_l) * s with W_(l+1) / s is the same function (for a power of two s, bit
+    for bit in float32).  The hidden activations between the two Linears are s times larger or smaller -- 2^-12 .. 2^12 --
+    which the operand scales must absorb: same 1e-5 bar against the oracle for every MLP of the model and both pairs of
+    Linears, and the oracle itself must not move."""
+    nodes, ea, ei = graph
+    nl, ms = 2, 2
+    base = orc.init_params(25, 4, 3, hidden, nl, ms, 300 + hidden)
+    ref0 = orc.epd_forward(base, nodes, ea, ei, nl, ms)
+    s = np.float32(2.0 ** log2s)
+    worst = 0.0
+    for mlp in MLPS:
+        for l in range(nl):
+            p = {k: v.copy() for k, v in base.items()}
+            p[f"{mlp}.{2 * l}.weight"] *= s
+            p[f"{mlp}.{2 * l}.bias"] *= s
+            p[f"{mlp}.{2 * l + 2}.weight"] /= s
+            ref = orc.epd_forward(p, nodes, ea, ei, nl, ms)
+            assert _rel(ref, ref0) <= 2e-6, (mlp, l)          # the function is unchanged (float32 oracle: rounding only)
+            m = _model(p, (25, 4, 3, hidden, nl, ms), dev, kernel)
+            with torch.no_grad():
+                out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+            assert m.status() == ei.shape[1]
+            err = _rel(out, ref)
+            worst = max(worst, err)
+            assert err <= 1e-5, (mlp, l, err)
+
+
+@pytest.mark.parametrize("hidden,kernel", [(128, "sys"), (64, "hm"), (256, "hm")])
+@pytest.mark.parametrize("c", [1e-6, 1e-3, 1e3, 1e4])
+def test_feature_magnitude_is_immaterial(dev, graph, hidden, kernel, c):
+    """Raw node and edge features of magnitude c (with the encoders' first Linears scaled by 1 / c: the same function) go
+    through the per-row power-of-two scale of the encoder kernels: 1e-5 against the float32 oracle for c = 1e-6 .. 1e4."""
+    nodes, ea, ei = graph
+    nl, ms = 2, 2
+    p = orc.init_params(25, 4, 3, hidden, nl, ms, 400 + hidden)
+    c32 = np.float32(c)
+    p["encoder.phi_node.0.weight"] = (p["encoder.phi_node.0.weight"] / c32).astype(np.float32)
+    p["encoder.phi_edge.0.weight"] = (p["encoder.phi_edge.0.weight"] / c32).astype(np.float32)
+    nodes_c, ea_c = (nodes * c32).astype(np.float32), (ea * c32).astype(np.float32)
+    ref = orc.epd_forward(p, nodes_c, ea_c, ei, nl, ms)
+    m = _model(p, (25, 4, 3, hidden, nl, ms), dev, kernel)
+    with torch.no_grad():
+        out = m.forward(_t(nodes_c, dev), _t(ea_c, dev), _t(ei, dev)).cpu().numpy()
+    assert m.status() == ei.shape[1]
+    assert _rel(out, ref) <= 1e-5, _rel(out, ref)
+
+
+def test_rows_of_very_different_magnitude(dev, graph):
+    """Every raw feature row gets its own scale: rows whose features differ by ten orders of magnitude inside one tile (and an
+    all-zero row) are each as accurate as in float32."""
+    nodes, ea, ei = graph
+    rng = np.random.Generator(np.random.PCG64(5))
+    p = orc.init_params(25, 4, 3, 128, 2, 2, 500)
+    nodes_s = (nodes * (10.0 ** rng.uniform(-6, 4, (nodes.shape[0], 1)))).astype(np.float32)
+    ea_s = (ea * (10.0 ** rng.uniform(-6, 4, (ea.shape[0], 1)))).astype(np.float32)
+    nodes_s[7] = 0.0
+    ea_s[11] = 0.0
+    ref = orc.epd_forward(p, nodes_s, ea_s, ei, 2, 2)
+    for kernel in ("sys", "hm"):
+        m = _model(p, (25, 4, 3, 128, 2, 2), dev, kernel)
+        with torch.no_grad():
+            out = m.forward(_t(nodes_s, dev), _t(ea_s, dev), _t(ei, dev)).cpu().numpy()
+        assert m.status() == ei.shape[1]
+        assert _rel(out, ref) <= 1e-5, (kernel, _rel(out, ref))
+
+
+@pytest.mark.parametrize("kernel", ["sys", "hm"])
+def test_unrepresentable_latents_are_reported_not_clamped(dev, graph, kernel):
+    """Latents enter the operand images at their natural magnitude: a LayerNorm gain of 1e6 in the node encoder puts |h| beyond
+    65504.  The float32 reference would stay finite; here the forward must say so -- status() raises, the prediction is NaN --
+    instead of returning saturated numbers."""
+    from gnn_manip_amd._lib import GMError
+    nodes, ea, ei = graph
+    p = orc.init_params(25, 4, 3, 128, 2, 2, 600)
+    p["encoder.phi_node.5.weight"] = (p["encoder.phi_node.5.weight"] * np.float32(1e6)).astype(np.float32)
+    m = _model(p, (25, 4, 3, 128, 2, 2), dev, kernel)
+    with torch.no_grad():
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+    with pytest.raises(GMError, match="fp16 split range"):
+        m.status()
+    assert torch.isnan(out).all()
+    # a healthy forward afterwards is clean again
+    q = orc.init_params(25, 4, 3, 128, 2, 2, 600)
+    m2 = _model(q, (25, 4, 3, 128, 2, 2), dev, kernel)
+    with torch.no_grad():
+        out2 = m2.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    assert m2.status() == ei.shape[1] and np.isfinite(out2).all()
+
+
+def test_deep_mlp_scales_stay_in_range(dev, graph):
+    """num_layers = 8 (nine Linears per MLP): the ridden scales are chosen from each Linear's gain, so the operand images stay in
+    range however deep the chain; hidden 64, streamed kernels, against the oracle."""
+    nodes, ea, ei = graph
+    p = orc.init_params(25, 4, 3, 64, 8, 1, 700)
+    ref = orc.epd_forward(p, nodes, ea, ei, 8, 1)
+    m = _model(p, (25, 4, 3, 64, 8, 1), dev, "hm")
+    with torch.no_grad():
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+    assert m.status() == ei.shape[1]
+    assert _rel(out, ref) <= 2e-5, _rel(out, ref)
