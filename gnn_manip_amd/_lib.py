@@ -119,24 +119,28 @@ def check(status):
         raise GMError(status, msg.decode() if msg else "unknown error")
 
 
-_last_device = None
+import threading
+
+_tls = threading.local()   # per host thread: two Python threads may drive two GPUs
 
 
 def ptr(t):
     """Device (or host) address of a contiguous torch tensor, or None."""
-    global _last_device
     if t is None:
         return None
     assert t.is_contiguous(), "libgnnmanip_hip needs contiguous tensors"
     if t.is_cuda:
-        _last_device = t.device
+        _tls.device = t.device
     return C.c_void_p(t.data_ptr())
 
 
 def current_stream(device=None):
-    """hipStream_t of torch's current stream on `device`; default: the device of the last tensor handed to ptr() --
-    i.e. of the tensors of the call being assembled (the stream argument comes last in every entry point).  The library
-    itself switches to the device that owns its pointer arguments (DevGuard in csrc/common.h)."""
+    """hipStream_t of torch's current stream on `device` (a torch.device or a CUDA tensor).  Without an argument: the device of
+    the last CUDA tensor THIS THREAD handed to ptr() -- the tensors of the call being assembled (the stream argument comes
+    last in every entry point); call sites that may pass only host / null pointers give the device explicitly.  The
+    library itself switches to the device that owns its pointer arguments (DevGuard in csrc/common.h)."""
     import torch
-    dev = device if device is not None else _last_device
+    if device is not None and not isinstance(device, torch.device):
+        device = device.device
+    dev = device if device is not None else getattr(_tls, "device", None)
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

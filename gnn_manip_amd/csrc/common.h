@@ -123,7 +123,8 @@ GraphWs carve_graph(void* ws, int64_t n, int max_nb);
 struct CsrHeader {
     int n_edges;
     int error_flags;
-    int pad[2];
+    int flow;      // 0: dst = edge_index[1] (receiver), src = edge_index[0] (sender); 1: the other way round
+    int pad;
 };
 struct CsrWs {
     CsrHeader* hdr;

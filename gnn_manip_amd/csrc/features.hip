@@ -87,14 +87,16 @@ __global__ void __launch_bounds__(256) edge_features_kernel(const float* __restr
     edge_feat(pos, stride, snd[i], rcv[i], cr, out + i * 4);
 }
 
-// same values, destination-sorted order: sender = src[p] (edge_index[0]), receiver = dst[p]
+// same values, destination-sorted order.  The feature is (p_sender - p_receiver) / r with sender = edge_index[0]: that is
+// src[p] -> dst[p] for flow 0 and dst[p] -> src[p] for flow 1 (the header records which row the structure aggregates at)
 __global__ void __launch_bounds__(256) edge_features_csr_kernel(const float* __restrict__ pos, int64_t stride,
                                                                  const CsrHeader* __restrict__ hdr,
                                                                  const int* __restrict__ src, const int* __restrict__ dst,
                                                                  float cr, float* __restrict__ out) {
     const int e = hdr->n_edges;
+    const bool swap = hdr->flow != 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x)
-        edge_feat(pos, stride, src[i], dst[i], cr, out + i * 4);
+        edge_feat(pos, stride, swap ? dst[i] : src[i], swap ? src[i] : dst[i], cr, out + i * 4);
 }
 
 // rollout_utils.py:145-158

@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(256) emit_edges_kernel(const int* __restrict__
 // destination-sorted structure
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) csr_clear_kernel(CsrHeader* hdr, int* __restrict__ in_ptr, int* __restrict__ cursor,
-                                                         int64_t n1) {
+                                                         int64_t n1, int flow) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) {
         in_ptr[i] = 0;
@@ -619,6 +619,8 @@ __global__ void __launch_bounds__(256) csr_clear_kernel(CsrHeader* hdr, int* __r
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr->n_edges = 0;
         hdr->error_flags = 0;
+        hdr->flow = flow;
+        hdr->pad = 0;
     }
 }
 
@@ -885,7 +887,7 @@ int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* c
     hipStream_t s = (hipStream_t)stream;
     {
         int cb = (int)cdiv(n + 1, 256);
-        hipLaunchKernelGGL(csr_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, c.hdr, c.in_ptr, c.cursor, n + 1);
+        hipLaunchKernelGGL(csr_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, c.hdr, c.in_ptr, c.cursor, n + 1, flow);
     }
     if (n > 0) {
         unsigned nb = (unsigned)cdiv(cap, 256);
@@ -919,7 +921,7 @@ int gm_csr_from_edge_index_flow(const int64_t* ei, int64_t n, int64_t e, int flo
     hipStream_t s = (hipStream_t)stream;
     {
         int cb = (int)cdiv(n + 1, 256);
-        hipLaunchKernelGGL(csr_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, c.hdr, c.in_ptr, c.cursor, n + 1);
+        hipLaunchKernelGGL(csr_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, c.hdr, c.in_ptr, c.cursor, n + 1, flow);
     }
     if (e > 0) {
         unsigned nb = (unsigned)cdiv(e, 256);

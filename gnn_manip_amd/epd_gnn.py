@@ -455,6 +455,8 @@ class EncProcDecGNN(nn.Module):
         """gm_model* for the current parameters on `device` (packed once, re-packed on change)."""
         return self._handle.get(self.model_desc(), list(self.parameters()), device)
 
+    auto_status = True   # check the previous inference forward's device-side error flags at the start of the next one
+
     EDGE_KERNELS = {"auto": 0, "16": 1, "classic": 2, "b3": 3, "b3p": 4, "sys": 5, "hm": 6}
 
     def profile(self, kind_mask):
@@ -496,6 +498,13 @@ class EncProcDecGNN(nn.Module):
                                           "(they are data in train_dyn.py); detach them")
             _check_edge_index(edge_index, n, e)
             return _EpdTrainFunction.apply(self, nodes, edge_attr, edge_index, *params)
+        if self.auto_status:
+            # the PREVIOUS inference forward of this model: a device-side error of it (edge_index entry out of range, fp16
+            # split range exceeded) surfaces here at the latest -- a reference-style caller never calls status() itself.
+            # One header read-back; by now that forward has normally finished.  (model.auto_status = False opts out.)
+            prev, self._last_csr = getattr(self, "_last_csr", None), None
+            if prev is not None:
+                prev.validate()
         h = self.device_handle(nodes.device)
         csr = DstCsr(edge_index, n, flow=self.convention[0])
         L = lib()
@@ -505,7 +514,7 @@ class EncProcDecGNN(nn.Module):
         check(L.gm_epd_forward(h, ptr(nodes), n, ptr(edge_attr), 0, ptr(csr.ws), e, ptr(out), ptr(fwd),
                                fwd.numel(), current_stream()))
         # no synchronisation here: an out-of-range edge_index entry is dropped by the destination sort and flagged in the
-        # CSR header; status() reports it
+        # CSR header, like a value outside the fp16 split range; status() -- or the next forward -- reports it
         self._last_csr = csr
         return out
 
@@ -513,7 +522,13 @@ class EncProcDecGNN(nn.Module):
         """Checks the last inference forward (synchronises): raises GMError if its edge_index held an entry outside
         [0, n_nodes) -- such edges were left out --, else returns its edge count."""
         csr = getattr(self, "_last_csr", None)
-        return csr.validate() if csr is not None else 0
+        if csr is None:
+            return 0
+        try:
+            return csr.validate()
+        except Exception:
+            self._last_csr = None   # reported once
+            raise
 
     # the reference's per-step helper, kept for API parity (epd_gnn.py:100-105)
     def _process(self, in_module, prev_latent_node, prev_latent_edge, edge_index):

@@ -88,7 +88,8 @@ int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream);
  * Features.
  * gm_edge_features      replaces get_edges_displacement   gnn_manip/utils/utils.py:43-61
  *                       out[e] = [(p[s]-p[r])/conn_r, ||.||], reference edge order.
- * gm_edge_features_csr  same values in the destination-sorted order of a csr workspace.
+ * gm_edge_features_csr  same values in the destination-sorted order of a csr workspace (sender = edge_index[0] whatever
+ *                       `flow` the workspace was built with: the header records it).
  * gm_node_features      replaces GraphBoundedMultimaterial(Control).compute_nodes
  *                       gnn_manip/utils/collate_utils.py:195-208,217-232 (+ get_nodes_vel,
  *                       utils.py:27-40).  obs: [k, N, D] float32 row-major.

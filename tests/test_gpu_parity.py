@@ -166,13 +166,23 @@ def test_bad_edge_index_raises(dev):
     m = EncProcDecGNN(25, 4, 3, 128, 2, 2).to(dev)
     with torch.no_grad():
         out = m.forward(torch.randn(3, 25, device=dev), torch.randn(3, 4, device=dev), ei)
+        assert torch.isfinite(out).all()
+        # a caller that never asks: the error of the previous forward surfaces at the start of the next one
+        with pytest.raises(GMError, match="out of range"):
+            m.forward(torch.zeros(3, 25, device=dev), torch.zeros(2, 4, device=dev), ei[:, :2].contiguous())
         good = m.forward(torch.zeros(3, 25, device=dev), torch.zeros(2, 4, device=dev), ei[:, :2].contiguous())
-    assert torch.isfinite(out).all() and torch.isfinite(good).all()
-    assert m.status() == 2          # the second (valid) forward
+    assert torch.isfinite(good).all()
+    assert m.status() == 2          # the valid forward
     with torch.no_grad():
         m.forward(torch.zeros(3, 25, device=dev), torch.zeros(3, 4, device=dev), ei)
     with pytest.raises(GMError, match="out of range"):
         m.status()
+    # opting out restores the fire-and-forget behaviour: nothing is checked until status()
+    m.auto_status = False
+    with torch.no_grad():
+        m.forward(torch.zeros(3, 25, device=dev), torch.zeros(3, 4, device=dev), ei)
+        good = m.forward(torch.zeros(3, 25, device=dev), torch.zeros(2, 4, device=dev), ei[:, :2].contiguous())
+    assert m.status() == 2
 
 
 # ------------------------------------------------------------------ K4-K9 model
@@ -678,3 +688,26 @@ def test_scatter_add_is_deterministic_with_hub_nodes(dev, kernel):
         h1, e1, _ = m.processor[0](_t(h0, dev), _t(e0, dev), _t(ei, dev))
     h1o, e1o = orc.interaction_network(params, "processor.0", h0, e0, ei, 2)
     np.testing.assert_allclose(h1.cpu().numpy(), h1o, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("flow", [0, 1])
+def test_edge_features_csr_is_flow_aware(dev, flow):
+    """gm_edge_features_csr on a structure built with either aggregation row returns the reference feature
+    (p_sender - p_receiver) / r, sender = edge_index[0] (utils.py:43-61) -- the same rows as gm_edge_features, in sorted order."""
+    import ctypes as C
+    from gnn_manip_amd._lib import check, current_stream, lib, ptr
+    rng = np.random.Generator(np.random.PCG64(17))
+    n, e = 300, 2500
+    pos = rng.random((n, 3)).astype(np.float32)
+    ei = rng.integers(0, n, size=(2, e)).astype(np.int64)
+    L = lib()
+    tp, tei = _t(pos, dev), _t(ei, dev)
+    ws = torch.empty(L.gm_csr_workspace_bytes(n, e), dtype=torch.uint8, device=dev)
+    check(L.gm_csr_from_edge_index_flow(ptr(tei), n, e, flow, ptr(ws), ws.numel(), current_stream(dev)))
+    out_csr = torch.empty((e, 4), dtype=torch.float32, device=dev)
+    check(L.gm_edge_features_csr(ptr(tp), 3, ptr(ws), n, e, 0.015, ptr(out_csr), current_stream(dev)))
+    out_ref = torch.empty((e, 4), dtype=torch.float32, device=dev)
+    check(L.gm_edge_features(ptr(tp), 3, ptr(tei[0].contiguous()), ptr(tei[1].contiguous()), e, 0.015, ptr(out_ref), current_stream(dev)))
+    a, b = out_csr.cpu().numpy(), out_ref.cpu().numpy()
+    np.testing.assert_array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])   # same rows, another order
+    np.testing.assert_allclose(b, orc.get_edges_displacement(pos, ei[0], ei[1], 0.015), rtol=2e-7, atol=0)
