@@ -44,6 +44,7 @@ _FD, _MD = C.POINTER(FeatureDesc), C.POINTER(ModelDesc)
 PROTOTYPES = {
     "gm_last_error": (C.c_char_p, []),
     "gm_abi_version": (_i32, []),
+    "gm_padded_hidden_size": (_i32, [_i32]),
     "gm_graph_workspace_bytes": (_sz, [_i64, _i32]),
     "gm_radius_graph_build": (_i32, [_vp, _i64, _i64, _f64, _i32, _vp, _sz, _vp]),
     "gm_radius_graph_build_batched": (_i32, [_vp, _i64, _i64, _i64, _f64, _i32, _vp, _sz, _vp]),

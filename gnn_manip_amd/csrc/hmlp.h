@@ -63,6 +63,7 @@ struct HmEdgeArgs {
     int residual;
     int k1;
     int nl;               // num_layers: nl + 1 Linears
+    int h_valid;          // features that exist (multiple of 32, <= H): the rest of the width is zero padding
     const int2* blk;      // processor: 32-edge block table (hedge.h)
     const int* head;      // processor: head list of the groups
     float* side;          // processor: [n_groups][H] head partials
@@ -84,6 +85,7 @@ struct HmNodeArgs {
     const float* ln_b;
     float eps;
     int nl;
+    int h_valid;          // features that exist (multiple of 32, <= H)
     int tail;             // 0 none, 1 projection P = h [W_i | W_j]^T (+ b1), 2 decoder
     const float* w_tail;  // tail 1: one Linear image (2H outputs); tail 2: nl images H -> H, then H -> 32 (zero-padded)
     float* P_out;
@@ -98,6 +100,8 @@ struct HmNodeArgs {
 };
 
 bool hm_supported(int H);
+// width the kernels run a model of hidden size h at: h zero-padded to 64 / 128 / 256 (multiples of 32 up to 256), else 0
+static inline int hm_padded_hidden(int h) { return (h < 32 || h > 256 || (h & 31)) ? 0 : (h <= 64 ? 64 : (h <= 128 ? 128 : 256)); }
 int launch_edge_hm(int H, bool enc, const HmEdgeArgs& a, hipStream_t s);
 int launch_node_hm(int H, int mode, const HmNodeArgs& a, hipStream_t s);
 

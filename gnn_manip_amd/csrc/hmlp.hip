@@ -242,25 +242,26 @@ __device__ __forceinline__ void ln_publish(const floatx16 (&acc)[RBW], float* ST
         *reinterpret_cast<float2v*>(ST + ((((RBW * rg + rb) * 2 * C::NJB) + 2 * jb + hi) * BE + n) * 2) = float2v{mh, q};
     }
 }
+// hv: the features that exist (a multiple of 32 <= H): the partials of the padded 32-feature blocks are left out
 template <int H>
-__device__ __forceinline__ void ln_merge(const float* ST, int rbg, int n, float t, float eps, float& k, float& m) {
+__device__ __forceinline__ void ln_merge(const float* ST, int rbg, int n, float t, float eps, int hv, float& k, float& m) {
     using C = Cfg<H>;
     constexpr int NP = 2 * C::NJB;
+    const int npv = hv >> 4;   // valid 16-feature partials: (jb, half) with jb < hv / 32
     const float* st = ST + (rbg * NP * BE + n) * 2;
     float mw[NP], m2 = 0.f, mean = 0.f;
 #pragma unroll
     for (int w = 0; w < NP; ++w) {
         const float2v s = *reinterpret_cast<const float2v*>(st + w * BE * 2);
         mw[w] = s[0];
-        m2 += s[1];
-        mean += s[0];
+        if (w < npv) { m2 += s[1]; mean += s[0]; }
     }
-    mean *= 1.0f / NP;
+    mean *= 1.0f / (float)npv;
 #pragma unroll
-    for (int w = 0; w < NP; ++w) { const float d = mw[w] - mean; m2 = fmaf(16.0f * d, d, m2); }
+    for (int w = 0; w < NP; ++w) { const float d = mw[w] - mean; if (w < npv) m2 = fmaf(16.0f * d, d, m2); }
     // accumulators carry the scale t (= U of the chain, times the row's own scale in the encoders):
     // (acc - mean) / sqrt(var_acc + eps t^2) is the normalised value
-    k = 1.0f / sqrtf(m2 * (1.0f / H) + eps * t * t);
+    k = 1.0f / sqrtf(m2 / (float)hv + eps * t * t);
     m = -mean * k;
 }
 
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             const int rbg = 4 * rg + rb;
             const int cnt = sb[rbg].y;
             float k, m;
-            ln_merge<H>(ST, rbg, n, L.u * rs[rb], A.eps, k, m);
+            ln_merge<H>(ST, rbg, n, L.u * rs[rb], A.eps, A.h_valid, k, m);
             const bool valid = n < cnt;
             const int p = pe[rb];
             const long long orow = A.eid_out ? A.eid_out[p] : p;
@@ -562,7 +563,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             for (int rb = 0; rb < RBW; ++rb) {
                 const int rbg = RBW * rg + rb;
                 float k, m;
-                ln_merge<H>(ST, rbg, n, L.u * rs[rb], A.eps, k, m);
+                ln_merge<H>(ST, rbg, n, L.u * rs[rb], A.eps, A.h_valid, k, m);
                 const int r = row0 + 32 * rbg + n;
                 const bool valid = r < N;
                 const size_t off = (size_t)(valid ? r : N - 1) * H + 32 * jb + 4 * hi;
@@ -868,7 +869,7 @@ int pack_hm(const PackHmJob* jobs, int n, PackHmJob* jobs_dev, float* stats, hip
     return GM_OK;
 }
 
-bool hm_supported(int H) { return H == 64 || H == 128 || H == 256; }
+bool hm_supported(int H) { return H == 64 || H == 128 || H == 256; }   // instantiated widths (hm_padded_hidden maps a model onto one)
 
 int launch_edge_hm(int H, bool enc, const HmEdgeArgs& a, hipStream_t s) {
     GM_REQUIRE(a.w && a.e_in && a.e_out && a.ln_g && a.ln_b, GM_ERR_INVALID_ARGUMENT, "launch_edge_hm: null pointer");

@@ -31,6 +31,7 @@ struct EdgeArgs {
     float eps;
     int residual;          // e_out = e' + e_in
     int k1;                // encoder: edge_dim
+    int h_valid;           // the model's hidden_size (<= the width H the kernel runs at; LayerNorm statistics are over these features)
     int debug;             // timing-ablation bits of the fp32 kernels; launch_edge always passes 0 (no run-time switch)
     unsigned long long* stamps;  // diagnostic build only: per-tile s_memrealtime stamps, or nullptr
 };
@@ -45,6 +46,7 @@ struct NodeArgs {
     int64_t n_nodes_tab, edge_capacity_tab;
     const float* side;
     int* err_flags;        // error flags of the forward (CsrHeader::error_flags: ERRF_SPLIT_RANGE), or nullptr
+    int h_valid;           // the model's hidden_size (<= the width H the kernel runs at)
     float* h_out;          // [N][H] (may alias x_in)
     int residual;
     const float* wstream;

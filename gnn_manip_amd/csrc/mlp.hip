@@ -1918,7 +1918,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     const bool fp32_forms = choice >= EK_16 && choice <= EK_B3P;   // explicitly selected fp32 / bf16 x 6 kernels
     // the systolic fp16 x 3 kernel (hedge.hip): processor step of the fused forward (rows in sorted order, device-side
     // edge count, block tables present), hidden 128 / num_layers 2
-    const bool sys_ok = H == 128 && NL == 2 && !enc && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
+    const bool sys_ok = H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && !enc && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
     if (sys_ok && (choice == EK_AUTO || choice == EK_SYS))
         return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), s);
     // the streamed fp16 x 3 kernels (hmlp.hip): every other case
@@ -1927,6 +1927,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         h.hdr = a.hdr; h.n_edges_host = a.n_edges_host; h.dst = a.dst; h.src = a.src; h.eid = a.eid; h.eid_out = a.eid_out;
         h.P = a.P; h.e_in = a.e_in; h.e_out = a.e_out; h.agg = a.agg; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b;
         h.eps = a.eps; h.residual = a.residual; h.k1 = a.k1; h.nl = NL; h.prof = a.prof;
+        h.h_valid = a.h_valid > 0 ? a.h_valid : H;
         h.flags = a.hdr ? const_cast<int*>(&a.hdr->error_flags) : nullptr;
         if (!enc) {
             const EdgeBlocks t = carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity);
@@ -2053,6 +2054,7 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
         h.residual = a.residual; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b; h.eps = a.eps; h.nl = NL;
         h.tail = mode == 2 ? 1 : a.tail; h.w_tail = a.tail_hm; h.P_out = a.P_out; h.dec_out = a.dec_out; h.out_dim = a.out_dim; h.prof = a.prof;
         h.flags = a.err_flags;
+        h.h_valid = a.h_valid > 0 ? a.h_valid : H;
         if (mode == 1 && a.edge_blocks && a.side) {   // lists + side buffer of the edge kernel's head partials (hedge.h)
             const EdgeBlocks t = carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, a.edge_capacity_tab);
             h.stitch = t.stitch; h.head = t.head; h.side = a.side; h.tab = t.hdr;

@@ -6,7 +6,8 @@
 
 struct gm_model {
     gm_model_desc d;
-    int H, NL, M;
+    int H, NL, M;                 // H: the model's hidden_size
+    int Hp = 0;                   // the width the inference kernels run at: H zero-padded to 64 / 128 / 256 (hm_padded_hidden)
     int ci = 0, cj = 1, ce = 2;   // column block of phi_e's first Linear that multiplies h_i, h_j, e (gm_model_desc.col_*)
     int ch = 0, ca = 1;           // column block of phi_v's first Linear for h, agg (gm_model_desc.node_agg_first)
     float* packed = nullptr;  // operand image of every Linear, stage-aligned streams

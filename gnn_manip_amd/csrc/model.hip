@@ -17,8 +17,8 @@ int check_desc(const gm_model_desc* d, const char* who) {
     // the reference's two ctor asserts (epd_gnn.py:26-27)
     GM_REQUIRE(d->num_layers >= 2, GM_ERR_INVALID_ARGUMENT, "The number of layers num_layers must be at least 2");
     GM_REQUIRE(d->m_steps >= 1, GM_ERR_INVALID_ARGUMENT, "The number of m_steps message pasting steps must be at least 1");
-    GM_REQUIRE(hm_supported(d->hidden_size), GM_ERR_UNSUPPORTED, "%s: hidden_size=%d: kernels are instantiated for 64, 128 and 256", who,
-               d->hidden_size);
+    GM_REQUIRE(hm_padded_hidden(d->hidden_size) > 0, GM_ERR_UNSUPPORTED,
+               "%s: hidden_size=%d: supported are the multiples of 32 up to 256 (run zero-padded at width 64, 128 or 256)", who, d->hidden_size);
     GM_REQUIRE(d->num_layers <= 16, GM_ERR_UNSUPPORTED, "%s: num_layers=%d: at most 16", who, d->num_layers);
     GM_REQUIRE(d->edge_dim >= 1 && d->edge_dim <= 8, GM_ERR_UNSUPPORTED, "%s: edge_dim=%d unsupported (1..8)", who, d->edge_dim);
     GM_REQUIRE(d->node_dim >= 1 && d->node_dim <= 32, GM_ERR_UNSUPPORTED, "%s: node_dim=%d unsupported (1..32)", who, d->node_dim);
@@ -71,7 +71,8 @@ size_t tensor_floats(const gm_model* m, int ti) {
 
 // (re)build the operand images + vec from the caller's tensors (device pointers)
 int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
-    const int H = m->H, NL = m->NL, M = m->M;
+    // H: the width the kernels run at (hidden_size zero-padded to 64 / 128 / 256: strides, image sizes); Hv: the model's hidden_size
+    const int H = m->Hp, Hv = m->H, NL = m->NL, M = m->M;
     const int PM = tensors_per_normed_mlp(NL);
     int rc = GM_OK;
     const int b_enc_edge = 0, b_enc_node = PM, b_dec = (2 + 2 * M) * PM;
@@ -96,36 +97,36 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
             jobs.push_back(j);
         };
         auto head = [&](float rms) { prev = -1; head_rms = rms; };
-        auto hh = [&](int ti, size_t& off) { lin(ti, H, 0, 0, H, H, H, H, H, H, true, H, off); };
+        auto hh = [&](int ti, size_t& off) { lin(ti, Hv, 0, 0, Hv, H, H, Hv, H, H, true, Hv, off); };
         auto hidden = [&](int base, size_t& off) { for (int l = 1; l <= NL; ++l) hh(base + 2 * l, off); };
         auto proj = [&](int k, size_t& off) {   // P = h [W_i | W_j]^T + [b1 | 0] of processor step k: a chain of its own (input h)
             head(1.f);
-            lin(b_edge(k), 3 * H, m->ci * H, m->cj * H, H, 2 * H, H, H, H, H, true, H, off);
+            lin(b_edge(k), 3 * Hv, m->ci * Hv, m->cj * Hv, Hv, 2 * H, H, Hv, H, H, true, Hv, off);
         };
         size_t off = m->hm_enc_edge;
         head(kHmRawInputRms);   // raw edge features: per-row power-of-two scale in the kernel
-        lin(b_enc_edge, m->d.edge_dim, 0, 0, H, H, H, m->d.edge_dim, 16, 16, true, H, off);
+        lin(b_enc_edge, m->d.edge_dim, 0, 0, Hv, H, H, m->d.edge_dim, 16, 16, true, Hv, off);
         hidden(b_enc_edge, off);
         off = m->hm_enc_node;
         head(kHmRawInputRms);
-        lin(b_enc_node, m->d.node_dim, 0, 0, H, H, H, m->d.node_dim, 32, 32, true, H, off);
+        lin(b_enc_node, m->d.node_dim, 0, 0, Hv, H, H, m->d.node_dim, 32, 32, true, Hv, off);
         hidden(b_enc_node, off);
         proj(0, off);
         for (int k = 0; k < M; ++k) {
             off = m->hm_edge[k];
             head(1.f);
             // the e block; b1 lives in P_i.  Its pre-activation also takes h_i and h_j: the gain is that of the whole [H x 3H] Linear
-            lin(b_edge(k), 3 * H, m->ce * H, 0, H, H, H, H, H, H, false, 0, off, 0, 3 * H);
+            lin(b_edge(k), 3 * Hv, m->ce * Hv, 0, Hv, H, H, Hv, H, H, false, 0, off, 0, 3 * Hv);
             hidden(b_edge(k), off);
             off = m->hm_node[k];
             head(1.f);
-            lin(b_node(k), 2 * H, m->ch * H, m->ca * H, H, H, H, H, 2 * H, H, true, H, off);
+            lin(b_node(k), 2 * Hv, m->ch * Hv, m->ca * Hv, Hv, H, H, Hv, 2 * H, H, true, Hv, off);
             hidden(b_node(k), off);
             if (k + 1 < M) proj(k + 1, off);
             else {
                 head(1.f);
                 for (int l = 0; l < NL; ++l) hh(b_dec + 2 * l, off);
-                lin(b_dec + 2 * NL, H, 0, 0, m->d.out_dim, 32, 32, H, H, H, true, m->d.out_dim, off);
+                lin(b_dec + 2 * NL, Hv, 0, 0, m->d.out_dim, 32, 32, Hv, H, H, true, m->d.out_dim, off);
             }
         }
         GM_REQUIRE(jobs.size() <= m->hm_jobs_cap, GM_ERR_INVALID_ARGUMENT, "model: %zu pack jobs, room for %zu", jobs.size(), m->hm_jobs_cap);
@@ -149,11 +150,11 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
         for (int l = 0; l <= NL; ++l) {
             const bool dec_out = !normed && l == NL;
             if (dec_out) queue_vec(T[base + 2 * l + 1], voff + (size_t)NL * H, m->d.out_dim, 32);
-            else queue_vec(T[base + 2 * l + 1], voff + (size_t)l * H, H, 0);
+            else queue_vec(T[base + 2 * l + 1], voff + (size_t)l * H, Hv, Hv < H ? H : 0);
         }
-        if (normed) {
-            queue_vec(T[base + 2 * (NL + 1)], voff + (size_t)(NL + 1) * H, H, 0);
-            queue_vec(T[base + 2 * (NL + 1) + 1], voff + (size_t)(NL + 2) * H, H, 0);
+        if (normed) {   // LayerNorm gamma / beta: zero on the padded features, which therefore stay exactly zero
+            queue_vec(T[base + 2 * (NL + 1)], voff + (size_t)(NL + 1) * H, Hv, Hv < H ? H : 0);
+            queue_vec(T[base + 2 * (NL + 1) + 1], voff + (size_t)(NL + 2) * H, Hv, Hv < H ? H : 0);
         }
     };
     vecs(b_enc_edge, true, m->v_enc_edge);
@@ -280,6 +281,8 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
 
 extern "C" {
 
+int gm_padded_hidden_size(int hidden_size) { return hm_padded_hidden(hidden_size); }
+
 int gm_model_num_tensors(const gm_model_desc* d) {
     if (!d) return 0;
     return (2 + 2 * d->m_steps) * tensors_per_normed_mlp(d->num_layers) + 2 * (d->num_layers + 1);
@@ -293,10 +296,12 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
     if (rc != GM_OK) return rc;
     gm_model* m = new gm_model();
     m->d = *desc;
-    const int H = m->H = desc->hidden_size, NL = m->NL = desc->num_layers, M = m->M = desc->m_steps;
+    m->H = desc->hidden_size;
+    const int H = m->Hp = hm_padded_hidden(desc->hidden_size);   // width the kernels run at (buffers, images); m->H: the model's
+    const int NL = m->NL = desc->num_layers, M = m->M = desc->m_steps;
     if (desc->col_i || desc->col_j || desc->col_e) { m->ci = desc->col_i; m->cj = desc->col_j; m->ce = desc->col_e; }
     if (desc->node_agg_first) { m->ch = 1; m->ca = 0; }
-    m->legacy = (H == 128 || H == 256) && NL == 2;   // sizes the fp32 kernels (selectable forward forms, training) exist for
+    m->legacy = (m->H == 128 || m->H == 256) && NL == 2;   // sizes the fp32 kernels (selectable forward forms, training) exist for
     m->S_HH = layer_stages(H, H);
     m->S_e0 = layer_stages(desc->edge_dim, H);
     m->S_n0 = layer_stages(desc->node_dim, H);
@@ -370,7 +375,7 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
         return GM_ERR_HIP;
     }
 #endif
-    if (H == 128 && NL == 2 && hipMalloc(&m->packed_h3, (size_t)M * h3_image_floats() * sizeof(float)) != hipSuccess) {
+    if (m->H == 128 && NL == 2 && hipMalloc(&m->packed_h3, (size_t)M * h3_image_floats() * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
         gm_model_destroy(m);
         return GM_ERR_HIP;
@@ -413,12 +418,12 @@ void gm_model_destroy(gm_model* m) {
 
 size_t gm_forward_workspace_bytes(const gm_model_desc* desc, int64_t n, int64_t cap) {
     if (!desc || n < 0 || cap < 0) return 0;
-    return carve_fwd(nullptr, desc->hidden_size, n, cap, cap).bytes;
+    return carve_fwd(nullptr, hm_padded_hidden(desc->hidden_size), n, cap, cap).bytes;
 }
 
 size_t gm_block_workspace_bytes(const gm_model_desc* desc, int64_t n, int64_t cap) {
     if (!desc || n < 0 || cap < 0) return 0;
-    return carve_fwd(nullptr, desc->hidden_size, n, 0, cap).bytes;
+    return carve_fwd(nullptr, hm_padded_hidden(desc->hidden_size), n, 0, cap).bytes;
 }
 
 }  // extern "C"
@@ -434,7 +439,8 @@ EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid
     a.wstream_hm = m->packed_hm + m->hm_enc_edge;
     a.kernel_choice = m->edge_kernel; a.prof = m->prof;
     const float* v = m->vec + m->v_enc_edge;
-    a.bias = v; a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
+    a.bias = v; a.ln_g = v + (size_t)(m->NL + 1) * m->Hp; a.ln_b = v + (size_t)(m->NL + 2) * m->Hp; a.eps = m->d.ln_eps;
+    a.h_valid = m->H;
     return a;
 }
 EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, int64_t n, const CsrHeader* hdr, int e_host, const int* eid,
@@ -451,8 +457,9 @@ EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, int64_t n, con
     a.n_nodes_tab = n;
     a.kernel_choice = m->edge_kernel; a.prof = m->prof;
     const float* v = m->vec + m->v_edge[k];
-    a.bias = v + m->H;  // layer-1 bias lives in P_i
-    a.ln_g = v + (size_t)(m->NL + 1) * m->H; a.ln_b = v + (size_t)(m->NL + 2) * m->H; a.eps = m->d.ln_eps;
+    a.bias = v + m->Hp;  // layer-1 bias lives in P_i
+    a.ln_g = v + (size_t)(m->NL + 1) * m->Hp; a.ln_b = v + (size_t)(m->NL + 2) * m->Hp; a.eps = m->d.ln_eps;
+    a.h_valid = m->H;
     return a;
 }
 void set_tail(const gm_model* m, NodeArgs& a, int next_edge_step /* -1: none, M: decoder */, float* P, float* out) {
@@ -481,7 +488,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     GM_REQUIRE(n >= 0 && cap >= 0 && n < ((int64_t)1 << 31) && cap < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: sizes out of range");
     if (n == 0) return GM_OK;
     GM_REQUIRE(nodes && out && (edge_attr || cap == 0), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: null tensor");
-    const int H = m->H, NL = m->NL, M = m->M;
+    const int H = m->Hp, NL = m->NL, M = m->M;   // the padded width: every latent array has this row stride
     FwdWs f = carve_fwd(fwd_ws, H, n, cap, cap);
     GM_REQUIRE(fwd_ws_bytes >= f.bytes, GM_ERR_WORKSPACE, "gm_epd_forward: workspace %zu < %zu", fwd_ws_bytes, f.bytes);
     CsrWs c = carve_csr(const_cast<void*>(csr_ws), n, cap);
@@ -489,6 +496,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     int rc = launch_edge(H, NL, true, enc_edge_args(m, edge_attr, attr_is_csr_order ? nullptr : c.eid, c.hdr, 0, f.e), cap, s);
     if (rc != GM_OK) return rc;
     NodeArgs na{};
+    na.h_valid = m->H;
     na.n_nodes = (int)n; na.x_in = nodes; na.k1 = m->d.node_dim; na.h_out = f.h;
     na.wstream = m->packed ? m->packed + m->s_enc_node : nullptr;
     na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel; na.prof = m->prof;
@@ -505,6 +513,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
         rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, f.side, 1), cap, s);
         if (rc != GM_OK) return rc;
         NodeArgs a{};
+        a.h_valid = m->H;
         a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.h_out = f.h; a.residual = 1;
         // the fp32 edge kernels add into agg atomically, so the rows consumed here are cleared for the next step; the
         // sys / hm kernels store every row with in-edges whole (rows without keep the zeros of the memset above)
@@ -529,16 +538,17 @@ int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n, c
     GM_REQUIRE(n >= 0 && e >= 0 && n < ((int64_t)1 << 31) && e < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "sizes out of range");
     GM_REQUIRE((n == 0 || (x && h_out)) && (e == 0 || (edge_attr && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_forward: null tensor");
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_edge(m->H, m->NL, true, enc_edge_args(m, edge_attr, nullptr, nullptr, (int)e, e_out), e, s);
+    int rc = launch_edge(m->Hp, m->NL, true, enc_edge_args(m, edge_attr, nullptr, nullptr, (int)e, e_out), e, s);
     if (rc != GM_OK) return rc;
     NodeArgs na{};
+    na.h_valid = m->H;
     na.n_nodes = (int)n; na.x_in = x; na.k1 = m->d.node_dim; na.h_out = h_out;
     na.wstream = m->packed ? m->packed + m->s_enc_node : nullptr;
     na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel; na.prof = m->prof;
     const float* v = m->vec + m->v_enc_node;
-    na.bias = v; na.ln_g = v + (size_t)(m->NL + 1) * m->H; na.ln_b = v + (size_t)(m->NL + 2) * m->H; na.eps = m->d.ln_eps;
-    na.tail = 0;
-    return launch_node(m->H, m->NL, 0, na, s);
+    na.bias = v; na.ln_g = v + (size_t)(m->NL + 1) * m->Hp; na.ln_b = v + (size_t)(m->NL + 2) * m->Hp; na.eps = m->d.ln_eps;
+    na.tail = 0; na.h_valid = m->H;
+    return launch_node(m->Hp, m->NL, 0, na, s);
 }
 
 int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int64_t n, const float* e,
@@ -550,13 +560,14 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     GM_REQUIRE(n >= 0 && cap >= 0 && n < ((int64_t)1 << 31) && cap < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "sizes out of range");
     if (n == 0) return GM_OK;
     GM_REQUIRE(h && h_out && (cap == 0 || (e && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward: null tensor");
-    const int H = m->H, NL = m->NL;
+    const int H = m->Hp, NL = m->NL;
     FwdWs f = carve_fwd(fwd_ws, H, n, 0, cap);  // P, agg and the side buffer are used
     GM_REQUIRE(fwd_ws_bytes >= f.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_forward: workspace %zu < %zu", fwd_ws_bytes, f.bytes);
     CsrWs c = carve_csr(const_cast<void*>(csr_ws), n, cap);
     hipStream_t s = (hipStream_t)stream;
     // projection P = h [W_i | W_j]^T (+ b1): the tail section of the preceding node stream
     NodeArgs pa{};
+    pa.h_valid = m->H;
     pa.n_nodes = (int)n; pa.x_in = h;
     pa.wstream = !m->packed ? nullptr
                  : k == 0   ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
@@ -570,6 +581,7 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, c.eid, f.P, e, e_out, f.agg, f.side, 0), cap, s);
     if (rc != GM_OK) return rc;
     NodeArgs a{};
+    a.h_valid = m->H;
     a.n_nodes = (int)n; a.x_in = h; a.agg = f.agg; a.h_out = h_out; a.residual = 0;
     a.edge_blocks = c.blocks; a.n_nodes_tab = n; a.edge_capacity_tab = cap; a.side = f.side;
     a.err_flags = &c.hdr->error_flags;

@@ -252,6 +252,19 @@ class DstCsr:
         return int(e.value)
 
 
+def padded_hidden(hidden):
+    """Width the kernels run a model of this hidden size at (gm_padded_hidden_size): multiples of 32 up to 256 are zero-padded
+    to 64 / 128 / 256; latent tensors handed to / returned by the standalone blocks have that row stride inside the library."""
+    w = int(lib().gm_padded_hidden_size(int(hidden)))
+    if w <= 0:
+        raise ValueError(f"hidden size {hidden}: supported are the multiples of 32 up to 256")
+    return w
+
+
+def _pad_cols(t, width):
+    return t if t.shape[1] == width else torch.nn.functional.pad(t, (0, width - t.shape[1]))
+
+
 def _zeros_mlp(fin, hidden, fout, num_layers, norm, device):
     t = [torch.zeros(hidden, fin, device=device), torch.zeros(hidden, device=device)]
     for _ in range(num_layers - 1):
@@ -297,10 +310,13 @@ class GraphIndependent(nn.Module):
             return h_out, e_out, None
         h = self._handle.get(desc, params, x.device)
         hidden = desc[3]
-        h_out = torch.empty((x.shape[0], hidden), dtype=torch.float32, device=x.device)
-        e_out = torch.empty((edge_attr.shape[0], hidden), dtype=torch.float32, device=x.device)
+        hp = padded_hidden(hidden)   # the library's row stride of latents; the padded columns come back as zeros
+        h_out = torch.empty((x.shape[0], hp), dtype=torch.float32, device=x.device)
+        e_out = torch.empty((edge_attr.shape[0], hp), dtype=torch.float32, device=x.device)
         check(lib().gm_graph_independent_forward(h, ptr(x), x.shape[0], ptr(edge_attr), edge_attr.shape[0],
                                                  ptr(h_out), ptr(e_out), current_stream()))
+        if hp != hidden:
+            h_out, e_out = h_out[:, :hidden].contiguous(), e_out[:, :hidden].contiguous()
         return h_out, e_out, None
 
 
@@ -350,8 +366,9 @@ class InteractionNetwork(nn.Module):
 
 
 def _run_block(handle, desc, k, x, edge_attr, edge_index, csr=None):
-    x = x.contiguous().float()
-    edge_attr = edge_attr.contiguous().float()
+    hidden, hp = desc[3], padded_hidden(desc[3])
+    x = _pad_cols(x.float(), hp).contiguous()            # library row stride (zero padding stays zero through the block)
+    edge_attr = _pad_cols(edge_attr.float(), hp).contiguous()
     n, e = x.shape[0], edge_attr.shape[0]
     if csr is None:
         csr = DstCsr(edge_index, n, flow=desc[7] if len(desc) > 7 else 0)
@@ -362,6 +379,8 @@ def _run_block(handle, desc, k, x, edge_attr, edge_index, csr=None):
     e_out = torch.empty_like(edge_attr)
     check(L.gm_interaction_network_forward(handle, k, ptr(x), n, ptr(edge_attr), ptr(csr.ws), e, ptr(h_out),
                                            ptr(e_out), ptr(fwd), fwd.numel(), current_stream()))
+    if hp != hidden:
+        h_out, e_out = h_out[:, :hidden].contiguous(), e_out[:, :hidden].contiguous()
     return h_out, e_out, None
 
 

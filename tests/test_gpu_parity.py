@@ -286,8 +286,8 @@ def _dev_kernels(m, dev):
 def test_unsupported_sizes_fail_loudly(dev):
     from gnn_manip_amd import EncProcDecGNN
     from gnn_manip_amd._lib import GMError
-    m = EncProcDecGNN(25, 4, 3, 96, 2, 2).to(dev)   # kernels: hidden 64 / 128 / 256
-    with pytest.raises(GMError, match="hidden_size=96"), torch.no_grad():
+    m = EncProcDecGNN(25, 4, 3, 100, 2, 2).to(dev)   # multiples of 32 up to 256 run (zero-padded to 64 / 128 / 256); others do not
+    with pytest.raises(GMError, match="hidden_size=100"), torch.no_grad():
         m.forward(torch.zeros(4, 25, device=dev), torch.zeros(4, 4, device=dev),
                   torch.zeros(2, 4, dtype=torch.long, device=dev))
     m = EncProcDecGNN(25, 4, 3, 64, 3, 2).to(dev)   # runs on the streamed kernels; the systolic one is for hidden 128 / num_layers 2
@@ -711,3 +711,36 @@ def test_edge_features_csr_is_flow_aware(dev, flow):
     a, b = out_csr.cpu().numpy(), out_ref.cpu().numpy()
     np.testing.assert_array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])   # same rows, another order
     np.testing.assert_allclose(b, orc.get_edges_displacement(pos, ei[0], ei[1], 0.015), rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("hidden,nl,ms", [(96, 2, 3), (32, 2, 2), (192, 3, 2), (224, 2, 1)])
+def test_hidden_sizes_between_the_instantiated_widths(dev, hidden, nl, ms):
+    """epd_gnn.py:13-14,72-84 take any hidden_size: a multiple of 32 runs zero-padded at the next instantiated width with the
+    LayerNorm statistics over the features that exist -- forward, standalone blocks and a short rollout against the oracle."""
+    from gnn_manip_amd import RolloutEngine, scene
+    obs = scene.make_scene(700, seed=140 + hidden, side=0.075)
+    params = orc.init_params(25, 4, 3, hidden, nl, ms, 900 + hidden)
+    m = _model(params, (25, 4, 3, hidden, nl, ms), dev)
+    nodes, ea, s, r, _ = orc.process(obs, None, control_idx=CTRL, **KW)
+    ei = np.stack((s, r))
+    with torch.no_grad():
+        out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
+        h0, e0, _ = m.encoder(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+        h1, e1, _ = m.processor[0](h0, e0, _t(ei, dev))
+    assert m.status() == ei.shape[1]
+    ref = orc.epd_forward(params, nodes, ea, ei, nl, ms)
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+    ho, eo = orc.graph_independent(params, "encoder", nodes, ea, nl)
+    assert tuple(h0.shape) == (nodes.shape[0], hidden) and tuple(e0.shape) == (ea.shape[0], hidden)
+    np.testing.assert_allclose(h0.cpu().numpy(), ho, rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(e0.cpu().numpy(), eo, rtol=1e-5, atol=5e-6)
+    h1o, e1o = orc.interaction_network(params, "processor.0", ho, eo, ei, nl)
+    np.testing.assert_allclose(h1.cpu().numpy(), h1o, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(e1.cpu().numpy(), e1o, rtol=1e-5, atol=1e-5)
+    if hidden == 96:
+        traj = scene.rigid_drift_trajectory(obs, 2)
+        eng = RolloutEngine(m, _ga(), obs.shape[1], device=dev)
+        with torch.no_grad():
+            final = eng.rollout(_t(obs, dev), _t(traj, dev), horizon=2).cpu().numpy()
+        refr = orc.rollout(params, obs, traj, 2, STATS, BOUNDS, 0.015, CART, MAT, CTRL, nl, ms)
+        np.testing.assert_allclose(final[:, :, 2:5], refr[:, :, 2:5], rtol=0, atol=5e-6)
