@@ -116,8 +116,9 @@ __device__ __forceinline__ void report_range(int bad, int* flags) {
 // acc[rb] += W[jb block, k-groups ks0 .. ks0 + nks) x image rows of row block rb.
 //   wf : this wave's fragments of the first k-group, + lane  (k-group stride 128 half8)
 //   im : image of the wave's first row block at k-group 0, + lane  (row-block stride img_ksn * 128, k-group stride 128)
+// nrb: row blocks of this wave that hold rows (the others' MFMAs are skipped: the last tile of a workgroup's range may be partial)
 template <int RBW>
-__device__ __forceinline__ void gemm(floatx16 (&acc)[RBW], const half8* __restrict__ wf, const half8* im, int img_ksn, int nks) {
+__device__ __forceinline__ void gemm(floatx16 (&acc)[RBW], const half8* __restrict__ wf, const half8* im, int img_ksn, int nks, int nrb = RBW) {
     half8 ah0 = wf[0], al0 = wf[64], ah1 = ah0, al1 = al0;
     if (nks > 1) { ah1 = wf[128]; al1 = wf[192]; }
     half8 bh[RBW], bl[RBW], ch[RBW], cl[RBW];
@@ -130,11 +131,11 @@ __device__ __forceinline__ void gemm(floatx16 (&acc)[RBW], const half8* __restri
             for (int rb = 0; rb < RBW; ++rb) { ch[rb] = im[(rb * img_ksn + ks + 1) * 128]; cl[rb] = im[(rb * img_ksn + ks + 1) * 128 + 64]; }
         }
 #pragma unroll
-        for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[rb], acc[rb], 0, 0, 0);
+        for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[rb], acc[rb], 0, 0, 0);
 #pragma unroll
-        for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[rb], acc[rb], 0, 0, 0);
+        for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[rb], acc[rb], 0, 0, 0);
 #pragma unroll
-        for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[rb], acc[rb], 0, 0, 0);
+        for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[rb], acc[rb], 0, 0, 0);
         if (ks + 2 < nks) { ah0 = wf[(ks + 2) * 128]; al0 = wf[(ks + 2) * 128 + 64]; }
         if (ks + 1 < nks) {
             if (ks + 2 < nks) {
@@ -142,11 +143,11 @@ __device__ __forceinline__ void gemm(floatx16 (&acc)[RBW], const half8* __restri
                 for (int rb = 0; rb < RBW; ++rb) { bh[rb] = im[(rb * img_ksn + ks + 2) * 128]; bl[rb] = im[(rb * img_ksn + ks + 2) * 128 + 64]; }
             }
 #pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, ch[rb], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, ch[rb], acc[rb], 0, 0, 0);
 #pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, cl[rb], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, cl[rb], acc[rb], 0, 0, 0);
 #pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, ch[rb], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, ch[rb], acc[rb], 0, 0, 0);
             if (ks + 3 < nks) { ah1 = wf[(ks + 3) * 128]; al1 = wf[(ks + 3) * 128 + 64]; }
         }
     }
@@ -477,7 +478,11 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
     const int n = lane & 31, hi = lane >> 5;
     const int N = A.n_nodes;
     if (N <= 0) return;
-    const int ntiles = (N + C::M - 1) / C::M;
+    // Every workgroup takes a contiguous range of 32-row blocks and walks it in tiles of up to NRB blocks; the blocks of a tile
+    // are dealt to the row groups in turn, so a short last tile costs what its rows cost (at N = 100k, hidden 128: 12.2 blocks
+    // per workgroup = one full tile + a half one, instead of two rounds of full tiles).
+    const int NBLK = (N + 31) / 32;
+    const int bq0 = (int)((long long)NBLK * blockIdx.x / gridDim.x), bq1 = (int)((long long)NBLK * (blockIdx.x + 1) / gridDim.x);
     constexpr int K0 = MODE == 0 ? 32 : 2 * H;
     const size_t lin0 = hm_lin_floats(H, K0), linh = hm_lin_floats(H, H);
 
@@ -494,10 +499,13 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
     const float* betp = GB + H + 32 * jb + 4 * hi;
 
 #pragma unroll 1
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int row0 = t * C::M;
+    for (int bt = bq0; bt < bq1; bt += C::NRB) {
+        const int nbt = min(C::NRB, bq1 - bt);                      // blocks of this tile
+        const int nrb = (nbt - rg + C::NRG - 1) / C::NRG;           // ... of which this wave's row group holds (image slots rb < nrb)
+        // first row of image slot rbg = RBW rg' + rb': tile block j = rb' NRG + rg'
+        auto slot_row0 = [&](int rbg) { return 32 * (bt + (rbg % RBW) * C::NRG + rbg / RBW); };
         auto row_of = [&](int rbg, int nn) -> long long {
-            const int r = row0 + 32 * rbg + nn;
+            const int r = slot_row0(rbg) + nn;
             return r < N ? r : N - 1;
         };
         __syncthreads();   // the previous tile's readers of the image are done
@@ -520,10 +528,10 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                 init_bias(acc, L.bias, jb, hi);
             }
             if (MODE == 0) {
-                gemm(acc, L.frag + (size_t)jb * 2 * 128 + lane, imgh + (size_t)(RBW * rg) * 2 * 128 + lane, 2, 2);
+                gemm(acc, L.frag + (size_t)jb * 2 * 128 + lane, imgh + (size_t)(RBW * rg) * 2 * 128 + lane, 2, 2, nrb);
                 check_rows(rng, acc);
             } else {
-                gemm(acc, L.frag + (size_t)jb * 2 * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, L.frag + (size_t)jb * 2 * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS, nrb);
                 check_rows(rng, acc);
                 __syncthreads();
                 // agg row + the head partials other groups hold of its segment, in group order (hedge.h)
@@ -540,7 +548,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                     }
                 });
                 __syncthreads();
-                gemm(acc, L.frag + ((size_t)jb * 2 * C::KS + C::KS) * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, L.frag + ((size_t)jb * 2 * C::KS + C::KS) * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS, nrb);
                 check_rows(rng, acc);
             }
             wp += lin0;
@@ -548,12 +556,12 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             for (int l = 1; l <= A.nl; ++l) {
                 __syncthreads();
 #pragma unroll
-                for (int rb = 0; rb < RBW; ++rb) acc_to_img<true>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
+                for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc_to_img<true>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
                 __syncthreads();
                 L = lin_at(wp, H);
                 if (MODE == 0) init_bias_rows(acc, L.bias, jb, hi, rs);
                 else init_bias(acc, L.bias, jb, hi);
-                gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS, nrb);
                 check_rows(rng, acc);
                 wp += linh;
             }
@@ -561,12 +569,13 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             __syncthreads();
 #pragma unroll
             for (int rb = 0; rb < RBW; ++rb) {
+                if (rb >= nrb) continue;
                 const int rbg = RBW * rg + rb;
                 float k, m;
                 ln_merge<H>(ST, rbg, n, L.u * rs[rb], A.eps, A.h_valid, k, m);
-                const int r = row0 + 32 * rbg + n;
-                const bool valid = r < N;
-                const size_t off = (size_t)(valid ? r : N - 1) * H + 32 * jb + 4 * hi;
+                const int r = slot_row0(rbg) + n;
+                const bool valid = rb < nrb && r < N;
+                const size_t off = (size_t)(r < N ? r : N - 1) * H + 32 * jb + 4 * hi;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     floatx4 y;
@@ -590,7 +599,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             if (A.tail == 0) continue;
             // the new h becomes the tail's input image (every wave has passed the barrier after the last Linear)
 #pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) acc_to_img<false>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
+            for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc_to_img<false>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
             __syncthreads();
         }
         if (A.tail == 1 || MODE == 2) {
@@ -599,12 +608,12 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             for (int half = 0; half < 2; ++half) {
                 const int jbv = jb + half * C::NJB;
                 init_bias(acc, LP.bias, jbv, hi);
-                gemm(acc, LP.frag + (size_t)jbv * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, LP.frag + (size_t)jbv * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS, nrb);
                 check_rows(rng, acc);
 #pragma unroll
                 for (int rb = 0; rb < RBW; ++rb) {
-                    const int r = row0 + 32 * (RBW * rg + rb) + n;
-                    if (r < N) {
+                    const int r = slot_row0(RBW * rg + rb) + n;
+                    if (rb < nrb && r < N) {
                         float* pp = A.P_out + (size_t)r * 2 * H + 32 * jbv + 4 * hi;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -622,24 +631,24 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             for (int l = 0; l < A.nl; ++l) {
                 const Lin LD = lin_at(wp, H);
                 init_bias(acc, LD.bias, jb, hi);
-                gemm(acc, LD.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, LD.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS, nrb);
                 check_rows(rng, acc);
                 __syncthreads();
 #pragma unroll
-                for (int rb = 0; rb < RBW; ++rb) acc_to_img<true>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
+                for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc_to_img<true>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
                 __syncthreads();
                 wp += linh;
             }
             if (jb == 0) {
                 const Lin LO = lin_at(wp, 32);
                 init_bias(acc, LO.bias, 0, hi);
-                gemm(acc, LO.frag + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS);
+                gemm(acc, LO.frag + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS, nrb);
                 check_rows(rng, acc);
                 if (hi == 0) {
 #pragma unroll
                     for (int rb = 0; rb < RBW; ++rb) {
-                        const int r = row0 + 32 * (RBW * rg + rb) + n;
-                        if (r < N) {
+                        const int r = slot_row0(RBW * rg + rb) + n;
+                        if (rb < nrb && r < N) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
                                 if (c < A.out_dim) A.dec_out[(size_t)r * A.out_dim + c] = (poisoned || rng) ? __builtin_nanf("") : acc[rb][c] * LO.inv_u;
