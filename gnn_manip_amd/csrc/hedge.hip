@@ -63,6 +63,9 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8];
 #define HEDGE_PRIO1 1
 #define HEDGE_PRIO2 3
 #endif
+#ifndef EPI_SPLIT
+#define EPI_SPLIT 2   // row groups (of 8 rows) of a block's LayerNorm + e_out epilogue that role 1 keeps; role 2 takes the others
+#endif
 #ifndef HEDGE_VAR
 #define HEDGE_VAR 0   // development builds: structural variants under A/B test (bit meanings at their use)
 #endif
@@ -92,6 +95,11 @@ __device__ __forceinline__ void acc_to_image(const floatx16& a, uintx4* img, int
 
 // slot of lane (n, kg) inside a fragment of the row-written image E (conflict-free for the 8-byte row-major writes)
 __device__ __forceinline__ int eslot(int n, int kg, int ksbit) { return (n ^ (2 * (ksbit + 2 * kg))) + 32 * kg; }
+
+// e rows are read (twice) and written once per launch, 3 GB in all at the target; P, 102 MB, is gathered 1 GB worth.  Streaming
+// cache policy for the former keeps the latter in L2 / the Infinity Cache (HEDGE_VAR & 2: A/B switch of development builds).
+__device__ __forceinline__ floatx4 ld_stream(const floatx4* p) { return (HEDGE_VAR & 2) ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_stream(floatx4* p, floatx4 v) { if (HEDGE_VAR & 2) __builtin_nontemporal_store(v, p); else *p = v; }
 
 #define GM_SB __builtin_amdgcn_sched_barrier(0)
 // One Linear for this wave's 32 output features: 8 k-groups x 3 MFMAs (lo*hi, hi*lo, hi*hi).  side(slot), slot = 0..23, runs
@@ -293,7 +301,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                         for (int j = 0; j < 4; ++j) {
                             int row = be.x + 8 * j + rr;
                             row = row < E ? row : E - 1;
-                            eq[j] = *reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
+                            eq[j] = ld_stream(reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq)));
                         }
                     }
                     be = be_next;
@@ -368,7 +376,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             float2v kmr;
             floatx4 zq;
             auto side = [&](int slot) {   // LayerNorm + e_out of block x-3, row group slot / SIDE_STRIDE
-                if (slot >= 4 * SIDE_STRIDE) return;
+                if (slot >= EPI_SPLIT * SIDE_STRIDE) return;   // the other row groups are role 2's (balance of the roles' ticks)
                 const int j = slot / SIDE_STRIDE, r = 8 * j + rr;
                 if (slot % SIDE_STRIDE == 0) {
                     kmr = *reinterpret_cast<const float2v*>(km + r * 2);
@@ -383,7 +391,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     // unconditional store (a branch around it would turn this wave's counted waits for its loads into
                     // waits for everything): rows past the block's end and the fill / drain ticks go to the workgroup's sink row
                     float* orow = (epi && r < cnt_a) ? a_e_out + (unsigned)((((HEDGE_ABL & 32) ? (st_a & 1023) : st_a) + r) * H) : sink;
-                    if (!(HEDGE_ABL & 4)) *reinterpret_cast<floatx4*>(orow + 32 * jb + 4 * cq) = o;
+                    if (!(HEDGE_ABL & 4)) st_stream(reinterpret_cast<floatx4*>(orow + 32 * jb + 4 * cq), o);
                 }
             };
             SYS_STAMP(t, 1);
@@ -394,10 +402,10 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
                 if (!(HEDGE_ABL & 1)) {  // rows of block x-2: consumed next tick (scaled by 0 when there is no residual)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < EPI_SPLIT; ++j) {
                         int row = st_a + 8 * j + rr;
                         row = row < E ? row : E - 1;
-                        er[j] = *reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq));
+                        er[j] = ld_stream(reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq)));
                     }
                 }
                 bi_c = a_blk[clampb(x)];
@@ -436,6 +444,13 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         int head_a = -1, head_b = -1;   // destination whose segment began in an earlier group (its sum over this group goes to the side buffer)
         int2 bn = make_int2(0, 0), sn = make_int2(0, 0);      // table entries of the block the next fetch() handles
         const float gam = vecs[2 * H + 32 * jb + (lane0 & 31)], bet = vecs[3 * H + 32 * jb + (lane0 & 31)];
+        // its share of the LayerNorm + e_out epilogue (row groups EPI_SPLIT .. 3 of block x-3, row-major: 8 lanes per row)
+        const float res_w = a_residual ? 1.f : 0.f;
+        float* const sink = a_sink + (blockIdx.x & (kSinkRows - 1)) * H;
+        floatx4 er[4];                  // e rows of block x-3 for the residual (the groups of this role)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) er[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        int st_a = 0, st_b = 0;         // first edge of blocks x-3, x-2
         float* km2 = KM2 + jb * BE * 2;
         auto init_acc = [&]() {   // accumulators <- b3 T3, read at the end of a tick for the next one
             const float* vb3 = vecs + H + 32 * jb + 4 * (lane0 >> 5);
@@ -447,7 +462,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             }
         };
         init_acc();
-        auto fetch = [&](int x, int2 bi, int2 si, int& cnt, int& fl, unsigned& cont, unsigned& last, int& head) {
+        auto fetch = [&](int x, int2 bi, int2 si, int& st, int& cnt, int& fl, unsigned& cont, unsigned& last, int& head) {
+            st = bi.x;
             if (!ok(x)) { cnt = 0; fl = 0; cont = 0; last = 0; return; }
             cnt = bi.y & 0xff;
             fl = bi.y >> 8;
@@ -472,13 +488,14 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 1);
             const unsigned cont = agg_on ? cont_a : 0u, last = agg_on ? last_a : 0u;
             // destinations of this lane's 16 rows: from the ring role 0 filled (no global load)
-            const intx4* drp = reinterpret_cast<const intx4*>(DR + ((x - 3) & (DR_SLOTS - 1)) * BE + 16 * hi);
+            const int* drp = DR + ((x - 3) & (DR_SLOTS - 1)) * BE + 16 * hi;   // read per stored row (about two per tick): no registers held
             const char* zb = reinterpret_cast<const char*>(Z + (par3 * 4 + jb) * 256) + 2048 * hi;   // row 16 hi of the tile (tile_q order)
             const floatx4* kmp = reinterpret_cast<const floatx4*>(km2 + 32 * hi);
-            floatx16 y;     // vectors: the store loop below indexes them with a (wave-uniform) run-time row
-            intx16 dq;
+            floatx16 y;     // a vector: the store loop below indexes it with a (wave-uniform) run-time row
             floatx4 kq0, kq1;
             float zz[4];
+            float2v ekm;
+            floatx4 ezq, gmq, btq;
             float cpend = 0.f;
             // value of an open segment handed to the next half: half 0 -> half 1 inside the tick, half 1 -> half 0 of the next block
             auto side = [&](int slot) {
@@ -492,10 +509,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                             const int r = 4 * c + i;
                             zz[i] = *reinterpret_cast<const float*>(zb + 128 * r + ((4 * n) ^ (16 * (r & 7))));
                         }
-                        {
-                            const intx4 dv = drp[c];
-                            dq[4 * c + 0] = dv[0]; dq[4 * c + 1] = dv[1]; dq[4 * c + 2] = dv[2]; dq[4 * c + 3] = dv[3];
-                        }
+
                     } else {
                         y[4 * c + 0] = fmaf(fmaf(zz[0], kq0[0], kq0[1]), gam, bet);
                         y[4 * c + 1] = fmaf(fmaf(zz[1], kq0[2], kq0[3]), gam, bet);
@@ -520,6 +534,37 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     const float from0 = lower_half_to_both(open0);
                     const float c1v = (cont & 0x10000u) ? from0 : 0.f;
                     cpend = hi ? c1v : c0v;
+                } else if (EPI_SPLIT < 4 && slot >= 14 && slot < 14 + 2 * (4 - EPI_SPLIT) + 1) {
+                    // this role's share of the e_out epilogue: row group j, loads at an even slot, arithmetic + store at the next
+                    const int rr = lane >> 3, cq = lane & 7;
+                    if (slot == 14 + 2 * (4 - EPI_SPLIT)) {
+                        // the residual rows of block x-2 for the next tick, into the registers just consumed
+                        if (!(HEDGE_ABL & 1)) {
+#pragma unroll
+                            for (int j = EPI_SPLIT; j < 4; ++j) {
+                                int row = st_b + 8 * j + rr;
+                                row = row < E ? row : E - 1;
+                                er[j] = ld_stream(reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq)));
+                            }
+                        }
+                    } else {
+                        const int j = EPI_SPLIT + ((slot - 14) >> 1), r = 8 * j + rr;
+                        if (!((slot - 14) & 1)) {
+                            ekm = *reinterpret_cast<const float2v*>(km2 + r * 2);
+                            ezq = (Z + (par3 * 4 + jb) * 256)[tile_q(r, cq)];
+                            gmq = *reinterpret_cast<const floatx4*>(vecs + 2 * H + 32 * jb + 4 * cq);   // read per use: this role has no registers to park them in
+                            btq = *reinterpret_cast<const floatx4*>(vecs + 3 * H + 32 * jb + 4 * cq);
+                        } else {
+                            floatx4 o;
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) {
+                                const float xh = fmaf(ezq[tt], ekm[0], ekm[1]);
+                                o[tt] = fmaf(er[j][tt], res_w, fmaf(xh, gmq[tt], btq[tt]));
+                            }
+                            float* orow = (agg_on && r < cnt_a) ? a_e_out + (unsigned)((st_a + r) * H) : sink;
+                            if (!(HEDGE_ABL & 4)) st_stream(reinterpret_cast<floatx4*>(orow + 32 * jb + 4 * cq), o);
+                        }
+                    }
                 }
             };
             const bool l3 = ok(x - 2);
@@ -567,7 +612,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     pend &= pend - 1;
                     const unsigned long long mk = (unsigned long long)(0u - ((last >> r) & 1u)) | ((unsigned long long)(0u - ((last >> (16 + r)) & 1u)) << 32);
                     if (__builtin_amdgcn_inverse_ballot_w64(mk)) {
-                        const int d = dq[r];
+                        const int d = drp[r];
                         const unsigned off = (d == head_a ? side_row : (unsigned)(d * H)) + 32 * jb + n;
                         if (!(HEDGE_ABL & 8)) a_agg[off] = y[r] + cpend;
                         cpend = 0.f;
@@ -579,7 +624,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             }
             cnt_a = cnt_b; fl_a = fl_b; cont_a = cont_b; last_a = last_b;
             if (fl_b & 1) head_a = head_b;
-            fetch(x - 1, bn, sn, cnt_b, fl_b, cont_b, last_b, head_b);
+            st_a = st_b;
+            fetch(x - 1, bn, sn, st_b, cnt_b, fl_b, cont_b, last_b, head_b);
             bn = a_blk[clampb(x)];
             sn = a_seg[clampb(x)];
             init_acc();
