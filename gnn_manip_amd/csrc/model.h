@@ -22,7 +22,8 @@ struct gm_model {
     size_t hm_jobs_cap = 0;
     size_t hm_floats = 0, hm_enc_edge = 0, hm_enc_node = 0, hm_enc_node_tail = 0;
     std::vector<size_t> hm_edge, hm_node, hm_node_tail;
-    bool legacy = false;         // hidden 128 / 256 with num_layers 2: the fp32 images (packed) exist
+    bool legacy = false;         // hidden 64 / 128 / 256: the fp32 images (packed) of the training kernels exist
+    bool dev_forms = false;      // hidden 128 / 256 with num_layers 2: the round-1 forward kernels can be selected (development builds)
     gm::ProfState* prof = nullptr;  // gm_model_profile
     int edge_kernel = 0;         // processor edge kernel of this model: 0 automatic, 1..5 see gm_model_set_edge_kernel
     std::vector<size_t> s16_edge;

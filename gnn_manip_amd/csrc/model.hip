@@ -167,7 +167,7 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
     flush_vec();
     if (rc != GM_OK || !m->packed) return rc;
 
-    // fp32 operand images (hidden 128 / 256, num_layers 2): training kernels and the selectable fp32 forward kernels
+    // fp32 operand images (hidden 64 / 128 / 256): training kernels and the selectable fp32 forward kernels
     PackJobs pj;
     pj.n = 0;
     auto flush_pack = [&]() {
@@ -301,7 +301,8 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
     const int NL = m->NL = desc->num_layers, M = m->M = desc->m_steps;
     if (desc->col_i || desc->col_j || desc->col_e) { m->ci = desc->col_i; m->cj = desc->col_j; m->ce = desc->col_e; }
     if (desc->node_agg_first) { m->ch = 1; m->ca = 0; }
-    m->legacy = (m->H == 128 || m->H == 256) && NL == 2;   // sizes the fp32 kernels (selectable forward forms, training) exist for
+    m->legacy = m->H == 64 || m->H == 128 || m->H == 256;   // widths the fp32 training kernels (and their operand images) exist for
+    m->dev_forms = (m->H == 128 || m->H == 256) && NL == 2;  // sizes of the selectable round-1 forward kernels (development builds)
     m->S_HH = layer_stages(H, H);
     m->S_e0 = layer_stages(desc->edge_dim, H);
     m->S_n0 = layer_stages(desc->node_dim, H);
@@ -353,7 +354,7 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
         }
     }
 #ifdef GM_DEV_KERNELS   // operand images of the round-1 inference kernels (development builds)
-    if (m->legacy && H == 128 && desc->edge_dim <= 16) {
+    if (m->dev_forms && H == 128 && desc->edge_dim <= 16) {
         size_t st16 = 0;
         m->s16_enc_edge = 0;
         st16 += layer_stages16(desc->edge_dim, H) + NL * layer_stages16(H, H);
@@ -369,7 +370,7 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             return GM_ERR_HIP;
         }
     }
-    if (m->legacy && H == 128 && hipMalloc(&m->packed_b3, (size_t)M * 3 * 4 * kB3StageFloats * sizeof(float)) != hipSuccess) {
+    if (m->dev_forms && H == 128 && hipMalloc(&m->packed_b3, (size_t)M * 3 * 4 * kB3StageFloats * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
         gm_model_destroy(m);
         return GM_ERR_HIP;
@@ -632,7 +633,7 @@ int gm_model_set_edge_kernel(gm_model* m, int choice) {
                "gm_model_set_edge_kernel: choices 1..4 (the round-1 fp32 / bf16 x 6 kernels) exist in development builds of the library only");
 #endif
     GM_REQUIRE(choice != 5 || m->packed_h3, GM_ERR_UNSUPPORTED, "gm_model_set_edge_kernel: the systolic kernel is for hidden_size 128, num_layers 2");
-    GM_REQUIRE(m->legacy || choice == 0 || choice == 6, GM_ERR_UNSUPPORTED,
+    GM_REQUIRE(m->dev_forms || choice == 0 || choice == 6, GM_ERR_UNSUPPORTED,
                "gm_model_set_edge_kernel: hidden_size=%d num_layers=%d has the streamed fp16-split kernels only (0 / 6)", m->H, m->NL);
     m->edge_kernel = choice;
     return GM_OK;

@@ -6,8 +6,7 @@ namespace gm {
 
 // activation tape of one MLP (all in the row order the MLP ran in)
 struct TapePtr {
-    float* a1;    // [rows][H] post-ReLU output of Linear 1
-    float* a2;    // [rows][H] post-ReLU output of Linear 2
+    float* a;     // [num_layers][rows][H] post-ReLU outputs of Linear 1 .. num_layers (a_l = a + (l - 1) rows H)
     float* xhat;  // [rows][H] normalised, pre-affine LayerNorm output (normed MLPs)
     float* rstd;  // [rows]    1 / sqrt(var + eps)
 };
@@ -23,7 +22,8 @@ struct TrainFwdArgs {
     const float* P;        // processor edge: [N][2H] = P_i (+ b1) | P_j
     const float* wstream;  // packed forward stream of this MLP
     const float* bias;     // bias of Linear 1 (unused by the processor edge MLP: it sits in P_i)
-    const float* bias_tail;  // biases of Linear 2, 3 (decoder: Linear 3's padded to 32)
+    const float* bias_tail;  // biases of Linear 2 .. num_layers + 1, H apart (decoder: the last one padded to 32)
+    int nl;                // num_layers: the MLP has nl + 1 Linears
     const float* ln_g;
     const float* ln_b;
     float eps;
@@ -43,11 +43,11 @@ struct TrainBwdArgs {
     const float* Gj;
     TapePtr tape;
     const float* ln_g;
-    const float* wstream;  // packed TRANSPOSED stream: [W_i^T, W_j^T (if Gi)] W3^T W2^T [W1^T ...]
+    const float* wstream;  // packed TRANSPOSED stream: [W_i^T, W_j^T (if Gi)] W_(nl+1)^T .. W_2^T [W_1^T ...]
     float* gy;             // [rows][H] total upstream gradient (for the LayerNorm parameter gradients)
-    float* dz3;            // [rows][H]
-    float* dz2;
-    float* dz1;
+    float* dz;             // [nl + 1][dz_stride]: pre-activation gradients dz_l = dz + (l - 1) dz_stride of Linear l = 1 .. nl + 1, rows of H
+    size_t dz_stride;      //   (the decoder's dz_(nl+1) is dY itself and is not written)
+    int nl;
     float* dx_resid;       // node: residual path; receives dY before dx adds the MLP's input gradient to it (may alias dY / dx)
     float* dx;             // edge: de_in; node: dh_in; decoder: dh; projection: dh_in
     const int* dxidx;      // edge: row of dx for row p (block API: the caller's edge order), or nullptr

@@ -128,12 +128,14 @@ __device__ __forceinline__ void layer_norm_bwd(floatx16 (&g)[NJB], floatx16 (&xh
 
 template <int H, int KIND>
 __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(TrainFwdArgs A) {
-    constexpr int NJB = H / 32, NL = 2;
+    constexpr int NJB = H / 32;
     constexpr int SL = (H / 8) * NJB / STAGE_PIECES;
+    const int NL = A.nl;   // any num_layers >= 2 (epd_gnn.py:72-84): the hidden Linears are a run-time loop
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ring = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
     const int R = A.rows;
+    const size_t tstride = (size_t)R * H;   // rows H between the tape's per-layer activation arrays
     const int ntiles = (R + TILE - 1) / TILE;
     WStream ws;
     ws.base = A.wstream;
@@ -181,16 +183,19 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
         // inputs, same values) so that their count is exact for run_layer<.., PEND>, which then does not
         // drain them; the bias loads go first so that waiting for them does not wait for the stores either.
         constexpr int NST = H / 8;  // vector stores of one store_feat
+#pragma unroll 1
+        for (int l = 1; l < NL; ++l) {   // Linear l + 1 (hidden)
+            relu_to(act, acc);
+            load_feat(acc, A.bias_tail + (size_t)(l - 1) * H, hi);
+            store_feat(act, A.tape.a + (size_t)(l - 1) * tstride + pc * H, hi);
+            run_layer<H / 8, NJB, NJB, NST>(acc, act, ws, more);
+        }
         relu_to(act, acc);
-        load_feat(acc, A.bias_tail, hi);
-        store_feat(act, A.tape.a1 + pc * H, hi);
-        run_layer<H / 8, NJB, NJB, NST>(acc, act, ws, more);
-        relu_to(act, acc);
-        if (KIND != TK_DEC) load_feat(acc, A.bias_tail + H, hi);
-        store_feat(act, A.tape.a2 + pc * H, hi);
+        if (KIND != TK_DEC) load_feat(acc, A.bias_tail + (size_t)(NL - 1) * H, hi);
+        store_feat(act, A.tape.a + (size_t)(NL - 1) * tstride + pc * H, hi);
         if (KIND == TK_DEC) {
             floatx16 o[1];
-            load_feat(o, A.bias_tail + H, hi);  // out bias, zero-padded to 32
+            load_feat(o, A.bias_tail + (size_t)(NL - 1) * H, hi);  // out bias, zero-padded to 32
             run_layer<H / 8, 1, NJB>(o, act, ws, more);
             if (valid && hi == 0) {
 #pragma unroll
@@ -224,6 +229,8 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
     float* ring = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
     const int R = A.rows;
+    const int NL = A.nl;
+    const size_t tstride = (size_t)R * H;
     const int ntiles = (R + TILE - 1) / TILE;
     const bool has_g = (KIND == TB_NODE || KIND == TB_ENC || KIND == TB_PROJ) && A.Gi != nullptr;
     WStream ws;
@@ -231,7 +238,8 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
     ws.ring = ring;
     constexpr int S_IN = (H / 8 + STAGE_PIECES - 1) / STAGE_PIECES;  // W1^T of an encoder: one 32-row block of outputs
     ws.total = (has_g ? 2 * SL : 0) +
-               (KIND == TB_ENC ? 2 * SL + (A.dx_in ? S_IN : 0) : KIND == TB_EDGE ? 3 * SL : KIND == TB_NODE ? 4 * SL : KIND == TB_PROJ ? 0 : 1 + 2 * SL);
+               (KIND == TB_ENC ? NL * SL + (A.dx_in ? S_IN : 0) : KIND == TB_EDGE ? (NL + 1) * SL : KIND == TB_NODE ? (NL + 2) * SL
+                : KIND == TB_PROJ ? 0 : 1 + NL * SL);
     ws.cur = 0;
     ws.parity = 0;
     ws.lane = lane;
@@ -274,18 +282,21 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
             load_feat(act, A.tape.xhat + pc * H, hi);
             layer_norm_bwd(acc, act, A.ln_g, A.tape.rstd[pc], hi);
             // dz stores: every lane (duplicates of the last row past the end), counted by run_layer<.., PEND>
-            store_feat(act, A.dz3 + pc * H, hi);
+            store_feat(act, A.dz + (size_t)NL * A.dz_stride + pc * H, hi);
             zero_feat(acc);
-            run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);  // W3^T dz3
+            run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);  // W_(NL+1)^T dz_(NL+1)
         }
-        mask_feat(acc, A.tape.a2 + pc * H, hi);
-        store_feat(acc, A.dz2 + pc * H, hi);
+#pragma unroll 1
+        for (int l = NL; l >= 2; --l) {   // dz_l = (W_(l+1)^T dz_(l+1)) [a_l > 0], then on through W_l^T
+            mask_feat(acc, A.tape.a + (size_t)(l - 1) * tstride + pc * H, hi);
+            store_feat(acc, A.dz + (size_t)(l - 1) * A.dz_stride + pc * H, hi);
 #pragma unroll
-        for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
-        zero_feat(acc);
-        run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);  // W2^T dz2
-        mask_feat(acc, A.tape.a1 + pc * H, hi);
-        store_feat(acc, A.dz1 + pc * H, hi);
+            for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
+            zero_feat(acc);
+            run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);
+        }
+        mask_feat(acc, A.tape.a + pc * H, hi);
+        store_feat(acc, A.dz + pc * H, hi);
         if (KIND == TB_ENC) {
             if (A.dx_in) {  // gradient w.r.t. the raw input features: dX = dz1 . W1  (k1 <= 32 columns)
 #pragma unroll
@@ -620,7 +631,7 @@ static int launch_train_fwd_h(int kind, const TrainFwdArgs& a, hipStream_t s) {
 }
 int launch_train_fwd(int H, int kind, const TrainFwdArgs& a, hipStream_t s) {
     if (a.rows <= 0) return GM_OK;
-    return H == 128 ? launch_train_fwd_h<128>(kind, a, s) : launch_train_fwd_h<256>(kind, a, s);
+    return H == 64 ? launch_train_fwd_h<64>(kind, a, s) : H == 128 ? launch_train_fwd_h<128>(kind, a, s) : launch_train_fwd_h<256>(kind, a, s);
 }
 
 template <int H>
@@ -639,7 +650,7 @@ static int launch_train_bwd_h(int kind, const TrainBwdArgs& a, hipStream_t s) {
 }
 int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s) {
     if (a.rows <= 0) return GM_OK;
-    return H == 128 ? launch_train_bwd_h<128>(kind, a, s) : launch_train_bwd_h<256>(kind, a, s);
+    return H == 64 ? launch_train_bwd_h<64>(kind, a, s) : H == 128 ? launch_train_bwd_h<128>(kind, a, s) : launch_train_bwd_h<256>(kind, a, s);
 }
 
 int wgrad_chunk(int64_t rows) {
@@ -677,7 +688,8 @@ int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, flo
     int64_t chunk = cdiv(rows, 512);
     if (chunk < 64) chunk = 64;
     const int G = (int)cdiv(rows, chunk);
-    if (H == 128) hipLaunchKernelGGL((ln_grads_kernel<128>), dim3(G), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, part);
+    if (H == 64) hipLaunchKernelGGL((ln_grads_kernel<64>), dim3(G), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, part);
+    else if (H == 128) hipLaunchKernelGGL((ln_grads_kernel<128>), dim3(G), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, part);
     else hipLaunchKernelGGL((ln_grads_kernel<256>), dim3(G), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, part);
     hipLaunchKernelGGL(ln_grads_reduce_kernel, dim3(2 * H / 32), dim3(256), 0, s, part, G, H, dgamma, dbeta);
     GM_LAUNCH_CHECK();
@@ -695,7 +707,8 @@ int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows
                        int64_t n, hipStream_t s) {
     if (n <= 0) return GM_OK;
     const unsigned grid = (unsigned)cdiv(n, 4);
-    if (H == 128) hipLaunchKernelGGL((segment_sum_kernel<2>), dim3(grid), dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n);
+    if (H == 64) hipLaunchKernelGGL((segment_sum_kernel<1>), dim3(grid), dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n);
+    else if (H == 128) hipLaunchKernelGGL((segment_sum_kernel<2>), dim3(grid), dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n);
     else hipLaunchKernelGGL((segment_sum_kernel<4>), dim3(grid), dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n);
     GM_LAUNCH_CHECK();
     return GM_OK;
@@ -714,6 +727,10 @@ int train_kernels_init() {
     const size_t lds = (size_t)2 * STAGE_FLOATS * 4;
     int rc = GM_OK;
 #define GM_SET(k) if (rc == GM_OK) rc = set_dyn_lds(k, lds)
+    GM_SET((train_fwd_kernel<64, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<64, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<64, TK_PROC_EDGE>));
+    GM_SET((train_fwd_kernel<64, TK_PROC_NODE>)); GM_SET((train_fwd_kernel<64, TK_DEC>));
+    GM_SET((train_bwd_kernel<64, TB_ENC>)); GM_SET((train_bwd_kernel<64, TB_EDGE>)); GM_SET((train_bwd_kernel<64, TB_NODE>)); GM_SET((train_bwd_kernel<64, TB_DEC>));
+    GM_SET((train_bwd_kernel<64, TB_PROJ>));
     GM_SET((train_fwd_kernel<128, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<128, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<128, TK_PROC_EDGE>));
     GM_SET((train_fwd_kernel<128, TK_PROC_NODE>)); GM_SET((train_fwd_kernel<128, TK_DEC>));
     GM_SET((train_fwd_kernel<256, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<256, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<256, TK_PROC_EDGE>));

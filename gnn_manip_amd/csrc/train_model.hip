@@ -23,10 +23,9 @@ struct Tape {
     size_t bytes;
 };
 
-TapePtr take_tape(Carver& c, int64_t rows, int H, bool normed) {
+TapePtr take_tape(Carver& c, int64_t rows, int H, int NL, bool normed) {
     TapePtr t{};
-    t.a1 = c.take<float>((size_t)rows * H);
-    t.a2 = c.take<float>((size_t)rows * H);
+    t.a = c.take<float>((size_t)NL * rows * H);   // post-ReLU outputs of Linear 1 .. NL, one [rows][H] array each
     if (normed) {
         t.xhat = c.take<float>((size_t)rows * H);
         t.rstd = c.take<float>((size_t)rows);
@@ -36,7 +35,7 @@ TapePtr take_tape(Carver& c, int64_t rows, int H, bool normed) {
 
 Tape carve_tape(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
     Tape t;
-    const int H = d->hidden_size, M = d->m_steps;
+    const int H = d->hidden_size, M = d->m_steps, NL = d->num_layers;
     Carver c(ws);
     t.csr_bytes = gm_csr_workspace_bytes(n, e);
     t.csr_dst = c.take<char>(t.csr_bytes);
@@ -49,21 +48,23 @@ Tape carve_tape(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
     for (int k = 0; k <= M; ++k) t.e[k] = c.take<float>((size_t)e * H);
     for (int k = 0; k < M; ++k) t.agg[k] = c.take<float>((size_t)n * H);
     t.P = c.take<float>((size_t)n * 2 * H);
-    t.ee = take_tape(c, e, H, true);
-    t.en = take_tape(c, n, H, true);
+    t.ee = take_tape(c, e, H, NL, true);
+    t.en = take_tape(c, n, H, NL, true);
     t.te.resize(M);
     t.tn.resize(M);
     for (int k = 0; k < M; ++k) {
-        t.te[k] = take_tape(c, e, H, true);
-        t.tn[k] = take_tape(c, n, H, true);
+        t.te[k] = take_tape(c, e, H, NL, true);
+        t.tn[k] = take_tape(c, n, H, NL, true);
     }
-    t.dec = take_tape(c, n, H, false);
+    t.dec = take_tape(c, n, H, NL, false);
     t.bytes = c.used();
     return t;
 }
 
 struct BwdWs {
-    float *packT, *gy, *dz1, *dz2, *dz3, *de, *dh, *dagg, *Gi, *Gj, *part;
+    float *packT, *gy, *dz, *de, *dh, *dagg, *Gi, *Gj, *part;
+    size_t dz_stride;   // floats between dz_l and dz_(l+1) (l = 1 .. NL + 1)
+    float* dzl(int l) const { return dz + (size_t)(l - 1) * dz_stride; }
     size_t off_dec, off_enc_edge, off_enc_node;
     std::vector<size_t> off_edge, off_node;
     size_t bytes;
@@ -71,26 +72,25 @@ struct BwdWs {
 
 BwdWs carve_bwd(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
     BwdWs b;
-    const int H = d->hidden_size, M = d->m_steps;
+    const int H = d->hidden_size, M = d->m_steps, NL = d->num_layers;
     const size_t U = (size_t)layer_stages(H, H) * kStageFloats;  // one HxH unit
     size_t off = 0;
-    b.off_dec = off; off += (size_t)layer_stages(d->out_dim, H) * kStageFloats + 2 * U;
+    b.off_dec = off; off += (size_t)layer_stages(d->out_dim, H) * kStageFloats + (size_t)NL * U;
     b.off_edge.resize(M);
     b.off_node.resize(M);
     for (int k = 0; k < M; ++k) {
-        b.off_node[k] = off; off += (k + 1 < M ? 2 * U : 0) + 4 * U;
-        b.off_edge[k] = off; off += 3 * U;
+        b.off_node[k] = off; off += (k + 1 < M ? 2 * U : 0) + (size_t)(NL + 2) * U;
+        b.off_edge[k] = off; off += (size_t)(NL + 1) * U;
     }
     const size_t UIN = (size_t)layer_stages(H, 32) * kStageFloats;  // W1^T of an encoder (input gradient, block API)
-    b.off_enc_node = off; off += 2 * U + 2 * U + UIN;
-    b.off_enc_edge = off; off += 2 * U + UIN;
+    b.off_enc_node = off; off += 2 * U + (size_t)NL * U + UIN;
+    b.off_enc_edge = off; off += (size_t)NL * U + UIN;
     Carver c(ws);
     b.packT = c.take<float>(off);
     const int64_t R = n > e ? n : e;
     b.gy = c.take<float>((size_t)R * H);
-    b.dz1 = c.take<float>((size_t)R * H);
-    b.dz2 = c.take<float>((size_t)R * H);
-    b.dz3 = c.take<float>((size_t)R * H);
+    b.dz_stride = align_up((size_t)R * H, 64);
+    b.dz = c.take<float>((size_t)(NL + 1) * b.dz_stride);
     b.de = c.take<float>((size_t)e * H);
     b.dh = c.take<float>((size_t)n * H);
     b.dagg = c.take<float>((size_t)n * H);
@@ -115,11 +115,11 @@ struct GiTape {
     TapePtr ee, en;
     size_t bytes;
 };
-GiTape carve_gi_tape(void* ws, int H, int64_t n, int64_t e) {
+GiTape carve_gi_tape(void* ws, int H, int NL, int64_t n, int64_t e) {
     GiTape t;
     Carver c(ws);
-    t.ee = take_tape(c, e, H, true);
-    t.en = take_tape(c, n, H, true);
+    t.ee = take_tape(c, e, H, NL, true);
+    t.en = take_tape(c, n, H, NL, true);
     t.bytes = c.used();
     return t;
 }
@@ -131,7 +131,7 @@ struct InTape {
     TapePtr te, tn;
     size_t bytes;
 };
-InTape carve_in_tape(void* ws, int H, int64_t n, int64_t e) {
+InTape carve_in_tape(void* ws, int H, int NL, int64_t n, int64_t e) {
     InTape t;
     Carver c(ws);
     t.csr_bytes = gm_csr_workspace_bytes(n, e);
@@ -140,8 +140,8 @@ InTape carve_in_tape(void* ws, int H, int64_t n, int64_t e) {
     t.ei2 = c.take<int64_t>((size_t)2 * e);
     t.P = c.take<float>((size_t)n * 2 * H);
     t.agg = c.take<float>((size_t)n * H);
-    t.te = take_tape(c, e, H, true);
-    t.tn = take_tape(c, n, H, true);
+    t.te = take_tape(c, e, H, NL, true);
+    t.tn = take_tape(c, n, H, NL, true);
     t.bytes = c.used();
     return t;
 }
@@ -168,7 +168,7 @@ size_t gm_train_backward_workspace_bytes(const gm_model_desc* desc, int64_t n, i
 
 int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, const int64_t* edge_index,
                          int64_t e, float* out, void* tape, size_t tape_bytes, void* stream) {
-    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_epd_forward_train");
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 64 / 128 / 256", "gm_epd_forward_train");
     gm::DevGuard dev_guard(nodes);
     int rc = check_sizes(m, n, e, "gm_epd_forward_train");
     if (rc != GM_OK) return rc;
@@ -191,7 +191,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
     const size_t U = (size_t)m->S_HH * kStageFloats;
     auto normed = [&](TrainFwdArgs& a, size_t voff) {
         const float* v = mlp_vec(m, voff);
-        a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
+        a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps; a.nl = NL;
     };
     {
         TrainFwdArgs a{};
@@ -244,7 +244,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
         TrainFwdArgs a{};
         a.rows = (int)n; a.x_in = t.h[M]; a.wstream = m->packed + m->s_node[M - 1] + (size_t)(NL + 2) * U;
         const float* v = mlp_vec(m, m->v_dec);
-        a.bias = v; a.bias_tail = v + H;
+        a.bias = v; a.bias_tail = v + H; a.nl = NL;
         a.tape = t.dec; a.out = out; a.out_dim = m->d.out_dim;
         rc = launch_train_fwd(H, TK_DEC, a, s);
         if (rc != GM_OK) return rc;
@@ -255,7 +255,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
 int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, const float* nodes, const float* edge_attr, int64_t n,
                     int64_t e, const float* grad_out, float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
                     void* stream) {
-    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_epd_backward");
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 64 / 128 / 256", "gm_epd_backward");
     gm::DevGuard dev_guard(nodes);
     int rc = check_sizes(m, n, e, "gm_epd_backward");
     if (rc != GM_OK) return rc;
@@ -265,7 +265,6 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     for (int i = 0; i < n_tensors; ++i)
         GM_REQUIRE(T[i] && grads[i], GM_ERR_INVALID_ARGUMENT, "gm_epd_backward: tensor / gradient %d is null", i);
     const int H = m->H, NL = m->NL, M = m->M, OD = m->d.out_dim;
-    GM_REQUIRE(NL == 2, GM_ERR_UNSUPPORTED, "gm_epd_backward: num_layers=%d not instantiated", NL);
     Tape t = carve_tape(tape, &m->d, n, e);
     GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_epd_backward: tape %zu < %zu", tape_bytes, t.bytes);
     BwdWs b = carve_bwd(ws, &m->d, n, e);
@@ -295,33 +294,30 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             j.W = W; j.w_rows = w_rows; j.ld = ld; j.col0 = col0; j.ksub = ksub; j.dst_off = off;
             off += (size_t)layer_stages(w_rows, ksub) * kStageFloats;
         };
+        // the hidden Linears NL + 1 .. 2 of an MLP, in the order its backward chain consumes them
+        auto packT_hidden = [&](int base, size_t& off) { for (int l = NL; l >= 1; --l) packT(T[base + 2 * l], H, H, 0, H, off); };
         size_t off = b.off_dec;
-        packT(T[b_dec + 4], OD, H, 0, H, off);
-        packT(T[b_dec + 2], H, H, 0, H, off);
-        packT(T[b_dec + 0], H, H, 0, H, off);
+        packT(T[b_dec + 2 * NL], OD, H, 0, H, off);
+        for (int l = NL - 1; l >= 0; --l) packT(T[b_dec + 2 * l], H, H, 0, H, off);
         for (int k = 0; k < M; ++k) {
             off = b.off_node[k];
             if (k + 1 < M) {
                 packT(T[b_edge(k + 1)], H, 3 * H, m->ci * H, H, off);
                 packT(T[b_edge(k + 1)], H, 3 * H, m->cj * H, H, off);
             }
-            packT(T[b_node(k) + 4], H, H, 0, H, off);
-            packT(T[b_node(k) + 2], H, H, 0, H, off);
+            packT_hidden(b_node(k), off);
             packT(T[b_node(k)], H, 2 * H, m->ch * H, H, off);
             packT(T[b_node(k)], H, 2 * H, m->ca * H, H, off);
             off = b.off_edge[k];
-            packT(T[b_edge(k) + 4], H, H, 0, H, off);
-            packT(T[b_edge(k) + 2], H, H, 0, H, off);
+            packT_hidden(b_edge(k), off);
             packT(T[b_edge(k)], H, 3 * H, m->ce * H, H, off);
         }
         off = b.off_enc_node;
         packT(T[b_edge(0)], H, 3 * H, m->ci * H, H, off);
         packT(T[b_edge(0)], H, 3 * H, m->cj * H, H, off);
-        packT(T[b_enc_node + 4], H, H, 0, H, off);
-        packT(T[b_enc_node + 2], H, H, 0, H, off);
+        packT_hidden(b_enc_node, off);
         off = b.off_enc_edge;
-        packT(T[b_enc_edge + 4], H, H, 0, H, off);
-        packT(T[b_enc_edge + 2], H, H, 0, H, off);
+        packT_hidden(b_enc_edge, off);
         flush();
         if (rc != GM_OK) return rc;
     }
@@ -332,23 +328,26 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     };
     // W3 (+ b3), W2 (+ b2) and the LayerNorm gradients of a normed MLP whose chain kernel has just run over `rows`
     // (b1 comes with the first-layer weight gradient at the call site)
+    auto act = [&](const TapePtr& tp, int l, int64_t rows) { return tp.a + (size_t)(l - 1) * rows * H; };   // a_l
     auto normed_tail_grads = [&](int base, const TapePtr& tp, int64_t rows) {
-        wgrad(b.dz3, H, H, tp.a2, H, H, nullptr, rows, grads[base + 4], H, 0, grads[base + 5]);
-        wgrad(b.dz2, H, H, tp.a1, H, H, nullptr, rows, grads[base + 2], H, 0, grads[base + 3]);
-        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 6], grads[base + 7], s);
+        for (int l = NL; l >= 1; --l)   // Linear l + 1: dW = dz_(l+1)^T a_l
+            wgrad(b.dzl(l + 1), H, H, act(tp, l, rows), H, H, nullptr, rows, grads[base + 2 * l], H, 0, grads[base + 2 * l + 1]);
+        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 2 * (NL + 1)], grads[base + 2 * (NL + 1) + 1], s);
     };
+    auto chain = [&](TrainBwdArgs& a) { a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; };
     auto ln_gamma = [&](size_t voff) { return m->vec + voff + (size_t)(NL + 1) * H; };
 
     // ---- decoder
     {
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = grad_out; a.out_dim = OD; a.tape = t.dec; a.wstream = b.packT + b.off_dec;
-        a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx = b.dh;
+        chain(a); a.dx = b.dh;
         rc = launch_train_bwd(H, TB_DEC, a, s);
         if (rc != GM_OK) return rc;
-        wgrad(grad_out, OD, OD, t.dec.a2, H, H, nullptr, n, grads[b_dec + 4], H, 0, grads[b_dec + 5]);
-        wgrad(b.dz2, H, H, t.dec.a1, H, H, nullptr, n, grads[b_dec + 2], H, 0, grads[b_dec + 3]);
-        wgrad(b.dz1, H, H, t.h[M], H, H, nullptr, n, grads[b_dec + 0], H, 0, grads[b_dec + 1]);
+        wgrad(grad_out, OD, OD, act(t.dec, NL, n), H, H, nullptr, n, grads[b_dec + 2 * NL], H, 0, grads[b_dec + 2 * NL + 1]);
+        for (int l = NL - 1; l >= 1; --l)
+            wgrad(b.dzl(l + 1), H, H, act(t.dec, l, n), H, H, nullptr, n, grads[b_dec + 2 * l], H, 0, grads[b_dec + 2 * l + 1]);
+        wgrad(b.dzl(1), H, H, t.h[M], H, H, nullptr, n, grads[b_dec + 0], H, 0, grads[b_dec + 1]);
         if (rc != GM_OK) return rc;
     }
     // ---- processor blocks, last to first
@@ -358,27 +357,27 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             TrainBwdArgs a{};
             a.rows = (int)n; a.dY = b.dh; a.Gi = has_next ? b.Gi : nullptr; a.Gj = has_next ? b.Gj : nullptr;
             a.tape = t.tn[k]; a.ln_g = ln_gamma(m->v_node[k]); a.wstream = b.packT + b.off_node[k];
-            a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
+            a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
             rc = launch_train_bwd(H, TB_NODE, a, s);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_node(k), t.tn[k], n);
-            wgrad(b.dz1, H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ch * H, grads[b_node(k) + 1]);
-            wgrad(b.dz1, H, H, t.agg[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ca * H, nullptr);
+            wgrad(b.dzl(1), H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ch * H, grads[b_node(k) + 1]);
+            wgrad(b.dzl(1), H, H, t.agg[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ca * H, nullptr);
             if (rc != GM_OK) return rc;
         }
         {
             TrainBwdArgs a{};
             a.rows = (int)e; a.dY = has_next ? b.de : nullptr; a.dagg = b.dagg; a.dst = c.dst;
             a.tape = t.te[k]; a.ln_g = ln_gamma(m->v_edge[k]); a.wstream = b.packT + b.off_edge[k];
-            a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx = b.de; a.residual = 1;
+            a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.de; a.residual = 1;
             rc = launch_train_bwd(H, TB_EDGE, a, s);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_edge(k), t.te[k], e);
-            wgrad(b.dz1, H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, m->ce * H, grads[b_edge(k) + 1]);
+            wgrad(b.dzl(1), H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, m->ce * H, grads[b_edge(k) + 1]);
             if (rc != GM_OK) return rc;
             // node-level sums of dz1: everything the factorised layer 1 needs
-            rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dz1, nullptr, nullptr, b.Gi, n, s);
-            if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dz1, nullptr, nullptr, b.Gj, n, s);
+            rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dzl(1), nullptr, nullptr, b.Gi, n, s);
+            if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dzl(1), nullptr, nullptr, b.Gj, n, s);
             wgrad(b.Gi, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, m->ci * H, nullptr);
             wgrad(b.Gj, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, m->cj * H, nullptr);
             if (rc != GM_OK) return rc;
@@ -389,21 +388,21 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = b.dh; a.Gi = b.Gi; a.Gj = b.Gj; a.tape = t.en; a.ln_g = ln_gamma(m->v_enc_node);
         a.wstream = b.packT + b.off_enc_node;
-        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1;
+        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
         normed_tail_grads(b_enc_node, t.en, n);
-        wgrad(b.dz1, H, H, nodes, m->d.node_dim, m->d.node_dim, nullptr, n, grads[b_enc_node], m->d.node_dim, 0, grads[b_enc_node + 1]);
+        wgrad(b.dzl(1), H, H, nodes, m->d.node_dim, m->d.node_dim, nullptr, n, grads[b_enc_node], m->d.node_dim, 0, grads[b_enc_node + 1]);
         if (rc != GM_OK) return rc;
     }
     if (e > 0) {
         TrainBwdArgs a{};
         a.rows = (int)e; a.dY = b.de; a.tape = t.ee; a.ln_g = ln_gamma(m->v_enc_edge); a.wstream = b.packT + b.off_enc_edge;
-        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1;
+        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
         normed_tail_grads(b_enc_edge, t.ee, e);
-        wgrad(b.dz1, H, H, edge_attr, m->d.edge_dim, m->d.edge_dim, c.eid, e, grads[b_enc_edge], m->d.edge_dim, 0, grads[b_enc_edge + 1]);
+        wgrad(b.dzl(1), H, H, edge_attr, m->d.edge_dim, m->d.edge_dim, c.eid, e, grads[b_enc_edge], m->d.edge_dim, 0, grads[b_enc_edge + 1]);
         if (rc != GM_OK) return rc;
     }
     return GM_OK;
@@ -415,7 +414,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
 // ------------------------------------------------------------------------------------------
 size_t gm_block_tape_bytes(const gm_model_desc* desc, int interaction_network, int64_t n, int64_t e) {
     if (!desc || n < 0 || e < 0) return 0;
-    return interaction_network ? carve_in_tape(nullptr, desc->hidden_size, n, e).bytes : carve_gi_tape(nullptr, desc->hidden_size, n, e).bytes;
+    return interaction_network ? carve_in_tape(nullptr, desc->hidden_size, desc->num_layers, n, e).bytes : carve_gi_tape(nullptr, desc->hidden_size, desc->num_layers, n, e).bytes;
 }
 
 size_t gm_block_backward_workspace_bytes(const gm_model_desc* desc, int64_t n, int64_t e) {
@@ -425,20 +424,20 @@ size_t gm_block_backward_workspace_bytes(const gm_model_desc* desc, int64_t n, i
 
 int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_t n, const float* edge_attr, int64_t e, float* h_out,
                                        float* e_out, void* tape, size_t tape_bytes, void* stream) {
-    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_graph_independent_forward_train");
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 64 / 128 / 256", "gm_graph_independent_forward_train");
     gm::DevGuard dev_guard(x ? (const void*)x : (const void*)edge_attr);
     int rc = check_sizes(m, n, e, "gm_graph_independent_forward_train");
     if (rc != GM_OK) return rc;
     GM_REQUIRE(x && h_out && tape && (e == 0 || (edge_attr && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_forward_train: null pointer");
     const int H = m->H, NL = m->NL;
-    GiTape t = carve_gi_tape(tape, H, n, e);
+    GiTape t = carve_gi_tape(tape, H, NL, n, e);
     GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_graph_independent_forward_train: tape %zu < %zu", tape_bytes, t.bytes);
     rc = train_kernels_init();
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     auto normed = [&](TrainFwdArgs& a, size_t voff) {
         const float* v = mlp_vec(m, voff);
-        a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
+        a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps; a.nl = NL;
     };
     TrainFwdArgs a{};
     a.rows = (int)e; a.x_in = edge_attr; a.k1 = m->d.edge_dim; a.wstream = m->packed + m->s_enc_edge;
@@ -456,7 +455,7 @@ int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_
 int gm_graph_independent_backward(const gm_model* m, const float* const* T, int n_tensors, const float* x, const float* edge_attr, int64_t n,
                                   int64_t e, const float* dh, const float* de, float* dx, float* dedge_attr, float* const* grads,
                                   void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
-    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_graph_independent_backward");
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 64 / 128 / 256", "gm_graph_independent_backward");
     gm::DevGuard dev_guard(x ? (const void*)x : (const void*)edge_attr);
     int rc = check_sizes(m, n, e, "gm_graph_independent_backward");
     if (rc != GM_OK) return rc;
@@ -466,7 +465,7 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
     const int H = m->H, NL = m->NL;
     const int PM = tensors_per_normed_mlp(NL);
     for (int i = 0; i < 2 * PM; ++i) GM_REQUIRE(T[i] && grads[i], GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_backward: tensor / gradient %d is null", i);
-    GiTape t = carve_gi_tape(tape, H, n, e);
+    GiTape t = carve_gi_tape(tape, H, NL, n, e);
     GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_graph_independent_backward: tape %zu < %zu", tape_bytes, t.bytes);
     BwdWs b = carve_block_bwd(ws, &m->d, n, e);
     GM_REQUIRE(ws_bytes >= b.bytes, GM_ERR_WORKSPACE, "gm_graph_independent_backward: workspace %zu < %zu", ws_bytes, b.bytes);
@@ -481,16 +480,16 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
         j.W = W; j.w_rows = H; j.ld = H; j.col0 = 0; j.ksub = H; j.dst_off = off;
     };
     // node stream sits behind the (unused) projection slots of the model layout
-    packT(T[PM + 4], b.off_enc_node + 2 * U);
-    packT(T[PM + 2], b.off_enc_node + 3 * U);
-    packT(T[4], b.off_enc_edge);
-    packT(T[2], b.off_enc_edge + U);
+    for (int l = NL; l >= 1; --l) {
+        packT(T[PM + 2 * l], b.off_enc_node + (size_t)(2 + NL - l) * U);
+        packT(T[2 * l], b.off_enc_edge + (size_t)(NL - l) * U);
+    }
     auto packT_in = [&](const float* W, int k1, size_t off) {  // (W1 [H, k1])^T as a Linear with k1 outputs, H inputs
         PackTJob& j = jobs.job[jobs.n++];
         j.W = W; j.w_rows = H; j.ld = k1; j.col0 = 0; j.ksub = k1; j.dst_off = off;
     };
-    if (dx) packT_in(T[PM], m->d.node_dim, b.off_enc_node + 4 * U);
-    if (dedge_attr) packT_in(T[0], m->d.edge_dim, b.off_enc_edge + 2 * U);
+    if (dx) packT_in(T[PM], m->d.node_dim, b.off_enc_node + (size_t)(NL + 2) * U);
+    if (dedge_attr) packT_in(T[0], m->d.edge_dim, b.off_enc_edge + (size_t)NL * U);
     rc = launch_pack_t_batch(jobs, b.packT, s);
     if (rc != GM_OK) return rc;
     auto run = [&](int base, const TapePtr& tp, int64_t rows, const float* dY, size_t voff, size_t woff, const float* X, int k1, float* dxin) {
@@ -498,12 +497,13 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
         TrainBwdArgs a{};
         a.rows = (int)rows; a.dY = dY; a.tape = tp; a.ln_g = m->vec + voff + (size_t)(NL + 1) * H; a.wstream = b.packT + woff;
         a.dx_in = dxin; a.k1 = k1;
-        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1;
+        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = launch_train_bwd(H, TB_ENC, a, s);
-        if (rc == GM_OK) rc = launch_wgrad(b.dz3, H, H, tp.a2, H, H, nullptr, rows, b.part, grads[base + 4], H, 0, grads[base + 5], s);
-        if (rc == GM_OK) rc = launch_wgrad(b.dz2, H, H, tp.a1, H, H, nullptr, rows, b.part, grads[base + 2], H, 0, grads[base + 3], s);
-        if (rc == GM_OK) rc = launch_wgrad(b.dz1, H, H, X, k1, k1, nullptr, rows, b.part, grads[base], k1, 0, grads[base + 1], s);
-        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 6], grads[base + 7], s);
+        for (int l = NL; l >= 1 && rc == GM_OK; --l)
+            rc = launch_wgrad(b.dzl(l + 1), H, H, tp.a + (size_t)(l - 1) * rows * H, H, H, nullptr, rows, b.part, grads[base + 2 * l], H, 0,
+                              grads[base + 2 * l + 1], s);
+        if (rc == GM_OK) rc = launch_wgrad(b.dzl(1), H, H, X, k1, k1, nullptr, rows, b.part, grads[base], k1, 0, grads[base + 1], s);
+        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 2 * (NL + 1)], grads[base + 2 * (NL + 1) + 1], s);
     };
     run(PM, t.en, n, dh, m->v_enc_node, b.off_enc_node + 2 * U, x, m->d.node_dim, dx);
     run(0, t.ee, e, de, m->v_enc_edge, b.off_enc_edge, edge_attr, m->d.edge_dim, dedge_attr);
@@ -512,14 +512,14 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
 
 int gm_interaction_network_forward_train(const gm_model* m, int k, const float* h, int64_t n, const float* e_in, const int64_t* edge_index,
                                          int64_t e, float* h_out, float* e_out, void* tape, size_t tape_bytes, void* stream) {
-    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_interaction_network_forward_train");
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 64 / 128 / 256", "gm_interaction_network_forward_train");
     gm::DevGuard dev_guard(h);
     int rc = check_sizes(m, n, e, "gm_interaction_network_forward_train");
     if (rc != GM_OK) return rc;
     GM_REQUIRE(k >= 0 && k < m->M, GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward_train: block %d out of range", k);
     GM_REQUIRE(h && h_out && tape && (e == 0 || (e_in && e_out && edge_index)), GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_forward_train: null pointer");
     const int H = m->H, NL = m->NL;
-    InTape t = carve_in_tape(tape, H, n, e);
+    InTape t = carve_in_tape(tape, H, NL, n, e);
     GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_forward_train: tape %zu < %zu", tape_bytes, t.bytes);
     rc = train_kernels_init();
     if (rc != GM_OK) return rc;
@@ -542,7 +542,7 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
     if (rc != GM_OK) return rc;
     auto normed = [&](TrainFwdArgs& a, size_t voff) {
         const float* v = mlp_vec(m, voff);
-        a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
+        a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps; a.nl = NL;
     };
     {
         TrainFwdArgs a{};
@@ -565,7 +565,7 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
 int gm_interaction_network_backward(const gm_model* m, int k, const float* const* T, int n_tensors, const float* h, const float* e_in,
                                     int64_t n, int64_t e, const float* dh_out, const float* de_out, float* dh_in, float* de_in,
                                     float* const* grads, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
-    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 128 / 256 with num_layers 2", "gm_interaction_network_backward");
+    GM_REQUIRE(!m || m->legacy, GM_ERR_UNSUPPORTED, "%s: the training kernels are instantiated for hidden_size 64 / 128 / 256", "gm_interaction_network_backward");
     gm::DevGuard dev_guard(h);
     int rc = check_sizes(m, n, e, "gm_interaction_network_backward");
     if (rc != GM_OK) return rc;
@@ -578,7 +578,7 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
     const int PM = tensors_per_normed_mlp(NL);
     const int be = (2 + 2 * k) * PM, bn = (3 + 2 * k) * PM;
     for (int i = be; i < bn + PM; ++i) GM_REQUIRE(T[i] && grads[i], GM_ERR_INVALID_ARGUMENT, "gm_interaction_network_backward: tensor / gradient %d is null", i);
-    InTape t = carve_in_tape(tape, H, n, e);
+    InTape t = carve_in_tape(tape, H, NL, n, e);
     GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_backward: tape %zu < %zu", tape_bytes, t.bytes);
     BwdWs b = carve_block_bwd(ws, &m->d, n, e);
     GM_REQUIRE(ws_bytes >= b.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_backward: workspace %zu < %zu", ws_bytes, b.bytes);
@@ -595,13 +595,13 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
             PackTJob& j = jobs.job[jobs.n++];
             j.W = W; j.w_rows = H; j.ld = ld; j.col0 = col0; j.ksub = H; j.dst_off = off;
         };
-        packT(T[bn + 4], H, 0, b.off_node[0]);
-        packT(T[bn + 2], H, 0, b.off_node[0] + U);
-        packT(T[bn], 2 * H, m->ch * H, b.off_node[0] + 2 * U);
-        packT(T[bn], 2 * H, m->ca * H, b.off_node[0] + 3 * U);
-        packT(T[be + 4], H, 0, b.off_edge[0]);
-        packT(T[be + 2], H, 0, b.off_edge[0] + U);
-        packT(T[be], 3 * H, m->ce * H, b.off_edge[0] + 2 * U);
+        for (int l = NL; l >= 1; --l) {
+            packT(T[bn + 2 * l], H, 0, b.off_node[0] + (size_t)(NL - l) * U);
+            packT(T[be + 2 * l], H, 0, b.off_edge[0] + (size_t)(NL - l) * U);
+        }
+        packT(T[bn], 2 * H, m->ch * H, b.off_node[0] + (size_t)NL * U);
+        packT(T[bn], 2 * H, m->ca * H, b.off_node[0] + (size_t)(NL + 1) * U);
+        packT(T[be], 3 * H, m->ce * H, b.off_edge[0] + (size_t)NL * U);
         packT(T[be], 3 * H, m->ci * H, b.off_enc_node);       // W_i^T, W_j^T: projection backward
         packT(T[be], 3 * H, m->cj * H, b.off_enc_node + U);
         rc = launch_pack_t_batch(jobs, b.packT, s);
@@ -614,31 +614,29 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
     {
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = dh_out; a.tape = t.tn; a.ln_g = m->vec + m->v_node[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_node[0];
-        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx = b.dh; a.dagg_out = b.dagg;
+        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.dh; a.dagg_out = b.dagg;
         rc = launch_train_bwd(H, TB_NODE, a, s);
         if (rc != GM_OK) return rc;
-        wgrad(b.dz3, t.tn.a2, n, grads[bn + 4], H, 0, grads[bn + 5]);
-        wgrad(b.dz2, t.tn.a1, n, grads[bn + 2], H, 0, grads[bn + 3]);
-        wgrad(b.dz1, h, n, grads[bn], 2 * H, m->ch * H, grads[bn + 1]);
-        wgrad(b.dz1, t.agg, n, grads[bn], 2 * H, m->ca * H, nullptr);
-        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.tn.xhat, n, b.part, grads[bn + 6], grads[bn + 7], s);
+        for (int l = NL; l >= 1; --l) wgrad(b.dzl(l + 1), t.tn.a + (size_t)(l - 1) * n * H, n, grads[bn + 2 * l], H, 0, grads[bn + 2 * l + 1]);
+        wgrad(b.dzl(1), h, n, grads[bn], 2 * H, m->ch * H, grads[bn + 1]);
+        wgrad(b.dzl(1), t.agg, n, grads[bn], 2 * H, m->ca * H, nullptr);
+        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.tn.xhat, n, b.part, grads[bn + 2 * (NL + 1)], grads[bn + 2 * (NL + 1) + 1], s);
         if (rc != GM_OK) return rc;
     }
     if (e > 0) {
         TrainBwdArgs a{};
         a.rows = (int)e; a.dY = de_out; a.dyidx = c.eid; a.dagg = b.dagg; a.dst = c.dst; a.tape = t.te;
         a.ln_g = m->vec + m->v_edge[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_edge[0];
-        a.gy = b.gy; a.dz3 = b.dz3; a.dz2 = b.dz2; a.dz1 = b.dz1; a.dx = de_in; a.dxidx = c.eid; a.residual = 0;
+        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = de_in; a.dxidx = c.eid; a.residual = 0;
         rc = launch_train_bwd(H, TB_EDGE, a, s);
         if (rc != GM_OK) return rc;
-        wgrad(b.dz3, t.te.a2, e, grads[be + 4], H, 0, grads[be + 5]);
-        wgrad(b.dz2, t.te.a1, e, grads[be + 2], H, 0, grads[be + 3]);
-        if (rc == GM_OK) rc = launch_wgrad(b.dz1, H, H, e_in, H, H, c.eid, e, b.part, grads[be], 3 * H, m->ce * H, grads[be + 1], s);
-        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.te.xhat, e, b.part, grads[be + 6], grads[be + 7], s);
+        for (int l = NL; l >= 1; --l) wgrad(b.dzl(l + 1), t.te.a + (size_t)(l - 1) * e * H, e, grads[be + 2 * l], H, 0, grads[be + 2 * l + 1]);
+        if (rc == GM_OK) rc = launch_wgrad(b.dzl(1), H, H, e_in, H, H, c.eid, e, b.part, grads[be], 3 * H, m->ce * H, grads[be + 1], s);
+        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.te.xhat, e, b.part, grads[be + 2 * (NL + 1)], grads[be + 2 * (NL + 1) + 1], s);
         if (rc != GM_OK) return rc;
     }
-    rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dz1, nullptr, nullptr, b.Gi, n, s);
-    if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dz1, nullptr, nullptr, b.Gj, n, s);
+    rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dzl(1), nullptr, nullptr, b.Gi, n, s);
+    if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dzl(1), nullptr, nullptr, b.Gj, n, s);
     wgrad(b.Gi, h, n, grads[be], 3 * H, m->ci * H, nullptr);
     wgrad(b.Gj, h, n, grads[be], 3 * H, m->cj * H, nullptr);
     if (rc != GM_OK) return rc;

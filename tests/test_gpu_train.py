@@ -85,6 +85,17 @@ def test_backward_hidden_256(dev):
     _check(m, params, nodes, ea, ei, dims, dev, 94)
 
 
+@pytest.mark.parametrize("hidden,num_layers,m_steps,seed", [(64, 2, 3, 120), (64, 3, 2, 121), (128, 3, 2, 122), (128, 4, 1, 123), (256, 3, 1, 124)])
+def test_backward_other_widths_and_depths(dev, hidden, num_layers, m_steps, seed):
+    """build_mlp takes any num_layers >= 2 (epd_gnn.py:72-84); the training kernels loop over the hidden Linears at run time
+    and are instantiated for hidden 64 / 128 / 256."""
+    dims = (25, 4, 3, hidden, num_layers, m_steps)
+    params = orc.init_params(*dims, seed)
+    m = _model(params, dims, dev)
+    nodes, ea, ei = _graph(700, 0.07, seed)
+    _check(m, params, nodes, ea, ei, dims, dev, seed)
+
+
 def test_backward_collated_batch_of_two(dev, golden):
     """The training loader's input: two graphs collated with the index offset (collate_utils.py:68-87)."""
     g4 = golden("g4_features.npz")
@@ -121,14 +132,15 @@ def test_training_step_reduces_loss_and_inference_sees_new_weights(dev):
     assert (out_train - out_inf).abs().max() <= 1e-5 * max(float(out_inf.abs().max()), 0.1)
 
 
-@pytest.mark.parametrize("n,side,seed,m_steps", [(800, 0.07, 108, 3), (150, 0.3, 98, 2)])
-def test_reference_wiring_over_standalone_blocks_trains(dev, n, side, seed, m_steps):
+@pytest.mark.parametrize("n,side,seed,m_steps,hidden,num_layers", [(800, 0.07, 108, 3, 128, 2), (150, 0.3, 98, 2, 128, 2),
+                                                                    (500, 0.07, 125, 2, 64, 3)])
+def test_reference_wiring_over_standalone_blocks_trains(dev, n, side, seed, m_steps, hidden, num_layers):
     """The reference's own forward (epd_gnn.py:86-105: encoder block, m x (block + residuals), torch decoder) run over
     the standalone GraphIndependent / InteractionNetwork modules under autograd: every parameter gradient against the
     float64 oracle.  Exercises the block-level backward incl. the InteractionNetwork's input gradients.  (Seeds without
     a float32 / float64 ReLU sign flip: the observed error is ~1e-6 on every tensor; with flips both this path and
     plain PyTorch float32 deviate by the same ~5e-4, see the module docstring.)"""
-    dims = (25, 4, 3, 128, 2, m_steps)
+    dims = (25, 4, 3, hidden, num_layers, m_steps)
     params = orc.init_params(*dims, seed)
     m = _model(params, dims, dev)
     nodes, ea, ei = _graph(n, side, seed)
@@ -141,8 +153,8 @@ def test_reference_wiring_over_standalone_blocks_trains(dev, n, side, seed, m_st
     out = m.decoder(h)  # plain torch Sequential, as in the reference
     loss = torch.nn.functional.l1_loss(out, _t(target, dev), reduction="sum") / out.shape[0]
     loss.backward()
-    ref_out, ref_loss, ref_g = torch_epd.loss_and_grads(params, nodes, ea, ei, target, 2, m_steps)
-    _, _, g32 = torch_epd.loss_and_grads(params, nodes, ea, ei, target, 2, m_steps, torch.float32)
+    ref_out, ref_loss, ref_g = torch_epd.loss_and_grads(params, nodes, ea, ei, target, num_layers, m_steps)
+    _, _, g32 = torch_epd.loss_and_grads(params, nodes, ea, ei, target, num_layers, m_steps, torch.float32)
     assert np.abs(out.detach().cpu().numpy() - ref_out).max() <= 1e-5 * max(np.abs(ref_out).max(), 1e-3)
     worst = ("", 0.0)
     for name, p in m.named_parameters():
