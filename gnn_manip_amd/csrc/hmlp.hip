@@ -44,6 +44,10 @@ constexpr size_t HM_BLK_BYTES = 2 * 16 * sizeof(int2);
 constexpr size_t HM_GB_BYTES = 2 * 256 * sizeof(float);    // gamma | beta
 constexpr size_t HM_RS_BYTES = 32 * 32 * sizeof(float);    // encoders: power-of-two scale of every row of the tile
 constexpr size_t HM_LDS_BYTES = HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES + HM_GB_BYTES + HM_RS_BYTES;
+// node kernels with RBW row blocks per wave: image and statistics shrink with the tile.  (Two workgroups per CU in the one-block
+// form, which then fits twice: measured +-0 at N = 100k; a two-block form needs > 128 VGPRs.)
+constexpr size_t hm_node_img_bytes(int rbw) { return HM_IMG_BYTES * rbw / 4; }
+constexpr size_t hm_node_lds_bytes(int rbw) { return hm_node_img_bytes(rbw) + HM_ST_BYTES * rbw / 4 + HM_BLK_BYTES + HM_GB_BYTES + HM_RS_BYTES; }
 
 // RBW: 32-row blocks per wave.  4 fills the LDS image (M * H = 32768); the node kernels also come with 1 for small
 // graphs (four times the tiles; per-row arithmetic is identical, so results do not depend on the choice).
@@ -117,39 +121,77 @@ __device__ __forceinline__ void report_range(int bad, int* flags) {
 //   wf : this wave's fragments of the first k-group, + lane  (k-group stride 128 half8)
 //   im : image of the wave's first row block at k-group 0, + lane  (row-block stride img_ksn * 128, k-group stride 128)
 // nrb: row blocks of this wave that hold rows (the others' MFMAs are skipped: the last tile of a workgroup's range may be partial)
+#ifndef HM_RING4
+#define HM_RING4(RBW) ((RBW) == 1)
+#endif
+// One k-group: the three partial products of every row block (lo.hi + hi.lo + hi.hi).
+template <int RBW>
+__device__ __forceinline__ void mfma3(floatx16 (&acc)[RBW], const half8& ah, const half8& al, const half8 (&bh)[RBW], const half8 (&bl)[RBW], int nrb) {
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[rb], acc[rb], 0, 0, 0);
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[rb], acc[rb], 0, 0, 0);
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[rb], acc[rb], 0, 0, 0);
+}
+
+// Fragment loads of the GEMM loop.  Every load is UNCONDITIONAL, from a clamped (always valid) k-group: a load inside a
+// branch makes hipcc wait with vmcnt(0) at the join, which also drains the prefetches issued since -- the loop then runs at
+// one L2 round trip per trip (that is what the round-2 form of this loop did: 3.3 ms per launch at hidden 256).  With
+// straight-line loads the waits are counted.  The requests are pinned where they are written (sched_barrier): under
+// register pressure the scheduler otherwise sinks every load to its first use.  The weights come from L2 (~1 us under
+// load), so the A fragments run a ring of 4 k-groups: a k-group is requested one and a half trips (36 MFMAs of this wave,
+// as many of the SIMD's other wave) before its use.  The redundant loads of the last trips re-read the last k-group.
 template <int RBW>
 __device__ __forceinline__ void gemm(floatx16 (&acc)[RBW], const half8* __restrict__ wf, const half8* im, int img_ksn, int nks, int nrb = RBW) {
-    half8 ah0 = wf[0], al0 = wf[64], ah1 = ah0, al1 = al0;
-    if (nks > 1) { ah1 = wf[128]; al1 = wf[192]; }
+    const int last = nks - 1;
     half8 bh[RBW], bl[RBW], ch[RBW], cl[RBW];
+    auto load_b = [&](half8 (&h)[RBW], half8 (&l)[RBW], int kg) {
 #pragma unroll
-    for (int rb = 0; rb < RBW; ++rb) { bh[rb] = im[rb * img_ksn * 128]; bl[rb] = im[rb * img_ksn * 128 + 64]; }
+        for (int rb = 0; rb < RBW; ++rb) { h[rb] = im[(rb * img_ksn + kg) * 128]; l[rb] = im[(rb * img_ksn + kg) * 128 + 64]; }
+    };
+    if (HM_RING4(RBW) && nks >= 4 && (nks & 3) == 0) {
+        half8 ah[4], al[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ah[q] = wf[q * 128]; al[q] = wf[q * 128 + 64]; }
+        load_b(bh, bl, 0);
+        load_b(ch, cl, 1);
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ks += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u += 2) {
+                mfma3(acc, ah[u], al[u], bh, bl, nrb);
+                __builtin_amdgcn_sched_barrier(0);
+                { const int ka = min(ks + u + 4, last); ah[u] = wf[ka * 128]; al[u] = wf[ka * 128 + 64]; }
+                load_b(bh, bl, min(ks + u + 2, last));
+                __builtin_amdgcn_sched_barrier(0);
+                mfma3(acc, ah[u + 1], al[u + 1], ch, cl, nrb);
+                __builtin_amdgcn_sched_barrier(0);
+                { const int ka = min(ks + u + 5, last); ah[u + 1] = wf[ka * 128]; al[u + 1] = wf[ka * 128 + 64]; }
+                load_b(ch, cl, min(ks + u + 3, last));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
+    // short inputs (the encoders' first Linear: 1 or 2 k-groups)
+    half8 ah0 = wf[0], al0 = wf[64];
+    half8 ah1 = wf[min(1, last) * 128], al1 = wf[min(1, last) * 128 + 64];
+    load_b(bh, bl, 0);
+    load_b(ch, cl, min(1, last));
 #pragma unroll 1
     for (int ks = 0; ks < nks; ks += 2) {
-        if (ks + 1 < nks) {
-#pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) { ch[rb] = im[(rb * img_ksn + ks + 1) * 128]; cl[rb] = im[(rb * img_ksn + ks + 1) * 128 + 64]; }
-        }
-#pragma unroll
-        for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[rb], acc[rb], 0, 0, 0);
-#pragma unroll
-        for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[rb], acc[rb], 0, 0, 0);
-#pragma unroll
-        for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[rb], acc[rb], 0, 0, 0);
-        if (ks + 2 < nks) { ah0 = wf[(ks + 2) * 128]; al0 = wf[(ks + 2) * 128 + 64]; }
-        if (ks + 1 < nks) {
-            if (ks + 2 < nks) {
-#pragma unroll
-                for (int rb = 0; rb < RBW; ++rb) { bh[rb] = im[(rb * img_ksn + ks + 2) * 128]; bl[rb] = im[(rb * img_ksn + ks + 2) * 128 + 64]; }
-            }
-#pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, ch[rb], acc[rb], 0, 0, 0);
-#pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, cl[rb], acc[rb], 0, 0, 0);
-#pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, ch[rb], acc[rb], 0, 0, 0);
-            if (ks + 3 < nks) { ah1 = wf[(ks + 3) * 128]; al1 = wf[(ks + 3) * 128 + 64]; }
-        }
+        const int k2 = min(ks + 2, last), k3 = min(ks + 3, last);
+        mfma3(acc, ah0, al0, bh, bl, nrb);
+        __builtin_amdgcn_sched_barrier(0);
+        ah0 = wf[k2 * 128]; al0 = wf[k2 * 128 + 64];
+        load_b(bh, bl, k2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < nks) mfma3(acc, ah1, al1, ch, cl, nrb);   // MFMAs only inside the branch (odd nks: the 16-wide edge features)
+        __builtin_amdgcn_sched_barrier(0);
+        ah1 = wf[k3 * 128]; al1 = wf[k3 * 128 + 64];
+        load_b(ch, cl, k3);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -248,21 +290,36 @@ template <int H>
 __device__ __forceinline__ void ln_merge(const float* ST, int rbg, int n, float t, float eps, int hv, float& k, float& m) {
     using C = Cfg<H>;
     constexpr int NP = 2 * C::NJB;
-    const int npv = hv >> 4;   // valid 16-feature partials: (jb, half) with jb < hv / 32
     const float* st = ST + (rbg * NP * BE + n) * 2;
     float mw[NP], m2 = 0.f, mean = 0.f;
+    if (hv == H) {   // every feature exists (wave-uniform): constant trip counts, no masks
 #pragma unroll
-    for (int w = 0; w < NP; ++w) {
-        const float2v s = *reinterpret_cast<const float2v*>(st + w * BE * 2);
-        mw[w] = s[0];
-        if (w < npv) { m2 += s[1]; mean += s[0]; }
+        for (int w = 0; w < NP; ++w) {
+            const float2v s = *reinterpret_cast<const float2v*>(st + w * BE * 2);
+            mw[w] = s[0];
+            m2 += s[1];
+            mean += s[0];
+        }
+        mean *= 1.0f / NP;
+#pragma unroll
+        for (int w = 0; w < NP; ++w) { const float d = mw[w] - mean; m2 = fmaf(16.0f * d, d, m2); }
+        m2 *= 1.0f / H;
+    } else {
+        const int npv = hv >> 4;   // valid 16-feature partials: (jb, half) with jb < hv / 32
+#pragma unroll
+        for (int w = 0; w < NP; ++w) {
+            const float2v s = *reinterpret_cast<const float2v*>(st + w * BE * 2);
+            mw[w] = s[0];
+            if (w < npv) { m2 += s[1]; mean += s[0]; }
+        }
+        mean *= 1.0f / (float)npv;
+#pragma unroll
+        for (int w = 0; w < NP; ++w) { const float d = mw[w] - mean; if (w < npv) m2 = fmaf(16.0f * d, d, m2); }
+        m2 /= (float)hv;
     }
-    mean *= 1.0f / (float)npv;
-#pragma unroll
-    for (int w = 0; w < NP; ++w) { const float d = mw[w] - mean; if (w < npv) m2 = fmaf(16.0f * d, d, m2); }
     // accumulators carry the scale t (= U of the chain, times the row's own scale in the encoders):
     // (acc - mean) / sqrt(var_acc + eps t^2) is the normalised value
-    k = 1.0f / sqrtf(m2 / (float)hv + eps * t * t);
+    k = 1.0f / sqrtf(m2 + eps * t * t);
     m = -mean * k;
 }
 
@@ -471,7 +528,8 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uintx4* img = reinterpret_cast<uintx4*>(smem);
     const half8* imgh = reinterpret_cast<const half8*>(smem);
-    float* ST = reinterpret_cast<float*>(smem + HM_IMG_BYTES);
+    constexpr size_t IMGB = hm_node_img_bytes(RBW), STB = HM_ST_BYTES * RBW / 4;
+    float* ST = reinterpret_cast<float*>(smem + IMGB);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jb = wave % C::NJB, rg = wave / C::NJB;
@@ -486,8 +544,8 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
     constexpr int K0 = MODE == 0 ? 32 : 2 * H;
     const size_t lin0 = hm_lin_floats(H, K0), linh = hm_lin_floats(H, H);
 
-    float* GB = reinterpret_cast<float*>(smem + HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES);   // gamma[H] | beta[H]
-    float* RS = reinterpret_cast<float*>(smem + HM_IMG_BYTES + HM_ST_BYTES + HM_BLK_BYTES + HM_GB_BYTES);   // encoder: row scales
+    float* GB = reinterpret_cast<float*>(smem + IMGB + STB + HM_BLK_BYTES);   // gamma[H] | beta[H]
+    float* RS = reinterpret_cast<float*>(smem + IMGB + STB + HM_BLK_BYTES + HM_GB_BYTES);   // encoder: row scales
     int rng = 0;
     // decoder tail: a range violation anywhere earlier in this forward (its kernels have finished: stream order) makes the
     // prediction NaN instead of a plausible wrong number -- a rollout then stops at its next graph build (non-finite position)
@@ -805,8 +863,8 @@ int device_cus() {
 }
 
 template <class K>
-int set_lds_attr(K kernel) {
-    GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HM_LDS_BYTES));
+int set_lds_attr(K kernel, size_t bytes = HM_LDS_BYTES) {
+    GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return GM_OK;
 }
 
@@ -827,11 +885,12 @@ int launch_edge_h(bool enc, const HmEdgeArgs& a, hipStream_t s) {
 
 template <int H, int RBW>
 int launch_node_hr(int mode, const HmNodeArgs& a, hipStream_t s) {
+    constexpr size_t LDS = hm_node_lds_bytes(RBW);
     static PerDeviceOnce once;
     const int rc_attr = once.run([]() -> int {
-        int rc = set_lds_attr(hm_node_kernel<H, 0, RBW>);
-        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 1, RBW>);
-        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 2, RBW>);
+        int rc = set_lds_attr(hm_node_kernel<H, 0, RBW>, LDS);
+        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 1, RBW>, LDS);
+        if (rc == GM_OK) rc = set_lds_attr(hm_node_kernel<H, 2, RBW>, LDS);
         return rc;
     });
     if (rc_attr != GM_OK) return rc_attr;
@@ -839,9 +898,9 @@ int launch_node_hr(int mode, const HmNodeArgs& a, hipStream_t s) {
     int grid = device_cus();
     if (tiles < grid) grid = tiles < 1 ? 1 : tiles;
     ProfScope prof(a.prof, mode == 0 ? PROF_ENC : PROF_NODE, s);
-    if (mode == 0) hipLaunchKernelGGL((hm_node_kernel<H, 0, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
-    else if (mode == 1) hipLaunchKernelGGL((hm_node_kernel<H, 1, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((hm_node_kernel<H, 2, RBW>), dim3(grid), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+    if (mode == 0) hipLaunchKernelGGL((hm_node_kernel<H, 0, RBW>), dim3(grid), dim3(HM_THREADS), LDS, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((hm_node_kernel<H, 1, RBW>), dim3(grid), dim3(HM_THREADS), LDS, s, a);
+    else hipLaunchKernelGGL((hm_node_kernel<H, 2, RBW>), dim3(grid), dim3(HM_THREADS), LDS, s, a);
     return GM_OK;
 }
 // small graphs: one 32-row block per wave, so that the tiles cover the CUs.  HM_NODE_SMALL_ROUNDS: the 4-block form is used
@@ -851,10 +910,13 @@ int launch_node_hr(int mode, const HmNodeArgs& a, hipStream_t s) {
 #ifndef HM_NODE_SMALL_ROUNDS
 #define HM_NODE_SMALL_ROUNDS 1
 #endif
+#ifndef HM_NODE_RBW
+#define HM_NODE_RBW 4
+#endif
 template <int H>
 int launch_node_h(int mode, const HmNodeArgs& a, hipStream_t s) {
     if (cdiv(a.n_nodes, Cfg<H, 4>::M) < (int64_t)HM_NODE_SMALL_ROUNDS * device_cus()) return launch_node_hr<H, 1>(mode, a, s);
-    return launch_node_hr<H, 4>(mode, a, s);
+    return launch_node_hr<H, HM_NODE_RBW>(mode, a, s);
 }
 
 }  // namespace
