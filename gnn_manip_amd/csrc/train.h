@@ -72,10 +72,34 @@ struct PackTJobs {
 int train_kernels_init();
 int launch_train_fwd(int H, int kind, const TrainFwdArgs& a, hipStream_t s);
 int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s);
+// Weight gradients: jobs are collected and run a batch per launch pair (GEMM over row chunks + fixed-order reduction).
+//   out[m][col0 + k] += sum_r dz[r][m] * X[xidx ? xidx[r] : r][k];  db[m] += sum_r dz[r][m] (db may be nullptr)
+// A job reads its operands when the batch is FLUSHED: flush before anything overwrites them.
+struct WgJob {
+    const float* dz;
+    const float* X;
+    const int* xidx;
+    float* out;
+    float* db;
+    int ldz, M, ldx, K, rows, ldw, col0;
+    int Mp, Kp, KT, tiles, chunk, G;
+    size_t part_off;   // floats from the partial buffer: [G][Mp][Kp] tiles, then [G][Mp] bias partials
+};
+constexpr int kWgJobsMax = 8;
+struct WgJobs {
+    int n;
+    WgJob job[kWgJobsMax];
+};
+struct WgradBatch {
+    WgJobs jobs{};
+    float* part = nullptr;   // wgrad_partial_floats(H) floats
+    size_t cap = 0, used = 0;
+    hipStream_t stream = nullptr;
+};
 size_t wgrad_partial_floats(int H);
-// out[m][col0 + k] += sum_r dz[r][m] * X[xidx ? xidx[r] : r][k];  db[m] += sum_r dz[r][m] (db may be nullptr)
-int launch_wgrad(const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* part,
-                 float* out, int ldw, int col0, float* db, hipStream_t s);
+int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* out,
+                  int ldw, int col0, float* db);
+int wgrad_flush(WgradBatch& b);
 // dgamma += colsum(gy * xhat), dbeta += colsum(gy)
 int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, float* part, float* dgamma, float* dbeta, hipStream_t s);
 int launch_pack_t_batch(const PackTJobs& jobs, float* base, hipStream_t s);

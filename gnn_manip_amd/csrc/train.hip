@@ -339,29 +339,69 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
 }
 
 // ------------------------------------------------------------------------------------------
-// dW = dz^T X  (+ db = column sums of dz), split over rows: partial[g][m][k], partial_b[g][m].
-// A wave owns a 64 x 64 block of dW (2 x 2 MFMA 32x32x2 tiles); per two-row step its A operands are
-// dz[r + hi][m0 + i], its B operands X[r + hi][k0 + i]: both are 128-byte coalesced reads of the
-// row-major arrays, no staging.  The operands of the next WG_U steps are requested before the MFMAs
-// of the current ones (register double buffer), so one wave per SIMD already keeps the matrix pipe
-// and the memory path busy at the same time.
+// dW = dz^T X  (+ db = column sums of dz), a batch of independent jobs per launch, each split over rows:
+// partial[g][m][k], partial_b[g][m], reduced in fixed order by wgrad_reduce_kernel (no atomics: deterministic).
+//
+// Arithmetic: the sum over rows is the K dimension of v_mfma_f32_32x32x16_bf16.  Both operands are split in registers
+// into three bf16 parts (x = hi + mid + lo, 24 significant bits, the full float exponent range -- gradients span many
+// orders of magnitude, which rules the fp16 split of the inference kernels out here) and six of the nine partial
+// products are accumulated in fp32 (hh, hm, mh, mm, hl, lh: what is left is below 2^-24 of a product): fp32 accuracy
+// at 2.7 x the matrix throughput of the fp32-input MFMA this kernel used before, which makes a job of E rows
+// bound by its 8 H E bytes of HBM reads instead.
+//
+// A wave owns a 64 x 64 block of dW (2 x 2 accumulator tiles).  K slot (lane >> 5, e) of a 16-row step is row
+// r0 + 8 (lane >> 5) + e in BOTH operands: lane (i, hi) reads dz[row][m0 + i] and X[row][k0 + i] -- every load
+// instruction covers two rows x 32 consecutive floats (two full 128-byte lines), straight from the row-major arrays.
+// The operands of the next step are requested before the splits / MFMAs of the current one (register double buffer);
+// every load is unconditional from a clamped (valid) address, so the waits are counted vmcnt.
 // ------------------------------------------------------------------------------------------
-constexpr int WG_U = 8;  // 2-row MFMA steps per operand batch
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2v __attribute__((ext_vector_type(2)));
 
-struct WgOperands {
-    float a0[WG_U], a1[WG_U], b0[WG_U], b1[WG_U];
+struct Bf3 {
+    bf16x8 h, m, l;
+};
+__device__ __forceinline__ Bf3 split_bf3(const float (&v)[8]) {
+    Bf3 o;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const floatx2v x = floatx2v{v[e], v[e + 1]};
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const floatx2v r1 = x - __builtin_convertvector(h, floatx2v);
+        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+        const floatx2v r2 = r1 - __builtin_convertvector(m, floatx2v);
+        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+        o.h[e] = h[0]; o.h[e + 1] = h[1];
+        o.m[e] = m[0]; o.m[e + 1] = m[1];
+        o.l[e] = l[0]; o.l[e + 1] = l[1];
+    }
+    return o;
+}
+__device__ __forceinline__ void mfma_bf3(floatx16& acc, const Bf3& a, const Bf3& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+
+struct WgRaw {
+    float a0[8], a1[8], b0[8], b1[8];
 };
 
 template <bool HAS_IDX>
-__global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(const float* __restrict__ dz, int ldz, int M, const float* __restrict__ X, int ldx,
-                                                            int K, const int* __restrict__ xidx, int rows, int chunk, float* __restrict__ part,
-                                                            float* __restrict__ partb, int Mp, int Kp) {
+__device__ __forceinline__ void wgrad_body(const WgJob& J, float* __restrict__ part) {
+    const float* __restrict__ dz = J.dz;
+    const float* __restrict__ X = J.X;
+    const int* __restrict__ xidx = J.xidx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
-    const int KT = Kp / 128;
-    const int mt = blockIdx.y / KT, kt = blockIdx.y % KT;
+    const int M = J.M, K = J.K, ldz = J.ldz, ldx = J.ldx;
+    const int mt = blockIdx.y / J.KT, kt = blockIdx.y % J.KT;
     const int m0 = mt * 128 + 64 * (wave >> 1), k0 = kt * 128 + 64 * (wave & 1);
-    const int r_begin = blockIdx.x * chunk;
-    const int r_end = min(rows, r_begin + chunk);
+    const int r_begin = blockIdx.x * J.chunk;
+    const int r_end = min(J.rows, r_begin + J.chunk);
     floatx16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -369,58 +409,54 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(const float* __restri
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // Every load is unconditional from a clamped (always valid) address; out-of-range rows / columns are
-    // zeroed by a multiplication with 0 afterwards (a select would let the compiler sink the loads into
-    // branches, with a full wait behind each).  No branches, no dependent waits inside a batch.
-    const float mv0 = m0 + i < M ? 1.f : 0.f, mv1 = m0 + 32 + i < M ? 1.f : 0.f, kv0 = k0 + i < K ? 1.f : 0.f, kv1 = k0 + 32 + i < K ? 1.f : 0.f;
+    // columns past M / K read a clamped (valid) column: their products land in partial entries nobody reads
     const int mc0 = min(m0 + i, M - 1), mc1 = min(m0 + 32 + i, M - 1), kc0 = min(k0 + i, K - 1), kc1 = min(k0 + 32 + i, K - 1);
     float bs0 = 0.f, bs1 = 0.f;  // column sums of dz (bias gradient), kept by the waves of k-block 0
-    auto load = [&](WgOperands& o, int r0) {
-        int64_t rx[WG_U];
+    auto load = [&](WgRaw& o, int r0) {
+        int64_t rz[8], rx[8];
 #pragma unroll
-        for (int u = 0; u < WG_U; ++u) {
-            const int r = min(r0 + 2 * u + hi, r_end - 1);
-            rx[u] = HAS_IDX ? xidx[r] : r;
+        for (int e = 0; e < 8; ++e) {
+            rz[e] = min(r0 + 8 * hi + e, r_end - 1);
+            rx[e] = HAS_IDX ? xidx[rz[e]] : rz[e];
         }
 #pragma unroll
-        for (int u = 0; u < WG_U; ++u) {
-            const int rr = r0 + 2 * u + hi;
-            const int64_t rz = min(rr, r_end - 1);
-            const float* zr = dz + rz * ldz;
-            const float* xr = X + rx[u] * ldx;
-            o.a0[u] = zr[mc0];
-            o.a1[u] = zr[mc1];
-            o.b0[u] = xr[kc0];
-            o.b1[u] = xr[kc1];
+        for (int e = 0; e < 8; ++e) {
+            const float* zr = dz + rz[e] * ldz;
+            const float* xr = X + rx[e] * ldx;
+            o.a0[e] = zr[mc0];
+            o.a1[e] = zr[mc1];
+            o.b0[e] = xr[kc0];
+            o.b1[e] = xr[kc1];
         }
     };
-    // the masks are applied here, where the values are consumed: applying them in load() would put the wait
-    // for a batch right behind its own requests
-    auto fma = [&](const WgOperands& o, int r0) {
+    auto fma = [&](WgRaw& o, int r0) {
+        if (r0 + 16 > r_end) {   // the chunk's last, partial step (wave-uniform; no loads inside): rows past the end count as zero
 #pragma unroll
-        for (int u = 0; u < WG_U; ++u) {
-            const float rv = r0 + 2 * u + hi < r_end ? 1.f : 0.f;
-            const float a0 = o.a0[u] * (rv * mv0), a1 = o.a1[u] * (rv * mv1), b0 = o.b0[u] * kv0, b1 = o.b1[u] * kv1;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            bs0 += a0;
-            bs1 += a1;
+            for (int e = 0; e < 8; ++e)
+                if (r0 + 8 * hi + e >= r_end) { o.a0[e] = 0.f; o.a1[e] = 0.f; }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bs0 += o.a0[e]; bs1 += o.a1[e]; }
+        const Bf3 a0 = split_bf3(o.a0), b0 = split_bf3(o.b0);
+        mfma_bf3(acc[0][0], a0, b0);
+        const Bf3 b1 = split_bf3(o.b1);
+        mfma_bf3(acc[0][1], a0, b1);
+        const Bf3 a1 = split_bf3(o.a1);
+        mfma_bf3(acc[1][0], a1, b0);
+        mfma_bf3(acc[1][1], a1, b1);
     };
-    WgOperands A, B;
+    WgRaw A, B;
     int r0 = r_begin;
     if (r0 < r_end) {
         load(A, r0);
         while (true) {
-            const int r1 = r0 + 2 * WG_U;
+            const int r1 = r0 + 16;
             load(B, r1);  // unconditional (clamped): a conditional request would make every wait below conservative
             __builtin_amdgcn_sched_barrier(0);
             fma(A, r0);
             __builtin_amdgcn_sched_barrier(0);
             if (r1 >= r_end) break;
-            const int r2 = r1 + 2 * WG_U;
+            const int r2 = r1 + 16;
             load(A, r2);
             __builtin_amdgcn_sched_barrier(0);
             fma(B, r1);
@@ -429,7 +465,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(const float* __restri
             r0 = r2;
         }
     }
-    float* out = part + (size_t)blockIdx.x * Mp * Kp;
+    float* out = part + J.part_off + (size_t)blockIdx.x * J.Mp * J.Kp;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -438,27 +474,39 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 32 * a + 8 * (r >> 2) + 4 * hi + (r & 3);
                 const int k = k0 + 32 * b + i;
-                out[(size_t)m * Kp + k] = acc[a][b][r];
+                out[(size_t)m * J.Kp + k] = acc[a][b][r];
             }
-    if (partb && kt == 0 && (wave & 1) == 0) {
+    if (J.db && kt == 0 && (wave & 1) == 0) {
+        float* partb = part + J.part_off + (size_t)J.G * J.Mp * J.Kp;
         bs0 += __shfl_xor(bs0, 32, 64);
         bs1 += __shfl_xor(bs1, 32, 64);
         if (hi == 0) {
-            partb[(size_t)blockIdx.x * Mp + m0 + i] = bs0;
-            partb[(size_t)blockIdx.x * Mp + m0 + 32 + i] = bs1;
+            partb[(size_t)blockIdx.x * J.Mp + m0 + i] = bs0;
+            partb[(size_t)blockIdx.x * J.Mp + m0 + 32 + i] = bs1;
         }
     }
 }
 
+// grid (max G, max tiles, jobs)
+__global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(WgJobs Js, float* __restrict__ part) {
+    const WgJob& J = Js.job[blockIdx.z];
+    if ((int)blockIdx.x >= J.G || (int)blockIdx.y >= J.tiles) return;
+    if (J.xidx) wgrad_body<true>(J, part);
+    else wgrad_body<false>(J, part);
+}
+
 // out[m][col0 + k] += sum_g part[g][m][k]; db[m] += sum_g partb[g][m].  32 outputs x 8 partial groups per
-// workgroup, fixed summation order (deterministic).
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ partb, int G, int Mp,
-                                                            int Kp, int M, int K, float* __restrict__ out, int ldw, int col0,
-                                                            float* __restrict__ db) {
+// workgroup, fixed summation order (deterministic).  grid (max outputs / 32, jobs)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgJobs Js, const float* __restrict__ part_all) {
+    const WgJob& J = Js.job[blockIdx.y];
     __shared__ float red[8][33];
     const int tid = threadIdx.x, i = tid & 31, gg = tid >> 5;
     const int o = blockIdx.x * 32 + i;
-    const int nw = M * K, total = nw + (db ? M : 0);
+    const int M = J.M, K = J.K, Mp = J.Mp, Kp = J.Kp, G = J.G;
+    const int nw = M * K, total = nw + (J.db ? M : 0);
+    if ((int)blockIdx.x * 32 >= total) return;
+    const float* part = part_all + J.part_off;
+    const float* partb = part + (size_t)G * Mp * Kp;
     float s = 0.f;
     if (o < nw) {
         const int m = o / K, k = o % K;
@@ -473,8 +521,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += red[q][i];
-        if (o < nw) out[(size_t)(o / K) * ldw + col0 + (o % K)] += t;
-        else db[o - nw] += t;
+        if (o < nw) J.out[(size_t)(o / K) * J.ldw + J.col0 + (o % K)] += t;
+        else J.db[o - nw] += t;
     }
 }
 
@@ -653,33 +701,58 @@ int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s) {
     return H == 64 ? launch_train_bwd_h<64>(kind, a, s) : H == 128 ? launch_train_bwd_h<128>(kind, a, s) : launch_train_bwd_h<256>(kind, a, s);
 }
 
-int wgrad_chunk(int64_t rows) {
-    // about two workgroups per CU; chunks are multiples of 16 rows (WG_U two-row steps), at least 64 rows
-    int64_t c = cdiv(rows, 512);
+// Workgroups per job: about 512 (two per CU) for the edge-sized ones; chunks are multiples of 16 rows (one MFMA step), at least 64 rows.
+static int wgrad_chunk(int64_t rows, int tiles) {
+    int64_t want = 512 / tiles;
+    if (want < 1) want = 1;
+    int64_t c = cdiv(rows, want);
     if (c < 64) c = 64;
     return (int)(cdiv(c, 16) * 16);
 }
+static size_t wgrad_job_floats(int G, int Mp, int Kp) { return (size_t)G * Mp * Kp + (size_t)G * Mp; }
 size_t wgrad_partial_floats(int H) {
-    const size_t Hp = (size_t)cdiv(H, 128) * 128;
-    return (size_t)512 * Hp * Hp + (size_t)512 * Hp;
+    // every job: G * tiles <= 512 + tiles, i.e. at most (512 + 4) 128 x 128 tiles + the bias partials; ln_grads shares the buffer
+    (void)H;
+    return (size_t)kWgJobsMax * ((size_t)(512 + 4) * 128 * 128 + (size_t)(512 + 4) * 256);
 }
 
-int launch_wgrad(const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* part,
-                 float* out, int ldw, int col0, float* db, hipStream_t s) {
-    if (rows <= 0 || M <= 0 || K <= 0) return GM_OK;
-    const int Mp = (int)cdiv(M, 128) * 128, Kp = (int)cdiv(K, 128) * 128;
-    const int chunk = wgrad_chunk(rows);
-    const int G = (int)cdiv(rows, chunk);
-    float* partb = part + (size_t)G * Mp * Kp;
-    if (xidx)
-        hipLaunchKernelGGL(wgrad_kernel<true>, dim3(G, (Mp / 128) * (Kp / 128)), dim3(THREADS), 0, s, dz, ldz, M, X, ldx, K, xidx, (int)rows,
-                           chunk, part, db ? partb : nullptr, Mp, Kp);
-    else
-        hipLaunchKernelGGL(wgrad_kernel<false>, dim3(G, (Mp / 128) * (Kp / 128)), dim3(THREADS), 0, s, dz, ldz, M, X, ldx, K, xidx, (int)rows,
-                           chunk, part, db ? partb : nullptr, Mp, Kp);
-    const int total = M * K + (db ? M : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 32)), dim3(256), 0, s, part, partb, G, Mp, Kp, M, K, out, ldw, col0, db);
+int wgrad_flush(WgradBatch& b) {
+    if (b.jobs.n <= 0) return GM_OK;
+    int maxG = 1, maxT = 1, maxO = 1;
+    for (int q = 0; q < b.jobs.n; ++q) {
+        const WgJob& j = b.jobs.job[q];
+        maxG = j.G > maxG ? j.G : maxG;
+        maxT = j.tiles > maxT ? j.tiles : maxT;
+        const int total = j.M * j.K + (j.db ? j.M : 0);
+        maxO = total > maxO ? total : maxO;
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(maxG, maxT, b.jobs.n), dim3(THREADS), 0, b.stream, b.jobs, b.part);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(maxO, 32), b.jobs.n), dim3(256), 0, b.stream, b.jobs, b.part);
+    b.jobs.n = 0;
+    b.used = 0;
     GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* out,
+                  int ldw, int col0, float* db) {
+    if (rows <= 0 || M <= 0 || K <= 0) return GM_OK;
+    WgJob j{};
+    j.dz = dz; j.X = X; j.xidx = xidx; j.out = out; j.db = db;
+    j.ldz = ldz; j.M = M; j.ldx = ldx; j.K = K; j.rows = (int)rows; j.ldw = ldw; j.col0 = col0;
+    j.Mp = (int)cdiv(M, 128) * 128; j.Kp = (int)cdiv(K, 128) * 128;
+    j.KT = j.Kp / 128; j.tiles = (j.Mp / 128) * j.KT;
+    j.chunk = wgrad_chunk(rows, j.tiles);
+    j.G = (int)cdiv(rows, j.chunk);
+    const size_t need = wgrad_job_floats(j.G, j.Mp, j.Kp);
+    GM_REQUIRE(need <= b.cap, GM_ERR_WORKSPACE, "wgrad: partial buffer too small (%zu > %zu floats)", need, b.cap);
+    if (b.jobs.n == kWgJobsMax || b.used + need > b.cap) {
+        const int rc = wgrad_flush(b);
+        if (rc != GM_OK) return rc;
+    }
+    j.part_off = b.used;
+    b.used += need;
+    b.jobs.job[b.jobs.n++] = j;
     return GM_OK;
 }
 

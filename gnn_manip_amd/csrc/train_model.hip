@@ -272,6 +272,8 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     rc = train_kernels_init();
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands
+    wb.part = b.part; wb.cap = wgrad_partial_floats(H); wb.stream = s;
     CsrWs c = carve_csr(t.csr_dst, n, e);
     CsrWs c2 = carve_csr(t.csr_src, n, e);
     const int PM = tensors_per_normed_mlp(NL);
@@ -324,7 +326,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
 
     auto wgrad = [&](const float* dz, int ldz, int Mo, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* out, int ldw,
                      int col0, float* db) {
-        if (rc == GM_OK) rc = launch_wgrad(dz, ldz, Mo, X, ldx, K, xidx, rows, b.part, out, ldw, col0, db, s);
+        if (rc == GM_OK) rc = wgrad_enqueue(wb, dz, ldz, Mo, X, ldx, K, xidx, rows, out, ldw, col0, db);
     };
     // W3 (+ b3), W2 (+ b2) and the LayerNorm gradients of a normed MLP whose chain kernel has just run over `rows`
     // (b1 comes with the first-layer weight gradient at the call site)
@@ -342,7 +344,8 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = grad_out; a.out_dim = OD; a.tape = t.dec; a.wstream = b.packT + b.off_dec;
         chain(a); a.dx = b.dh;
-        rc = launch_train_bwd(H, TB_DEC, a, s);
+        rc = wgrad_flush(wb);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_DEC, a, s);
         if (rc != GM_OK) return rc;
         wgrad(grad_out, OD, OD, act(t.dec, NL, n), H, H, nullptr, n, grads[b_dec + 2 * NL], H, 0, grads[b_dec + 2 * NL + 1]);
         for (int l = NL - 1; l >= 1; --l)
@@ -358,7 +361,8 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             a.rows = (int)n; a.dY = b.dh; a.Gi = has_next ? b.Gi : nullptr; a.Gj = has_next ? b.Gj : nullptr;
             a.tape = t.tn[k]; a.ln_g = ln_gamma(m->v_node[k]); a.wstream = b.packT + b.off_node[k];
             a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
-            rc = launch_train_bwd(H, TB_NODE, a, s);
+            rc = wgrad_flush(wb);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_node(k), t.tn[k], n);
             wgrad(b.dzl(1), H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ch * H, grads[b_node(k) + 1]);
@@ -370,7 +374,8 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             a.rows = (int)e; a.dY = has_next ? b.de : nullptr; a.dagg = b.dagg; a.dst = c.dst;
             a.tape = t.te[k]; a.ln_g = ln_gamma(m->v_edge[k]); a.wstream = b.packT + b.off_edge[k];
             a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.de; a.residual = 1;
-            rc = launch_train_bwd(H, TB_EDGE, a, s);
+            rc = wgrad_flush(wb);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_edge(k), t.te[k], e);
             wgrad(b.dzl(1), H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, m->ce * H, grads[b_edge(k) + 1]);
@@ -389,7 +394,8 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         a.rows = (int)n; a.dY = b.dh; a.Gi = b.Gi; a.Gj = b.Gj; a.tape = t.en; a.ln_g = ln_gamma(m->v_enc_node);
         a.wstream = b.packT + b.off_enc_node;
         a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
-        rc = launch_train_bwd(H, TB_ENC, a, s);
+        rc = wgrad_flush(wb);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
         normed_tail_grads(b_enc_node, t.en, n);
         wgrad(b.dzl(1), H, H, nodes, m->d.node_dim, m->d.node_dim, nullptr, n, grads[b_enc_node], m->d.node_dim, 0, grads[b_enc_node + 1]);
@@ -399,13 +405,14 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         TrainBwdArgs a{};
         a.rows = (int)e; a.dY = b.de; a.tape = t.ee; a.ln_g = ln_gamma(m->v_enc_edge); a.wstream = b.packT + b.off_enc_edge;
         a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
-        rc = launch_train_bwd(H, TB_ENC, a, s);
+        rc = wgrad_flush(wb);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
         normed_tail_grads(b_enc_edge, t.ee, e);
         wgrad(b.dzl(1), H, H, edge_attr, m->d.edge_dim, m->d.edge_dim, c.eid, e, grads[b_enc_edge], m->d.edge_dim, 0, grads[b_enc_edge + 1]);
         if (rc != GM_OK) return rc;
     }
-    return GM_OK;
+    return wgrad_flush(wb);
 }
 
 
@@ -472,6 +479,8 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
     rc = train_kernels_init();
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands
+    wb.part = b.part; wb.cap = wgrad_partial_floats(H); wb.stream = s;
     const size_t U = (size_t)m->S_HH * kStageFloats;
     PackTJobs jobs;
     jobs.n = 0;
@@ -498,15 +507,17 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
         a.rows = (int)rows; a.dY = dY; a.tape = tp; a.ln_g = m->vec + voff + (size_t)(NL + 1) * H; a.wstream = b.packT + woff;
         a.dx_in = dxin; a.k1 = k1;
         a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
-        rc = launch_train_bwd(H, TB_ENC, a, s);
+        rc = wgrad_flush(wb);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
         for (int l = NL; l >= 1 && rc == GM_OK; --l)
-            rc = launch_wgrad(b.dzl(l + 1), H, H, tp.a + (size_t)(l - 1) * rows * H, H, H, nullptr, rows, b.part, grads[base + 2 * l], H, 0,
-                              grads[base + 2 * l + 1], s);
-        if (rc == GM_OK) rc = launch_wgrad(b.dzl(1), H, H, X, k1, k1, nullptr, rows, b.part, grads[base], k1, 0, grads[base + 1], s);
+            rc = wgrad_enqueue(wb, b.dzl(l + 1), H, H, tp.a + (size_t)(l - 1) * rows * H, H, H, nullptr, rows, grads[base + 2 * l], H, 0,
+                              grads[base + 2 * l + 1]);
+        if (rc == GM_OK) rc = wgrad_enqueue(wb, b.dzl(1), H, H, X, k1, k1, nullptr, rows, grads[base], k1, 0, grads[base + 1]);
         if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 2 * (NL + 1)], grads[base + 2 * (NL + 1) + 1], s);
     };
     run(PM, t.en, n, dh, m->v_enc_node, b.off_enc_node + 2 * U, x, m->d.node_dim, dx);
     run(0, t.ee, e, de, m->v_enc_edge, b.off_enc_edge, edge_attr, m->d.edge_dim, dedge_attr);
+    if (rc == GM_OK) rc = wgrad_flush(wb);
     return rc;
 }
 
@@ -585,6 +596,8 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
     rc = train_kernels_init();
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands
+    wb.part = b.part; wb.cap = wgrad_partial_floats(H); wb.stream = s;
     CsrWs c = carve_csr(t.csr_dst, n, e);
     CsrWs c2 = carve_csr(t.csr_src, n, e);
     const size_t U = (size_t)m->S_HH * kStageFloats;
@@ -608,14 +621,15 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         if (rc != GM_OK) return rc;
     }
     auto wgrad = [&](const float* dz, const float* X, int64_t rows, float* out, int ldw, int col0, float* db) {
-        if (rc == GM_OK) rc = launch_wgrad(dz, H, H, X, H, H, nullptr, rows, b.part, out, ldw, col0, db, s);
+        if (rc == GM_OK) rc = wgrad_enqueue(wb, dz, H, H, X, H, H, nullptr, rows, out, ldw, col0, db);
     };
     // node MLP: dY = dh_out (no residual inside the block); dx = W_h^T dz1 -> b.dh, dagg -> b.dagg
     {
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = dh_out; a.tape = t.tn; a.ln_g = m->vec + m->v_node[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_node[0];
         a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.dh; a.dagg_out = b.dagg;
-        rc = launch_train_bwd(H, TB_NODE, a, s);
+        rc = wgrad_flush(wb);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s);
         if (rc != GM_OK) return rc;
         for (int l = NL; l >= 1; --l) wgrad(b.dzl(l + 1), t.tn.a + (size_t)(l - 1) * n * H, n, grads[bn + 2 * l], H, 0, grads[bn + 2 * l + 1]);
         wgrad(b.dzl(1), h, n, grads[bn], 2 * H, m->ch * H, grads[bn + 1]);
@@ -628,10 +642,11 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         a.rows = (int)e; a.dY = de_out; a.dyidx = c.eid; a.dagg = b.dagg; a.dst = c.dst; a.tape = t.te;
         a.ln_g = m->vec + m->v_edge[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_edge[0];
         a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = de_in; a.dxidx = c.eid; a.residual = 0;
-        rc = launch_train_bwd(H, TB_EDGE, a, s);
+        rc = wgrad_flush(wb);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s);
         if (rc != GM_OK) return rc;
         for (int l = NL; l >= 1; --l) wgrad(b.dzl(l + 1), t.te.a + (size_t)(l - 1) * e * H, e, grads[be + 2 * l], H, 0, grads[be + 2 * l + 1]);
-        if (rc == GM_OK) rc = launch_wgrad(b.dzl(1), H, H, e_in, H, H, c.eid, e, b.part, grads[be], 3 * H, m->ce * H, grads[be + 1], s);
+        if (rc == GM_OK) rc = wgrad_enqueue(wb, b.dzl(1), H, H, e_in, H, H, c.eid, e, grads[be], 3 * H, m->ce * H, grads[be + 1]);
         if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.te.xhat, e, b.part, grads[be + 2 * (NL + 1)], grads[be + 2 * (NL + 1) + 1], s);
         if (rc != GM_OK) return rc;
     }
@@ -643,6 +658,8 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
     // dh_in = W_h^T dz1 (node MLP) + W_i^T G_i + W_j^T G_j (edge MLP, factorised layer 1)
     TrainBwdArgs a{};
     a.rows = (int)n; a.dY = b.dh; a.Gi = b.Gi; a.Gj = b.Gj; a.wstream = b.packT + b.off_enc_node; a.dx = dh_in;
+    rc = wgrad_flush(wb);
+    if (rc != GM_OK) return rc;
     return launch_train_bwd(H, TB_PROJ, a, s);
 }
 
