@@ -655,8 +655,9 @@ struct PackH3Jobs {
     float* dst[kPackH3Max];
 };
 
-__global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
-    __shared__ float red[256];
+constexpr int H3_PACK_THREADS = 1024;
+__global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) {
+    __shared__ float red[H3_PACK_THREADS];
     __shared__ float tsc[4];
     const int job = blockIdx.x, tid = threadIdx.x;
     const float* Wl[3] = {J.W1[job], J.W2[job], J.W3[job]};
@@ -670,7 +671,7 @@ __global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
     for (int l = 0; l < 3; ++l) {
         float ss = 0.f, wm = 0.f;
         const int cols = l == 0 ? 3 * H : H;
-        for (int i = tid; i < H * cols; i += 256) {
+        for (int i = tid; i < H * cols; i += H3_PACK_THREADS) {
             const int col = i % cols;
             const float v = Wl[l][(size_t)(i / cols) * ld[l] + (l == 0 ? 0 : c0[l]) + col];
             ss = fmaf(v, v, ss);
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
         }
         red[tid] = ss;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
+        for (int s = H3_PACK_THREADS / 2; s > 0; s >>= 1) {
             if (tid < s) red[tid] += red[tid + s];
             __syncthreads();
         }
@@ -686,7 +687,7 @@ __global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
         __syncthreads();
         red[tid] = wm;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
+        for (int s = H3_PACK_THREADS / 2; s > 0; s >>= 1) {
             if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
             __syncthreads();
         }
@@ -722,7 +723,7 @@ __global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
     float* dst = J.dst[job];
     if (tid == 0) { dst[0] = T1; dst[1] = 1.0f / T3; dst[2] = 0.f; dst[3] = 0.f; }
     float* vec = dst + HW_HEADER_FLOATS;
-    for (int i = tid; i < H; i += 256) {
+    for (int i = tid; i < H; i += H3_PACK_THREADS) {
         vec[i] = J.b2[job][i] * T2;
         vec[H + i] = J.b3[job][i] * T3;
         vec[2 * H + i] = J.gamma[job][i];
@@ -730,7 +731,7 @@ __global__ void __launch_bounds__(256) pack_h3_kernel(PackH3Jobs J) {
     }
     _Float16* img = reinterpret_cast<_Float16*>(dst + HW_HEADER_FLOATS + HW_VEC_FLOATS);
     // element (l, w, ks, lane = (i, kg), j): W_l[32 w + i][16 ks + 8 (j >> 2) + 4 kg + (j & 3)]
-    for (int idx = tid; idx < 3 * 4 * 8 * 64 * 8; idx += 256) {
+    for (int idx = tid; idx < 3 * 4 * 8 * 64 * 8; idx += H3_PACK_THREADS) {
         const int j = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 7, w = (idx >> 12) & 3, l = idx >> 14;
         const int i = lane & 31, kg = lane >> 5;
         const int kcol = 16 * ks + 8 * (j >> 2) + 4 * kg + (j & 3);
@@ -833,7 +834,7 @@ int pack_h3(const PackH3Job* jobs, int n, hipStream_t s) {
             J.W1[i] = j.W1; J.c1[i] = j.W1_col0; J.W2[i] = j.W2; J.W3[i] = j.W3; J.b1[i] = j.b1; J.b2[i] = j.b2; J.b3[i] = j.b3; J.gamma[i] = j.gamma; J.beta[i] = j.beta;
             J.dst[i] = j.dst;
         }
-        hipLaunchKernelGGL(pack_h3_kernel, dim3(J.n), dim3(256), 0, s, J);
+        hipLaunchKernelGGL(pack_h3_kernel, dim3(J.n), dim3(H3_PACK_THREADS), 0, s, J);
         GM_LAUNCH_CHECK();
     }
     return GM_OK;

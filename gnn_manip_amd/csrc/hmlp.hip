@@ -727,6 +727,7 @@ struct PackHmJobs {
     PackHmJob job[kPackHmMax];
 };
 
+constexpr int HM_PACK_THREADS = 1024;   // one workgroup per Linear: the packing kernels run on few CUs, so each uses a full one
 __device__ __forceinline__ float hm_value(const PackHmJob& j, int o, int k) {
     const int os = o / j.out_seg, ro = o % j.out_seg, is = k / j.k_seg, rk = k % j.k_seg;
     if (ro >= j.out_valid || rk >= j.k_valid) return 0.f;
@@ -735,18 +736,18 @@ __device__ __forceinline__ float hm_value(const PackHmJob& j, int o, int k) {
 
 // phase 1: statistics of every Linear -> stats[4 job ..]: gain ||W||_F / sqrt(out) / sqrt(2) over the columns that make its
 // pre-activation, rms and maximum of the bias, maximum |W| of the packed block.  Also resets the job's row-scale cap slot.
-__global__ void __launch_bounds__(256) pack_hm_stats_kernel(PackHmJobs J, float* __restrict__ stats) {
+__global__ void __launch_bounds__(HM_PACK_THREADS) pack_hm_stats_kernel(PackHmJobs J, float* __restrict__ stats) {
     const PackHmJob& j = J.job[blockIdx.x];
-    __shared__ float red[256];
+    __shared__ float red[HM_PACK_THREADS];
     const int tid = threadIdx.x;
     float ss = 0.f, wm = 0.f;
     if (j.gain_cols > 0) {
-        for (int i = tid; i < j.out_valid * j.gain_cols; i += 256) {
+        for (int i = tid; i < j.out_valid * j.gain_cols; i += HM_PACK_THREADS) {
             const float v = j.W[(size_t)(i / j.gain_cols) * j.ld + j.gain_col0 + (i % j.gain_cols)];
             ss = fmaf(v, v, ss);
         }
     }
-    for (int i = tid; i < j.out_pad * j.k_pad; i += 256) {
+    for (int i = tid; i < j.out_pad * j.k_pad; i += HM_PACK_THREADS) {
         const float v = hm_value(j, i / j.k_pad, i % j.k_pad);
         if (j.gain_cols <= 0) ss = fmaf(v, v, ss);
         wm = fmaxf(wm, fabsf(v));
@@ -754,7 +755,7 @@ __global__ void __launch_bounds__(256) pack_hm_stats_kernel(PackHmJobs J, float*
     auto reduce = [&](float v, bool is_max) {
         red[tid] = v;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
+        for (int s = HM_PACK_THREADS / 2; s > 0; s >>= 1) {
             if (tid < s) red[tid] = is_max ? fmaxf(red[tid], red[tid + s]) : red[tid] + red[tid + s];
             __syncthreads();
         }
@@ -797,7 +798,7 @@ __device__ __forceinline__ float hm_pow2_floor(float want) {
 // phase 2: walk the chain from its head to this Linear (scales of every predecessor from the phase-1 statistics), then pack.
 // m = estimated rms of the activations in the chain's units: a ReLU layer maps the second moment  m^2 -> gain^2 m^2 + b_rms^2 / 2
 // (zero-mean weights; the bias term is what deep chains settle on).  U_l = power of two nearest kHmTargetRms / m_l.
-__global__ void __launch_bounds__(256) pack_hm_kernel(PackHmJobs J, const PackHmJob* __restrict__ all, const float* __restrict__ stats) {
+__global__ void __launch_bounds__(HM_PACK_THREADS) pack_hm_kernel(PackHmJobs J, const PackHmJob* __restrict__ all, const float* __restrict__ stats) {
     const PackHmJob& j = J.job[blockIdx.x];
     __shared__ float sc[2];
     const int tid = threadIdx.x;
@@ -837,11 +838,11 @@ __global__ void __launch_bounds__(256) pack_hm_kernel(PackHmJobs J, const PackHm
     __syncthreads();
     const float t = sc[0], U = sc[1];
     if (tid == 0) { j.dst[0] = t; j.dst[1] = 1.f / U; j.dst[2] = U; }
-    for (int o = tid; o < j.out_pad; o += 256) j.dst[4 + o] = (j.bias && o < j.bias_n) ? j.bias[o] * U : 0.f;
+    for (int o = tid; o < j.out_pad; o += HM_PACK_THREADS) j.dst[4 + o] = (j.bias && o < j.bias_n) ? j.bias[o] * U : 0.f;
     _Float16* frag = reinterpret_cast<_Float16*>(j.dst + 4 + j.out_pad);
     const int ksn = j.k_pad / 16;
     const int entries = (j.out_pad / 32) * ksn * 64;   // (jb, ks, lane); two parts each
-    for (int e = tid; e < entries; e += 256) {
+    for (int e = tid; e < entries; e += HM_PACK_THREADS) {
         const int lane = e & 63, ks = (e >> 6) % ksn, jbv = (e >> 6) / ksn;
         const int o = 32 * jbv + (lane & 31), kg = lane >> 5;
         _Float16* hi_p = frag + ((size_t)((jbv * ksn + ks) * 2 + 0) * 64 + lane) * 8;
@@ -932,8 +933,8 @@ int pack_hm(const PackHmJob* jobs, int n, PackHmJob* jobs_dev, float* stats, hip
             J.n = n - off < kPackHmMax ? n - off : kPackHmMax;
             J.first = off;
             for (int i = 0; i < J.n; ++i) J.job[i] = jobs[off + i];
-            if (phase == 0) hipLaunchKernelGGL(pack_hm_stats_kernel, dim3(J.n), dim3(256), 0, s, J, stats);
-            else hipLaunchKernelGGL(pack_hm_kernel, dim3(J.n), dim3(256), 0, s, J, jobs_dev, stats);
+            if (phase == 0) hipLaunchKernelGGL(pack_hm_stats_kernel, dim3(J.n), dim3(HM_PACK_THREADS), 0, s, J, stats);
+            else hipLaunchKernelGGL(pack_hm_kernel, dim3(J.n), dim3(HM_PACK_THREADS), 0, s, J, jobs_dev, stats);
             GM_LAUNCH_CHECK();
         }
     }

@@ -48,6 +48,9 @@ struct TrainBwdArgs {
     float* dz;             // [nl + 1][dz_stride]: pre-activation gradients dz_l = dz + (l - 1) dz_stride of Linear l = 1 .. nl + 1, rows of H
     size_t dz_stride;      //   (the decoder's dz_(nl+1) is dY itself and is not written)
     int nl;
+    float* ln_part;        // normed MLPs: scratch [workgroups][2H] for the LayerNorm parameter gradients (column sums of gy xhat | gy)
+    float* dgamma;         //   ... which launch_train_bwd then adds, in workgroup order, to dgamma / dbeta  (nullptr: not computed)
+    float* dbeta;
     float* dx_resid;       // node: residual path; receives dY before dx adds the MLP's input gradient to it (may alias dY / dx)
     float* dx;             // edge: de_in; node: dh_in; decoder: dh; projection: dh_in
     const int* dxidx;      // edge: row of dx for row p (block API: the caller's edge order), or nullptr
@@ -100,8 +103,7 @@ size_t wgrad_partial_floats(int H);
 int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* out,
                   int ldw, int col0, float* db);
 int wgrad_flush(WgradBatch& b);
-// dgamma += colsum(gy * xhat), dbeta += colsum(gy)
-int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, float* part, float* dgamma, float* dbeta, hipStream_t s);
+size_t train_bwd_ln_part_floats(int H);   // size of TrainBwdArgs.ln_part
 int launch_pack_t_batch(const PackTJobs& jobs, float* base, hipStream_t s);
 int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows, const float* scale, const float* shift, float* out,
                        int64_t n, hipStream_t s);

@@ -122,6 +122,39 @@ __device__ __forceinline__ void layer_norm_bwd(floatx16 (&g)[NJB], floatx16 (&xh
         for (int r = 0; r < 16; ++r) xh[jb][r] = rstd * (g[jb][r] - m1 - xh[jb][r] * m2);
 }
 
+// LayerNorm parameter gradients inside the backward chain: dgamma[c] += sum_rows gy[row][c] xhat[row][c], dbeta[c] += sum_rows gy[row][c].
+// Rows sit on the lanes (32 per half wave), so a column sum is a 32-lane reduction per register: DPP prefix adds inside the
+// 16-lane rows (row_shr 1 / 2 / 4 / 8, zeros shifted in) and row_bcast:15 across them leave the totals in lanes 31 / 63, which
+// add them to the wave's slots of an LDS accumulator (one writer per address).  ~1.4k vector instructions per 32-row block
+// against the ~1000 MFMAs of its chain; it replaces a kernel that re-read gy and xhat (8 H bytes per row) from HBM.
+__device__ __forceinline__ float half_wave_sum(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));
+    return x;   // lanes 31 and 63: the sum over their 32 lanes
+}
+template <int NJB>
+__device__ __forceinline__ void ln_param_sums(const floatx16 (&g)[NJB], const floatx16 (&xh)[NJB], bool valid, float* acc_w /*LDS [2 H]*/, int n, int hi) {
+    constexpr int H = 32 * NJB;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float gv = valid ? g[jb][r] : 0.f;
+            const float a = half_wave_sum(gv * xh[jb][r]);
+            const float b = half_wave_sum(gv);
+            if (n == 31) {
+                const int f = 32 * jb + 8 * (r >> 2) + 4 * hi + (r & 3);
+                acc_w[f] += a;
+                acc_w[H + f] += b;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward with tape
 // ------------------------------------------------------------------------------------------
@@ -233,6 +266,12 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
     const size_t tstride = (size_t)R * H;
     const int ntiles = (R + TILE - 1) / TILE;
     const bool has_g = (KIND == TB_NODE || KIND == TB_ENC || KIND == TB_PROJ) && A.Gi != nullptr;
+    constexpr bool NORMED = KIND == TB_NODE || KIND == TB_ENC || KIND == TB_EDGE;
+    float* lnacc = ring + 2 * STAGE_FLOATS;   // [4 waves][2 H]: this workgroup's share of the LayerNorm parameter gradients
+    if (NORMED && A.ln_part) {
+        for (int i = tid; i < 4 * 2 * H; i += THREADS) lnacc[i] = 0.f;
+        __syncthreads();
+    }
     WStream ws;
     ws.base = A.wstream;
     ws.ring = ring;
@@ -280,6 +319,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
                 if (KIND == TB_NODE && A.dx_resid) store_feat(acc, A.dx_resid + pc * H, hi);  // residual path: dh_in starts as dY
             }
             load_feat(act, A.tape.xhat + pc * H, hi);
+            if (NORMED && A.ln_part) ln_param_sums(acc, act, valid, lnacc + wave * 2 * H, n, hi);
             layer_norm_bwd(acc, act, A.ln_g, A.tape.rstd[pc], hi);
             // dz stores: every lane (duplicates of the last row past the end), counted by run_layer<.., PEND>
             store_feat(act, A.dz + (size_t)NL * A.dz_stride + pc * H, hi);
@@ -336,6 +376,11 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NORMED && A.ln_part) {
+        __syncthreads();
+        for (int i = tid; i < 2 * H; i += THREADS)
+            A.ln_part[(size_t)blockIdx.x * 2 * H + i] = (lnacc[i] + lnacc[2 * H + i]) + (lnacc[4 * H + i] + lnacc[6 * H + i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -527,53 +572,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgJobs Js, const floa
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm parameter gradients: dgamma[c] += sum_r gy[r][c] * xhat[r][c],  dbeta[c] += sum_r gy[r][c]
-// (streaming; a thread owns 4 columns and every (256 / (H/4))-th row of its workgroup's chunk)
-// ------------------------------------------------------------------------------------------
-template <int H>
-__global__ void __launch_bounds__(256) ln_grads_kernel(const float* __restrict__ gy, const float* __restrict__ xhat, int rows, int chunk,
-                                                        float* __restrict__ part /*[G][2H]*/) {
-    constexpr int CT = H / 4, PH = 256 / CT;
-    __shared__ floatx4 rg[256], rb[256];
-    const int tid = threadIdx.x, c = tid % CT, ph = tid / CT;
-    const int r_begin = blockIdx.x * chunk, r_end = min(rows, r_begin + chunk);
-    floatx4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
-    int r = r_begin + ph;
-    for (; r + 3 * PH < r_end; r += 4 * PH) {
-        floatx4 g[4], x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            g[u] = *reinterpret_cast<const floatx4*>(gy + (size_t)(r + u * PH) * H + 4 * c);
-            x[u] = *reinterpret_cast<const floatx4*>(xhat + (size_t)(r + u * PH) * H + 4 * c);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            sg += g[u] * x[u];
-            sb += g[u];
-        }
-    }
-    for (; r < r_end; r += PH) {
-        const floatx4 g = *reinterpret_cast<const floatx4*>(gy + (size_t)r * H + 4 * c);
-        const floatx4 x = *reinterpret_cast<const floatx4*>(xhat + (size_t)r * H + 4 * c);
-        sg += g * x;
-        sb += g;
-    }
-    rg[tid] = sg;
-    rb[tid] = sb;
-    __syncthreads();
-    if (tid < CT) {
-        floatx4 tg = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < PH; ++q) {
-            tg += rg[q * CT + tid];
-            tb += rb[q * CT + tid];
-        }
-        float* o = part + (size_t)blockIdx.x * 2 * H;
-        *reinterpret_cast<floatx4*>(o + 4 * tid) = tg;
-        *reinterpret_cast<floatx4*>(o + H + 4 * tid) = tb;
-    }
-}
-
-// second stage: dgamma[c] += sum_g part[g][c], dbeta[c] += sum_g part[g][H + c]  (fixed order: deterministic)
+// LayerNorm parameter gradients, second stage: dgamma[c] += sum_g part[g][c], dbeta[c] += sum_g part[g][H + c]  (fixed order: deterministic)
 __global__ void __launch_bounds__(256) ln_grads_reduce_kernel(const float* __restrict__ part, int G, int H, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta) {
     __shared__ float red[8][33];
@@ -682,10 +681,24 @@ int launch_train_fwd(int H, int kind, const TrainFwdArgs& a, hipStream_t s) {
     return H == 64 ? launch_train_fwd_h<64>(kind, a, s) : H == 128 ? launch_train_fwd_h<128>(kind, a, s) : launch_train_fwd_h<256>(kind, a, s);
 }
 
+static int device_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+}
+size_t train_bwd_ln_part_floats(int H) { return (size_t)2 * 1024 * 2 * H; }   // workgroups of a backward launch: <= 2 per CU
+
 template <int H>
 static int launch_train_bwd_h(int kind, const TrainBwdArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)2 * STAGE_FLOATS * 4;
-    const int grid = grid_tiles(a.rows);
+    const size_t lds = (size_t)2 * STAGE_FLOATS * 4 + (size_t)4 * 2 * H * 4;
+    int grid = grid_tiles(a.rows);
+    const bool ln = a.ln_part && (kind == TB_ENC || kind == TB_EDGE || kind == TB_NODE);
+    if (ln) {
+        // as many workgroups as are resident at once, each walking its tiles: one partial row of the LayerNorm parameter sums each
+        const int resident = device_cus() * (H <= 128 ? 2 : 1);
+        if (grid > resident) grid = resident;
+        GM_REQUIRE((size_t)grid * 2 * H <= train_bwd_ln_part_floats(H), GM_ERR_WORKSPACE, "launch_train_bwd: %d workgroups", grid);
+    }
     switch (kind) {
         case TB_ENC: hipLaunchKernelGGL((train_bwd_kernel<H, TB_ENC>), dim3(grid), dim3(THREADS), lds, s, a); break;
         case TB_EDGE: hipLaunchKernelGGL((train_bwd_kernel<H, TB_EDGE>), dim3(grid), dim3(THREADS), lds, s, a); break;
@@ -693,6 +706,7 @@ static int launch_train_bwd_h(int kind, const TrainBwdArgs& a, hipStream_t s) {
         case TB_PROJ: hipLaunchKernelGGL((train_bwd_kernel<H, TB_PROJ>), dim3(grid), dim3(THREADS), lds, s, a); break;
         default: hipLaunchKernelGGL((train_bwd_kernel<H, TB_DEC>), dim3(grid), dim3(THREADS), lds, s, a); break;
     }
+    if (ln && a.dgamma && a.dbeta) hipLaunchKernelGGL(ln_grads_reduce_kernel, dim3(2 * H / 32), dim3(256), 0, s, a.ln_part, grid, H, a.dgamma, a.dbeta);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -756,19 +770,6 @@ int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X
     return GM_OK;
 }
 
-int launch_ln_grads(int H, const float* gy, const float* xhat, int64_t rows, float* part, float* dgamma, float* dbeta, hipStream_t s) {
-    if (rows <= 0) return GM_OK;
-    int64_t chunk = cdiv(rows, 512);
-    if (chunk < 64) chunk = 64;
-    const int G = (int)cdiv(rows, chunk);
-    if (H == 64) hipLaunchKernelGGL((ln_grads_kernel<64>), dim3(G), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, part);
-    else if (H == 128) hipLaunchKernelGGL((ln_grads_kernel<128>), dim3(G), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, part);
-    else hipLaunchKernelGGL((ln_grads_kernel<256>), dim3(G), dim3(256), 0, s, gy, xhat, (int)rows, (int)chunk, part);
-    hipLaunchKernelGGL(ln_grads_reduce_kernel, dim3(2 * H / 32), dim3(256), 0, s, part, G, H, dgamma, dbeta);
-    GM_LAUNCH_CHECK();
-    return GM_OK;
-}
-
 int launch_pack_t_batch(const PackTJobs& jobs, float* base, hipStream_t s) {
     if (jobs.n <= 0) return GM_OK;
     hipLaunchKernelGGL(pack_t_batch_kernel, dim3(16, jobs.n), dim3(256), 0, s, jobs, base);
@@ -797,7 +798,7 @@ int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_
 int train_kernels_init() {
     static PerDeviceOnce done_dev;
     return done_dev.run([]() -> int {
-    const size_t lds = (size_t)2 * STAGE_FLOATS * 4;
+    const size_t lds = (size_t)2 * STAGE_FLOATS * 4 + (size_t)4 * 2 * 256 * 4;   // weight ring + the backward kernels' LayerNorm sums
     int rc = GM_OK;
 #define GM_SET(k) if (rc == GM_OK) rc = set_dyn_lds(k, lds)
     GM_SET((train_fwd_kernel<64, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<64, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<64, TK_PROC_EDGE>));

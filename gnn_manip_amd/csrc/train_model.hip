@@ -334,9 +334,9 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     auto normed_tail_grads = [&](int base, const TapePtr& tp, int64_t rows) {
         for (int l = NL; l >= 1; --l)   // Linear l + 1: dW = dz_(l+1)^T a_l
             wgrad(b.dzl(l + 1), H, H, act(tp, l, rows), H, H, nullptr, rows, grads[base + 2 * l], H, 0, grads[base + 2 * l + 1]);
-        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 2 * (NL + 1)], grads[base + 2 * (NL + 1) + 1], s);
     };
     auto chain = [&](TrainBwdArgs& a) { a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; };
+    // (the LayerNorm parameter gradients are summed inside the chain kernels: TrainBwdArgs.ln_part / dgamma / dbeta)
     auto ln_gamma = [&](size_t voff) { return m->vec + voff + (size_t)(NL + 1) * H; };
 
     // ---- decoder
@@ -360,7 +360,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             TrainBwdArgs a{};
             a.rows = (int)n; a.dY = b.dh; a.Gi = has_next ? b.Gi : nullptr; a.Gj = has_next ? b.Gj : nullptr;
             a.tape = t.tn[k]; a.ln_g = ln_gamma(m->v_node[k]); a.wstream = b.packT + b.off_node[k];
-            a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
+            a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[b_node(k) + 2 * (NL + 1)]; a.dbeta = grads[b_node(k) + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
             rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s);
             if (rc != GM_OK) return rc;
@@ -373,7 +373,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             TrainBwdArgs a{};
             a.rows = (int)e; a.dY = has_next ? b.de : nullptr; a.dagg = b.dagg; a.dst = c.dst;
             a.tape = t.te[k]; a.ln_g = ln_gamma(m->v_edge[k]); a.wstream = b.packT + b.off_edge[k];
-            a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.de; a.residual = 1;
+            a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[b_edge(k) + 2 * (NL + 1)]; a.dbeta = grads[b_edge(k) + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.de; a.residual = 1;
             rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s);
             if (rc != GM_OK) return rc;
@@ -393,7 +393,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = b.dh; a.Gi = b.Gi; a.Gj = b.Gj; a.tape = t.en; a.ln_g = ln_gamma(m->v_enc_node);
         a.wstream = b.packT + b.off_enc_node;
-        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
+        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[b_enc_node + 2 * (NL + 1)]; a.dbeta = grads[b_enc_node + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
@@ -404,7 +404,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     if (e > 0) {
         TrainBwdArgs a{};
         a.rows = (int)e; a.dY = b.de; a.tape = t.ee; a.ln_g = ln_gamma(m->v_enc_edge); a.wstream = b.packT + b.off_enc_edge;
-        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
+        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[b_enc_edge + 2 * (NL + 1)]; a.dbeta = grads[b_enc_edge + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
@@ -506,14 +506,13 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
         TrainBwdArgs a{};
         a.rows = (int)rows; a.dY = dY; a.tape = tp; a.ln_g = m->vec + voff + (size_t)(NL + 1) * H; a.wstream = b.packT + woff;
         a.dx_in = dxin; a.k1 = k1;
-        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
+        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[base + 2 * (NL + 1)]; a.dbeta = grads[base + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
         for (int l = NL; l >= 1 && rc == GM_OK; --l)
             rc = wgrad_enqueue(wb, b.dzl(l + 1), H, H, tp.a + (size_t)(l - 1) * rows * H, H, H, nullptr, rows, grads[base + 2 * l], H, 0,
                               grads[base + 2 * l + 1]);
         if (rc == GM_OK) rc = wgrad_enqueue(wb, b.dzl(1), H, H, X, k1, k1, nullptr, rows, grads[base], k1, 0, grads[base + 1]);
-        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, tp.xhat, rows, b.part, grads[base + 2 * (NL + 1)], grads[base + 2 * (NL + 1) + 1], s);
     };
     run(PM, t.en, n, dh, m->v_enc_node, b.off_enc_node + 2 * U, x, m->d.node_dim, dx);
     run(0, t.ee, e, de, m->v_enc_edge, b.off_enc_edge, edge_attr, m->d.edge_dim, dedge_attr);
@@ -627,27 +626,25 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
     {
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = dh_out; a.tape = t.tn; a.ln_g = m->vec + m->v_node[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_node[0];
-        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.dh; a.dagg_out = b.dagg;
+        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[bn + 2 * (NL + 1)]; a.dbeta = grads[bn + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.dh; a.dagg_out = b.dagg;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s);
         if (rc != GM_OK) return rc;
         for (int l = NL; l >= 1; --l) wgrad(b.dzl(l + 1), t.tn.a + (size_t)(l - 1) * n * H, n, grads[bn + 2 * l], H, 0, grads[bn + 2 * l + 1]);
         wgrad(b.dzl(1), h, n, grads[bn], 2 * H, m->ch * H, grads[bn + 1]);
         wgrad(b.dzl(1), t.agg, n, grads[bn], 2 * H, m->ca * H, nullptr);
-        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.tn.xhat, n, b.part, grads[bn + 2 * (NL + 1)], grads[bn + 2 * (NL + 1) + 1], s);
         if (rc != GM_OK) return rc;
     }
     if (e > 0) {
         TrainBwdArgs a{};
         a.rows = (int)e; a.dY = de_out; a.dyidx = c.eid; a.dagg = b.dagg; a.dst = c.dst; a.tape = t.te;
         a.ln_g = m->vec + m->v_edge[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_edge[0];
-        a.gy = b.gy; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = de_in; a.dxidx = c.eid; a.residual = 0;
+        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[be + 2 * (NL + 1)]; a.dbeta = grads[be + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = de_in; a.dxidx = c.eid; a.residual = 0;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s);
         if (rc != GM_OK) return rc;
         for (int l = NL; l >= 1; --l) wgrad(b.dzl(l + 1), t.te.a + (size_t)(l - 1) * e * H, e, grads[be + 2 * l], H, 0, grads[be + 2 * l + 1]);
         if (rc == GM_OK) rc = wgrad_enqueue(wb, b.dzl(1), H, H, e_in, H, H, c.eid, e, grads[be], 3 * H, m->ce * H, grads[be + 1]);
-        if (rc == GM_OK) rc = launch_ln_grads(H, b.gy, t.te.xhat, e, b.part, grads[be + 2 * (NL + 1)], grads[be + 2 * (NL + 1) + 1], s);
         if (rc != GM_OK) return rc;
     }
     rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dzl(1), nullptr, nullptr, b.Gi, n, s);
