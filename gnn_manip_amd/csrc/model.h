@@ -36,6 +36,12 @@ struct gm_model {
     size_t v_enc_edge, v_enc_node, v_dec;
     std::vector<size_t> v_edge, v_node;
     int S_HH, S_e0, S_n0, S_out;
+    // bf16 x 3 weight streams of the training kernels (train.hip): same MLP order as `packed`, stages of kStageFloatsB3
+    float* packed_t3 = nullptr;
+    size_t packed_t3_floats = 0;
+    size_t t_enc_edge = 0, t_enc_node = 0;
+    std::vector<size_t> t_edge, t_node;
+    int T_HH = 0, T_e0 = 0, T_n0 = 0, T_out = 0;
 };
 
 namespace gm {

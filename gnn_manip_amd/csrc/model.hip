@@ -4,6 +4,7 @@
 #include "common.h"
 #include "mlp.h"
 #include "model.h"
+#include "train.h"
 #include "hedge.h"
 #include "hmlp.h"
 
@@ -165,9 +166,50 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
     }
     vecs(b_dec, false, m->v_dec);
     flush_vec();
-    if (rc != GM_OK || !m->packed) return rc;
-
-    // fp32 operand images (hidden 64 / 128 / 256): training kernels and the selectable fp32 forward kernels
+    if (rc != GM_OK) return rc;
+    if (m->packed_t3) {   // bf16 x 3 streams of the training kernels: the forward Linears in the order the chains consume them
+        PackTJobs tj;
+        tj.n = 0;
+        auto flush_t = [&]() {
+            if (rc == GM_OK && tj.n > 0) rc = launch_pack_b3_batch(tj, m->packed_t3, s);
+            tj.n = 0;
+        };
+        auto pack3 = [&](int ti, int out_rows, int ld, int col0, int k, size_t& off) {
+            if (tj.n == kPackTJobsMax) flush_t();
+            PackTJob& j = tj.job[tj.n++];
+            j.W = T[ti]; j.w_rows = k; j.ld = ld; j.col0 = col0; j.ksub = out_rows; j.fwd = 1; j.dst_off = off;
+            off += (size_t)layer_stages_b3(k, out_rows) * kStageFloatsB3;
+        };
+        auto hidden3 = [&](int base, size_t& off) { for (int l = 1; l <= NL; ++l) pack3(base + 2 * l, H, H, 0, H, off); };
+        size_t off = m->t_enc_edge;
+        pack3(b_enc_edge, H, m->d.edge_dim, 0, m->d.edge_dim, off);
+        hidden3(b_enc_edge, off);
+        off = m->t_enc_node;
+        pack3(b_enc_node, H, m->d.node_dim, 0, m->d.node_dim, off);
+        hidden3(b_enc_node, off);
+        pack3(b_edge(0), H, 3 * H, m->ci * H, H, off);  // W_i of processor 0
+        pack3(b_edge(0), H, 3 * H, m->cj * H, H, off);  // W_j
+        for (int k = 0; k < M; ++k) {
+            off = m->t_edge[k];
+            pack3(b_edge(k), H, 3 * H, m->ce * H, H, off);  // W_e
+            hidden3(b_edge(k), off);
+            off = m->t_node[k];
+            pack3(b_node(k), H, 2 * H, m->ch * H, H, off);  // W_h
+            pack3(b_node(k), H, 2 * H, m->ca * H, H, off);  // W_agg
+            hidden3(b_node(k), off);
+            if (k + 1 < M) {
+                pack3(b_edge(k + 1), H, 3 * H, m->ci * H, H, off);
+                pack3(b_edge(k + 1), H, 3 * H, m->cj * H, H, off);
+            } else {
+                for (int l = 0; l < NL; ++l) pack3(b_dec + 2 * l, H, H, 0, H, off);
+                pack3(b_dec + 2 * NL, m->d.out_dim, H, 0, H, off);
+            }
+        }
+        flush_t();
+        if (rc != GM_OK) return rc;
+    }
+    if (m->packed) {
+    // fp32 operand images of the selectable round-1 forward kernels (development builds)
     PackJobs pj;
     pj.n = 0;
     auto flush_pack = [&]() {
@@ -225,6 +267,7 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
         }
     }
     flush_pack();
+    }
 #ifdef GM_DEV_KERNELS
     if (m->packed_b3) {  // three-part bf16 image of the processor edge MLPs
         for (int k = 0; k < M && rc == GM_OK; ++k) {
@@ -317,6 +360,22 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
         m->s_node[k] = st * kStageFloats; st += (NL + 2) * m->S_HH + (k + 1 < M ? 2 * m->S_HH : NL * m->S_HH + m->S_out);
     }
     m->packed_floats = st * kStageFloats;
+    {   // the same sequence as bf16 x 3 streams (training kernels)
+        m->T_HH = layer_stages_b3(H, H);
+        m->T_e0 = layer_stages_b3(desc->edge_dim, H);
+        m->T_n0 = layer_stages_b3(desc->node_dim, H);
+        m->T_out = layer_stages_b3(H, desc->out_dim);
+        size_t t = 0;
+        m->t_enc_edge = t * kStageFloatsB3; t += m->T_e0 + NL * m->T_HH;
+        m->t_enc_node = t * kStageFloatsB3; t += m->T_n0 + NL * m->T_HH + 2 * m->T_HH;
+        m->t_edge.resize(M);
+        m->t_node.resize(M);
+        for (int k = 0; k < M; ++k) {
+            m->t_edge[k] = t * kStageFloatsB3; t += (NL + 1) * m->T_HH;
+            m->t_node[k] = t * kStageFloatsB3; t += (NL + 2) * m->T_HH + (k + 1 < M ? 2 * m->T_HH : NL * m->T_HH + m->T_out);
+        }
+        m->packed_t3_floats = t * kStageFloatsB3;
+    }
     size_t v = 0;
     const size_t VM = (size_t)(NL + 3) * H;
     m->v_enc_edge = v; v += VM;
@@ -382,7 +441,12 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
         return GM_ERR_HIP;
     }
     m->edge_kernel = 0;   // automatic; gm_model_set_edge_kernel changes it per handle (no process-wide switch)
-    if ((m->legacy && hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess) ||
+    bool fp32_images = false;   // operand images of the round-1 fp32 forward kernels
+#ifdef GM_DEV_KERNELS
+    fp32_images = m->dev_forms;
+#endif
+    if ((fp32_images && hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess) ||
+        (m->legacy && hipMalloc(&m->packed_t3, m->packed_t3_floats * sizeof(float)) != hipSuccess) ||
         hipMalloc(&m->vec, m->vec_floats * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
         gm_model_destroy(m);
@@ -406,6 +470,7 @@ int gm_model_update(gm_model* m, const float* const* tensors, int n_tensors, int
 void gm_model_destroy(gm_model* m) {
     if (!m) return;
     if (m->packed) hipFree(m->packed);
+    if (m->packed_t3) hipFree(m->packed_t3);
     if (m->packed16) hipFree(m->packed16);
     if (m->packed_b3) hipFree(m->packed_b3);
     if (m->packed_h3) hipFree(m->packed_h3);

@@ -44,7 +44,6 @@ struct TrainBwdArgs {
     TapePtr tape;
     const float* ln_g;
     const float* wstream;  // packed TRANSPOSED stream: [W_i^T, W_j^T (if Gi)] W_(nl+1)^T .. W_2^T [W_1^T ...]
-    float* gy;             // [rows][H] total upstream gradient (for the LayerNorm parameter gradients)
     float* dz;             // [nl + 1][dz_stride]: pre-activation gradients dz_l = dz + (l - 1) dz_stride of Linear l = 1 .. nl + 1, rows of H
     size_t dz_stride;      //   (the decoder's dz_(nl+1) is dY itself and is not written)
     int nl;
@@ -61,9 +60,11 @@ struct TrainBwdArgs {
     int out_dim;
 };
 
+// bf16 x 3 operand image (train.hip) of a Linear with `ksub` outputs and `w_rows` inputs taken from the row-major W:
+// element (o, k) = W[o][col0 + k] (fwd) or W[k][col0 + o] (transposed block: the backward product's weight)
 struct PackTJob {
-    const float* W;   // row-major [w_rows][ld]
-    int w_rows, ld, col0, ksub;
+    const float* W;
+    int w_rows, ld, col0, ksub, fwd;
     size_t dst_off;   // floats from the base of the packed buffer
 };
 constexpr int kPackTJobsMax = 96;
@@ -71,6 +72,8 @@ struct PackTJobs {
     int n;
     PackTJob job[kPackTJobsMax];
 };
+constexpr int kStageFloatsB3 = 6144;      // one stage of the bf16 x 3 weight stream: 8 groups of 3 KiB
+int layer_stages_b3(int k, int out);      // stages of a Linear with k inputs and `out` outputs
 
 int train_kernels_init();
 int launch_train_fwd(int H, int kind, const TrainFwdArgs& a, hipStream_t s);
@@ -104,7 +107,7 @@ int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X
                   int ldw, int col0, float* db);
 int wgrad_flush(WgradBatch& b);
 size_t train_bwd_ln_part_floats(int H);   // size of TrainBwdArgs.ln_part
-int launch_pack_t_batch(const PackTJobs& jobs, float* base, hipStream_t s);
+int launch_pack_b3_batch(const PackTJobs& jobs, float* base, hipStream_t s);
 int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows, const float* scale, const float* shift, float* out,
                        int64_t n, hipStream_t s);
 int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_t s);

@@ -28,7 +28,120 @@
 namespace gm {
 
 // ------------------------------------------------------------------------------------------
-// small register helpers on the 32x32x2 feature layout (see mlp_dev.h)
+// Arithmetic of the chains and of the weight gradients: fp32 products on the bf16 matrix pipe.  Every operand is split into
+// three bf16 parts (x = hi + mid + lo: 24 significant bits with the FULL float exponent range -- gradients span many
+// orders of magnitude, which rules out the fp16 split of the inference kernels here without a scale search per array) and
+// six of the nine partial products are accumulated in fp32 (hh, hm, mh, mm, hl, lh: what is dropped is below 2^-24 of a
+// product).  v_mfma_f32_32x32x16_bf16 does 8 x the flop of the fp32-input MFMA per issue slot: 2.7 x the throughput at
+// fp32 accuracy.  Weights are split when their images are packed, activations / gradients in registers.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2v __attribute__((ext_vector_type(2)));
+
+struct Bf3 {
+    bf16x8 h, m, l;
+};
+__device__ __forceinline__ Bf3 split_bf3(const float (&v)[8]) {
+    Bf3 o;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const floatx2v x = floatx2v{v[e], v[e + 1]};
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const floatx2v r1 = x - __builtin_convertvector(h, floatx2v);
+        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+        const floatx2v r2 = r1 - __builtin_convertvector(m, floatx2v);
+        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+        o.h[e] = h[0]; o.h[e + 1] = h[1];
+        o.m[e] = m[0]; o.m[e + 1] = m[1];
+        o.l[e] = l[0]; o.l[e + 1] = l[1];
+    }
+    return o;
+}
+__device__ __forceinline__ void mfma_bf3(floatx16& acc, const Bf3& a, const Bf3& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight stream of the chains.  Image of a Linear with K inputs and OUT outputs: groups g = kg * NJB + jb (kg = 16-wide
+// k-group, jb = 32-row output block), each group = 3 parts (hi, mid, lo) x 64 lanes x 8 bf16 = 3 KiB: the A fragments of
+// v_mfma_f32_32x32x16_bf16.  K slot (lane >> 5, e) of k-group kg carries input feature 16 kg + 8 (e >> 2) + 4 (lane >> 5) + (e & 3),
+// which is where the 32x32 accumulator layout keeps that feature (registers 8 q .. 8 q + 7 of block jb are the eight
+// slots of k-group 2 jb + q on the same lane): a Linear's output becomes the next one's B fragments without leaving the
+// registers.  Stages of 8 groups (24 KiB) are streamed L2 -> LDS by DMA one stage ahead, shared by the workgroup's waves.
+// ------------------------------------------------------------------------------------------
+constexpr int B3_GROUP_FLOATS = 768;
+constexpr int B3_STAGE_GROUPS = 8;
+constexpr int B3_STAGE_FLOATS = B3_GROUP_FLOATS * B3_STAGE_GROUPS;   // = kStageFloatsB3
+static_assert(B3_STAGE_FLOATS == kStageFloatsB3, "stage size");
+
+__device__ __forceinline__ void issue_stage3(const WStream& ws, int stage, int buf) {
+#pragma unroll
+    for (int c = 0; c < 3 * B3_STAGE_GROUPS / 4; ++c) {
+        const int piece = c * 4 + ws.wave;  // one wave-instruction = one contiguous 1 KiB piece
+        const float* g = ws.base + (size_t)stage * B3_STAGE_FLOATS + piece * PIECE_FLOATS + ws.lane * 4;
+        float* l = ws.ring + buf * B3_STAGE_FLOATS + piece * PIECE_FLOATS;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+}
+
+// One Linear: acc[jb] += W(block jb) . act.  NKG = K / 16 k-groups, NJB = OUT / 32 blocks, act in the accumulator layout.
+// more / PEND: as run_layer (mlp_dev.h).
+template <int NKG, int NJB, int NKB, int PEND = 0>
+__device__ __forceinline__ void run_layer_b3(floatx16 (&acc)[NJB], const floatx16 (&act)[NKB], WStream& ws, bool more_tiles) {
+    constexpr int NG = NKG * NJB;
+    constexpr int NST = (NG + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS;
+    Bf3 b;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        if (PEND > 0 && s == 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
+            lds_barrier();  // LDS-only barrier: __syncthreads() would drain the pending stores
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // stage `cur` has landed for every wave; the other buffer is free
+        }
+        int nxt = ws.cur + 1;
+        const bool wrap = nxt == ws.total;
+        if (wrap) nxt = 0;
+        {
+            int st = nxt;
+            asm volatile("" : "+s"(st));   // launder: keeps the DMA addresses from being precomputed per stage outside the tile loop
+            if (!wrap || more_tiles) issue_stage3(ws, st, ws.parity ^ 1);
+            __builtin_amdgcn_sched_barrier(0);   // the DMA issue stays right behind the barrier
+        }
+        const bf16x8* buf = reinterpret_cast<const bf16x8*>(ws.ring + ws.parity * B3_STAGE_FLOATS) + ws.lane;
+#pragma unroll
+        for (int u = 0; u < B3_STAGE_GROUPS; ++u) {
+            const int g = s * B3_STAGE_GROUPS + u;
+            if (g < NG) {
+                const int kg = g / NJB, jb = g % NJB;
+                if (jb == 0) {   // a new k-group: its B fragments from the activation registers
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act[kg >> 1][8 * (kg & 1) + e];
+                    b = split_bf3(v);
+                }
+                Bf3 a;
+                a.h = buf[(u * 3 + 0) * 64];
+                a.m = buf[(u * 3 + 1) * 64];
+                a.l = buf[(u * 3 + 2) * 64];
+                mfma_bf3(acc[jb], a, b);
+            }
+        }
+        ws.cur = nxt;
+        ws.parity ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small register helpers on the 32x32 feature layout (see mlp_dev.h)
 // ------------------------------------------------------------------------------------------
 template <int NKB>
 __device__ __forceinline__ void zero_feat(floatx16 (&v)[NKB]) {
@@ -162,7 +275,7 @@ __device__ __forceinline__ void ln_param_sums(const floatx16 (&g)[NJB], const fl
 template <int H, int KIND>
 __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(TrainFwdArgs A) {
     constexpr int NJB = H / 32;
-    constexpr int SL = (H / 8) * NJB / STAGE_PIECES;
+    constexpr int SL = ((H / 16) * NJB + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS;   // stages of one H x H Linear
     const int NL = A.nl;   // any num_layers >= 2 (epd_gnn.py:72-84): the hidden Linears are a run-time loop
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ring = reinterpret_cast<float*>(smem);
@@ -174,15 +287,15 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
     ws.base = A.wstream;
     ws.ring = ring;
     ws.total = KIND == TK_ENC_EDGE ? 1 + NL * SL
-             : KIND == TK_ENC_NODE ? (4 * NJB + STAGE_PIECES - 1) / STAGE_PIECES + NL * SL
+             : KIND == TK_ENC_NODE ? (2 * NJB + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS + NL * SL
              : KIND == TK_PROC_EDGE ? (NL + 1) * SL
              : KIND == TK_PROC_NODE ? (NL + 2) * SL
-                                   : NL * SL + (H / 8 + STAGE_PIECES - 1) / STAGE_PIECES;
+                                   : NL * SL + (H / 16 + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS;
     ws.cur = 0;
     ws.parity = 0;
     ws.lane = lane;
     ws.wave = wave;
-    if ((int)blockIdx.x < ntiles) issue_stage(ws, 0, 0);
+    if ((int)blockIdx.x < ntiles) issue_stage3(ws, 0, 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < ntiles;
         const int p = tile * TILE + wave * 32 + n;
@@ -193,23 +306,23 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
             const int64_t rin = A.rowidx ? A.rowidx[pc] : pc;
             load_feat_guard(act, A.x_in + rin * A.k1, hi, A.k1);
             load_feat(acc, A.bias, hi);
-            if (KIND == TK_ENC_EDGE) run_layer<1, NJB, NJB>(acc, act, ws, more);
-            else run_layer<4, NJB, NJB>(acc, act, ws, more);
+            if (KIND == TK_ENC_EDGE) run_layer_b3<1, NJB, NJB>(acc, act, ws, more);
+            else run_layer_b3<2, NJB, NJB>(acc, act, ws, more);
         } else if (KIND == TK_PROC_EDGE) {
             load_feat(acc, A.P + (int64_t)A.dst[pc] * (2 * H), hi);
             add_feat(acc, A.P + (int64_t)A.src[pc] * (2 * H) + H, hi);
             load_feat(act, A.x_in + (A.rowidx ? (int64_t)A.rowidx[pc] : pc) * H, hi);
-            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+            run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
         } else if (KIND == TK_PROC_NODE) {
             load_feat(act, A.x_in + pc * H, hi);
             load_feat(acc, A.bias, hi);
-            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+            run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
             load_feat(act, A.agg + pc * H, hi);
-            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+            run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
         } else {
             load_feat(act, A.x_in + pc * H, hi);
             load_feat(acc, A.bias, hi);
-            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+            run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
         }
         // hidden layers 2..NL and the output layer; bias_tail = bias of layer 2
         // Tape stores are issued by every lane (rows past the end write a duplicate of the last row: same
@@ -221,7 +334,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
             relu_to(act, acc);
             load_feat(acc, A.bias_tail + (size_t)(l - 1) * H, hi);
             store_feat(act, A.tape.a + (size_t)(l - 1) * tstride + pc * H, hi);
-            run_layer<H / 8, NJB, NJB, NST>(acc, act, ws, more);
+            run_layer_b3<H / 16, NJB, NJB, NST>(acc, act, ws, more);
         }
         relu_to(act, acc);
         if (KIND != TK_DEC) load_feat(acc, A.bias_tail + (size_t)(NL - 1) * H, hi);
@@ -229,14 +342,14 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
         if (KIND == TK_DEC) {
             floatx16 o[1];
             load_feat(o, A.bias_tail + (size_t)(NL - 1) * H, hi);  // out bias, zero-padded to 32
-            run_layer<H / 8, 1, NJB>(o, act, ws, more);
+            run_layer_b3<H / 16, 1, NJB>(o, act, ws, more);
             if (valid && hi == 0) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < A.out_dim) A.out[pc * A.out_dim + c] = o[0][c];
             }
         } else {
-            run_layer<H / 8, NJB, NJB, NST>(acc, act, ws, more);
+            run_layer_b3<H / 16, NJB, NJB, NST>(acc, act, ws, more);
             const float rstd = layer_norm_tape(acc, act, A.ln_g, A.ln_b, A.eps, hi);
             if (valid) {
                 store_feat(act, A.tape.xhat + pc * H, hi);
@@ -257,7 +370,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
 template <int H, int KIND>
 __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(TrainBwdArgs A) {
     constexpr int NJB = H / 32;
-    constexpr int SL = (H / 8) * NJB / STAGE_PIECES;
+    constexpr int SL = ((H / 16) * NJB + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS;   // stages of one H x H Linear
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ring = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
@@ -267,7 +380,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
     const int ntiles = (R + TILE - 1) / TILE;
     const bool has_g = (KIND == TB_NODE || KIND == TB_ENC || KIND == TB_PROJ) && A.Gi != nullptr;
     constexpr bool NORMED = KIND == TB_NODE || KIND == TB_ENC || KIND == TB_EDGE;
-    float* lnacc = ring + 2 * STAGE_FLOATS;   // [4 waves][2 H]: this workgroup's share of the LayerNorm parameter gradients
+    float* lnacc = ring + 2 * B3_STAGE_FLOATS;   // [4 waves][2 H]: this workgroup's share of the LayerNorm parameter gradients
     if (NORMED && A.ln_part) {
         for (int i = tid; i < 4 * 2 * H; i += THREADS) lnacc[i] = 0.f;
         __syncthreads();
@@ -275,7 +388,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
     WStream ws;
     ws.base = A.wstream;
     ws.ring = ring;
-    constexpr int S_IN = (H / 8 + STAGE_PIECES - 1) / STAGE_PIECES;  // W1^T of an encoder: one 32-row block of outputs
+    constexpr int S_IN = (H / 16 + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS;  // W1^T of an encoder: one 32-row block of outputs
     ws.total = (has_g ? 2 * SL : 0) +
                (KIND == TB_ENC ? NL * SL + (A.dx_in ? S_IN : 0) : KIND == TB_EDGE ? (NL + 1) * SL : KIND == TB_NODE ? (NL + 2) * SL
                 : KIND == TB_PROJ ? 0 : 1 + NL * SL);
@@ -283,7 +396,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
     ws.parity = 0;
     ws.lane = lane;
     ws.wave = wave;
-    if ((int)blockIdx.x < ntiles) issue_stage(ws, 0, 0);
+    if ((int)blockIdx.x < ntiles) issue_stage3(ws, 0, 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < ntiles;
         const int p = tile * TILE + wave * 32 + n;
@@ -294,7 +407,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
             // dz3 = dY [rows][out_dim]; first product has K = out_dim (one k-octet)
             load_feat_guard(act, A.dY + pc * A.out_dim, hi, A.out_dim);
             zero_feat(acc);
-            run_layer<1, NJB, NJB>(acc, act, ws, more);
+            run_layer_b3<1, NJB, NJB>(acc, act, ws, more);
         } else {
             // total upstream gradient of the MLP output row
             if (A.dY) {
@@ -306,25 +419,22 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
             if (KIND == TB_EDGE && A.dagg) add_feat(acc, A.dagg + (int64_t)A.dst[pc] * H, hi);
             if (has_g) {  // + W_i^T G_i + W_j^T G_j : input gradient of the NEXT edge step's factorised layer 1
                 load_feat(act, A.Gi + pc * H, hi);
-                run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+                run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
                 load_feat(act, A.Gj + pc * H, hi);
-                run_layer<H / 8, NJB, NJB>(acc, act, ws, more);
+                run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
             }
             if (KIND == TB_PROJ) {
                 if (valid) store_feat(acc, A.dx + pc * H, hi);
                 continue;
             }
-            if (valid) {
-                store_feat(acc, A.gy + pc * H, hi);
-                if (KIND == TB_NODE && A.dx_resid) store_feat(acc, A.dx_resid + pc * H, hi);  // residual path: dh_in starts as dY
-            }
+            if (valid && KIND == TB_NODE && A.dx_resid) store_feat(acc, A.dx_resid + pc * H, hi);  // residual path: dh_in starts as dY
             load_feat(act, A.tape.xhat + pc * H, hi);
             if (NORMED && A.ln_part) ln_param_sums(acc, act, valid, lnacc + wave * 2 * H, n, hi);
             layer_norm_bwd(acc, act, A.ln_g, A.tape.rstd[pc], hi);
             // dz stores: every lane (duplicates of the last row past the end), counted by run_layer<.., PEND>
             store_feat(act, A.dz + (size_t)NL * A.dz_stride + pc * H, hi);
             zero_feat(acc);
-            run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);  // W_(NL+1)^T dz_(NL+1)
+            run_layer_b3<H / 16, NJB, NJB, H / 8>(acc, act, ws, more);  // W_(NL+1)^T dz_(NL+1)
         }
 #pragma unroll 1
         for (int l = NL; l >= 2; --l) {   // dz_l = (W_(l+1)^T dz_(l+1)) [a_l > 0], then on through W_l^T
@@ -333,7 +443,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
 #pragma unroll
             for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
             zero_feat(acc);
-            run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);
+            run_layer_b3<H / 16, NJB, NJB, H / 8>(acc, act, ws, more);
         }
         mask_feat(acc, A.tape.a + pc * H, hi);
         store_feat(acc, A.dz + pc * H, hi);
@@ -343,7 +453,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
                 for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
                 floatx16 o[1];
                 zero_feat(o);
-                run_layer<H / 8, 1, NJB, H / 8>(o, act, ws, more);
+                run_layer_b3<H / 16, 1, NJB, H / 8>(o, act, ws, more);
                 if (valid) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -357,7 +467,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
 #pragma unroll
         for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
         zero_feat(acc);
-        run_layer<H / 8, NJB, NJB, H / 8>(acc, act, ws, more);  // W1^T dz1 (edge: W_e block; node: W_h block; decoder: W1)
+        run_layer_b3<H / 16, NJB, NJB, H / 8>(acc, act, ws, more);  // W1^T dz1 (edge: W_e block; node: W_h block; decoder: W1)
         if (KIND == TB_EDGE) {
             // de_in = W_e^T dz1 (+ de_out through the residual), written over the row it came from
             if (A.residual && A.dY) {
@@ -369,7 +479,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
             if (A.dx_resid) add_feat(acc, A.dx_resid + pc * H, hi);  // same thread wrote this row above
             if (valid) store_feat(acc, A.dx + pc * H, hi);
             zero_feat(acc);
-            run_layer<H / 8, NJB, NJB>(acc, act, ws, more);  // W_agg^T dz1
+            run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);  // W_agg^T dz1
             if (valid) store_feat(acc, A.dagg_out + pc * H, hi);
         } else {
             if (valid) store_feat(acc, A.dx + pc * H, hi);
@@ -400,38 +510,6 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
 // The operands of the next step are requested before the splits / MFMAs of the current one (register double buffer);
 // every load is unconditional from a clamped (valid) address, so the waits are counted vmcnt.
 // ------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float floatx2v __attribute__((ext_vector_type(2)));
-
-struct Bf3 {
-    bf16x8 h, m, l;
-};
-__device__ __forceinline__ Bf3 split_bf3(const float (&v)[8]) {
-    Bf3 o;
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const floatx2v x = floatx2v{v[e], v[e + 1]};
-        const bf16x2 h = __builtin_convertvector(x, bf16x2);
-        const floatx2v r1 = x - __builtin_convertvector(h, floatx2v);
-        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
-        const floatx2v r2 = r1 - __builtin_convertvector(m, floatx2v);
-        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
-        o.h[e] = h[0]; o.h[e + 1] = h[1];
-        o.m[e] = m[0]; o.m[e + 1] = m[1];
-        o.l[e] = l[0]; o.l[e + 1] = l[1];
-    }
-    return o;
-}
-__device__ __forceinline__ void mfma_bf3(floatx16& acc, const Bf3& a, const Bf3& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
-}
-
 struct WgRaw {
     float a0[8], a1[8], b0[8], b1[8];
 };
@@ -591,23 +669,36 @@ __global__ void __launch_bounds__(256) ln_grads_reduce_kernel(const float* __res
     }
 }
 
-// Transposed operand images of many Linears in one launch (blockIdx.y = job)
-__global__ void __launch_bounds__(256) pack_t_batch_kernel(PackTJobs J, float* __restrict__ base) {
+// bf16 x 3 operand images of many Linears in one launch (blockIdx.y = job).  A job describes a Linear with `ksub` outputs and
+// `w_rows` inputs: element (o, k) = W[o][col0 + k] (fwd) or W[k][col0 + o] (the transposed block: the weight of the backward,
+// input-gradient product dX = dZ . W).
+__device__ __forceinline__ unsigned short bf16_rne_bits(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__global__ void __launch_bounds__(256) pack_b3_batch_kernel(PackTJobs J, float* __restrict__ base) {
     const PackTJob j = J.job[blockIdx.y];
-    const int nkq = (j.w_rows + 7) / 8, njb = (j.ksub + 31) / 32;
-    const int64_t total = (int64_t)((nkq * njb + STAGE_PIECES - 1) / STAGE_PIECES) * STAGE_FLOATS;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int p = (int)(idx / PIECE_FLOATS);
-        const int within = (int)(idx % PIECE_FLOATS);
-        const int lane = within >> 2, t = within & 3;
-        const int i = lane & 31, hi = lane >> 5;
+    const int nkg = (j.w_rows + 15) / 16, njb = (j.ksub + 31) / 32;
+    const int groups = nkg * njb;
+    const int total = ((groups + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS) * B3_STAGE_GROUPS * 512;   // (group, lane, e)
+    unsigned short* dst = reinterpret_cast<unsigned short*>(base + j.dst_off);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, g = idx >> 9;
         float v = 0.f;
-        if (p < nkq * njb) {
-            const int kq = p / njb, jb = p % njb;
-            const int row = 32 * jb + i, col = 8 * kq + 4 * hi + t;
-            if (row < j.ksub && col < j.w_rows) v = j.W[(int64_t)col * j.ld + j.col0 + row];
+        if (g < groups) {
+            const int kg = g / njb, jb = g % njb;
+            const int o = 32 * jb + (lane & 31), k = 16 * kg + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+            if (o < j.ksub && k < j.w_rows) v = j.fwd ? j.W[(int64_t)o * j.ld + j.col0 + k] : j.W[(int64_t)k * j.ld + j.col0 + o];
         }
-        base[j.dst_off + idx] = v;
+        const unsigned short hi = bf16_rne_bits(v);
+        const float r1 = v - __uint_as_float((unsigned)hi << 16);
+        const unsigned short mid = bf16_rne_bits(r1);
+        const unsigned short lo = bf16_rne_bits(r1 - __uint_as_float((unsigned)mid << 16));
+        const size_t at = ((size_t)(g * 3) * 64 + lane) * 8 + e;
+        dst[at] = hi;
+        dst[at + 512] = mid;
+        dst[at + 1024] = lo;
     }
 }
 
@@ -664,7 +755,7 @@ static int set_dyn_lds(Kern k, size_t bytes) {
 
 template <int H>
 static int launch_train_fwd_h(int kind, const TrainFwdArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)2 * STAGE_FLOATS * 4;
+    const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4;
     const int grid = grid_tiles(a.rows);
     switch (kind) {
         case TK_ENC_EDGE: hipLaunchKernelGGL((train_fwd_kernel<H, TK_ENC_EDGE>), dim3(grid), dim3(THREADS), lds, s, a); break;
@@ -690,7 +781,7 @@ size_t train_bwd_ln_part_floats(int H) { return (size_t)2 * 1024 * 2 * H; }   //
 
 template <int H>
 static int launch_train_bwd_h(int kind, const TrainBwdArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)2 * STAGE_FLOATS * 4 + (size_t)4 * 2 * H * 4;
+    const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4 + (size_t)4 * 2 * H * 4;
     int grid = grid_tiles(a.rows);
     const bool ln = a.ln_part && (kind == TB_ENC || kind == TB_EDGE || kind == TB_NODE);
     if (ln) {
@@ -770,9 +861,14 @@ int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X
     return GM_OK;
 }
 
-int launch_pack_t_batch(const PackTJobs& jobs, float* base, hipStream_t s) {
+int layer_stages_b3(int k, int out) {
+    const int nkg = (k + 15) / 16, njb = (out + 31) / 32;
+    return (nkg * njb + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS;
+}
+
+int launch_pack_b3_batch(const PackTJobs& jobs, float* base, hipStream_t s) {
     if (jobs.n <= 0) return GM_OK;
-    hipLaunchKernelGGL(pack_t_batch_kernel, dim3(16, jobs.n), dim3(256), 0, s, jobs, base);
+    hipLaunchKernelGGL(pack_b3_batch_kernel, dim3(16, jobs.n), dim3(256), 0, s, jobs, base);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -798,7 +894,7 @@ int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_
 int train_kernels_init() {
     static PerDeviceOnce done_dev;
     return done_dev.run([]() -> int {
-    const size_t lds = (size_t)2 * STAGE_FLOATS * 4 + (size_t)4 * 2 * 256 * 4;   // weight ring + the backward kernels' LayerNorm sums
+    const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4 + (size_t)4 * 2 * 256 * 4;   // weight ring + the backward kernels' LayerNorm sums
     int rc = GM_OK;
 #define GM_SET(k) if (rc == GM_OK) rc = set_dyn_lds(k, lds)
     GM_SET((train_fwd_kernel<64, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<64, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<64, TK_PROC_EDGE>));

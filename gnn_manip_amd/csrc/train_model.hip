@@ -62,7 +62,7 @@ Tape carve_tape(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
 }
 
 struct BwdWs {
-    float *packT, *gy, *dz, *de, *dh, *dagg, *Gi, *Gj, *part;
+    float *packT, *dz, *de, *dh, *dagg, *Gi, *Gj, *part;
     size_t dz_stride;   // floats between dz_l and dz_(l+1) (l = 1 .. NL + 1)
     float* dzl(int l) const { return dz + (size_t)(l - 1) * dz_stride; }
     size_t off_dec, off_enc_edge, off_enc_node;
@@ -73,22 +73,21 @@ struct BwdWs {
 BwdWs carve_bwd(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
     BwdWs b;
     const int H = d->hidden_size, M = d->m_steps, NL = d->num_layers;
-    const size_t U = (size_t)layer_stages(H, H) * kStageFloats;  // one HxH unit
+    const size_t U = (size_t)layer_stages_b3(H, H) * kStageFloatsB3;  // one HxH unit
     size_t off = 0;
-    b.off_dec = off; off += (size_t)layer_stages(d->out_dim, H) * kStageFloats + (size_t)NL * U;
+    b.off_dec = off; off += (size_t)layer_stages_b3(d->out_dim, H) * kStageFloatsB3 + (size_t)NL * U;
     b.off_edge.resize(M);
     b.off_node.resize(M);
     for (int k = 0; k < M; ++k) {
         b.off_node[k] = off; off += (k + 1 < M ? 2 * U : 0) + (size_t)(NL + 2) * U;
         b.off_edge[k] = off; off += (size_t)(NL + 1) * U;
     }
-    const size_t UIN = (size_t)layer_stages(H, 32) * kStageFloats;  // W1^T of an encoder (input gradient, block API)
+    const size_t UIN = (size_t)layer_stages_b3(H, 32) * kStageFloatsB3;  // W1^T of an encoder (input gradient, block API)
     b.off_enc_node = off; off += 2 * U + (size_t)NL * U + UIN;
     b.off_enc_edge = off; off += (size_t)NL * U + UIN;
     Carver c(ws);
     b.packT = c.take<float>(off);
     const int64_t R = n > e ? n : e;
-    b.gy = c.take<float>((size_t)R * H);
     b.dz_stride = align_up((size_t)R * H, 64);
     b.dz = c.take<float>((size_t)(NL + 1) * b.dz_stride);
     b.de = c.take<float>((size_t)e * H);
@@ -188,14 +187,14 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
     rc = gm_csr_from_edge_index(t.ei2, n, e, t.csr_src, t.csr_bytes, stream);
     if (rc != GM_OK) return rc;
 
-    const size_t U = (size_t)m->S_HH * kStageFloats;
+    const size_t U = (size_t)m->T_HH * kStageFloatsB3;
     auto normed = [&](TrainFwdArgs& a, size_t voff) {
         const float* v = mlp_vec(m, voff);
         a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps; a.nl = NL;
     };
     {
         TrainFwdArgs a{};
-        a.rows = (int)e; a.x_in = edge_attr; a.rowidx = c.eid; a.k1 = m->d.edge_dim; a.wstream = m->packed + m->s_enc_edge;
+        a.rows = (int)e; a.x_in = edge_attr; a.rowidx = c.eid; a.k1 = m->d.edge_dim; a.wstream = m->packed_t3 + m->t_enc_edge;
         normed(a, m->v_enc_edge);
         a.tape = t.ee; a.out = t.e[0];
         rc = launch_train_fwd(H, TK_ENC_EDGE, a, s);
@@ -203,7 +202,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
     }
     {
         TrainFwdArgs a{};
-        a.rows = (int)n; a.x_in = nodes; a.k1 = m->d.node_dim; a.wstream = m->packed + m->s_enc_node;
+        a.rows = (int)n; a.x_in = nodes; a.k1 = m->d.node_dim; a.wstream = m->packed_t3 + m->t_enc_node;
         normed(a, m->v_enc_node);
         a.tape = t.en; a.out = t.h[0];
         rc = launch_train_fwd(H, TK_ENC_NODE, a, s);
@@ -213,8 +212,6 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
         // P = h_k [W_i | W_j]^T (+ b1): the projection section of the preceding node stream
         NodeArgs pa{};
         pa.n_nodes = (int)n; pa.x_in = t.h[k];
-        pa.wstream = k == 0 ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
-                            : m->packed + m->s_node[k - 1] + (size_t)(NL + 2) * U;
         pa.tail = 1; pa.proj_bias = m->vec + m->v_edge[k]; pa.P_out = t.P;
         pa.tail_hm = m->packed_hm + (k == 0 ? m->hm_enc_node_tail : m->hm_node_tail[k - 1]);   // the streamed fp16 x 3 projection kernel
         rc = launch_node(H, NL, 2, pa, s);
@@ -222,7 +219,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
         const float* ve = mlp_vec(m, m->v_edge[k]);
         {
             TrainFwdArgs a{};
-            a.rows = (int)e; a.x_in = t.e[k]; a.dst = c.dst; a.src = c.src; a.P = t.P; a.wstream = m->packed + m->s_edge[k];
+            a.rows = (int)e; a.x_in = t.e[k]; a.dst = c.dst; a.src = c.src; a.P = t.P; a.wstream = m->packed_t3 + m->t_edge[k];
             normed(a, m->v_edge[k]);
             a.tape = t.te[k]; a.out = t.e[k + 1]; a.residual = 1;
             rc = launch_train_fwd(H, TK_PROC_EDGE, a, s);
@@ -233,7 +230,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
         if (rc != GM_OK) return rc;
         {
             TrainFwdArgs a{};
-            a.rows = (int)n; a.x_in = t.h[k]; a.agg = t.agg[k]; a.wstream = m->packed + m->s_node[k];
+            a.rows = (int)n; a.x_in = t.h[k]; a.agg = t.agg[k]; a.wstream = m->packed_t3 + m->t_node[k];
             normed(a, m->v_node[k]);
             a.tape = t.tn[k]; a.out = t.h[k + 1]; a.residual = 1;
             rc = launch_train_fwd(H, TK_PROC_NODE, a, s);
@@ -242,7 +239,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
     }
     {
         TrainFwdArgs a{};
-        a.rows = (int)n; a.x_in = t.h[M]; a.wstream = m->packed + m->s_node[M - 1] + (size_t)(NL + 2) * U;
+        a.rows = (int)n; a.x_in = t.h[M]; a.wstream = m->packed_t3 + m->t_node[M - 1] + (size_t)(NL + 2) * U;
         const float* v = mlp_vec(m, m->v_dec);
         a.bias = v; a.bias_tail = v + H; a.nl = NL;
         a.tape = t.dec; a.out = out; a.out_dim = m->d.out_dim;
@@ -280,21 +277,21 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     const int b_enc_edge = 0, b_enc_node = PM, b_dec = (2 + 2 * M) * PM;
     auto b_edge = [&](int k) { return (2 + 2 * k) * PM; };
     auto b_node = [&](int k) { return (3 + 2 * k) * PM; };
-    const size_t U = (size_t)m->S_HH * kStageFloats;
+    const size_t U = (size_t)m->T_HH * kStageFloatsB3;
 
     // ---- transposed operand images of every Linear on the backward path (batched: a few launches)
     {
         PackTJobs jobs;
         jobs.n = 0;
         auto flush = [&]() {
-            if (rc == GM_OK && jobs.n > 0) rc = launch_pack_t_batch(jobs, b.packT, s);
+            if (rc == GM_OK && jobs.n > 0) rc = launch_pack_b3_batch(jobs, b.packT, s);
             jobs.n = 0;
         };
         auto packT = [&](const float* W, int w_rows, int ld, int col0, int ksub, size_t& off) {
             if (jobs.n == kPackTJobsMax) flush();
             PackTJob& j = jobs.job[jobs.n++];
-            j.W = W; j.w_rows = w_rows; j.ld = ld; j.col0 = col0; j.ksub = ksub; j.dst_off = off;
-            off += (size_t)layer_stages(w_rows, ksub) * kStageFloats;
+            j.W = W; j.w_rows = w_rows; j.ld = ld; j.col0 = col0; j.ksub = ksub; j.fwd = 0; j.dst_off = off;
+            off += (size_t)layer_stages_b3(w_rows, ksub) * kStageFloatsB3;
         };
         // the hidden Linears NL + 1 .. 2 of an MLP, in the order its backward chain consumes them
         auto packT_hidden = [&](int base, size_t& off) { for (int l = NL; l >= 1; --l) packT(T[base + 2 * l], H, H, 0, H, off); };
@@ -360,7 +357,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             TrainBwdArgs a{};
             a.rows = (int)n; a.dY = b.dh; a.Gi = has_next ? b.Gi : nullptr; a.Gj = has_next ? b.Gj : nullptr;
             a.tape = t.tn[k]; a.ln_g = ln_gamma(m->v_node[k]); a.wstream = b.packT + b.off_node[k];
-            a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[b_node(k) + 2 * (NL + 1)]; a.dbeta = grads[b_node(k) + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
+            a.ln_part = b.part; a.dgamma = grads[b_node(k) + 2 * (NL + 1)]; a.dbeta = grads[b_node(k) + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
             rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s);
             if (rc != GM_OK) return rc;
@@ -373,7 +370,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             TrainBwdArgs a{};
             a.rows = (int)e; a.dY = has_next ? b.de : nullptr; a.dagg = b.dagg; a.dst = c.dst;
             a.tape = t.te[k]; a.ln_g = ln_gamma(m->v_edge[k]); a.wstream = b.packT + b.off_edge[k];
-            a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[b_edge(k) + 2 * (NL + 1)]; a.dbeta = grads[b_edge(k) + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.de; a.residual = 1;
+            a.ln_part = b.part; a.dgamma = grads[b_edge(k) + 2 * (NL + 1)]; a.dbeta = grads[b_edge(k) + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.de; a.residual = 1;
             rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s);
             if (rc != GM_OK) return rc;
@@ -393,7 +390,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = b.dh; a.Gi = b.Gi; a.Gj = b.Gj; a.tape = t.en; a.ln_g = ln_gamma(m->v_enc_node);
         a.wstream = b.packT + b.off_enc_node;
-        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[b_enc_node + 2 * (NL + 1)]; a.dbeta = grads[b_enc_node + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
+        a.ln_part = b.part; a.dgamma = grads[b_enc_node + 2 * (NL + 1)]; a.dbeta = grads[b_enc_node + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
@@ -404,7 +401,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     if (e > 0) {
         TrainBwdArgs a{};
         a.rows = (int)e; a.dY = b.de; a.tape = t.ee; a.ln_g = ln_gamma(m->v_enc_edge); a.wstream = b.packT + b.off_enc_edge;
-        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[b_enc_edge + 2 * (NL + 1)]; a.dbeta = grads[b_enc_edge + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
+        a.ln_part = b.part; a.dgamma = grads[b_enc_edge + 2 * (NL + 1)]; a.dbeta = grads[b_enc_edge + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
         if (rc != GM_OK) return rc;
@@ -447,13 +444,13 @@ int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_
         a.bias = v; a.bias_tail = v + H; a.ln_g = v + (size_t)(NL + 1) * H; a.ln_b = v + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps; a.nl = NL;
     };
     TrainFwdArgs a{};
-    a.rows = (int)e; a.x_in = edge_attr; a.k1 = m->d.edge_dim; a.wstream = m->packed + m->s_enc_edge;
+    a.rows = (int)e; a.x_in = edge_attr; a.k1 = m->d.edge_dim; a.wstream = m->packed_t3 + m->t_enc_edge;
     normed(a, m->v_enc_edge);
     a.tape = t.ee; a.out = e_out;
     rc = launch_train_fwd(H, TK_ENC_EDGE, a, s);
     if (rc != GM_OK) return rc;
     TrainFwdArgs b{};
-    b.rows = (int)n; b.x_in = x; b.k1 = m->d.node_dim; b.wstream = m->packed + m->s_enc_node;
+    b.rows = (int)n; b.x_in = x; b.k1 = m->d.node_dim; b.wstream = m->packed_t3 + m->t_enc_node;
     normed(b, m->v_enc_node);
     b.tape = t.en; b.out = h_out;
     return launch_train_fwd(H, TK_ENC_NODE, b, s);
@@ -481,12 +478,12 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
     hipStream_t s = (hipStream_t)stream;
     WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands
     wb.part = b.part; wb.cap = wgrad_partial_floats(H); wb.stream = s;
-    const size_t U = (size_t)m->S_HH * kStageFloats;
+    const size_t U = (size_t)m->T_HH * kStageFloatsB3;
     PackTJobs jobs;
     jobs.n = 0;
     auto packT = [&](const float* W, size_t off) {
         PackTJob& j = jobs.job[jobs.n++];
-        j.W = W; j.w_rows = H; j.ld = H; j.col0 = 0; j.ksub = H; j.dst_off = off;
+        j.W = W; j.w_rows = H; j.ld = H; j.col0 = 0; j.ksub = H; j.fwd = 0; j.dst_off = off;
     };
     // node stream sits behind the (unused) projection slots of the model layout
     for (int l = NL; l >= 1; --l) {
@@ -495,18 +492,18 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
     }
     auto packT_in = [&](const float* W, int k1, size_t off) {  // (W1 [H, k1])^T as a Linear with k1 outputs, H inputs
         PackTJob& j = jobs.job[jobs.n++];
-        j.W = W; j.w_rows = H; j.ld = k1; j.col0 = 0; j.ksub = k1; j.dst_off = off;
+        j.W = W; j.w_rows = H; j.ld = k1; j.col0 = 0; j.ksub = k1; j.fwd = 0; j.dst_off = off;
     };
     if (dx) packT_in(T[PM], m->d.node_dim, b.off_enc_node + (size_t)(NL + 2) * U);
     if (dedge_attr) packT_in(T[0], m->d.edge_dim, b.off_enc_edge + (size_t)NL * U);
-    rc = launch_pack_t_batch(jobs, b.packT, s);
+    rc = launch_pack_b3_batch(jobs, b.packT, s);
     if (rc != GM_OK) return rc;
     auto run = [&](int base, const TapePtr& tp, int64_t rows, const float* dY, size_t voff, size_t woff, const float* X, int k1, float* dxin) {
         if (rows <= 0 || rc != GM_OK) return;
         TrainBwdArgs a{};
         a.rows = (int)rows; a.dY = dY; a.tape = tp; a.ln_g = m->vec + voff + (size_t)(NL + 1) * H; a.wstream = b.packT + woff;
         a.dx_in = dxin; a.k1 = k1;
-        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[base + 2 * (NL + 1)]; a.dbeta = grads[base + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
+        a.ln_part = b.part; a.dgamma = grads[base + 2 * (NL + 1)]; a.dbeta = grads[base + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
         for (int l = NL; l >= 1 && rc == GM_OK; --l)
@@ -541,11 +538,9 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
     if (rc != GM_OK) return rc;
     rc = gm_csr_from_edge_index(t.ei2, n, e, t.csr_src, t.csr_bytes, stream);
     if (rc != GM_OK) return rc;
-    const size_t U = (size_t)m->S_HH * kStageFloats;
+    const size_t U = (size_t)m->T_HH * kStageFloatsB3;
     NodeArgs pa{};
     pa.n_nodes = (int)n; pa.x_in = h;
-    pa.wstream = k == 0 ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
-                        : m->packed + m->s_node[k - 1] + (size_t)(NL + 2) * U;
     pa.tail = 1; pa.proj_bias = m->vec + m->v_edge[k]; pa.P_out = t.P;
     pa.tail_hm = m->packed_hm + (k == 0 ? m->hm_enc_node_tail : m->hm_node_tail[k - 1]);   // the streamed fp16 x 3 projection kernel
     rc = launch_node(H, NL, 2, pa, s);
@@ -556,7 +551,7 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
     };
     {
         TrainFwdArgs a{};
-        a.rows = (int)e; a.x_in = e_in; a.rowidx = c.eid; a.dst = c.dst; a.src = c.src; a.P = t.P; a.wstream = m->packed + m->s_edge[k];
+        a.rows = (int)e; a.x_in = e_in; a.rowidx = c.eid; a.dst = c.dst; a.src = c.src; a.P = t.P; a.wstream = m->packed_t3 + m->t_edge[k];
         normed(a, m->v_edge[k]);
         a.tape = t.te; a.out = e_out; a.residual = 0;
         rc = launch_train_fwd(H, TK_PROC_EDGE, a, s);
@@ -566,7 +561,7 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
     rc = launch_segment_sum(H, c.in_ptr, nullptr, t.te.xhat, ve + (size_t)(NL + 1) * H, ve + (size_t)(NL + 2) * H, t.agg, n, s);
     if (rc != GM_OK) return rc;
     TrainFwdArgs a{};
-    a.rows = (int)n; a.x_in = h; a.agg = t.agg; a.wstream = m->packed + m->s_node[k];
+    a.rows = (int)n; a.x_in = h; a.agg = t.agg; a.wstream = m->packed_t3 + m->t_node[k];
     normed(a, m->v_node[k]);
     a.tape = t.tn; a.out = h_out; a.residual = 0;
     return launch_train_fwd(H, TK_PROC_NODE, a, s);
@@ -599,13 +594,13 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
     wb.part = b.part; wb.cap = wgrad_partial_floats(H); wb.stream = s;
     CsrWs c = carve_csr(t.csr_dst, n, e);
     CsrWs c2 = carve_csr(t.csr_src, n, e);
-    const size_t U = (size_t)m->S_HH * kStageFloats;
+    const size_t U = (size_t)m->T_HH * kStageFloatsB3;
     {
         PackTJobs jobs;
         jobs.n = 0;
         auto packT = [&](const float* W, int ld, int col0, size_t off) {
             PackTJob& j = jobs.job[jobs.n++];
-            j.W = W; j.w_rows = H; j.ld = ld; j.col0 = col0; j.ksub = H; j.dst_off = off;
+            j.W = W; j.w_rows = H; j.ld = ld; j.col0 = col0; j.ksub = H; j.fwd = 0; j.dst_off = off;
         };
         for (int l = NL; l >= 1; --l) {
             packT(T[bn + 2 * l], H, 0, b.off_node[0] + (size_t)(NL - l) * U);
@@ -616,7 +611,7 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         packT(T[be], 3 * H, m->ce * H, b.off_edge[0] + (size_t)NL * U);
         packT(T[be], 3 * H, m->ci * H, b.off_enc_node);       // W_i^T, W_j^T: projection backward
         packT(T[be], 3 * H, m->cj * H, b.off_enc_node + U);
-        rc = launch_pack_t_batch(jobs, b.packT, s);
+        rc = launch_pack_b3_batch(jobs, b.packT, s);
         if (rc != GM_OK) return rc;
     }
     auto wgrad = [&](const float* dz, const float* X, int64_t rows, float* out, int ldw, int col0, float* db) {
@@ -626,7 +621,7 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
     {
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = dh_out; a.tape = t.tn; a.ln_g = m->vec + m->v_node[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_node[0];
-        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[bn + 2 * (NL + 1)]; a.dbeta = grads[bn + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.dh; a.dagg_out = b.dagg;
+        a.ln_part = b.part; a.dgamma = grads[bn + 2 * (NL + 1)]; a.dbeta = grads[bn + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.dh; a.dagg_out = b.dagg;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s);
         if (rc != GM_OK) return rc;
@@ -639,7 +634,7 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         TrainBwdArgs a{};
         a.rows = (int)e; a.dY = de_out; a.dyidx = c.eid; a.dagg = b.dagg; a.dst = c.dst; a.tape = t.te;
         a.ln_g = m->vec + m->v_edge[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_edge[0];
-        a.gy = b.gy; a.ln_part = b.part; a.dgamma = grads[be + 2 * (NL + 1)]; a.dbeta = grads[be + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = de_in; a.dxidx = c.eid; a.residual = 0;
+        a.ln_part = b.part; a.dgamma = grads[be + 2 * (NL + 1)]; a.dbeta = grads[be + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = de_in; a.dxidx = c.eid; a.residual = 0;
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s);
         if (rc != GM_OK) return rc;
