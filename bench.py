@@ -388,7 +388,19 @@ def extra_train(dev, steps=5, warmup=2):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # Algorithmic HBM bytes of one step with a float32 tape: per processor block and edge 4H(5L + 12) bytes --
+    # forward rows + tape 4H(L + 3), aggregation 4H, backward chain 4H(2L + 4), weight gradients 8H(L + 1), the two
+    # segment sums of dz1 8H -- and per node 4H(5L + 16) on the node side; encoders / decoder the same way without the aggregation.
+    L, E, N = 2, int(edge_attr.shape[0]), int(nodes.shape[0])
+    per_block = 4 * H * ((5 * L + 12) * E + (5 * L + 16) * N)
+    enc_dec = 4 * H * ((5 * L + 9) * (E + N) + (4 * L + 6) * N)
+    alg_bytes = M * per_block + enc_dec
+    flop = 3 * ((10 * H * H * E + 8 * H * H * N) * M + 2 * (4 * H + 2 * H * H) * E + 2 * (25 * H + 2 * H * H) * N + 2 * (2 * H * H + 3 * H) * N)
     return {"value": 1.0 / dt, "unit": "training steps/s", "ms": dt * 1e3, "loss": float(loss.detach()),
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg_bytes / dt / 8e12,
+                         "traffic": None, "alg_bytes_per_step": alg_bytes,
+                         "mfma": {"alg_tflops": flop / dt / 1e12, "note": "forward + 2 x forward flop of the backward; run as six bf16 partial products per multiply"}},
+            "arithmetic": "float32 results: operands split into three bf16 parts, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation",
             "config": {"workload": f"batch of {bsz} synthetic scenes x N={n} (collated), hidden={H}, {M} MP steps, L1 loss, Adam",
                        "nodes": int(nodes.shape[0]), "edges": int(edge_attr.shape[0]), "steps": steps, "warmup": warmup}}
 

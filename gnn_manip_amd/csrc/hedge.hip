@@ -6,21 +6,30 @@
 // fp16 subnormals, which v_mfma_f32_32x32x16_f16 honours -- checked on gfx950).  A product of two fp16 values is exact in
 // fp32, so  lo*hi + hi*lo + hi*hi  accumulated in fp32 reproduces the fp32 product to 2^-22; through the whole model
 // this scheme is as accurate against float64 as plain float32 (tools/f16_split_study.py: 1.1e-6 vs 0.9e-6).  Weights are
-// pre-scaled by a power of two per Linear so that their low parts stay normal; the scales ride on through the
-// activations, biases and P and leave in the LayerNorm statistics: no run-time multiplies.
+// pre-scaled by a power of two per Linear (chosen from its gain, hmlp.h: operand images at rms ~2^4, both halves of every
+// weight normal); the scales ride on through the activations, biases and P and leave in the LayerNorm statistics: no
+// run-time multiplies.  A value that does not fit fp16 is detected (NaN accumulator row) and reported, never clamped.
 //
 // Structure.  12 waves per workgroup, one workgroup per CU, three waves per SIMD.  Wave (role, jb): role = Linear 1 / 2 /
 // 3, jb = 32-feature output block; the wave keeps only ITS Linear's 32 weight rows in registers (64 VGPRs) for the whole
 // launch.  Work advances in ticks of one 32-edge block with ONE workgroup barrier per tick; every LDS buffer is
 // double-buffered by block parity:
-//   role 0: P_i[dst] + P_j[src] of block x -> accumulators, Linear 1 on the operand image E, ReLU, image X1;
-//   role 1: e of block x+1 -> image E; Linear 2 of block x-1 (X1 -> X2); LayerNorm + e_out = e + e' of block x-3;
-//   role 2: Linear 3 of block x-2 (X2 -> Z + LayerNorm partial statistics); aggregation of block x-3: segmented DPP scan
-//           over the destination-sorted edges with the carry of an open segment kept in registers, one row store per
-//           finished segment -- to its agg row, or, for the piece of a segment that began in an earlier group of 4 blocks,
-//           to that group's row of the side buffer, which the node kernel adds in group order: no atomics.  The rows'
-//           destinations come from a small LDS ring that role 0 fills from the indices it loads anyway (role 2 issues no
-//           global loads per tick); roles run at different s_setprio levels (role 2 first, then role 0).
+//   role 0: all the tick's requests at its top (P rows and indices of block x+1, e rows of block x+2: unconditional,
+//           clamped); P_i[dst] + P_j[src] of block x -> accumulators; e of block x+1 -> operand image E (between the
+//           MFMAs); Linear 1 on E, ReLU, image X1; destinations of the block into a small LDS ring for role 2;
+//   role 1: Linear 2 of block x-1 (X1 -> X2); LayerNorm + e_out = e + e' of the first EPI_SPLIT row groups of block x-3
+//           (row-major, 8 lanes per row; unconditional stores, rows that do not exist go to the workgroup's sink rows);
+//   role 2: Linear 3 of block x-2 (X2 -> Z + LayerNorm partial statistics); the other row groups of that epilogue;
+//           aggregation of block x-3 on a TRANSPOSED view (lane = feature, 16 rows of a half block in registers): the
+//           segment structure of the destination-sorted rows is the same for every feature, so it lives in scalar
+//           registers (continuation / last-row bit masks from the block tables) and the segmented scan is 15 masked adds
+//           down the registers; one 128-byte store per finished segment and half wave -- to its agg row, or, for the piece
+//           of a segment that began in an earlier group of 4 blocks, to that group's row of the side buffer, which the
+//           node kernel adds in group order: no atomics.  Role 2 issues no vector loads; roles run at different s_setprio
+//           levels (role 2 first).
+// hipcc's counted vmcnt waits assume the path with the fewest younger operations and share one in-order counter between
+// loads and stores: every global access of the tick loops is therefore branch-free, the weights are waited for before the
+// loops, and the block tables come through scalar loads (separate __restrict__ kernel parameters).
 // A wave's MFMAs form one dependent chain, so its other work of the tick is placed BETWEEN them with the order pinned
 // (one MFMA shadows about three vector instructions of the same wave).  Global rows move as whole 128-byte lines
 // (8 lanes per row); the register <-> MFMA-fragment re-layouts go through XOR-swizzled, conflict-free LDS images.
