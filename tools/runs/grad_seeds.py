@@ -1,3 +1,5 @@
+"""Development: gradient error of the training path against float64 over a run of seeds, next to PyTorch float32's
+(which seeds have a ReLU sign flip between float32-accurate evaluations).  python tools/runs/grad_seeds.py HIDDEN NUM_LAYERS M_STEPS"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))

@@ -1,4 +1,7 @@
 #!/bin/bash
+# Development: same-box bisect of a benchmark line over commits.  Build each commit in a worktree first:
+#   for c in <shas>; do git worktree add -f variants/wt/$c $c; (cd variants/wt/$c && python -m gnn_manip_amd.build); done
+# then  gpurun -- 'bash tools/runs/run_bisect.sh'  (variants/ is git-ignored but travels to the GPU box).
 set -o pipefail
 mkdir -p gpurun_out
 R=$PWD

@@ -1,4 +1,5 @@
 #!/bin/bash
+# The round-end check on the GPU box: all GPU tests, then the default bench line with its sub-records.
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/full_tests.log 2>&1
