@@ -35,6 +35,18 @@ namespace gm {
 
 namespace {
 
+#ifdef HM_STAMPS
+// development build only: s_memtime stamps of wave 0 / lane 0 of four workgroups at the phase boundaries of the node kernel's
+// first four tiles; read back with gm_debug_hm_stamps (tools/hm_stamps.py)
+__device__ unsigned long long g_hm_stamps[4 * 4 * 16];
+#define HM_STAMP(tile_i, slot)                                                                                         \
+    do {                                                                                                               \
+        if ((blockIdx.x & 63) == 0 && blockIdx.x < 256 && threadIdx.x == 0 && (tile_i) < 4)                              \
+            g_hm_stamps[((blockIdx.x >> 6) * 4 + (tile_i)) * 16 + (slot)] = __builtin_readcyclecounter();             \
+    } while (0)
+#else
+#define HM_STAMP(tile_i, slot) do { } while (0)
+#endif
 constexpr int HM_THREADS = 512;
 constexpr int HM_WAVES = 8;
 constexpr int BE = 32;
@@ -120,7 +132,8 @@ __device__ __forceinline__ void report_range(int bad, int* flags) {
 // acc[rb] += W[jb block, k-groups ks0 .. ks0 + nks) x image rows of row block rb.
 //   wf : this wave's fragments of the first k-group, + lane  (k-group stride 128 half8)
 //   im : image of the wave's first row block at k-group 0, + lane  (row-block stride img_ksn * 128, k-group stride 128)
-// nrb: row blocks of this wave that hold rows (the others' MFMAs are skipped: the last tile of a workgroup's range may be partial)
+// nrb: row blocks of this wave that hold rows (the others' MFMAs are skipped: the last tile of a workgroup's range may be partial;
+// a branch-free copy of the loop for full tiles was measured: -4 %, it costs registers the kernels do not have)
 #ifndef HM_RING4
 #define HM_RING4(RBW) ((RBW) == 1)
 #endif
@@ -232,6 +245,72 @@ __device__ __forceinline__ void rows_to_image(const float* __restrict__ src, uin
         split4(v1[0], v1[1], v1[2], v1[3], h1, l1);
         img[((rbg * C::KS + ks) * 2 + 0) * 64 + nn + 32 * kg] = uintx4{h0[0], h0[1], h1[0], h1[1]};
         img[((rbg * C::KS + ks) * 2 + 1) * 64 + nn + 32 * kg] = uintx4{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
+// The agg rows of a node tile -> image.  Per batch of pieces: every row piece is requested first, together with the piece of the
+// first head partial another group holds of the row's segment (hedge.h; SC[slot] = 2 g + more for the first such group g of
+// the row, or -1, looked up at the start of the tile and resolved under the first GEMM -- rows without one read side row 0,
+// a cache hit, and drop it); then the pieces are combined, in group order, and split into the image.  `more` (the next
+// group holds a partial of the same row too: in-degree beyond a group's 128 edges) takes the loop.
+// (The first form waited for a stitch[] and a head[] look-up per piece, two pieces at a time: a third of the tile's time.)
+template <int H, int RBW, class R>
+__device__ __forceinline__ void agg_rows_to_image(const float* __restrict__ agg, uintx4* img, int wave, int lane, R&& row_of, const int* SC,
+                                                  const float* __restrict__ side, const int* __restrict__ head, int ng) {
+    using C = Cfg<H, RBW>;
+    constexpr int NB = RBW >= 2 ? RBW : 2;   // pieces per batch: bounds the registers held by requests in flight
+#pragma unroll
+    for (int b0 = 0; b0 < 2 * RBW; b0 += NB) {
+        floatx4 v0[NB], v1[NB], s0[NB], s1[NB];
+        long long rows[NB];
+        int gs[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int u = (b0 + q) * 8 + wave;
+            const int rowhalf = u % (2 * C::NRB);
+            gs[q] = SC ? SC[(rowhalf >> 1) * 32 + 16 * (rowhalf & 1) + (lane & 15)] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int u = (b0 + q) * 8 + wave;
+            const int rowhalf = u % (2 * C::NRB), kspair = u / (2 * C::NRB);
+            const int rbg = rowhalf >> 1, nn = 16 * (rowhalf & 1) + (lane & 15), c = lane >> 4, ks = 2 * kspair + (c >> 1), kg = c & 1;
+            rows[q] = row_of(rbg, nn);
+            const float* p = agg + rows[q] * H + 16 * ks + 4 * kg;
+            v0[q] = *reinterpret_cast<const floatx4*>(p);
+            v1[q] = *reinterpret_cast<const floatx4*>(p + 8);
+            if (SC) {
+                const float* sp = side + (size_t)(gs[q] < 0 ? 0 : gs[q] >> 1) * H + 16 * ks + 4 * kg;
+                s0[q] = *reinterpret_cast<const floatx4*>(sp);
+                s1[q] = *reinterpret_cast<const floatx4*>(sp + 8);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int u = (b0 + q) * 8 + wave;
+            const int rowhalf = u % (2 * C::NRB), kspair = u / (2 * C::NRB);
+            const int rbg = rowhalf >> 1, nn = 16 * (rowhalf & 1) + (lane & 15), c = lane >> 4, ks = 2 * kspair + (c >> 1), kg = c & 1;
+            if (SC) {
+                const float keep = gs[q] >= 0 ? 1.f : 0.f;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) { v0[q][tt] = fmaf(s0[q][tt], keep, v0[q][tt]); v1[q][tt] = fmaf(s1[q][tt], keep, v1[q][tt]); }
+                if (gs[q] >= 0 && (gs[q] & 1)) {
+                    int g = (gs[q] >> 1) + 1;
+                    do {
+                        const float* sp = side + (size_t)g * H + 16 * ks + 4 * kg;
+                        const floatx4 t0 = *reinterpret_cast<const floatx4*>(sp), t1 = *reinterpret_cast<const floatx4*>(sp + 8);
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) { v0[q][tt] += t0[tt]; v1[q][tt] += t1[tt]; }
+                        ++g;
+                    } while (g < ng && head[g] == (int)rows[q]);
+                }
+            }
+            uintx2 h0, l0, h1, l1;
+            split4(v0[q][0], v0[q][1], v0[q][2], v0[q][3], h0, l0);
+            split4(v1[q][0], v1[q][1], v1[q][2], v1[q][3], h1, l1);
+            img[((rbg * C::KS + ks) * 2 + 0) * 64 + nn + 32 * kg] = uintx4{h0[0], h0[1], h1[0], h1[1]};
+            img[((rbg * C::KS + ks) * 2 + 1) * 64 + nn + 32 * kg] = uintx4{l0[0], l0[1], l1[0], l1[1]};
+        }
     }
 }
 
@@ -556,8 +635,10 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
     const float* gamp = GB + 32 * jb + 4 * hi;
     const float* betp = GB + H + 32 * jb + 4 * hi;
 
+    int tile_i = 0;
 #pragma unroll 1
-    for (int bt = bq0; bt < bq1; bt += C::NRB) {
+    for (int bt = bq0; bt < bq1; bt += C::NRB, ++tile_i) {
+        HM_STAMP(tile_i, 0);
         const int nbt = min(C::NRB, bq1 - bt);                      // blocks of this tile
         const int nrb = (nbt - rg + C::NRG - 1) / C::NRG;           // ... of which this wave's row group holds (image slots rb < nrb)
         // first row of image slot rbg = RBW rg' + rb': tile block j = rb' NRG + rg'
@@ -567,6 +648,14 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             return r < N ? r : N - 1;
         };
         __syncthreads();   // the previous tile's readers of the image are done
+        // head partials of this tile's agg rows (MODE 1): the stitch[] look-up is requested now and resolved under the first GEMM
+        int* SC = reinterpret_cast<int*>(RS);   // [NRB * 32] first group holding a head partial of the row, or -1 (RS is the encoders')
+        const bool stitched = MODE == 1 && A.stitch != nullptr;
+        int sc_row = 0, sc_c = -1;
+        if (stitched && tid < C::NRB * 32) {
+            sc_row = (int)row_of(tid >> 5, tid & 31);
+            sc_c = A.stitch[sc_row];
+        }
         floatx16 acc[RBW];
         Lin L;
         float rs[RBW];
@@ -575,6 +664,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
         if (MODE == 0) narrow_rows_to_image<H, RBW, 2>(A.x_in, A.k1, img, RS, A.w[3], tid, row_of);
         else rows_to_image<H, RBW, 2 * RBW>(A.x_in, img, wave, lane, row_of, [](long long, int, floatx4&, floatx4&) {});
         __syncthreads();
+        HM_STAMP(tile_i, 1);   // h rows in the image
         if (MODE != 2) {
             const float* wp = A.w;
             L = lin_at(wp, H);
@@ -589,27 +679,27 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                 gemm(acc, L.frag + (size_t)jb * 2 * 128 + lane, imgh + (size_t)(RBW * rg) * 2 * 128 + lane, 2, 2, nrb);
                 check_rows(rng, acc);
             } else {
+                int sc_head = -2;
+                const int ng = stitched ? A.tab->n_groups : 0;
+                int sc_head1 = -2;
+                if (stitched && tid < C::NRB * 32 && sc_c >= 0 && sc_c < ng) {   // both land under the GEMM
+                    sc_head = A.head[sc_c];
+                    if (sc_c + 1 < ng) sc_head1 = A.head[sc_c + 1];
+                }
                 gemm(acc, L.frag + (size_t)jb * 2 * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS, nrb);
                 check_rows(rng, acc);
+                if (stitched && tid < C::NRB * 32) SC[tid] = sc_head == sc_row ? 2 * sc_c + (sc_head1 == sc_row ? 1 : 0) : -1;
                 __syncthreads();
+                HM_STAMP(tile_i, 2);   // GEMM 1a (h part)
                 // agg row + the head partials other groups hold of its segment, in group order (hedge.h)
-                rows_to_image<H, RBW, 2>(A.agg, img, wave, lane, row_of, [&](long long row, int f0, floatx4& v0, floatx4& v1) {
-                    if (!A.stitch) return;
-                    int c = A.stitch[row];
-                    const int ng = A.tab->n_groups;
-                    while (c >= 0 && c < ng && A.head[c] == (int)row) {
-                        const float* sp = A.side + (size_t)c * H + f0;
-                        const floatx4 s0 = *reinterpret_cast<const floatx4*>(sp), s1 = *reinterpret_cast<const floatx4*>(sp + 8);
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt) { v0[tt] += s0[tt]; v1[tt] += s1[tt]; }
-                        ++c;
-                    }
-                });
+                agg_rows_to_image<H, RBW>(A.agg, img, wave, lane, row_of, stitched ? SC : nullptr, A.side, A.head, ng);
                 __syncthreads();
+                HM_STAMP(tile_i, 3);   // agg rows (+ head partials) in the image
                 gemm(acc, L.frag + ((size_t)jb * 2 * C::KS + C::KS) * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS, nrb);
                 check_rows(rng, acc);
             }
             wp += lin0;
+            HM_STAMP(tile_i, 4);   // GEMM 1b (agg part)
 #pragma unroll 1
             for (int l = 1; l <= A.nl; ++l) {
                 __syncthreads();
@@ -623,8 +713,10 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                 check_rows(rng, acc);
                 wp += linh;
             }
+            HM_STAMP(tile_i, 5);   // hidden Linears
             ln_publish<H, RBW>(acc, ST, rg, jb, n, hi);
             __syncthreads();
+            HM_STAMP(tile_i, 6);   // LayerNorm statistics published
 #pragma unroll
             for (int rb = 0; rb < RBW; ++rb) {
                 if (rb >= nrb) continue;
@@ -641,6 +733,8 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) y[tt] = fmaf(fmaf(acc[rb][4 * g + tt], k, m), gm4[tt], bt4[tt]);
                     if (A.residual) {
+                        // (requesting these rows ahead of the previous row block's stores, or all of them before the epilogue, was
+                        // measured: -4 % / -17 %: the 16 .. 64 registers they hold spill elsewhere in this 256-VGPR kernel)
                         const floatx4 h0 = *reinterpret_cast<const floatx4*>(A.x_in + off + 8 * g);
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) y[tt] += h0[tt];
@@ -654,11 +748,13 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                     for (int g = 0; g < 4; ++g) *reinterpret_cast<floatx4*>(A.agg_clear + off + 8 * g) = floatx4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+            HM_STAMP(tile_i, 7);   // epilogue: residual read, h stores
             if (A.tail == 0) continue;
             // the new h becomes the tail's input image (every wave has passed the barrier after the last Linear)
 #pragma unroll
             for (int rb = 0; rb < RBW; ++rb) if (rb < nrb) acc_to_img<false>(acc[rb], img + (size_t)(RBW * rg + rb) * C::KS * 128, jb, lane);
             __syncthreads();
+            HM_STAMP(tile_i, 8);   // h in the image
         }
         if (A.tail == 1 || MODE == 2) {
             const Lin LP = lin_at(A.w_tail, 2 * H);
@@ -682,6 +778,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                         }
                     }
                 }
+                HM_STAMP(tile_i, 9 + half);   // projection half: GEMM + P stores
             }
         } else if (A.tail == 2) {
             const float* wp = A.w_tail;
@@ -940,6 +1037,12 @@ int pack_hm(const PackHmJob* jobs, int n, PackHmJob* jobs_dev, float* stats, hip
     }
     return GM_OK;
 }
+
+#ifdef HM_STAMPS
+extern "C" int gm_debug_hm_stamps(unsigned long long* out) {   // 4 workgroups x 4 tiles x 16 slots, development builds only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hm_stamps), sizeof(unsigned long long) * 4 * 4 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool hm_supported(int H) { return H == 64 || H == 128 || H == 256; }   // instantiated widths (hm_padded_hidden maps a model onto one)
 
