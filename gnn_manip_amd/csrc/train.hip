@@ -1,23 +1,22 @@
 // Training path of the encode-process-decode model: forward with an activation tape and the full
 // backward pass (callers: examples/train_dyn.py:45-72 -> loss.backward()).
 //
-// Design.  The per-row work (everything that is "one graph element through an MLP") reuses the
-// transposed fp32-MFMA chain of mlp.hip: a wave carries 32 rows x H features through consecutive
-// Linear layers in registers.  The backward of  y = LN(W3 relu(W2 relu(W1 x + b1) + b2) + b3)  is the
-// same kind of chain run with TRANSPOSED weights (pack_linear_t):
-//     dz3 = LN'(dy);  dz2 = (W3^T dz3) * [a2 > 0];  dz1 = (W2^T dz2) * [a1 > 0];  dx = W1^T dz1
-// so one kernel per MLP produces dz1..dz3 and the input gradient.  Everything that reduces over ROWS
-// (weight, bias and LayerNorm-parameter gradients) is done by two generic kernels on the arrays the
-// chain kernels leave in HBM: wgrad_kernel (dW = dz^T X as a split-K MFMA GEMM, operands read in
-// their natural row-major layout, bias gradient = column sums of the same operand, deterministic
-// two-stage reduction) and ln_grads_kernel.
+// Design.  The per-row work (everything that is "one graph element through an MLP") is a transposed MFMA chain: a wave
+// carries 32 rows x H features through consecutive Linear layers in registers, weights streamed L2 -> LDS in stages.  The
+// backward of  y = LN(W_(L+1) relu(... relu(W_1 x + b_1) ...) + b_(L+1))  is the same kind of chain run with TRANSPOSED weights:
+//     dz_(L+1) = LN'(dy);  dz_l = (W_(l+1)^T dz_(l+1)) * [a_l > 0];  dx = W_1^T dz_1
+// so one kernel per MLP produces dz_1 .. dz_(L+1), the input gradient and -- summed over its rows -- the LayerNorm parameter
+// gradients.  What else reduces over ROWS (weight and bias gradients) is done by wgrad_kernel on the arrays the chain kernels
+// leave in HBM: dW = dz^T X with the rows on the K dimension of the MFMA, operands read in their natural row-major layout,
+// bias gradient = column sums of the same operand, jobs batched per launch, deterministic two-stage reduction.
+// Arithmetic of both: three-way bf16 operand splits, six partial products, fp32 accumulation (below).
 //
 // The layer-1 factorisation of the edge MLP (P = h [W_i|W_j]^T per node) carries over to the backward:
 // by linearity  dh_i = W_i^T sum_{edges into i} dz1  and  dW_i = (sum_{edges into i} dz1)^T h, so the
 // per-edge dz1 rows are first segment-summed per destination (G_i) and per source (G_j) node and both
 // products run over N rows instead of E.
 //
-// Tape (saved by the forward, one set per MLP): post-ReLU activations a1, a2, the normalised
+// Tape (saved by the forward, one set per MLP): post-ReLU activations a_1 .. a_L, the normalised
 // pre-affine LayerNorm output xhat and 1/std per row; plus the block inputs h_k, e_k, agg_k.
 #include <vector>
 #include "common.h"
