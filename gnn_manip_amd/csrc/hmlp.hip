@@ -36,16 +36,24 @@ namespace gm {
 namespace {
 
 #ifdef HM_STAMPS
-// development build only: s_memtime stamps of wave 0 / lane 0 of four workgroups at the phase boundaries of the node kernel's
-// first four tiles; read back with gm_debug_hm_stamps (tools/hm_stamps.py)
+// development build only: s_memtime stamps of wave 0 / lane 0 of four workgroups at the phase boundaries of their first four
+// tiles -- of the node kernels, or (-DHM_STAMPS_EDGE) of the edge kernels; read back with gm_debug_hm_stamps (tools/hm_stamps.py)
 __device__ unsigned long long g_hm_stamps[4 * 4 * 16];
-#define HM_STAMP(tile_i, slot)                                                                                         \
+#define HM_STAMP_DO(tile_i, slot)                                                                                      \
     do {                                                                                                               \
         if ((blockIdx.x & 63) == 0 && blockIdx.x < 256 && threadIdx.x == 0 && (tile_i) < 4)                              \
             g_hm_stamps[((blockIdx.x >> 6) * 4 + (tile_i)) * 16 + (slot)] = __builtin_readcyclecounter();             \
     } while (0)
+#endif
+#if defined(HM_STAMPS) && !defined(HM_STAMPS_EDGE)
+#define HM_STAMP(tile_i, slot) HM_STAMP_DO(tile_i, slot)
 #else
 #define HM_STAMP(tile_i, slot) do { } while (0)
+#endif
+#if defined(HM_STAMPS) && defined(HM_STAMPS_EDGE)
+#define HM_STAMP_E(tile_i, slot) HM_STAMP_DO(tile_i, slot)
+#else
+#define HM_STAMP_E(tile_i, slot) do { } while (0)
 #endif
 constexpr int HM_THREADS = 512;
 constexpr int HM_WAVES = 8;
@@ -435,6 +443,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
 #pragma unroll 1
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++iter) {
         int2* sb = s_blk + (iter & 1) * 16;
+        HM_STAMP_E(iter, 0);
         if (tid < C::NRB) {
             const int b = t * C::NRB + tid;
             int2 e = make_int2(E, 0);
@@ -458,6 +467,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
         if (ENC) narrow_rows_to_image<H, 4, 1>(A.e_in, A.k1, img, RS, A.w[3], tid, in_row);
         else rows_to_image<H, 4, 8>(A.e_in, img, wave, lane, in_row, [](long long, int, floatx4&, floatx4&) {});
         __syncthreads();
+        HM_STAMP_E(iter, 1);   // e rows in the image
 
         const float* wp = A.w;
         Lin L = lin_at(wp, H);
@@ -489,9 +499,11 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                 }
             }
         }
+        HM_STAMP_E(iter, 2);   // P gather issued (accumulators initialised: waits land in the GEMM)
         gemm(acc, L.frag + (size_t)jb * KS0 * 128 + lane, imgh + (size_t)(4 * rg) * KS0 * 128 + lane, KS0, KS0);
         check_rows(rng, acc);
         wp += lin0;
+        HM_STAMP_E(iter, 3);   // GEMM 1
 #pragma unroll 1
         for (int l = 1; l <= A.nl; ++l) {
             __syncthreads();
@@ -505,9 +517,11 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             check_rows(rng, acc);
             wp += linh;
         }
+        HM_STAMP_E(iter, 4);   // hidden Linears
         // LayerNorm
         ln_publish<H, 4>(acc, ST, rg, jb, n, hi);
         __syncthreads();
+        HM_STAMP_E(iter, 5);   // statistics exchanged
         float carry[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) carry[r] = 0.f;
@@ -594,6 +608,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                 prev_last = cnt == BE ? __builtin_amdgcn_readlane(dnv, 31) : -3;
             }
         }
+        HM_STAMP_E(iter, 6);   // epilogue: LayerNorm, residual, e_out stores, scatter-add
     }
     report_range(rng, A.flags);
 }

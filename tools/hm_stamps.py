@@ -15,7 +15,7 @@ from gnn_manip_amd import EncProcDecGNN, _lib, get_connectivity  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 dev = torch.device("cuda:0")
-m = EncProcDecGNN(25, 4, 3, 128, 2, int(os.environ.get("HM_STAMPS_STEPS", "2"))).to(dev)
+m = EncProcDecGNN(25, 4, 3, int(os.environ.get("HM_STAMPS_HIDDEN", "128")), 2, int(os.environ.get("HM_STAMPS_STEPS", "2"))).to(dev)
 rng = np.random.default_rng(0)
 side = (n / 5000) ** (1 / 3) * 0.13
 pos = torch.tensor(rng.uniform(0, side, (n, 3)), dtype=torch.float32, device=dev)
@@ -34,7 +34,9 @@ L.gm_debug_hm_stamps.restype = C.c_int
 buf = (C.c_ulonglong * (4 * 4 * 16))()
 assert L.gm_debug_hm_stamps(buf) == 0
 st = np.array(buf, dtype=np.int64).reshape(4, 4, 16)
-names = ["tile start", "h rows -> image", "GEMM 1a (h)", "agg rows -> image", "GEMM 1b (agg)", "hidden Linears", "LN publish + barrier",
+EDGE = os.environ.get("HM_STAMPS_EDGE") == "1"   # the stamps of hm_edge_kernel (hidden 256: the processor edge kernel of C4)
+names = ["tile start", "e rows -> image", "P gather issue", "GEMM 1 (+ P arrival)", "hidden Linears", "LN exchange", "epilogue (LN, residual, stores, scatter-add)",
+         "", "", "", ""] if EDGE else ["tile start", "h rows -> image", "GEMM 1a (h)", "agg rows -> image", "GEMM 1b (agg)", "hidden Linears", "LN publish + barrier",
          "epilogue (residual, h stores)", "h -> image", "projection half 0 (+ P stores)", "projection half 1 (+ P stores)"]
 # the last launch that wrote the stamps is the last node kernel with a projection tail (step 1 of 2 has the decoder tail instead)
 t_min = min(int(st[w, 0, 0]) for w in range(4) if st[w, 0, 0] > 0)
@@ -47,8 +49,8 @@ for wg in range(4):
         if row[0] == 0 or row[1] <= row[0]:
             continue
         d = np.diff(row[:11])
-        tot = row[10] - row[0] if row[10] > row[0] else row[8] - row[0]
+        tot = (row[6] - row[0]) if EDGE else (row[10] - row[0] if row[10] > row[0] else row[8] - row[0])
         print(f"workgroup {64 * wg} tile {t}: total {tot} counts (shader-clock counts, ~2.35 GHz)")
-        for k in range(10):
+        for k in range(6 if EDGE else 10):
             if row[k + 1] > row[k]:
                 print(f"    {names[k + 1]:34s} {d[k]:7d}  {100.0 * d[k] / max(tot, 1):5.1f} %")
