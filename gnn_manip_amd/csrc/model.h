@@ -1,5 +1,6 @@
 // Model handle shared by model.hip (inference) and train_model.hip (training).
 #pragma once
+#include <mutex>
 #include <vector>
 #include "common.h"
 #include "hmlp.h"
@@ -42,7 +43,16 @@ struct gm_model {
     size_t t_enc_edge = 0, t_enc_node = 0;
     std::vector<size_t> t_edge, t_node;
     int T_HH = 0, T_e0 = 0, T_n0 = 0, T_out = 0;
+    // The model's own copy of the raw tensors (device).  A weight update refreshes it and the cheap images (vec, the training
+    // streams); the inference images (packed_hm, packed_h3) are re-packed from it by the first inference call that follows
+    // (ensure_inference_images): a training loop, which updates the weights every step, never pays for them.
+    float* raw = nullptr;
+    std::vector<size_t> raw_off;
+    size_t raw_floats = 0;
+    bool infer_stale = true;
+    std::mutex lazy_mu;
 };
+int ensure_inference_images(const gm_model* m, hipStream_t s);   // model.hip; called by every inference entry point
 
 namespace gm {
 inline int tensors_per_normed_mlp(int NL) { return 2 * (NL + 1) + 2; }

@@ -71,7 +71,9 @@ size_t tensor_floats(const gm_model* m, int ti) {
 }
 
 // (re)build the operand images + vec from the caller's tensors (device pointers)
-int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
+constexpr int kPackCommon = 1;      // vec + the training streams (+ the fp32 images of development builds)
+constexpr int kPackInference = 2;   // packed_hm, packed_h3 (+ the bf16 x 6 image of development builds)
+int load_weights_device(gm_model* m, const float* const* T, hipStream_t s, int what) {
     // H: the width the kernels run at (hidden_size zero-padded to 64 / 128 / 256: strides, image sizes); Hv: the model's hidden_size
     const int H = m->Hp, Hv = m->H, NL = m->NL, M = m->M;
     const int PM = tensors_per_normed_mlp(NL);
@@ -80,7 +82,7 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
     auto b_edge = [&](int k) { return (2 + 2 * k) * PM; };
     auto b_node = [&](int k) { return (3 + 2 * k) * PM; };
 
-    if (m->packed_hm) {   // fp16 hi / lo images of every Linear (hmlp.h); consecutive Linears of an MLP form a scale chain
+    if (m->packed_hm && (what & kPackInference)) {   // fp16 hi / lo images of every Linear (hmlp.h); consecutive Linears of an MLP form a scale chain
         std::vector<PackHmJob>& jobs = m->hm_jobs;
         jobs.clear();
         int prev = -1;   // job whose output feeds the next lin() (-1: the next one heads a chain)
@@ -135,6 +137,7 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
         if (rc != GM_OK) return rc;
     }
 
+    if (what & kPackCommon) {
     // biases + LayerNorm vectors (fp32 kernels, training, LayerNorm of every kernel)
     VecJobs vj;
     vj.n = 0;
@@ -268,6 +271,8 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
     }
     flush_pack();
     }
+    }   // kPackCommon
+    if (!(what & kPackInference)) return rc;
 #ifdef GM_DEV_KERNELS
     if (m->packed_b3) {  // three-part bf16 image of the processor edge MLPs
         for (int k = 0; k < M && rc == GM_OK; ++k) {
@@ -293,34 +298,60 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s) {
     return rc;
 }
 
-// Host-resident weights are first copied to the device as they are, so that both kinds of caller get every operand image
-// (and with it the same kernels).
+// The raw tensors are first copied into the model's own device buffer (host- or device-resident callers alike), then the cheap
+// images are packed from that copy; the inference images follow on first use (ensure_inference_images).
 int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hipStream_t s) {
     GM_REQUIRE(nt == gm_model_num_tensors(&m->d), GM_ERR_INVALID_ARGUMENT, "model: expected %d tensors, got %d",
                gm_model_num_tensors(&m->d), nt);
     for (int i = 0; i < nt; ++i) GM_REQUIRE(T[i] != nullptr, GM_ERR_INVALID_ARGUMENT, "model: tensor %d is null", i);
-    if (on_device) return load_weights_device(m, T, s);
-    size_t total = 0;
-    std::vector<size_t> offs((size_t)nt);
-    for (int i = 0; i < nt; ++i) { offs[(size_t)i] = total; total += (tensor_floats(m, i) + 3) & ~(size_t)3; }
-    float* stage = nullptr;
-    GM_HIP_CHECK(hipMalloc(&stage, total * sizeof(float)));
-    std::vector<const float*> D((size_t)nt);
-    int rc = GM_OK;
-    for (int i = 0; i < nt && rc == GM_OK; ++i) {
-        D[(size_t)i] = stage + offs[(size_t)i];
-        if (hipMemcpyAsync(stage + offs[(size_t)i], T[i], tensor_floats(m, i) * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) {
-            gm::set_error("model: copy of tensor %d to the device failed", i);
-            rc = GM_ERR_HIP;
-        }
+    std::lock_guard<std::mutex> guard(m->lazy_mu);
+    if (!m->raw) {
+        m->raw_off.resize((size_t)nt);
+        size_t total = 0;
+        for (int i = 0; i < nt; ++i) { m->raw_off[(size_t)i] = total; total += (tensor_floats(m, i) + 3) & ~(size_t)3; }
+        m->raw_floats = total;
+        GM_HIP_CHECK(hipMalloc(&m->raw, total * sizeof(float)));
     }
-    if (rc == GM_OK) rc = load_weights_device(m, D.data(), s);
-    (void)hipStreamSynchronize(s);
-    (void)hipFree(stage);
-    return rc;
+    int rc = GM_OK;
+    if (on_device) {
+        VecJobs vj;
+        vj.n = 0;
+        for (int i = 0; i < nt && rc == GM_OK; ++i) {
+            if (vj.n == kVecJobsMax) { rc = launch_vec_batch(vj, m->raw, s); vj.n = 0; }
+            VecJob& j = vj.job[vj.n++];
+            j.src = T[i]; j.dst_off = m->raw_off[(size_t)i]; j.count = (int)tensor_floats(m, i); j.zero_to = 0;
+        }
+        if (rc == GM_OK && vj.n > 0) rc = launch_vec_batch(vj, m->raw, s);
+    } else {
+        for (int i = 0; i < nt && rc == GM_OK; ++i) {
+            if (hipMemcpyAsync(m->raw + m->raw_off[(size_t)i], T[i], tensor_floats(m, i) * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) {
+                gm::set_error("model: copy of tensor %d to the device failed", i);
+                rc = GM_ERR_HIP;
+            }
+        }
+        if (rc == GM_OK) (void)hipStreamSynchronize(s);   // the caller's host buffers may go away when this returns
+    }
+    if (rc != GM_OK) return rc;
+    std::vector<const float*> D((size_t)nt);
+    for (int i = 0; i < nt; ++i) D[(size_t)i] = m->raw + m->raw_off[(size_t)i];
+    m->infer_stale = true;
+    return load_weights_device(m, D.data(), s, kPackCommon);
 }
 
 }  // namespace
+
+int ensure_inference_images(const gm_model* cm, hipStream_t s) {
+    gm_model* m = const_cast<gm_model*>(cm);
+    std::lock_guard<std::mutex> guard(m->lazy_mu);
+    if (!m->infer_stale) return GM_OK;
+    GM_REQUIRE(m->raw, GM_ERR_INVALID_ARGUMENT, "model: no weights loaded");
+    const size_t nt = m->raw_off.size();
+    std::vector<const float*> D(nt);
+    for (size_t i = 0; i < nt; ++i) D[i] = m->raw + m->raw_off[i];
+    const int rc = load_weights_device(m, D.data(), s, kPackInference);
+    if (rc == GM_OK) m->infer_stale = false;
+    return rc;
+}
 
 extern "C" {
 
@@ -478,6 +509,7 @@ void gm_model_destroy(gm_model* m) {
     if (m->hm_jobs_dev) hipFree(m->hm_jobs_dev);
     if (m->hm_stats) hipFree(m->hm_stats);
     if (m->vec) hipFree(m->vec);
+    if (m->raw) hipFree(m->raw);
     delete m->prof;
     delete m;
 }
@@ -559,7 +591,9 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     GM_REQUIRE(fwd_ws_bytes >= f.bytes, GM_ERR_WORKSPACE, "gm_epd_forward: workspace %zu < %zu", fwd_ws_bytes, f.bytes);
     CsrWs c = carve_csr(const_cast<void*>(csr_ws), n, cap);
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_edge(H, NL, true, enc_edge_args(m, edge_attr, attr_is_csr_order ? nullptr : c.eid, c.hdr, 0, f.e), cap, s);
+    int rc = ensure_inference_images(m, s);
+    if (rc != GM_OK) return rc;
+    rc = launch_edge(H, NL, true, enc_edge_args(m, edge_attr, attr_is_csr_order ? nullptr : c.eid, c.hdr, 0, f.e), cap, s);
     if (rc != GM_OK) return rc;
     NodeArgs na{};
     na.h_valid = m->H;
@@ -604,7 +638,9 @@ int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n, c
     GM_REQUIRE(n >= 0 && e >= 0 && n < ((int64_t)1 << 31) && e < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "sizes out of range");
     GM_REQUIRE((n == 0 || (x && h_out)) && (e == 0 || (edge_attr && e_out)), GM_ERR_INVALID_ARGUMENT, "gm_graph_independent_forward: null tensor");
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_edge(m->Hp, m->NL, true, enc_edge_args(m, edge_attr, nullptr, nullptr, (int)e, e_out), e, s);
+    int rc = ensure_inference_images(m, s);
+    if (rc != GM_OK) return rc;
+    rc = launch_edge(m->Hp, m->NL, true, enc_edge_args(m, edge_attr, nullptr, nullptr, (int)e, e_out), e, s);
     if (rc != GM_OK) return rc;
     NodeArgs na{};
     na.h_valid = m->H;
@@ -631,6 +667,10 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     GM_REQUIRE(fwd_ws_bytes >= f.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_forward: workspace %zu < %zu", fwd_ws_bytes, f.bytes);
     CsrWs c = carve_csr(const_cast<void*>(csr_ws), n, cap);
     hipStream_t s = (hipStream_t)stream;
+    {
+        const int rc_img = ensure_inference_images(m, s);
+        if (rc_img != GM_OK) return rc_img;
+    }
     // projection P = h [W_i | W_j]^T (+ b1): the tail section of the preceding node stream
     NodeArgs pa{};
     pa.h_valid = m->H;

@@ -112,7 +112,7 @@ int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows
                        int64_t n, hipStream_t s);
 int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_t s);
 
-enum : int { TK_ENC_EDGE = 0, TK_ENC_NODE = 1, TK_PROC_EDGE = 2, TK_PROC_NODE = 3, TK_DEC = 4 };
+enum : int { TK_ENC_EDGE = 0, TK_ENC_NODE = 1, TK_PROC_EDGE = 2, TK_PROC_NODE = 3, TK_DEC = 4, TK_PROJ = 5 };   // TK_PROJ: out [N][2H] = h [W_i | W_j]^T + [b1 | 0]
 enum : int { TB_ENC = 0, TB_EDGE = 1, TB_NODE = 2, TB_DEC = 3, TB_PROJ = 4 };  // TB_PROJ: dx = dY + W_i^T Gi + W_j^T Gj only
 
 }  // namespace gm

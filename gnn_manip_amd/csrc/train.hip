@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
              : KIND == TK_ENC_NODE ? (2 * NJB + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS + NL * SL
              : KIND == TK_PROC_EDGE ? (NL + 1) * SL
              : KIND == TK_PROC_NODE ? (NL + 2) * SL
+             : KIND == TK_PROJ ? 2 * SL
                                    : NL * SL + (H / 16 + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS;
     ws.cur = 0;
     ws.parity = 0;
@@ -312,6 +313,16 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
             add_feat(acc, A.P + (int64_t)A.src[pc] * (2 * H) + H, hi);
             load_feat(act, A.x_in + (A.rowidx ? (int64_t)A.rowidx[pc] : pc) * H, hi);
             run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
+        } else if (KIND == TK_PROJ) {
+            // the next edge step's factorised layer 1: P = [h W_i^T + b1 | h W_j^T] per node (what the inference node kernels' tail does)
+            load_feat(act, A.x_in + pc * H, hi);
+            load_feat(acc, A.bias, hi);
+            run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
+            if (valid) store_feat(acc, A.out + pc * (2 * H), hi);
+            zero_feat(acc);
+            run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
+            if (valid) store_feat(acc, A.out + pc * (2 * H) + H, hi);
+            continue;
         } else if (KIND == TK_PROC_NODE) {
             load_feat(act, A.x_in + pc * H, hi);
             load_feat(acc, A.bias, hi);
@@ -761,6 +772,7 @@ static int launch_train_fwd_h(int kind, const TrainFwdArgs& a, hipStream_t s) {
         case TK_ENC_NODE: hipLaunchKernelGGL((train_fwd_kernel<H, TK_ENC_NODE>), dim3(grid), dim3(THREADS), lds, s, a); break;
         case TK_PROC_EDGE: hipLaunchKernelGGL((train_fwd_kernel<H, TK_PROC_EDGE>), dim3(grid), dim3(THREADS), lds, s, a); break;
         case TK_PROC_NODE: hipLaunchKernelGGL((train_fwd_kernel<H, TK_PROC_NODE>), dim3(grid), dim3(THREADS), lds, s, a); break;
+        case TK_PROJ: hipLaunchKernelGGL((train_fwd_kernel<H, TK_PROJ>), dim3(grid), dim3(THREADS), lds, s, a); break;
         default: hipLaunchKernelGGL((train_fwd_kernel<H, TK_DEC>), dim3(grid), dim3(THREADS), lds, s, a); break;
     }
     GM_LAUNCH_CHECK();
@@ -897,7 +909,8 @@ int train_kernels_init() {
     int rc = GM_OK;
 #define GM_SET(k) if (rc == GM_OK) rc = set_dyn_lds(k, lds)
     GM_SET((train_fwd_kernel<64, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<64, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<64, TK_PROC_EDGE>));
-    GM_SET((train_fwd_kernel<64, TK_PROC_NODE>)); GM_SET((train_fwd_kernel<64, TK_DEC>));
+    GM_SET((train_fwd_kernel<64, TK_PROC_NODE>)); GM_SET((train_fwd_kernel<64, TK_DEC>)); GM_SET((train_fwd_kernel<64, TK_PROJ>));
+    GM_SET((train_fwd_kernel<128, TK_PROJ>)); GM_SET((train_fwd_kernel<256, TK_PROJ>));
     GM_SET((train_bwd_kernel<64, TB_ENC>)); GM_SET((train_bwd_kernel<64, TB_EDGE>)); GM_SET((train_bwd_kernel<64, TB_NODE>)); GM_SET((train_bwd_kernel<64, TB_DEC>));
     GM_SET((train_bwd_kernel<64, TB_PROJ>));
     GM_SET((train_fwd_kernel<128, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<128, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<128, TK_PROC_EDGE>));

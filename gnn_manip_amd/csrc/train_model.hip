@@ -210,11 +210,13 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
     }
     for (int k = 0; k < M; ++k) {
         // P = h_k [W_i | W_j]^T (+ b1): the projection section of the preceding node stream
-        NodeArgs pa{};
-        pa.n_nodes = (int)n; pa.x_in = t.h[k];
-        pa.tail = 1; pa.proj_bias = m->vec + m->v_edge[k]; pa.P_out = t.P;
-        pa.tail_hm = m->packed_hm + (k == 0 ? m->hm_enc_node_tail : m->hm_node_tail[k - 1]);   // the streamed fp16 x 3 projection kernel
-        rc = launch_node(H, NL, 2, pa, s);
+        {
+            TrainFwdArgs pa{};   // P = [h W_i^T + b1 | h W_j^T] of this step's edge MLP
+            pa.rows = (int)n; pa.x_in = t.h[k]; pa.bias = m->vec + m->v_edge[k]; pa.out = t.P; pa.nl = NL;
+            pa.wstream = k == 0 ? m->packed_t3 + m->t_enc_node + (size_t)(m->T_n0 + NL * m->T_HH) * kStageFloatsB3
+                                : m->packed_t3 + m->t_node[k - 1] + (size_t)(NL + 2) * U;
+            rc = launch_train_fwd(H, TK_PROJ, pa, s);
+        }
         if (rc != GM_OK) return rc;
         const float* ve = mlp_vec(m, m->v_edge[k]);
         {
@@ -539,11 +541,13 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
     rc = gm_csr_from_edge_index(t.ei2, n, e, t.csr_src, t.csr_bytes, stream);
     if (rc != GM_OK) return rc;
     const size_t U = (size_t)m->T_HH * kStageFloatsB3;
-    NodeArgs pa{};
-    pa.n_nodes = (int)n; pa.x_in = h;
-    pa.tail = 1; pa.proj_bias = m->vec + m->v_edge[k]; pa.P_out = t.P;
-    pa.tail_hm = m->packed_hm + (k == 0 ? m->hm_enc_node_tail : m->hm_node_tail[k - 1]);   // the streamed fp16 x 3 projection kernel
-    rc = launch_node(H, NL, 2, pa, s);
+    {
+        TrainFwdArgs pa{};   // P = [h W_i^T + b1 | h W_j^T] of this block's edge MLP
+        pa.rows = (int)n; pa.x_in = h; pa.bias = m->vec + m->v_edge[k]; pa.out = t.P; pa.nl = NL;
+        pa.wstream = k == 0 ? m->packed_t3 + m->t_enc_node + (size_t)(m->T_n0 + NL * m->T_HH) * kStageFloatsB3
+                            : m->packed_t3 + m->t_node[k - 1] + (size_t)(NL + 2) * U;
+        rc = launch_train_fwd(H, TK_PROJ, pa, s);
+    }
     if (rc != GM_OK) return rc;
     auto normed = [&](TrainFwdArgs& a, size_t voff) {
         const float* v = mlp_vec(m, voff);

@@ -180,12 +180,16 @@ typedef struct gm_model_desc {
  * statistics are taken over the h features that exist, the padded features stay exactly zero.  Returns that width (0:
  * unsupported).  It is the ROW STRIDE of every latent array that crosses this interface: h / e of
  * gm_graph_independent_forward and gm_interaction_network_forward (inputs zero-padded by the caller, outputs padded with
- * zeros); gm_epd_forward and the rollout entry points have no latent arguments.  Training entry points: hidden 128 / 256. */
+ * zeros); gm_epd_forward and the rollout entry points have no latent arguments.  Training entry points: hidden 64 / 128 / 256. */
 int gm_padded_hidden_size(int hidden_size);
 
 int gm_model_num_tensors(const gm_model_desc* desc);
 int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int n_tensors,
                     int tensors_on_device, void* stream, gm_model** out);
+/* create / update copy the tensors into the model (stream-ordered for device tensors; host tensors are read before the call
+ * returns): the caller's buffers are not referenced afterwards.  The operand images of the training kernels are packed by the
+ * call itself; those of the inference kernels by the first inference call that follows (on that call's stream) -- a training
+ * loop, which updates the weights every step, never pays for them. */
 int gm_model_update(gm_model* m, const float* const* tensors, int n_tensors, int tensors_on_device,
                     void* stream);
 void gm_model_destroy(gm_model* m);
