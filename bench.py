@@ -192,16 +192,23 @@ def roofline_record(model, ek, hidden, edges, n_nodes, workload_key):
            "fp32_equivalent_tflops": issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
            "alg_flops_per_launch": alg, "alg_tflops": alg / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
            "alg_bytes_per_launch": alg_bytes, "mfma": mfma, "hbm": hbmr}
-    # HBM traffic of the same kernel from rocprofv3 PMC passes of THIS round's build (collected separately with
-    # tools/profile_round.sh, committed under profiles/); absent or of another kernel: null
+    # HBM traffic of the same kernel from rocprofv3 PMC passes (collected separately with tools/profile_round.sh, committed
+    # under profiles/).  Reported only when the newest file was collected from THIS tree's kernel sources (it records their
+    # digest); otherwise null with the reason.
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+        import glob
+        from gnn_manip_amd.build import source_digest
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+        tr = json.load(open(files[-1]))
+        name = "profiles/" + os.path.basename(files[-1])
         ent = tr.get(workload_key)
-        if ent and ent.get("kernel") == kname:
+        if tr.get("source_digest") != source_digest():
+            rec["traffic_source"] = f"null: {name} was collected from other kernel sources than this tree's (digest mismatch)"
+        elif ent and ent.get("kernel") == kname:
             rec["traffic"] = ent["traffic_bytes_per_launch"]
-            rec["traffic_source"] = ("profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this "
-                                     "round's build, FETCH doubled per the guide)")
-    except (OSError, ValueError, KeyError):
+            rec["traffic_source"] = (f"{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this build, FETCH doubled "
+                                     "per the guide)")
+    except (OSError, ValueError, KeyError, IndexError):
         pass
     return rec, k_ms
 
@@ -405,6 +412,52 @@ def extra_train(dev, steps=5, warmup=2):
                        "nodes": int(nodes.shape[0]), "edges": int(edge_attr.shape[0]), "steps": steps, "warmup": warmup}}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, the env
+    rendezvous torch.distributed.run would have set up, 127.0.0.1), relay rank 0's JSON line, return non-zero if any
+    rank failed.  The parent makes no GPU call and replaces no process (gpurun rules): children are ordinary
+    subprocesses, rank 0's stdout is piped, everything else is inherited."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = list(procs)
+    while live:   # a rank that fails takes the others down with it (they would wait in the rendezvous / a collective)
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    q.terminate()   # exactly the PIDs started above
+    reader.join(timeout=10.0)
+    out0 = b"".join(chunks).decode(errors="replace")
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        rc = 1
+    if rc:
+        sys.stderr.write(f"bench.py: a rank failed (exit status {rc})\n")
+    return 1 if rc else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -421,11 +474,16 @@ def main():
                     help="processor edge kernel (per-model option): auto = systolic fp16 x 3 kernel for hidden 128 (DESIGN.md 5.1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU)
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher's environment says WORLD_SIZE={world}")
+    if os.environ.get("GM_BENCH_FAIL_RANK") == str(rank) and world > 1:   # tests: a rank that dies before the rendezvous
+        raise SystemExit(3)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
     # GM_BENCH_REHEARSE=1: all ranks on cuda:0 with gloo (multi-rank rehearsal on a one-GPU box; RCCL refuses two ranks per
     # device).  Never set by the driver.

@@ -19,6 +19,18 @@ if os.environ.get("GM_DEV_KERNELS") == "1":
     EXTRA_FLAGS["mlp.hip"] = ["-munsafe-fp-atomics"]
 
 
+def source_digest():
+    """sha256 (first 16 hex digits) over the kernel sources: profiles/<tag>_traffic.json records the digest of the build its PMC
+    passes ran, and bench.py reports the measured traffic only while it still matches the tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 

@@ -219,3 +219,40 @@ def test_bench_c5_two_rank_rehearsal(dev):
     assert cfg["candidates"] == 6 and cfg["candidates_per_rank"] == 3 and cfg["block_diagonal_batch"] == 2 and cfg["horizon"] == 4
     assert np.isfinite(cfg["loss_mean"]) and rec["value"] > 0
     assert rec["collective_ms"] >= 0.0 and rec["collective_ms"] < cfg["generation_s"] * 1e3
+
+
+def test_bench_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2 ...` as ONE command with no launcher around it (how the driver may start the scaling runs):
+    the parent starts two fresh rank processes itself and relays rank 0's single JSON line.  Rehearsed on one card
+    (GM_BENCH_REHEARSE=1: gloo, both ranks on cuda:0), default workload at a reduced step count and the C5 shape."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GM_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for extra, scaling in ((["--workload", "c5", "--candidates-total", "4", "--batch", "2", "--steps", "3"], "strong"),
+                           (["--workload", "c2", "--steps", "3", "--warmup", "1"], "weak")):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + extra, env=env, capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace")
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["scaling"] == scaling and rec["value"] > 0 and rec["unit"] == "rollout steps/s"
+
+
+def test_bench_launcher_reports_a_failed_rank(dev):
+    """A rank that dies must turn the whole `bench.py --gpus N` command into a non-zero exit, not a hang."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GM_BENCH_REHEARSE="1", GM_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "2", "--warmup", "0"],
+                       env=env, capture_output=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]

@@ -59,6 +59,9 @@ for wl in ("target", "c2", "c4"):
 out["note"] = ("processor edge kernel of each workload (see its `kernel`); rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE "
                "doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B for 16-B-per-lane loads; the kernel's row gathers are not "
                "the calibrated streaming pattern, so the corrected figure is an upper bound); Infinity-Cache hits are counted")
+sys.path.insert(0, root)
+from gnn_manip_amd.build import source_digest  # noqa: E402
+out["source_digest"] = source_digest()   # bench.py reports `traffic` only while the kernel sources still hash to this
 json.dump(out, open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
 for wl in ("target", "c2", "c4"):
