@@ -54,5 +54,11 @@ size_t h3_image_floats();
 int pack_h3(const PackH3Job* jobs, int n, hipStream_t s);
 
 int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s);
+// whether the kernel's 32-bit byte offsets cover a graph of this size (P < 4 GiB, agg + side buffer < 4 GiB: about 4M nodes at
+// hidden 128); larger launches take the streamed kernel
+bool edge_sys_fits(int64_t n_nodes, int64_t edge_capacity);
+// rows the latent edge array must own behind edge_capacity (the kernel reads whole 32-row blocks), zeroed by zero_edge_pad_rows
+constexpr int kEdgePadRows = 32;
+int zero_edge_pad_rows(const CsrHeader* hdr, float* e, int row_floats, hipStream_t s);
 
 }  // namespace gm

@@ -39,6 +39,7 @@
 //
 // Built with -fno-slp-vectorize: packed fp32 VALU beside MFMAs is slow (guide) and hipcc's v_pk_fma_f32 form of the
 // LayerNorm epilogue returned wrong low lanes on gfx950 in this kernel.
+#include <type_traits>
 #include "common.h"
 #include "mlp.h"
 #include "hedge.h"
@@ -53,7 +54,7 @@ constexpr int H = 128;
 constexpr int BE = 32;             // edges per block
 constexpr int SYS_THREADS = 768;
 #ifndef SIDE_STRIDE
-#define SIDE_STRIDE 6   // MFMA slots per row group of role 1's e_out epilogue (24 slots per tick)
+#define SIDE_STRIDE 6   // MFMA slots per row group of role 1's e_out epilogue (24 slots per tick, 4 row groups)
 #endif
 #ifdef HEDGE_STAMPS
 // development build only: s_memtime stamps of the three roles (workgroup 0, waves jb = 0, lane 0) at the phase boundaries of
@@ -86,89 +87,114 @@ constexpr int HW_VEC_FLOATS = 4 * H;           // b2*T2 | b3*T3 | gamma | beta
 constexpr int HW_IMAGE_HALF8 = 3 * 4 * 8 * 2 * 64;   // [layer][jb][ks][part][lane]
 
 
-// accumulator registers 8q..8q+7 of a wave's 32-feature block are the elements of B fragment ks = 2 jb + q (same lane):
-// K slot (lane >> 5, j) of k-group ks carries feature 16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) in both operands
-__device__ __forceinline__ void acc_to_image(const floatx16& a, uintx4* img, int jb, int lane) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = relu(a[8 * q + j]);
-        uintx2 h0, l0, h1, l1;
-        split4(v[0], v[1], v[2], v[3], h0, l0);
-        split4(v[4], v[5], v[6], v[7], h1, l1);
-        img[((2 * jb + q) * 2 + 0) * 64 + lane] = uintx4{h0[0], h0[1], h1[0], h1[1]};
-        img[((2 * jb + q) * 2 + 1) * 64 + lane] = uintx4{l0[0], l0[1], l1[0], l1[1]};
-    }
-}
+// ---- LDS map (bytes).  The 32 x 32-float tiles (PS, Z) have a row stride of 144 bytes: conflict-free for the row-major
+// accesses (8 lanes per row) and for the accumulator-layout ones (lane = row, 16-byte quads), and every access of the tick
+// loops is "lane-constant base + immediate".
+constexpr int TILE_ROW_B = 144;
+constexpr int TILE_B = 32 * TILE_ROW_B;
+constexpr int IMG_B = 16384;                      // one operand image: [8 ks][2 parts][64 slots] x 16 B
+constexpr int L_E = 0;                            // [2] images of e rows (eslot() order)
+constexpr int L_X1 = L_E + 2 * IMG_B;
+constexpr int L_X2 = L_X1 + 2 * IMG_B;
+constexpr int L_Z = L_X2 + 2 * IMG_B;             // [2][4 jb] tiles: Linear-3 accumulators
+constexpr int L_PS = L_Z + 8 * TILE_B;            // [4 jb] tiles: role-0 staging of P_i + P_j
+constexpr int L_ST = L_PS + 4 * TILE_B;           // [2][4 jb][32 rows] floats: sum of squares of a row's 32 features of wave jb
+constexpr int L_KM = L_ST + 2 * 32 * 4 * 4;       // [4 jb][32] floats: role 1's 1 / (T sigma) per row
+constexpr int L_KM2 = L_KM + 4 * 32 * 4;          // [4 jb][32]: role 2's
+constexpr int L_ZERO_END = L_KM2 + 4 * 32 * 4;    // everything below starts zeroed
+constexpr int L_VEC = L_ZERO_END;                 // 4 x 128 floats: b2 T2 | b3' T3 | gamma | beta
+constexpr int DR_SLOTS = 8;                       // ring of per-block destination ids handed from role 0 to role 2
+constexpr int L_DR = L_VEC + 4 * H * 4;           // [DR_SLOTS][32] ints
+constexpr size_t SYS_LDS_BYTES = L_DR + DR_SLOTS * BE * 4;
+static_assert(SYS_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // slot of lane (n, kg) inside a fragment of the row-written image E (conflict-free for the 8-byte row-major writes)
 __device__ __forceinline__ int eslot(int n, int kg, int ksbit) { return (n ^ (2 * (ksbit + 2 * kg))) + 32 * kg; }
 
-// e rows are read (twice) and written once per launch, 3 GB in all at the target; P, 102 MB, is gathered 1 GB worth.  Streaming
-// cache policy for the former keeps the latter in L2 / the Infinity Cache (HEDGE_VAR & 2: A/B switch of development builds).
-__device__ __forceinline__ floatx4 ld_stream(const floatx4* p) { return (HEDGE_VAR & 2) ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ void st_stream(floatx4* p, floatx4 v) { if (HEDGE_VAR & 2) __builtin_nontemporal_store(v, p); else *p = v; }
+// ---- buffer addressing.  Every global access of the tick loops is a buffer instruction: a scalar resource (base, byte
+// count), a lane-constant VGPR offset (range-checked against the byte count: a store beyond it is dropped, a load returns 0), a
+// scalar offset that moves with the block and an immediate -- no per-lane 64-bit address arithmetic in the loops.
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000); }
+__device__ __forceinline__ floatx4 bld4(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
+__device__ __forceinline__ intx4 bldi4(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(intx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
+__device__ __forceinline__ void bst4(srd_t r, unsigned voff, unsigned soff, floatx4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), r, voff, soff, 0); }
+__device__ __forceinline__ void bst1(srd_t r, unsigned voff, unsigned soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0); }
+// scalar clamp to [0, hi]: written as SALU so that the values that feed a resource stay in scalar registers
+__device__ __forceinline__ int s_clamp0(int v, int hi) {
+    int r;
+    asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, %2" : "=s"(r) : "s"(v), "s"(hi) : "scc");
+    return r;
+}
 
+#define LDS(T, off) (*reinterpret_cast<T*>(smem + (off)))
+// A lane-constant LDS / buffer base: made opaque so that hipcc addresses "base register + 16-bit immediate" instead of folding
+// every region offset into a register of its own (the DS immediate reaches 64 KiB, the regions lie further apart than that).
+__device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 #define GM_SB __builtin_amdgcn_sched_barrier(0)
+
+// ReLU as ONE instruction (fmaxf and the med3 builtin cost two: hipcc canonicalises the operand first).  Inline asm is NOT
+// padded against the MFMA -> VALU read hazard: the callers read the accumulators with a compiler-visible instruction first
+// (the range check) and pin the order with a scheduling barrier.
+__device__ __forceinline__ float relu1(float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }
+
+// accumulator registers 8q..8q+7 of a wave's 32-feature block are the elements of B fragment ks = 2 jb + q (same lane):
+// K slot (lane >> 5, j) of k-group ks carries feature 16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) in both operands.
+// a: byte address of this lane's slot in fragment (ks = 2 jb, hi part) of the image.
+__device__ __forceinline__ void acc_to_image(const floatx16& a, char* smem, unsigned addr) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = relu1(a[8 * q + j]);
+        uintx2 h0, l0, h1, l1;
+        split4(v[0], v[1], v[2], v[3], h0, l0);
+        split4(v[4], v[5], v[6], v[7], h1, l1);
+        LDS(uintx4, addr + (q * 2 + 0) * 1024) = uintx4{h0[0], h0[1], h1[0], h1[1]};
+        LDS(uintx4, addr + (q * 2 + 1) * 1024) = uintx4{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
 // One Linear for this wave's 32 output features: 8 k-groups x 3 MFMAs (lo*hi, hi*lo, hi*hi).  side(slot), slot = 0..23, runs
-// after each MFMA with the instruction order pinned.  B fragments are fetched one k-group ahead.
-template <bool SWZ, class F>
-__device__ __forceinline__ void mlp_layer(floatx16& acc, const half8 (&wh)[8], const half8 (&wl)[8], const half8* img, int lane, F&& side) {
-    const int s0 = SWZ ? eslot(lane & 31, lane >> 5, 0) : lane;
-    const int s1 = SWZ ? eslot(lane & 31, lane >> 5, 1) : lane;
-    half8 bh = img[0 * 64 + s0], bl = img[1 * 64 + s0];
+// after each MFMA with the instruction order pinned.  B fragments are fetched one k-group (hi part) / two MFMAs (lo part) ahead.  a0 / a1: byte address of this
+// lane's slot in fragment (0, hi part) for the even / odd k-groups (they differ in the swizzled image E only); c0: initial
+// accumulators (the first MFMA's C operand).
+template <class F>
+__device__ __forceinline__ void mlp_layer(floatx16& acc, const floatx16& c0, const half8 (&wh)[8], const half8 (&wl)[8], char* smem, unsigned a0, unsigned a1, F&& side) {
+    half8 bh = LDS(half8, a0), bl = LDS(half8, a0 + 1024);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        half8 nh = bh, nl = bl;
+        half8 nh = bh;
+        const unsigned an = (((ks + 1) & 1) ? a1 : a0) + (ks + 1) * 2048;
         GM_SB;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], bh, ks == 0 ? c0 : acc, 0, 0, 0);
         GM_SB;
-        if (ks + 1 < 8) {
-            nh = img[((ks + 1) * 2 + 0) * 64 + (((ks + 1) & 1) ? s1 : s0)];
-            nl = img[((ks + 1) * 2 + 1) * 64 + (((ks + 1) & 1) ? s1 : s0)];
-        }
+        if (ks + 1 < 8) nh = LDS(half8, an);
         side(3 * ks);
         GM_SB;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bl, acc, 0, 0, 0);
         GM_SB;
+        if (ks + 1 < 8) bl = LDS(half8, an + 1024);   // the low part is read by the middle MFMA only: its registers are free again
         side(3 * ks + 1);
         GM_SB;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bh, acc, 0, 0, 0);
         GM_SB;
         side(3 * ks + 2);
         bh = nh;
-        bl = nl;
     }
     GM_SB;
 }
 
-// LayerNorm of an edge from the eight 16-feature partials (mean_p, M2_p) of the SCALED accumulators (one per wave and
-// lane half): parallel-variance merge; returns k, m with  x_hat = acc * k + m   (k = rstd / T, m = -mean_acc * k)
-__device__ __forceinline__ void ln_merge(const float* st, int n, float inv_T, float eps, float& k, float& m) {
-    float mw[8], m2 = 0.f, mean = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const float2v s = *reinterpret_cast<const float2v*>(st + (w * BE + n) * 2);
-        mw[w] = s[0];
-        m2 += s[1];
-        mean += s[0];
-    }
-    mean *= 0.125f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) { const float d = mw[w] - mean; m2 = fmaf(16.0f * d, d, m2); }
-    const float var = m2 * (1.0f / 128.0f) * inv_T * inv_T;
+// 1 / (T sigma) of a row from the four 32-feature sums of squares of its SCALED, CENTRED Linear-3 outputs (the image holds
+// W3 and b3 with their mean over the output features removed, so the outputs have zero mean: x_hat = acc * k)
+__device__ __forceinline__ float ln_k(char* smem, unsigned st, float inv_T, float eps) {   // st: address of the row's entry for jb = 0
+    const float q = (LDS(float, st) + LDS(float, st + 128)) + (LDS(float, st + 256) + LDS(float, st + 384));
     // 1 / sqrt(var + eps): v_rsq_f32 (1 ulp) + one Newton step instead of the ~25 instructions of an IEEE sqrt and divide
-    const float v = var + eps;
+    const float v = fmaf(q * (1.0f / 128.0f) * inv_T, inv_T, eps);
     float r = __builtin_amdgcn_rsqf(v);
     r = r * fmaf(-0.5f * v * r, r, 1.5f);
-    k = inv_T * r;
-    m = -mean * k;
+    return inv_T * r;
 }
-
-// 32 rows x 8 quads (16 bytes) tile, quad index XORed with the row: conflict-free for row-major and for
-// accumulator-layout accesses.  Returns the float4 index inside the 4 KiB tile.
-__device__ __forceinline__ int tile_q(int row, int quad) { return row * 8 + (quad ^ (row & 7)); }
 
 // v_permlane32_swap: the upper half of the first operand and the lower half of the second change places
 __device__ __forceinline__ float lower_half_to_both(float v) {   // every lane l gets the value of lane l & 31
@@ -179,28 +205,48 @@ __device__ __forceinline__ float upper_half_to_both(float v) {   // every lane l
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float sum_of_halves(float v) {        // every lane l gets v[l & 31] + v[32 | l]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
-constexpr int DR_SLOTS = 8;   // ring of per-block destination ids handed from role 0 to role 2 (written 2 ticks before it is read)
-constexpr size_t SYS_LDS_BYTES = 3 * 2 * 16384 + 2 * 16384 + 16384 + 2 * 8 * BE * 2 * 4 + 4 * BE * 2 * 4 + 4 * H * 4 + DR_SLOTS * BE * 4 + 4 * BE * 2 * 4;
+// Three rows of the segmented scan down the registers: y[r] += y[r-1] on the lanes whose half has bit r (half 0) / 16 + r
+// (half 1) of `cont` set -- the mask is the same for every lane of a half, so it goes into EXEC by two scalar bit-field
+// extracts and the add itself is the only vector instruction per row.
+template <int R>
+__device__ __forceinline__ void scan3_t(float& ya, float& yb, float& yc, float yprev, unsigned cont) {
+    asm volatile("s_bfe_i32 exec_lo, %4, %5\n\ts_bfe_i32 exec_hi, %4, %6\n\tv_add_f32 %0, %0, %3\n\t"
+                 "s_bfe_i32 exec_lo, %4, %7\n\ts_bfe_i32 exec_hi, %4, %8\n\tv_add_f32 %1, %1, %0\n\t"
+                 "s_bfe_i32 exec_lo, %4, %9\n\ts_bfe_i32 exec_hi, %4, %10\n\tv_add_f32 %2, %2, %1\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(ya), "+v"(yb), "+v"(yc)
+                 : "v"(yprev), "s"(cont), "n"(0x10000 | R), "n"(0x10000 | (16 + R)), "n"(0x10000 | (R + 1)), "n"(0x10000 | (17 + R)),
+                   "n"(0x10000 | (R + 2)), "n"(0x10000 | (18 + R))
+                 : "scc");
+}
+__device__ __forceinline__ void scan3(float& ya, float& yb, float& yc, float yprev, unsigned cont, int r) {
+    switch (r) {   // r is a constant wherever this is called (unrolled filler slots)
+        case 1: scan3_t<1>(ya, yb, yc, yprev, cont); break;
+        case 4: scan3_t<4>(ya, yb, yc, yprev, cont); break;
+        case 7: scan3_t<7>(ya, yb, yc, yprev, cont); break;
+        case 10: scan3_t<10>(ya, yb, yc, yprev, cont); break;
+        default: scan3_t<13>(ya, yb, yc, yprev, cont); break;
+    }
+}
 
 __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeader* a_hdr, const int* __restrict__ a_dst, const int* __restrict__ a_src, const float* __restrict__ a_P,
                                                                        const float* a_e_in, float* a_e_out, float* __restrict__ a_agg, const float* __restrict__ a_hw,
                                                                        const int2* __restrict__ a_blk, const int2* __restrict__ a_seg, const int* __restrict__ a_head,
-                                                                       const EdgeBlockHeader* __restrict__ a_tab, float* a_sink, unsigned a_side_off, int* a_flags, float a_eps, int a_residual) {
+                                                                       const EdgeBlockHeader* __restrict__ a_tab, unsigned a_side_off, unsigned a_agg_bytes, unsigned a_P_bytes,
+                                                                       int* a_flags, float a_eps, int a_residual) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half8* Eimg = reinterpret_cast<half8*>(smem);            // [2][8 ks][2 parts][64]  2 x 16 KiB, eslot() order
-    half8* X1 = Eimg + 2 * 1024;
-    half8* X2 = X1 + 2 * 1024;
-    floatx4* Z = reinterpret_cast<floatx4*>(X2 + 2 * 1024);  // [2][4 jb][256] float4 (tile_q order): Linear-3 accumulators
-    floatx4* PS = Z + 2 * 1024;                               // [4 jb][256]: role-0 staging of P_i + P_j
-    float* ST = reinterpret_cast<float*>(PS + 1024);          // [2][4 jb][2 halves][32][2]: LayerNorm partials
-    float* KM = ST + 2 * 8 * BE * 2;                          // [4 jb][32][2]: role-1 merged statistics
-    float* vecs = KM + 4 * BE * 2;                            // 4 x 128: b2 T2 | b3 T3 | gamma | beta
-    int* DR = reinterpret_cast<int*>(vecs + 4 * H);           // [DR_SLOTS][32]: destination of every row of a block (role 0 -> role 2)
-    float* KM2 = reinterpret_cast<float*>(DR + DR_SLOTS * BE); // [4 jb][32][2]: role-2 merged statistics
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef HEDGE_FORCE_ROLE   // development: register census of one role (tools/kernel_resources.py ... -DHEDGE_FORCE_ROLE=k)
+    const int role = HEDGE_FORCE_ROLE, jb = wave & 3;
+#else
     const int role = wave >> 2, jb = wave & 3;
+#endif
     const int E = a_hdr->n_edges;
     const int nchunks = a_tab->n_groups;   // the workgroup takes a contiguous range of whole groups (4 blocks each)
     const int c0 = (int)((long long)blockIdx.x * nchunks / gridDim.x);
@@ -219,28 +265,45 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         wh[ks] = wimg[(((role * 4 + jb) * 8 + ks) * 2 + 0) * 64 + lane0];
         wl[ks] = wimg[(((role * 4 + jb) * 8 + ks) * 2 + 1) * 64 + lane0];
     }
-    // every buffer starts finite: the pipeline's fill / drain ticks compute on them, and 0 * NaN would leak through the
-    // flag-multiplied scan
-    for (int i = tid; i < (int)((reinterpret_cast<char*>(vecs) - smem) / 16); i += SYS_THREADS) reinterpret_cast<uintx4*>(smem)[i] = uintx4{0u, 0u, 0u, 0u};
-    for (int i = tid; i < 4 * H; i += SYS_THREADS) vecs[i] = hvec[i];
+    // every buffer starts finite: the pipeline's fill / drain ticks compute on them
+    for (int i = tid; i < L_ZERO_END / 16; i += SYS_THREADS) LDS(uintx4, i * 16) = uintx4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < 4 * H; i += SYS_THREADS) LDS(float, L_VEC + 4 * i) = hvec[i];
     // The weight registers must have ARRIVED before the tick loops: otherwise hipcc places their counted vmcnt waits at the first
-    // uses inside the loop, where (loads and stores share the counter, in issue order) they wait for the tick's own row stores
-    // and index loads every tick.
+    // uses inside the loop, where (loads and stores share the counter, in issue order) they wait for the tick's own accesses.
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), a form the compiler's wait-count bookkeeping sees
     __syncthreads();
     auto ok = [&](int x) { return x >= b0 && x < b1; };
     auto clampb = [&](int x) { return x < b0 ? b0 : (x < b1 ? x : b1 - 1); };
-    auto nothing = [](int) {};
+    // The workgroup's edges are contiguous: its e rows and indices are addressed relative to its first edge, so the scalar
+    // offsets stay small whatever the size of the arrays.  Rows past the end of the edge list are READ (the blocks are whole):
+    // the forward keeps 32 zero rows behind the list (model.hip: pad rows), index reads are range-checked.
+    const int e0 = a_blk[b0].x;
+    const srd_t srd_ein = make_srd(a_e_in + (size_t)e0 * H, 0xffffffffu);
+    const int n = lane0 & 31, hi = lane0 >> 5, rr = lane0 >> 3, cq = lane0 & 7;
+    const unsigned v_eoff = opaque(rr * 512 + jb * 128 + cq * 16);   // row 8 j + rr of a block, this wave's 128-byte slab: + 4096 j by the scalar offset
+    std::integral_constant<int, 0> even;
+    std::integral_constant<int, 1> odd;
 
     // Instruction arbitration: role 2 (Linear 3 + statistics + the scatter-add's scan) is the longest instruction stream of
-    // a tick and role 0 feeds the pipeline; measured at the target: 0.943 ms with equal priorities, 0.897 with these
-    // (role 1 above role 0 loses the gain).
+    // a tick and role 0 feeds the pipeline.
     if (role == 2) __builtin_amdgcn_s_setprio(HEDGE_PRIO2);        // the builtin takes an immediate
     else if (role == 0) __builtin_amdgcn_s_setprio(HEDGE_PRIO0);
     else __builtin_amdgcn_s_setprio(HEDGE_PRIO1);
     if (role == 0) {
         // ------------------------------------------------------------------ role 0
-        floatx4 pi[4], pj[4];   // row-major quads of rows 8 j + rr: P_i / P_j of block x
+        // Rows of a block are dealt to the lanes two ways: e rows as 8 j + rr (the image E's swizzle needs j in the high bits),
+        // P rows as 4 rr + j (so that a lane's four row indices are ONE 16-byte load of the index arrays).
+        const srd_t srd_P = make_srd(a_P, a_P_bytes);
+        const unsigned idx_bytes = (unsigned)s_clamp0(E - e0, 1 << 28) * 4u;
+        const srd_t srd_dst = make_srd(a_dst + e0, idx_bytes), srd_src = make_srd(a_src + e0, idx_bytes);
+        const unsigned v_poff = opaque(jb * 128 + cq * 16), v_ioff = opaque(rr * 16);
+        const unsigned ps_w = opaque(L_PS + jb * TILE_B + 4 * rr * TILE_ROW_B + cq * 16);   // + j rows
+        const unsigned ps_r = opaque(L_PS + jb * TILE_B + n * TILE_ROW_B + hi * 16);        // + 32 g
+        const int kg = cq & 1, ksb = cq >> 2, half = (cq >> 1) & 1;
+        const unsigned e_w = opaque(L_E + ((2 * jb + ksb) * 2 * 64 + ((rr ^ (2 * (ksb + 2 * kg))) + 32 * kg)) * 16 + half * 8);   // + 128 j, + 1024: lo part
+        const unsigned e_r0 = opaque(L_E + eslot(n, hi, 0) * 16), e_r1 = opaque(L_E + eslot(n, hi, 1) * 16);
+        const unsigned x1_w = opaque(L_X1 + 4 * jb * 1024 + lane0 * 16);
+        floatx4 pi[4], pj[4];   // row-major quads of rows 4 rr + j: P_i / P_j of block x
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pi[j] = floatx4{0.f, 0.f, 0.f, 0.f}; pj[j] = pi[j]; }
         int rng = 0;            // range check of the fp16 split: set once an accumulator row turns NaN
@@ -248,194 +311,144 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
 #pragma unroll
         for (int j = 0; j < 4; ++j) eq[j] = floatx4{0.f, 0.f, 0.f, 0.f};
         floatx16 acc;
-        int dl1 = 0, sl1 = 0, dl2 = 0, sl2 = 0;   // destination / source of row (lane & 31): blocks x+1 and x+2
-        int2 be = a_blk[b0];    // table entry of block x+2 (its .x = first edge): the rows requested this tick
-        // Every global load of the tick loops is issued unconditionally with a clamped index (blocks past the workgroup's range
-        // repeat its last block): hipcc's counted vmcnt waits assume the path with the fewest younger operations, so a load
-        // or store inside a branch turns the waits for older loads into waits for (almost) everything.
-        int2 bn = a_blk[clampb(b0 + 1)];   // table entry of the block the next fetch() handles
-        auto fetch = [&](int2 bi, int& dl, int& sl) {
-            const int cnt = bi.y & 0xff, n = lane0 & 31;
-            int p = bi.x + (n < cnt ? n : cnt - 1);
-            p = p < 0 ? 0 : (p < E ? p : E - 1);
-            dl = a_dst[p];
-            sl = a_src[p];
-        };
-        fetch(a_blk[b0], dl2, sl2);
-        floatx4* ps = PS + jb * 256;
-#pragma unroll 1
-        for (int t = -2; t <= nb + 2; ++t) {
+        intx4 di = bldi4(srd_dst, v_ioff, 0), si = bldi4(srd_src, v_ioff, 0);   // indices of the rows of block b0 ( = "x+1" of the first tick's requests)
+        int2 be = a_blk[b0];    // table entry of block x+2 (its .x = first edge): the rows and indices requested this tick
+        auto tick = [&](auto par_c, int t) {
+            constexpr int PAR = decltype(par_c)::value;   // parity of x: the images' double buffers are compile-time offsets
             const int x = b0 + t;
-            // per-tick copy of the lane coordinates, laundered so that the per-lane address arithmetic is recomputed per
-            // tick instead of being hoisted out of the loop (which costs registers the three-waves-per-SIMD budget lacks)
-            int lane_t = lane0;
-            asm volatile("" : "+v"(lane_t));
-            const int lane = lane_t, n = lane & 31, hi = lane >> 5, rr = lane >> 3, cq = lane & 7;
             SYS_STAMP(t, 0);
             // accumulator = (P_i[dst] + P_j[src]) * T1: row-major sum -> tile -> accumulator layout
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ps[tile_q(8 * j + rr, cq)] = (pi[j] + pj[j]) * T1;
+            for (int j = 0; j < 4; ++j) LDS(floatx4, ps_w + j * TILE_ROW_B) = (pi[j] + pj[j]) * T1;
             SYS_STAMP(t, 1);   // P rows of this block have arrived
             // Requests, all at the top of the tick so that they have a whole tick to arrive (loads and stores complete in issue
-            // order on one counter: whatever is requested last is what the next tick's first wait waits for).
-            // P rows of block x+1 (whole 128-byte lines: 8 lanes per row).  Its destinations (loaded two ticks ago) also go to
-            // role 2, which needs them in two ticks: its waves issue no vector loads at all.
-            if (jb == 0 && hi == 0) DR[((x + 1) & (DR_SLOTS - 1)) * BE + n] = dl1;
+            // order on one counter).  P rows of block x+1 (whole 128-byte lines: 8 lanes per row); its destinations also go to
+            // role 2, which needs them in four ticks: its waves issue no vector loads at all.
+            if (jb == 0 && cq == 0) LDS(intx4, v_ioff + (L_DR + ((x + 1) & (DR_SLOTS - 1)) * (BE * 4))) = di;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int d = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, dl1);
-                const int s = __builtin_amdgcn_ds_bpermute((8 * j + rr) * 4, sl1);
-                pi[j] = *reinterpret_cast<const floatx4*>(a_P + (unsigned)(d * (2 * H) + 32 * jb + 4 * cq));
-                pj[j] = *reinterpret_cast<const floatx4*>(a_P + (unsigned)(((HEDGE_ABL & 2) ? d : s) * (2 * H) + H + 32 * jb + 4 * cq));
+                pi[j] = bld4(srd_P, (unsigned)(di[j] << 10) + v_poff, 0);
+                pj[j] = bld4(srd_P, (unsigned)(si[j] << 10) + v_poff + H * 4, 0);   // P_j: second half of the row
             }
-            dl1 = dl2; sl1 = sl2;
-            fetch(bn, dl2, sl2);          // indices of block x+3
-            const int2 be_next = bn;      // entry of block x+3 = next tick's x+2
-            bn = a_blk[clampb(x + 4)];
+            const unsigned rel = (unsigned)(be.x - e0);
+            di = bldi4(srd_dst, v_ioff + rel * 4, 0);     // indices of block x+2
+            si = bldi4(srd_src, v_ioff + rel * 4, 0);
+            const int2 be_next = a_blk[clampb(x + 3)];
             // e of block x+1 -> operand image E (this role reads it next tick), one row group per call, between the MFMAs;
             // then the rows of block x+2 are requested into the same registers
-            uintx2* ew = reinterpret_cast<uintx2*>(Eimg + ((x + 1) & 1) * 1024);
             auto side = [&](int slot) {
                 if (slot < 8 && !(slot & 1)) {
-                    const int j = slot >> 1, r = 8 * j + rr;
+                    const int j = slot >> 1;
                     uintx2 h, l;
                     split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
-                    const int kks = 2 * jb + (cq >> 2), kg = cq & 1, half = (cq >> 1) & 1;
-                    const int slot_e = eslot(r, kg, cq >> 2);
-                    ew[((kks * 2 + 0) * 64 + slot_e) * 2 + half] = h;
-                    ew[((kks * 2 + 1) * 64 + slot_e) * 2 + half] = l;
+                    LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128) = h;
+                    LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128 + 1024) = l;
                 } else if (slot == 8) {
-                    if (!(HEDGE_ABL & 16)) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            int row = be.x + 8 * j + rr;
-                            row = row < E ? row : E - 1;
-                            eq[j] = ld_stream(reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq)));
-                        }
-                    }
+                    for (int j = 0; j < 4; ++j) eq[j] = bld4(srd_ein, v_eoff, rel * 512 + j * 4096);
                     be = be_next;
                 }
             };
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            floatx16 c0v;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const floatx4 v = ps[tile_q(n, 2 * g + hi)];
+                const floatx4 v = LDS(floatx4, ps_r + 32 * g);
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
+                for (int tt = 0; tt < 4; ++tt) c0v[4 * g + tt] = v[tt];
             }
             SYS_STAMP(t, 2);
-            if (HEDGE_VAR & 1) mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, nothing);
-            else mlp_layer<true>(acc, wh, wl, Eimg + (x & 1) * 1024, lane, side);
+            mlp_layer(acc, c0v, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
             SYS_STAMP(t, 3);
             // range check of the fp16 split: a value that does not fit an operand image is (inf, -inf) as a pair and turns every
             // accumulator of its row into NaN (hmlp.hip: check_rows) -- one comparison per tick, wave-uniform verdict
             rng |= __any(acc[0] != acc[0]) ? 1 : 0;
-            acc_to_image(acc, reinterpret_cast<uintx4*>(X1 + (x & 1) * 1024), jb, lane);
+            GM_SB;
+            acc_to_image(acc, smem, x1_w + PAR * IMG_B);
             SYS_STAMP(t, 4);
-            if (HEDGE_VAR & 1) {
-#pragma unroll
-                for (int sl = 0; sl < 24; ++sl) side(sl);
-            }
             SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);
+        };
+#pragma unroll 1
+        for (int t = -2; t <= nb + 2; t += 2) {   // an even number of ticks (the last one drains like the one before it)
+            tick(even, t);
+            tick(odd, t + 1);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else if (role == 1) {
         // ------------------------------------------------------------------ role 1
         floatx16 acc;
         int rng = 0;
-        floatx4 er[4];                      // e rows (row-major quads) of block x-3 for the residual
-        int st_a = 0, cnt_a = 0, st_b = 0, cnt_b = 0;  // blocks x-3, x-2
-        int2 bi_c = make_int2(0, 0);                    // raw table entry of block x-1 (decoded a tick after its load)
+        floatx4 er[EPI_SPLIT];              // e rows (row-major quads, rows 8 j + rr) of block x-3 for the residual
+        int st_a = e0, cnt_a = 0, st_b = e0, cnt_b = 0;  // blocks x-3, x-2
+        int2 bi_c = a_blk[b0];                          // raw table entry of block x-1 (decoded a tick after its load)
         const float res_w = a_residual ? 1.f : 0.f;
-        float* const sink = a_sink + (blockIdx.x & (kSinkRows - 1)) * H;
-        // LayerNorm gamma / beta of this lane's feature quad: constant over the launch (8 registers instead of 8 LDS reads per tick)
-        const floatx4 gm = *reinterpret_cast<const floatx4*>(vecs + 2 * H + 32 * jb + 4 * (lane0 & 7));
-        const floatx4 bt = *reinterpret_cast<const floatx4*>(vecs + 3 * H + 32 * jb + 4 * (lane0 & 7));
-        // accumulators <- b2 T2: read at the end of a tick for the next one (behind the barrier's LDS wait, off the critical path)
+        // LayerNorm gamma / beta of this lane's feature quad and the bias of Linear 2 in accumulator layout: constant over the launch
+        const floatx4 gm = LDS(floatx4, L_VEC + (2 * H + 32 * jb + 4 * cq) * 4);
+        const floatx4 bt = LDS(floatx4, L_VEC + (3 * H + 32 * jb + 4 * cq) * 4);
+        floatx16 b2v;   // b2 T2 in accumulator layout: read at the end of a tick for the next one (behind the barrier's LDS wait)
         auto init_acc = [&]() {
-            const float* vb2 = vecs + 32 * jb + 4 * (lane0 >> 5);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const floatx4 v = *reinterpret_cast<const floatx4*>(vb2 + 8 * g);
+                const floatx4 v = LDS(floatx4, L_VEC + (32 * jb + 4 * hi + 8 * g) * 4);
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
+                for (int tt = 0; tt < 4; ++tt) b2v[4 * g + tt] = v[tt];
             }
         };
         init_acc();
-        float* km = KM + jb * BE * 2;
+        const unsigned st_r = opaque(L_ST + n * 4);
+        const unsigned km_w = opaque(L_KM + jb * 128 + n * 4), km_r = opaque(L_KM + jb * 128 + rr * 4);
+        const unsigned z_r = opaque(L_Z + jb * TILE_B + rr * TILE_ROW_B + cq * 16);
+        const unsigned x_in = opaque(L_X1 + lane0 * 16), x_out = opaque(L_X2 + 4 * jb * 1024 + lane0 * 16);
+        float* const e_out_wg = a_e_out + (size_t)e0 * H;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) er[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int t = -2; t <= nb + 2; ++t) {
+        for (int j = 0; j < EPI_SPLIT; ++j) er[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        auto tick = [&](auto par_c, int t) {
+            constexpr int PAR = decltype(par_c)::value, P1 = 1 - PAR, P3 = 1 - PAR;   // parities of blocks x, x-1, x-3
             const int x = b0 + t;
-            int lane_t = lane0;
-            asm volatile("" : "+v"(lane_t));
-            const int lane = lane_t, n = lane & 31, hi = lane >> 5, rr = lane >> 3, cq = lane & 7;
-            const bool epi = ok(x - 3);
-            const int par3 = (x - 3) & 1;
             SYS_STAMP(t, 0);
-            {  // merged statistics of block x-3: lane n (both halves) -> km[n]
-                float k, m;
-                ln_merge(ST + par3 * 8 * BE * 2, n, inv_T, a_eps, k, m);
-                if (hi == 0) *reinterpret_cast<float2v*>(km + n * 2) = float2v{k, m};
-            }
-            const floatx4* zt = Z + (par3 * 4 + jb) * 256;
-            float2v kmr;
+            // 1 / (T sigma) of the rows of block x-3: lane n (both halves) -> this wave's table
+            LDS(float, km_w) = ln_k(smem, st_r + P3 * 512, inv_T, a_eps);
+            const int cnt_st = ok(x - 3) ? cnt_a : 0;   // rows of block x-3 that exist (none in the fill / drain ticks)
+            const unsigned rel_a = (unsigned)(st_a - e0), rel_b = (unsigned)(st_b - e0);
+            float kr;
             floatx4 zq;
             auto side = [&](int slot) {   // LayerNorm + e_out of block x-3, row group slot / SIDE_STRIDE
                 if (slot >= EPI_SPLIT * SIDE_STRIDE) return;   // the other row groups are role 2's (balance of the roles' ticks)
-                const int j = slot / SIDE_STRIDE, r = 8 * j + rr;
+                const int j = slot / SIDE_STRIDE;
                 if (slot % SIDE_STRIDE == 0) {
-                    kmr = *reinterpret_cast<const float2v*>(km + r * 2);
-                    zq = zt[tile_q(r, cq)];
+                    kr = LDS(float, km_r + j * 32);
+                    zq = LDS(floatx4, z_r + P3 * 4 * TILE_B + j * 8 * TILE_ROW_B);
                 } else if (slot % SIDE_STRIDE == 2) {
                     floatx4 o;
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const float xh = fmaf(zq[tt], kmr[0], kmr[1]);
-                        o[tt] = fmaf(er[j][tt], res_w, fmaf(xh, gm[tt], bt[tt]));
-                    }
-                    // unconditional store (a branch around it would turn this wave's counted waits for its loads into
-                    // waits for everything): rows past the block's end and the fill / drain ticks go to the workgroup's sink row
-                    float* orow = (epi && r < cnt_a) ? a_e_out + (unsigned)((((HEDGE_ABL & 32) ? (st_a & 1023) : st_a) + r) * H) : sink;
-                    if (!(HEDGE_ABL & 4)) st_stream(reinterpret_cast<floatx4*>(orow + 32 * jb + 4 * cq), o);
+                    for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(er[j][tt], res_w, fmaf(zq[tt] * kr, gm[tt], bt[tt]));
+                    // rows past the block's end (and every row of a fill / drain tick) lie beyond the resource's byte count: dropped
+                    // (the block's position is in the resource's base: gfx9 subtracts a scalar offset from the byte count)
+                    bst4(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
+                    er[j] = bld4(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
                 }
             };
             SYS_STAMP(t, 1);
             SYS_STAMP(t, 2);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // km visible to this wave's own reads
-            auto request_er = [&]() {
-                st_a = st_b; cnt_a = cnt_b;
-                st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
-                if (!(HEDGE_ABL & 1)) {  // rows of block x-2: consumed next tick (scaled by 0 when there is no residual)
-#pragma unroll
-                    for (int j = 0; j < EPI_SPLIT; ++j) {
-                        int row = st_a + 8 * j + rr;
-                        row = row < E ? row : E - 1;
-                        er[j] = ld_stream(reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq)));
-                    }
-                }
-                bi_c = a_blk[clampb(x)];
-            };
-            if (HEDGE_VAR & 1) {
-#pragma unroll
-                for (int sl = 0; sl < 24; ++sl) side(sl);
-                request_er();   // a whole tick in flight
-                mlp_layer<false>(acc, wh, wl, X1 + ((x - 1) & 1) * 1024, lane, nothing);
-            } else {
-                mlp_layer<false>(acc, wh, wl, X1 + ((x - 1) & 1) * 1024, lane, side);
-            }
+            mlp_layer(acc, b2v, wh, wl, smem, x_in + P1 * IMG_B, x_in + P1 * IMG_B, side);
             SYS_STAMP(t, 3);
             rng |= __any(acc[0] != acc[0]) ? 1 : 0;
-            acc_to_image(acc, reinterpret_cast<uintx4*>(X2 + ((x - 1) & 1) * 1024), jb, lane);
+            GM_SB;
+            acc_to_image(acc, smem, x_out + P1 * IMG_B);
             SYS_STAMP(t, 4);
-            if (!(HEDGE_VAR & 1)) request_er();
+            st_a = st_b; cnt_a = cnt_b;
+            st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
+            bi_c = a_blk[clampb(x)];
             init_acc();
             SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);
+        };
+#pragma unroll 1
+        for (int t = -2; t <= nb + 2; t += 2) {
+            tick(even, t);
+            tick(odd, t + 1);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else {
@@ -451,23 +464,34 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         int cnt_a = 0, fl_a = 0, cnt_b = 0, fl_b = 0;    // blocks x-3, x-2 (cnt = 0 while there is none)
         unsigned cont_a = 0, last_a = 0, cont_b = 0, last_b = 0;
         int head_a = -1, head_b = -1;   // destination whose segment began in an earlier group (its sum over this group goes to the side buffer)
-        int2 bn = make_int2(0, 0), sn = make_int2(0, 0);      // table entries of the block the next fetch() handles
-        const float gam = vecs[2 * H + 32 * jb + (lane0 & 31)], bet = vecs[3 * H + 32 * jb + (lane0 & 31)];
+        int2 bn = a_blk[b0], sn = make_int2(0, 0);      // table entries of the block the next fetch() handles
+        const float gam = LDS(float, L_VEC + (2 * H + 32 * jb + n) * 4), bet = LDS(float, L_VEC + (3 * H + 32 * jb + n) * 4);
         // its share of the LayerNorm + e_out epilogue (row groups EPI_SPLIT .. 3 of block x-3, row-major: 8 lanes per row)
         const float res_w = a_residual ? 1.f : 0.f;
-        float* const sink = a_sink + (blockIdx.x & (kSinkRows - 1)) * H;
-        floatx4 er[4];                  // e rows of block x-3 for the residual (the groups of this role)
+        floatx4 er[4 - EPI_SPLIT + 1];  // e rows of block x-3 for the residual (the groups of this role)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) er[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        int st_a = 0, st_b = 0;         // first edge of blocks x-3, x-2
-        float* km2 = KM2 + jb * BE * 2;
-        auto init_acc = [&]() {   // accumulators <- b3 T3, read at the end of a tick for the next one
-            const float* vb3 = vecs + H + 32 * jb + 4 * (lane0 >> 5);
+        for (int j = 0; j < 4 - EPI_SPLIT; ++j) er[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        int st_a = e0, st_b = e0;       // first edge of blocks x-3, x-2
+        const unsigned km_re = opaque(L_KM2 + jb * 128 + rr * 4);                          // + 32 j
+        const unsigned z_e = opaque(L_Z + jb * TILE_B + rr * TILE_ROW_B + cq * 16);         // + 8 j rows
+        float* const e_out_wg = a_e_out + (size_t)e0 * H;
+        // this wave's entry of row n in the statistics tables (ST; KM2 at + L_KM2 - L_ST) and, relative to a resource that starts
+        // L_ST bytes before agg, this lane's column of an agg row
+        const unsigned v_aoff = opaque(L_ST + jb * 128 + n * 4);
+        const unsigned st_r = opaque(L_ST + n * 4);
+        const unsigned km_rq = opaque(L_KM2 + jb * 128 + 64 * hi);                         // + 16 c: rows 16 hi + 4 c .. + 3
+        const unsigned z_w = opaque(L_Z + jb * TILE_B + n * TILE_ROW_B + hi * 16);          // + 32 g
+        const unsigned z_t = opaque(L_Z + jb * TILE_B + 16 * hi * TILE_ROW_B + n * 4);      // + r rows: transposed reads
+        const unsigned x_in = opaque(L_X2 + lane0 * 16);
+        const unsigned dr_r = opaque(L_DR + 64 * hi);
+        const srd_t srd_agg = make_srd(reinterpret_cast<const char*>(a_agg) - L_ST, a_agg_bytes + L_ST);   // see v_aoff
+        floatx16 b3v;   // stays in LDS: read at the end of a tick for the next one (behind the barrier's LDS wait)
+        auto init_acc = [&]() {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const floatx4 v = *reinterpret_cast<const floatx4*>(vb3 + 8 * g);
+                const floatx4 v = LDS(floatx4, L_VEC + (H + 32 * jb + 4 * hi + 8 * g) * 4);
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) acc[4 * g + tt] = v[tt];
+                for (int tt = 0; tt < 4; ++tt) b3v[4 * g + tt] = v[tt];
             }
         };
         init_acc();
@@ -480,62 +504,42 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             last = (unsigned)si.y;
             if (fl & 1) head = a_head[x >> 2];
         };
-#pragma unroll 1
-        for (int t = -2; t <= nb + 2; ++t) {
+        auto tick = [&](auto par_c, int t) {
+            constexpr int PAR = decltype(par_c)::value, P2 = PAR, P3 = 1 - PAR;   // parities of blocks x-2, x-3
             const int x = b0 + t;
-            int lane_t = lane0;
-            asm volatile("" : "+v"(lane_t));
-            const int lane = lane_t, n = lane & 31, hi = lane >> 5;
             const bool agg_on = ok(x - 3);
-            const int par3 = (x - 3) & 1;
             SYS_STAMP(t, 0);
-            {   // merged statistics of block x-3 (lane = row) -> this wave's table, read back per register row below
-                float k, m;
-                ln_merge(ST + par3 * 8 * BE * 2, n, inv_T, a_eps, k, m);
-                if (hi == 0) *reinterpret_cast<float2v*>(km2 + n * 2) = float2v{k, m};
-            }
+            // 1 / (T sigma) of the rows of block x-3 (lane = row) -> this wave's table, read back per register row below
+            LDS(float, v_aoff + (L_KM2 - L_ST)) = ln_k(smem, st_r + P3 * 512, inv_T, a_eps);
             SYS_STAMP(t, 1);
             const unsigned cont = agg_on ? cont_a : 0u, last = agg_on ? last_a : 0u;
-            // destinations of this lane's 16 rows: from the ring role 0 filled (no global load)
-            const int* drp = DR + ((x - 3) & (DR_SLOTS - 1)) * BE + 16 * hi;   // read per stored row (about two per tick): no registers held
-            const char* zb = reinterpret_cast<const char*>(Z + (par3 * 4 + jb) * 256) + 2048 * hi;   // row 16 hi of the tile (tile_q order)
-            const floatx4* kmp = reinterpret_cast<const floatx4*>(km2 + 32 * hi);
+            const int cnt_st = agg_on ? cnt_a : 0;
+            const unsigned rel_a = (unsigned)(st_a - e0), rel_b = (unsigned)(st_b - e0);
             floatx16 y;     // a vector: the store loop below indexes it with a (wave-uniform) run-time row
-            floatx4 kq0, kq1;
+            floatx4 kq;
             float zz[4];
-            float2v ekm;
-            floatx4 ezq, gmq, btq;
+            float ek;
+            floatx4 ezq;
             float cpend = 0.f;
             // value of an open segment handed to the next half: half 0 -> half 1 inside the tick, half 1 -> half 0 of the next block
             auto side = [&](int slot) {
                 if (slot < 8) {
                     const int c = slot >> 1;
-                    if (!(slot & 1)) {   // requests of rows 4c .. 4c+3: (k, m) pairs, z values (quad index XORed with the row)
-                        kq0 = kmp[2 * c];
-                        kq1 = kmp[2 * c + 1];
+                    if (!(slot & 1)) {   // requests of rows 4c .. 4c+3: their k, their z values of this lane's feature
+                        kq = LDS(floatx4, km_rq + 16 * c);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int r = 4 * c + i;
-                            zz[i] = *reinterpret_cast<const float*>(zb + 128 * r + ((4 * n) ^ (16 * (r & 7))));
-                        }
-
+                        for (int i = 0; i < 4; ++i) zz[i] = LDS(float, z_t + P3 * 4 * TILE_B + (4 * c + i) * TILE_ROW_B);
                     } else {
-                        y[4 * c + 0] = fmaf(fmaf(zz[0], kq0[0], kq0[1]), gam, bet);
-                        y[4 * c + 1] = fmaf(fmaf(zz[1], kq0[2], kq0[3]), gam, bet);
-                        y[4 * c + 2] = fmaf(fmaf(zz[2], kq1[0], kq1[1]), gam, bet);
-                        y[4 * c + 3] = fmaf(fmaf(zz[3], kq1[2], kq1[3]), gam, bet);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[4 * c + i] = fmaf(zz[i] * kq[i], gam, bet);
                     }
                 } else if (slot < 13) {
-                    // segmented scan down the registers: y[r] += y[r-1] where row r continues row r-1's segment (lane mask from the
-                    // two halves' bits: scalar work)
-#pragma unroll
-                    for (int r = 3 * (slot - 8) + 1; r <= 3 * (slot - 8) + 3; ++r) {
-                        const unsigned long long mk = (unsigned long long)(unsigned)__builtin_amdgcn_sbfe((int)cont, r, 1) |
-                                                      ((unsigned long long)(unsigned)__builtin_amdgcn_sbfe((int)cont, 16 + r, 1) << 32);
-                        float tq;
-                        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(tq) : "v"(y[r - 1]), "s"(mk));
-                        y[r] += tq;
-                    }
+                    // segmented scan down the registers: y[r] += y[r-1] where row r continues row r-1's segment
+                    const int r = 3 * (slot - 8) + 1;
+                    float ya = y[r], yb = y[r + 1], yc = y[r + 2];
+                    const float yp = y[r - 1];
+                    scan3(ya, yb, yc, yp, cont, r);
+                    y[r] = ya; y[r + 1] = yb; y[r + 2] = yc;
                 } else if (slot == 13) {
                     // what enters each half at its first row: half 0 the previous block's open sum, half 1 the sum half 0 leaves open
                     const float c0v = (cont & 1u) ? carry : 0.f;
@@ -543,87 +547,62 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     const float from0 = lower_half_to_both(open0);
                     const float c1v = (cont & 0x10000u) ? from0 : 0.f;
                     cpend = hi ? c1v : c0v;
-                } else if (EPI_SPLIT < 4 && slot >= 14 && slot < 14 + 2 * (4 - EPI_SPLIT) + 1) {
+                } else if (EPI_SPLIT < 4 && slot >= 14 && slot < 14 + 2 * (4 - EPI_SPLIT)) {
                     // this role's share of the e_out epilogue: row group j, loads at an even slot, arithmetic + store at the next
-                    const int rr = lane >> 3, cq = lane & 7;
-                    if (slot == 14 + 2 * (4 - EPI_SPLIT)) {
-                        // the residual rows of block x-2 for the next tick, into the registers just consumed
-                        if (!(HEDGE_ABL & 1)) {
-#pragma unroll
-                            for (int j = EPI_SPLIT; j < 4; ++j) {
-                                int row = st_b + 8 * j + rr;
-                                row = row < E ? row : E - 1;
-                                er[j] = ld_stream(reinterpret_cast<const floatx4*>(a_e_in + (unsigned)(row * H + 32 * jb + 4 * cq)));
-                            }
-                        }
-                    } else {
-                        const int j = EPI_SPLIT + ((slot - 14) >> 1), r = 8 * j + rr;
+                    {
+                        const int j = EPI_SPLIT + ((slot - 14) >> 1);
                         if (!((slot - 14) & 1)) {
-                            ekm = *reinterpret_cast<const float2v*>(km2 + r * 2);
-                            ezq = (Z + (par3 * 4 + jb) * 256)[tile_q(r, cq)];
-                            gmq = *reinterpret_cast<const floatx4*>(vecs + 2 * H + 32 * jb + 4 * cq);   // read per use: this role has no registers to park them in
-                            btq = *reinterpret_cast<const floatx4*>(vecs + 3 * H + 32 * jb + 4 * cq);
+                            ek = LDS(float, km_re + j * 32);
+                            ezq = LDS(floatx4, z_e + P3 * 4 * TILE_B + j * 8 * TILE_ROW_B);
                         } else {
+                            const floatx4 gmq = LDS(floatx4, L_VEC + (2 * H + 32 * jb + 4 * cq) * 4);   // read per use: registers are scarcer than LDS slots here
+                            const floatx4 btq = LDS(floatx4, L_VEC + (3 * H + 32 * jb + 4 * cq) * 4);
                             floatx4 o;
 #pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) {
-                                const float xh = fmaf(ezq[tt], ekm[0], ekm[1]);
-                                o[tt] = fmaf(er[j][tt], res_w, fmaf(xh, gmq[tt], btq[tt]));
-                            }
-                            float* orow = (agg_on && r < cnt_a) ? a_e_out + (unsigned)((st_a + r) * H) : sink;
-                            if (!(HEDGE_ABL & 4)) st_stream(reinterpret_cast<floatx4*>(orow + 32 * jb + 4 * cq), o);
+                            for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(er[j - EPI_SPLIT][tt], res_w, fmaf(ezq[tt] * ek, gmq[tt], btq[tt]));
+                            bst4(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
+                            er[j - EPI_SPLIT] = bld4(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
                         }
                     }
                 }
             };
-            const bool l3 = ok(x - 2);
-            const int par2 = (x - 2) & 1;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // km2 visible to this wave's own reads
-            SYS_STAMP(t, 2);   // accumulators initialised
-            if (HEDGE_VAR & 1) {
-#pragma unroll
-                for (int sl = 0; sl < 24; ++sl) side(sl);
-                mlp_layer<false>(acc, wh, wl, X2 + par2 * 1024, lane, nothing);
-            } else {
-                mlp_layer<false>(acc, wh, wl, X2 + par2 * 1024, lane, side);
-            }
+            SYS_STAMP(t, 2);
+            mlp_layer(acc, b3v, wh, wl, smem, x_in + P2 * IMG_B, x_in + P2 * IMG_B, side);
             SYS_STAMP(t, 3);   // 24 MFMAs with the scatter-add between them
             rng |= __any(acc[0] != acc[0]) ? 1 : 0;
             {
-                // LayerNorm partial statistics of the scaled accumulators (16 features per lane); raw accumulators to Z
-                float sacc = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[r];
-                const float mh = sacc * (1.0f / 16.0f);
+                // LayerNorm statistics of the scaled accumulators: the image's W3 / b3 are centred over the output features, so a
+                // row's outputs have zero mean and its variance is the mean square.  Sum of squares of this wave's 32 features
+                // of row n (16 per lane half); raw accumulators to Z.
                 float q = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float d = acc[r] - mh; q = fmaf(d, d, q); }
-                if (l3) *reinterpret_cast<float2v*>(ST + ((par2 * 8 + jb * 2 + hi) * BE + n) * 2) = float2v{mh, q};
-                floatx4* zt = Z + (par2 * 4 + jb) * 256;
+                for (int r = 0; r < 16; ++r) q = fmaf(acc[r], acc[r], q);
+                LDS(float, v_aoff + P2 * 512) = sum_of_halves(q);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     floatx4 z;
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) z[tt] = acc[4 * g + tt];
-                    zt[tile_q(n, 2 * g + hi)] = z;
+                    LDS(floatx4, z_w + P2 * 4 * TILE_B + 32 * g) = z;
                 }
             }
-            SYS_STAMP(t, 4);   // partial statistics + Z written
+            SYS_STAMP(t, 4);   // statistics + Z written
             {
                 // Stores of the finished segments: one iteration per row index r that ends a segment in either half (about two
                 // per tick on a dense graph), ascending, so that the first store of a half takes its pending carry.  A segment's
                 // sum goes to its agg row, or -- the piece of a segment that began in an earlier group -- to this group's row of
-                // the side buffer (one allocation with agg: 32-bit element offsets from a_agg).
+                // the side buffer (one allocation with agg: byte offsets from a_agg).
                 unsigned pend = (last | (last >> 16)) & 0xffffu;
-                const unsigned side_row = a_side_off + (unsigned)(((x - 3) >> 2) * H);
+                const unsigned side_row = (a_side_off + (unsigned)(((x - 3) >> 2) * H)) * 4u;
+                const unsigned drp = dr_r + ((x - 3) & (DR_SLOTS - 1)) * (BE * 4);
                 while (pend) {
                     const int r = __builtin_ctz(pend);
                     pend &= pend - 1;
                     const unsigned long long mk = (unsigned long long)(0u - ((last >> r) & 1u)) | ((unsigned long long)(0u - ((last >> (16 + r)) & 1u)) << 32);
                     if (__builtin_amdgcn_inverse_ballot_w64(mk)) {
-                        const int d = drp[r];
-                        const unsigned off = (d == head_a ? side_row : (unsigned)(d * H)) + 32 * jb + n;
-                        if (!(HEDGE_ABL & 8)) a_agg[off] = y[r] + cpend;
+                        const int d = LDS(int, drp + 4 * r);
+                        const unsigned off = (d == head_a ? side_row : (unsigned)d * (H * 4u)) + v_aoff;
+                        bst1(srd_agg, off, 0, y[r] + cpend);
                         cpend = 0.f;
                     }
                 }
@@ -641,6 +620,11 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);   // every wave of the workgroup has finished the tick
+        };
+#pragma unroll 1
+        for (int t = -2; t <= nb + 2; t += 2) {
+            tick(even, t);
+            tick(odd, t + 1);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     }
@@ -668,8 +652,21 @@ constexpr int H3_PACK_THREADS = 1024;
 __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) {
     __shared__ float red[H3_PACK_THREADS];
     __shared__ float tsc[4];
+    __shared__ float cmean[H + 1];   // Linear 3: mean of every column of W3 over the output features, then the mean of b3
     const int job = blockIdx.x, tid = threadIdx.x;
     const float* Wl[3] = {J.W1[job], J.W2[job], J.W3[job]};
+    // LayerNorm subtracts the mean over the output features of Linear 3; with W3' = W3 - 1 mean_rows(W3), b3' = b3 - mean(b3)
+    // the outputs are z - mean(z) exactly, so the kernel needs no mean: variance = mean square, x_hat = z' / sigma.
+    if (tid < H) {
+        float a = 0.f;
+        for (int o = 0; o < H; ++o) a += J.W3[job][(size_t)o * H + tid];
+        cmean[tid] = a * (1.0f / H);
+    } else if (tid == H) {
+        float a = 0.f;
+        for (int o = 0; o < H; ++o) a += J.b3[job][o];
+        cmean[H] = a * (1.0f / H);
+    }
+    __syncthreads();
     const int ld[3] = {3 * H, H, H}, c0[3] = {J.c1[job], 0, 0};
     // Scales as in the streamed kernels (hmlp.h / pack_hm_kernel): m = estimated rms of the activations, a ReLU layer maps
     // m^2 -> gain^2 m^2 + rms(b)^2 / 2 with gain = ||W_l||_F / sqrt(out) / sqrt(2); U_l = power of two nearest kHmTargetRms / m_l,
@@ -682,7 +679,8 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
         const int cols = l == 0 ? 3 * H : H;
         for (int i = tid; i < H * cols; i += H3_PACK_THREADS) {
             const int col = i % cols;
-            const float v = Wl[l][(size_t)(i / cols) * ld[l] + (l == 0 ? 0 : c0[l]) + col];
+            float v = Wl[l][(size_t)(i / cols) * ld[l] + (l == 0 ? 0 : c0[l]) + col];
+            if (l == 2) v -= cmean[col];
             ss = fmaf(v, v, ss);
             if (l != 0 || (col >= c0[0] && col < c0[0] + H)) wm = fmaxf(wm, fabsf(v));   // the packed block
         }
@@ -703,7 +701,10 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
         if (tid == 0) {
             const float wmax = red[0];
             float bs = 0.f;
-            for (int o = 0; o < H; ++o) bs = fmaf(bl[l][o], bl[l][o], bs);
+            for (int o = 0; o < H; ++o) {
+                const float bv = bl[l][o] - (l == 2 ? cmean[H] : 0.f);
+                bs = fmaf(bv, bv, bs);
+            }
             const float g2 = ss_all / (float)H * 0.5f;
             float m = sqrtf(fmaf(0.5f, bs / (float)H, g2 * m_est * m_est));
             if (!(m > 1.0e-30f) || !(m < 1.0e30f)) m = 1.f;
@@ -734,7 +735,7 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
     float* vec = dst + HW_HEADER_FLOATS;
     for (int i = tid; i < H; i += H3_PACK_THREADS) {
         vec[i] = J.b2[job][i] * T2;
-        vec[H + i] = J.b3[job][i] * T3;
+        vec[H + i] = (J.b3[job][i] - cmean[H]) * T3;
         vec[2 * H + i] = J.gamma[job][i];
         vec[3 * H + i] = J.beta[job][i];
     }
@@ -744,7 +745,7 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
         const int j = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 7, w = (idx >> 12) & 3, l = idx >> 14;
         const int i = lane & 31, kg = lane >> 5;
         const int kcol = 16 * ks + 8 * (j >> 2) + 4 * kg + (j & 3);
-        const float v = Wl[l][(size_t)(32 * w + i) * ld[l] + c0[l] + kcol] * tsc[l];
+        const float v = (Wl[l][(size_t)(32 * w + i) * ld[l] + c0[l] + kcol] - (l == 2 ? cmean[kcol] : 0.f)) * tsc[l];
         const _Float16 h = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)h);
         const size_t base = ((((size_t)(l * 4 + w) * 8 + ks) * 2) * 64 + lane) * 8 + j;
@@ -896,11 +897,18 @@ int build_edge_blocks(const int* in_ptr, const int* dst, int64_t n_nodes, int64_
     return GM_OK;
 }
 
+bool edge_sys_fits(int64_t n_nodes, int64_t edge_capacity) {
+    // byte offsets of the P gathers and of the agg / side-buffer stores are 32-bit (buffer addressing)
+    const uint64_t agg_rows = (uint64_t)n_nodes + edge_groups_max(n_nodes, edge_capacity);
+    return (uint64_t)n_nodes * 2 * H * 4 < (1ull << 32) && agg_rows * H * 4 < (1ull << 32);
+}
+
 int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
     GM_REQUIRE(a.hdr && a.wstream_h3 && a.agg && a.side && !a.eid && !a.eid_out, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: unsupported argument combination");
-    // the scatter-add addresses agg rows and side rows with 32-bit element offsets from agg (carve_fwd puts them in one workspace)
-    GM_REQUIRE(a.side >= a.agg && (uint64_t)(a.side - a.agg) + (uint64_t)(t.max_blocks / 4 + 1 + kSinkRows) * H < (1ull << 32), GM_ERR_INVALID_ARGUMENT,
-               "launch_edge_sys: the side buffer must follow agg within 2^32 floats");
+    // the scatter-add addresses agg rows and side rows with 32-bit byte offsets from agg (carve_fwd puts them in one workspace)
+    const uint64_t agg_bytes = ((uint64_t)(a.side - a.agg) + (uint64_t)(t.max_blocks / 4 + 1) * H) * 4;
+    GM_REQUIRE(a.side >= a.agg && agg_bytes < (1ull << 32) && (uint64_t)a.n_nodes_tab * 2 * H * 4 < (1ull << 32), GM_ERR_INVALID_ARGUMENT,
+               "launch_edge_sys: P and agg + side buffer must each stay below 4 GiB (edge_sys_fits)");
     static PerDeviceOnce attr_done;
     const int rc_attr = attr_done.run([]() -> int {
         GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
@@ -909,11 +917,24 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
     if (rc_attr != GM_OK) return rc_attr;
     {
         ProfScope prof(a.prof, PROF_EDGE, s);
-        // pointers as separate __restrict__ parameters (e_in / e_out may be the same array): the table and index reads are
-        // then provably unclobbered and become scalar loads where their address is wave-uniform
+        // pointers as separate __restrict__ parameters (e_in / e_out may be the same array): the table reads are then provably
+        // unclobbered and become scalar loads
         hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
-                           a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, a.side + (size_t)(t.max_blocks / 4 + 1) * H, (unsigned)(a.side - a.agg), const_cast<int*>(&a.hdr->error_flags), a.eps, a.residual);
+                           a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, (unsigned)(a.side - a.agg), (unsigned)agg_bytes,
+                           (unsigned)((uint64_t)a.n_nodes_tab * 2 * H * 4), const_cast<int*>(&a.hdr->error_flags), a.eps, a.residual);
     }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+// The systolic kernel reads whole 32-row blocks: the (up to 31) rows behind the last edge of the list must hold finite values
+// (a NaN there would raise the range flag).  One tiny launch per forward keeps kEdgePadRows zero rows behind row n_edges.
+__global__ void __launch_bounds__(256) edge_pad_rows_kernel(const CsrHeader* hdr, float* e, int row_floats) {
+    const size_t base = (size_t)hdr->n_edges * row_floats;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kEdgePadRows * row_floats; i += gridDim.x * blockDim.x) e[base + i] = 0.f;
+}
+int zero_edge_pad_rows(const CsrHeader* hdr, float* e, int row_floats, hipStream_t s) {
+    hipLaunchKernelGGL(edge_pad_rows_kernel, dim3(4), dim3(256), 0, s, hdr, e, row_floats);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -1919,7 +1919,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     // the systolic fp16 x 3 kernel (hedge.hip): processor step of the fused forward (rows in sorted order, device-side
     // edge count, block tables present), hidden 128 / num_layers 2
     const bool sys_ok = H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && !enc && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
-    if (sys_ok && (choice == EK_AUTO || choice == EK_SYS))
+    if (sys_ok && (choice == EK_AUTO || choice == EK_SYS) && edge_sys_fits(a.n_nodes_tab, edge_capacity))
         return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), s);
     // the streamed fp16 x 3 kernels (hmlp.hip): every other case
     if (!fp32_forms && a.wstream_hm && hm_supported(H) && (enc || (a.edge_blocks && (a.side || !a.agg)))) {

@@ -48,7 +48,7 @@ FwdWs carve_fwd(void* ws, int H, int64_t n, int64_t cap_e, int64_t cap_side) {
     f.P = c.take<float>((size_t)n * 2 * H);
     f.agg = c.take<float>((size_t)n * H);
     f.side = c.take<float>(edge_groups_max(n, cap_side) * H);
-    f.e = c.take<float>((size_t)cap_e * H);
+    f.e = c.take<float>((size_t)(cap_e > 0 ? cap_e + kEdgePadRows : 0) * H);   // + zero rows behind the list (hedge.h)
     f.bytes = c.used();
     return f;
 }
@@ -595,6 +595,10 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     if (rc != GM_OK) return rc;
     rc = launch_edge(H, NL, true, enc_edge_args(m, edge_attr, attr_is_csr_order ? nullptr : c.eid, c.hdr, 0, f.e), cap, s);
     if (rc != GM_OK) return rc;
+    if (cap > 0) {
+        rc = zero_edge_pad_rows(c.hdr, f.e, H, s);
+        if (rc != GM_OK) return rc;
+    }
     NodeArgs na{};
     na.h_valid = m->H;
     na.n_nodes = (int)n; na.x_in = nodes; na.k1 = m->d.node_dim; na.h_out = f.h;
