@@ -79,6 +79,18 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8];
 #ifndef HEDGE_VAR
 #define HEDGE_VAR 0   // development builds: structural variants under A/B test (bit meanings at their use)
 #endif
+#ifndef HEDGE_ROT0
+#define HEDGE_ROT0 0   // role 0 runs its MFMAs at the top of the tick and prepares the next block's accumulators behind them
+#endif
+#ifndef HEDGE_PSPREAD
+#define HEDGE_PSPREAD 0   // role 0 issues its P-row requests between its first MFMAs instead of before them
+#endif
+#ifndef HEDGE_NT
+#define HEDGE_NT 0     // non-temporal hint on: 1 the e rows role 0 reads, 2 the residual re-read, 4 the e_out stores
+#endif
+#ifndef HEDGE_ROT2
+#define HEDGE_ROT2 0   // role 2 runs the scatter-add of block x-3 before its MFMAs instead of between them
+#endif
 #ifndef HEDGE_ABL
 #define HEDGE_ABL 0   // development builds: timing ablations (1 no residual read, 2 P_j from the P_i row, 4 no e_out store, 8 no agg store, 16 no e read, 32 e_out rows folded onto 1024 rows)
 #endif
@@ -117,6 +129,11 @@ __device__ __forceinline__ int eslot(int n, int kg, int ksbit) { return (n ^ (2 
 typedef __amdgpu_buffer_rsrc_t srd_t;
 __device__ __forceinline__ srd_t make_srd(const void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000); }
 __device__ __forceinline__ floatx4 bld4(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
+// the same with the non-temporal hint (aux bit 1): rows that are read once per launch
+template <int NT>
+__device__ __forceinline__ floatx4 bld4s(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, NT ? 2 : 0)); }
+template <int NT>
+__device__ __forceinline__ void bst4s(srd_t r, unsigned voff, unsigned soff, floatx4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), r, voff, soff, NT ? 2 : 0); }
 __device__ __forceinline__ intx4 bldi4(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(intx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
 __device__ __forceinline__ void bst4(srd_t r, unsigned voff, unsigned soff, floatx4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), r, voff, soff, 0); }
 __device__ __forceinline__ void bst1(srd_t r, unsigned voff, unsigned soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0); }
@@ -133,11 +150,6 @@ __device__ __forceinline__ int s_clamp0(int v, int hi) {
 __device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 #define GM_SB __builtin_amdgcn_sched_barrier(0)
 
-// ReLU as ONE instruction (fmaxf and the med3 builtin cost two: hipcc canonicalises the operand first).  Inline asm is NOT
-// padded against the MFMA -> VALU read hazard: the callers read the accumulators with a compiler-visible instruction first
-// (the range check) and pin the order with a scheduling barrier.
-__device__ __forceinline__ float relu1(float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }
-
 // accumulator registers 8q..8q+7 of a wave's 32-feature block are the elements of B fragment ks = 2 jb + q (same lane):
 // K slot (lane >> 5, j) of k-group ks carries feature 16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) in both operands.
 // a: byte address of this lane's slot in fragment (ks = 2 jb, hi part) of the image.
@@ -146,7 +158,7 @@ __device__ __forceinline__ void acc_to_image(const floatx16& a, char* smem, unsi
     for (int q = 0; q < 2; ++q) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = relu1(a[8 * q + j]);
+        for (int j = 0; j < 8; ++j) v[j] = relu(a[8 * q + j]);
         uintx2 h0, l0, h1, l1;
         split4(v[0], v[1], v[2], v[3], h0, l0);
         split4(v[4], v[5], v[6], v[7], h1, l1);
@@ -310,29 +322,45 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         floatx4 eq[4];          // e rows of block x+1 on their way into the operand image E
 #pragma unroll
         for (int j = 0; j < 4; ++j) eq[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        floatx16 acc;
+        floatx16 acc, c0v;   // c0v: (P_i + P_j) T1 of the block, the first MFMA's C operand
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0v[r] = 0.f;
         intx4 di = bldi4(srd_dst, v_ioff, 0), si = bldi4(srd_src, v_ioff, 0);   // indices of the rows of block b0 ( = "x+1" of the first tick's requests)
         int2 be = a_blk[b0];    // table entry of block x+2 (its .x = first edge): the rows and indices requested this tick
         auto tick = [&](auto par_c, int t) {
             constexpr int PAR = decltype(par_c)::value;   // parity of x: the images' double buffers are compile-time offsets
             const int x = b0 + t;
             SYS_STAMP(t, 0);
-            // accumulator = (P_i[dst] + P_j[src]) * T1: row-major sum -> tile -> accumulator layout
+            auto prepare = [&]() {   // accumulator = (P_i[dst] + P_j[src]) * T1: row-major sum -> tile -> accumulator layout
 #pragma unroll
-            for (int j = 0; j < 4; ++j) LDS(floatx4, ps_w + j * TILE_ROW_B) = (pi[j] + pj[j]) * T1;
-            SYS_STAMP(t, 1);   // P rows of this block have arrived
+                for (int j = 0; j < 4; ++j) LDS(floatx4, ps_w + j * TILE_ROW_B) = (pi[j] + pj[j]) * T1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const floatx4 v = LDS(floatx4, ps_r + 32 * g);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) c0v[4 * g + tt] = v[tt];
+                }
+            };
+            if (!HEDGE_ROT0) prepare();   // P rows of this block (requested a tick ago)
+            SYS_STAMP(t, 1);
             // Requests, all at the top of the tick so that they have a whole tick to arrive (loads and stores complete in issue
             // order on one counter).  P rows of block x+1 (whole 128-byte lines: 8 lanes per row); its destinations also go to
             // role 2, which needs them in four ticks: its waves issue no vector loads at all.
             if (jb == 0 && cq == 0) LDS(intx4, v_ioff + (L_DR + ((x + 1) & (DR_SLOTS - 1)) * (BE * 4))) = di;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pi[j] = bld4(srd_P, (unsigned)(di[j] << 10) + v_poff, 0);
-                pj[j] = bld4(srd_P, (unsigned)(si[j] << 10) + v_poff + H * 4, 0);   // P_j: second half of the row
-            }
             const unsigned rel = (unsigned)(be.x - e0);
-            di = bldi4(srd_dst, v_ioff + rel * 4, 0);     // indices of block x+2
-            si = bldi4(srd_src, v_ioff + rel * 4, 0);
+            auto p_loads = [&](int j) {
+                pi[j] = bld4(srd_P, (unsigned)(di[j] << 10) + v_poff, 0);
+                pj[j] = bld4(srd_P, (unsigned)(((HEDGE_ABL & 2) ? di[j] : si[j]) << 10) + v_poff + H * 4, 0);   // P_j: second half of the row
+            };
+            auto idx_loads = [&]() {
+                di = bldi4(srd_dst, v_ioff + rel * 4, 0);     // indices of block x+2
+                si = bldi4(srd_src, v_ioff + rel * 4, 0);
+            };
+            if (!HEDGE_PSPREAD) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p_loads(j);
+                idx_loads();
+            }
             const int2 be_next = a_blk[clampb(x + 3)];
             // e of block x+1 -> operand image E (this role reads it next tick), one row group per call, between the MFMAs;
             // then the rows of block x+2 are requested into the same registers
@@ -343,19 +371,17 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
                     LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128) = h;
                     LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128 + 1024) = l;
+                } else if (HEDGE_PSPREAD && slot < 8) {
+                    // the tick's requests one pair per MFMA slot instead of a burst at its top: the CU's one address pipe takes a
+                    // kilobyte-wide request every ~16+ cycles, and a burst of 10 from each of the four role-0 waves holds their MFMAs back
+                    p_loads(slot >> 1);
+                    if (slot == 7) idx_loads();
                 } else if (slot == 8) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) eq[j] = bld4(srd_ein, v_eoff, rel * 512 + j * 4096);
+                    for (int j = 0; j < 4; ++j) if (!(HEDGE_ABL & 16)) eq[j] = bld4s<(HEDGE_NT & 1)>(srd_ein, v_eoff, rel * 512 + j * 4096);
                     be = be_next;
                 }
             };
-            floatx16 c0v;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const floatx4 v = LDS(floatx4, ps_r + 32 * g);
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) c0v[4 * g + tt] = v[tt];
-            }
             SYS_STAMP(t, 2);
             mlp_layer(acc, c0v, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
             SYS_STAMP(t, 3);
@@ -365,6 +391,10 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             GM_SB;
             acc_to_image(acc, smem, x1_w + PAR * IMG_B);
             SYS_STAMP(t, 4);
+            // Rotated tick (HEDGE_ROT0): this wave's MFMAs open the tick -- while roles 1 and 2 merge statistics -- and the
+            // accumulators of block x+1 (rows requested at the top of this tick) are prepared here, behind them, and cross the
+            // barrier in registers: the three roles' matrix phases spread over the tick instead of piling up in its middle.
+            if (HEDGE_ROT0) prepare();
             SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);
@@ -425,8 +455,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(er[j][tt], res_w, fmaf(zq[tt] * kr, gm[tt], bt[tt]));
                     // rows past the block's end (and every row of a fill / drain tick) lie beyond the resource's byte count: dropped
                     // (the block's position is in the resource's base: gfx9 subtracts a scalar offset from the byte count)
-                    bst4(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
-                    er[j] = bld4(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
+                    if (!(HEDGE_ABL & 4)) bst4s<(HEDGE_NT & 4)>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
+                    if (!(HEDGE_ABL & 1)) er[j] = bld4s<(HEDGE_NT & 2)>(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
                 }
             };
             SYS_STAMP(t, 1);
@@ -560,14 +590,47 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                             floatx4 o;
 #pragma unroll
                             for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(er[j - EPI_SPLIT][tt], res_w, fmaf(ezq[tt] * ek, gmq[tt], btq[tt]));
-                            bst4(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
-                            er[j - EPI_SPLIT] = bld4(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
+                            if (!(HEDGE_ABL & 4)) bst4s<(HEDGE_NT & 4)>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
+                            if (!(HEDGE_ABL & 1)) er[j - EPI_SPLIT] = bld4s<(HEDGE_NT & 2)>(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
                         }
                     }
                 }
             };
             SYS_STAMP(t, 2);
-            mlp_layer(acc, b3v, wh, wl, smem, x_in + P2 * IMG_B, x_in + P2 * IMG_B, side);
+            auto stores = [&]() {
+                // Stores of the finished segments: one iteration per row index r that ends a segment in either half (about two
+                // per tick on a dense graph), ascending, so that the first store of a half takes its pending carry.  A segment's
+                // sum goes to its agg row, or -- the piece of a segment that began in an earlier group -- to this group's row of
+                // the side buffer (one allocation with agg: byte offsets from a_agg).
+                unsigned pend = (last | (last >> 16)) & 0xffffu;
+                const unsigned side_row = (a_side_off + (unsigned)(((x - 3) >> 2) * H)) * 4u;
+                const unsigned drp = dr_r + ((x - 3) & (DR_SLOTS - 1)) * (BE * 4);
+                while (pend) {
+                    const int r = __builtin_ctz(pend);
+                    pend &= pend - 1;
+                    const unsigned long long mk = (unsigned long long)(0u - ((last >> r) & 1u)) | ((unsigned long long)(0u - ((last >> (16 + r)) & 1u)) << 32);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mk)) {
+                        const int d = LDS(int, drp + 4 * r);
+                        const unsigned off = (d == head_a ? side_row : (unsigned)d * (H * 4u)) + v_aoff;
+                        if (!(HEDGE_ABL & 8)) bst1(srd_agg, off, 0, y[r] + cpend);
+                        cpend = 0.f;
+                    }
+                }
+                // the sum left open at the end of the block (half 1's last row) becomes the next block's carry, in both halves
+                const float nc = upper_half_to_both(y[15] + cpend);
+                carry = (((last >> 31) & 1u) || !agg_on || cnt_a < BE) ? 0.f : nc;
+            };
+            if (HEDGE_ROT2) {
+                // Late matrix phase: the scatter-add of block x-3 runs first, as plain code, and this wave's MFMAs start when the
+                // other roles' are under way (the three roles' matrix phases spread over the tick); only the e_out epilogue stays
+                // between the MFMAs.
+#pragma unroll
+                for (int sl = 0; sl < 14; ++sl) side(sl);
+                stores();
+                mlp_layer(acc, b3v, wh, wl, smem, x_in + P2 * IMG_B, x_in + P2 * IMG_B, [&](int slot) { if (slot >= 14) side(slot); });
+            } else {
+                mlp_layer(acc, b3v, wh, wl, smem, x_in + P2 * IMG_B, x_in + P2 * IMG_B, side);
+            }
             SYS_STAMP(t, 3);   // 24 MFMAs with the scatter-add between them
             rng |= __any(acc[0] != acc[0]) ? 1 : 0;
             {
@@ -587,29 +650,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 }
             }
             SYS_STAMP(t, 4);   // statistics + Z written
-            {
-                // Stores of the finished segments: one iteration per row index r that ends a segment in either half (about two
-                // per tick on a dense graph), ascending, so that the first store of a half takes its pending carry.  A segment's
-                // sum goes to its agg row, or -- the piece of a segment that began in an earlier group -- to this group's row of
-                // the side buffer (one allocation with agg: byte offsets from a_agg).
-                unsigned pend = (last | (last >> 16)) & 0xffffu;
-                const unsigned side_row = (a_side_off + (unsigned)(((x - 3) >> 2) * H)) * 4u;
-                const unsigned drp = dr_r + ((x - 3) & (DR_SLOTS - 1)) * (BE * 4);
-                while (pend) {
-                    const int r = __builtin_ctz(pend);
-                    pend &= pend - 1;
-                    const unsigned long long mk = (unsigned long long)(0u - ((last >> r) & 1u)) | ((unsigned long long)(0u - ((last >> (16 + r)) & 1u)) << 32);
-                    if (__builtin_amdgcn_inverse_ballot_w64(mk)) {
-                        const int d = LDS(int, drp + 4 * r);
-                        const unsigned off = (d == head_a ? side_row : (unsigned)d * (H * 4u)) + v_aoff;
-                        bst1(srd_agg, off, 0, y[r] + cpend);
-                        cpend = 0.f;
-                    }
-                }
-                // the sum left open at the end of the block (half 1's last row) becomes the next block's carry, in both halves
-                const float nc = upper_half_to_both(y[15] + cpend);
-                carry = (((last >> 31) & 1u) || !agg_on || cnt_a < BE) ? 0.f : nc;
-            }
+            if (!HEDGE_ROT2) stores();
             cnt_a = cnt_b; fl_a = fl_b; cont_a = cont_b; last_a = last_b;
             if (fl_b & 1) head_a = head_b;
             st_a = st_b;

@@ -36,6 +36,8 @@ struct PackHmJob {
     float in_rms;       // chain heads: assumed rms of the input operand image (1 for natural-magnitude inputs)
     int gain_cols;      // columns [gain_col0, gain_col0 + gain_cols) of W that make this Linear's pre-activation (0: the packed ones;
     int gain_col0;      //   phi_e's first Linear is packed as its e block, but h_i and h_j feed the same pre-activation)
+    int center;         // this Linear feeds a LayerNorm: pack W - 1 mean_rows(W) and b - mean(b) (means over the valid outputs), so that
+                        // its outputs have zero mean over the features and the kernels' statistics are a sum of squares
     float* dst;
 };
 constexpr int kPackHmMax = 20;
@@ -63,7 +65,7 @@ struct HmEdgeArgs {
     int residual;
     int k1;
     int nl;               // num_layers: nl + 1 Linears
-    int h_valid;          // features that exist (multiple of 32, <= H): the rest of the width is zero padding
+    int h_valid;          // features that exist (<= H): the rest of the width is zero padding
     const int2* blk;      // processor: 32-edge block table (hedge.h)
     const int* head;      // processor: head list of the groups
     float* side;          // processor: [n_groups][H] head partials
@@ -85,7 +87,7 @@ struct HmNodeArgs {
     const float* ln_b;
     float eps;
     int nl;
-    int h_valid;          // features that exist (multiple of 32, <= H)
+    int h_valid;          // features that exist (<= H)
     int tail;             // 0 none, 1 projection P = h [W_i | W_j]^T (+ b1), 2 decoder
     const float* w_tail;  // tail 1: one Linear image (2H outputs); tail 2: nl images H -> H, then H -> 32 (zero-padded)
     float* P_out;
@@ -100,8 +102,8 @@ struct HmNodeArgs {
 };
 
 bool hm_supported(int H);
-// width the kernels run a model of hidden size h at: h zero-padded to 64 / 128 / 256 (multiples of 32 up to 256), else 0
-static inline int hm_padded_hidden(int h) { return (h < 32 || h > 256 || (h & 31)) ? 0 : (h <= 64 ? 64 : (h <= 128 ? 128 : 256)); }
+// width the kernels run a model of hidden size h at: h (1 .. 256) zero-padded to 64 / 128 / 256, else 0
+static inline int hm_padded_hidden(int h) { return (h < 1 || h > 256) ? 0 : (h <= 64 ? 64 : (h <= 128 ? 128 : 256)); }
 int launch_edge_hm(int H, bool enc, const HmEdgeArgs& a, hipStream_t s);
 int launch_node_hm(int H, int mode, const HmNodeArgs& a, hipStream_t s);
 

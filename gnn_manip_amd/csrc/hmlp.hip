@@ -355,59 +355,39 @@ __device__ __forceinline__ void narrow_rows_to_image(const float* __restrict__ s
     }
 }
 
-// LayerNorm statistics of the wave's rows.  Each lane first publishes (mean, M2) of its 16 accumulator values per row
-// block; after the barrier every wave merges the 2 NJB partials of its rows: x_hat = acc * k + m.
+// LayerNorm statistics of the wave's rows.  The Linear in front of a LayerNorm is packed centred over its output features
+// (hmlp.h: PackHmJob::center), so a row's accumulators have zero mean and its variance is its mean square -- over the features
+// that exist: the zero-padded ones are exactly zero and add nothing, whatever the hidden size.  Each lane publishes the sum of
+// squares of its 16 accumulator values per row block; after the barrier every wave adds the 2 NJB partials of its rows:
+// x_hat = acc * k (+ m = 0).
 template <int H, int RBW>
 __device__ __forceinline__ void ln_publish(const floatx16 (&acc)[RBW], float* ST, int rg, int jb, int n, int hi) {
     using C = Cfg<H>;
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[rb][r];
-        const float mh = s * (1.0f / 16.0f);
         float q = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float d = acc[rb][r] - mh; q = fmaf(d, d, q); }
-        *reinterpret_cast<float2v*>(ST + ((((RBW * rg + rb) * 2 * C::NJB) + 2 * jb + hi) * BE + n) * 2) = float2v{mh, q};
+        for (int r = 0; r < 16; ++r) q = fmaf(acc[rb][r], acc[rb][r], q);
+        ST[(((RBW * rg + rb) * 2 * C::NJB) + 2 * jb + hi) * BE + n] = q;
     }
 }
-// hv: the features that exist (a multiple of 32 <= H): the partials of the padded 32-feature blocks are left out
+// hv: the features that exist (<= H)
 template <int H>
 __device__ __forceinline__ void ln_merge(const float* ST, int rbg, int n, float t, float eps, int hv, float& k, float& m) {
     using C = Cfg<H>;
     constexpr int NP = 2 * C::NJB;
-    const float* st = ST + (rbg * NP * BE + n) * 2;
-    float mw[NP], m2 = 0.f, mean = 0.f;
-    if (hv == H) {   // every feature exists (wave-uniform): constant trip counts, no masks
+    const float* st = ST + rbg * NP * BE + n;
+    float m2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < NP; ++w) {
-            const float2v s = *reinterpret_cast<const float2v*>(st + w * BE * 2);
-            mw[w] = s[0];
-            m2 += s[1];
-            mean += s[0];
-        }
-        mean *= 1.0f / NP;
-#pragma unroll
-        for (int w = 0; w < NP; ++w) { const float d = mw[w] - mean; m2 = fmaf(16.0f * d, d, m2); }
-        m2 *= 1.0f / H;
-    } else {
-        const int npv = hv >> 4;   // valid 16-feature partials: (jb, half) with jb < hv / 32
-#pragma unroll
-        for (int w = 0; w < NP; ++w) {
-            const float2v s = *reinterpret_cast<const float2v*>(st + w * BE * 2);
-            mw[w] = s[0];
-            if (w < npv) { m2 += s[1]; mean += s[0]; }
-        }
-        mean *= 1.0f / (float)npv;
-#pragma unroll
-        for (int w = 0; w < NP; ++w) { const float d = mw[w] - mean; if (w < npv) m2 = fmaf(16.0f * d, d, m2); }
-        m2 /= (float)hv;
-    }
+    for (int w = 0; w < NP; ++w) m2 += st[w * BE];
+    m2 *= 1.0f / (float)hv;
     // accumulators carry the scale t (= U of the chain, times the row's own scale in the encoders):
-    // (acc - mean) / sqrt(var_acc + eps t^2) is the normalised value
-    k = 1.0f / sqrtf(m2 + eps * t * t);
-    m = -mean * k;
+    // acc / sqrt(var_acc + eps t^2) is the normalised value
+    const float v = fmaf(eps * t, t, m2);
+    float r = __builtin_amdgcn_rsqf(v);   // 1 ulp + one Newton step
+    r = r * fmaf(-0.5f * v * r, r, 1.5f);
+    k = r;
+    m = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -947,10 +927,28 @@ __global__ void __launch_bounds__(HM_PACK_THREADS) pack_hm_kernel(PackHmJobs J, 
         sc[0] = t;
         sc[1] = U;
     }
+    // centred form (this Linear feeds a LayerNorm): column means of W over the valid outputs and the mean of the bias
+    __shared__ float cmean[513];
+    for (int k = tid; k < j.k_pad && k < 512; k += HM_PACK_THREADS) {
+        float a = 0.f;
+        if (j.center) {
+            for (int o = 0; o < j.out_valid; ++o) a += hm_value(j, o, k);
+            a /= (float)(j.out_valid > 0 ? j.out_valid : 1);
+        }
+        cmean[k] = a;
+    }
+    if (tid == 0) {
+        float a = 0.f;
+        if (j.center && j.bias) {
+            for (int o = 0; o < j.bias_n; ++o) a += j.bias[o];
+            a /= (float)(j.bias_n > 0 ? j.bias_n : 1);
+        }
+        cmean[512] = a;
+    }
     __syncthreads();
     const float t = sc[0], U = sc[1];
     if (tid == 0) { j.dst[0] = t; j.dst[1] = 1.f / U; j.dst[2] = U; }
-    for (int o = tid; o < j.out_pad; o += HM_PACK_THREADS) j.dst[4 + o] = (j.bias && o < j.bias_n) ? j.bias[o] * U : 0.f;
+    for (int o = tid; o < j.out_pad; o += HM_PACK_THREADS) j.dst[4 + o] = (j.bias && o < j.bias_n) ? (j.bias[o] - cmean[512]) * U : 0.f;
     _Float16* frag = reinterpret_cast<_Float16*>(j.dst + 4 + j.out_pad);
     const int ksn = j.k_pad / 16;
     const int entries = (j.out_pad / 32) * ksn * 64;   // (jb, ks, lane); two parts each
@@ -961,7 +959,8 @@ __global__ void __launch_bounds__(HM_PACK_THREADS) pack_hm_kernel(PackHmJobs J, 
         _Float16* lo_p = frag + ((size_t)((jbv * ksn + ks) * 2 + 1) * 64 + lane) * 8;
         for (int q = 0; q < 8; ++q) {
             const int k = 16 * ks + 8 * (q >> 2) + 4 * kg + (q & 3);
-            const float v = hm_value(j, o, k) * t;
+            const bool valid = (o % j.out_seg) < j.out_valid && (k % j.k_seg) < j.k_valid;   // padding stays exactly zero
+            const float v = (hm_value(j, o, k) - (valid ? cmean[k < 512 ? k : 0] : 0.f)) * t;
             const _Float16 h = (_Float16)v;
             hi_p[q] = h;
             lo_p[q] = (_Float16)(v - (float)h);

@@ -37,11 +37,13 @@ namespace {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) { unsigned u; asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b)); return u; }
-// compiler-visible on purpose: it is the first reader of MFMA results, and hipcc pads the MFMA -> VALU hazard only for
-// instructions it knows (an inline-asm reader sees stale accumulators)
+// ReLU as ONE instruction: fmaxf (and the med3 builtin) cost two -- hipcc canonicalises the operand first.  hipcc pads the MFMA ->
+// VALU read hazard only for instructions it knows, so an inline-asm reader must not be the FIRST reader of MFMA results: every
+// caller reads the accumulators with compiler-visible code first (the range check of the rows) and has a barrier -- a workgroup
+// barrier or a scheduling barrier -- between that and this.
 // No clamp: a value beyond the fp16 range is not saturated silently.  Every value written to an operand image is range-checked
 // by its kernel instead (ERRF_SPLIT_RANGE, common.h).
-__device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
+__device__ __forceinline__ float relu(float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }
 
 // low part of a pair straight to fp16: x - hi is exact in fp32, so one rounding either way (v_fma_mixlo / mixhi write one half
 // of the destination and keep the other)

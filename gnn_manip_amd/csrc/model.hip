@@ -19,7 +19,7 @@ int check_desc(const gm_model_desc* d, const char* who) {
     GM_REQUIRE(d->num_layers >= 2, GM_ERR_INVALID_ARGUMENT, "The number of layers num_layers must be at least 2");
     GM_REQUIRE(d->m_steps >= 1, GM_ERR_INVALID_ARGUMENT, "The number of m_steps message pasting steps must be at least 1");
     GM_REQUIRE(hm_padded_hidden(d->hidden_size) > 0, GM_ERR_UNSUPPORTED,
-               "%s: hidden_size=%d: supported are the multiples of 32 up to 256 (run zero-padded at width 64, 128 or 256)", who, d->hidden_size);
+               "%s: hidden_size=%d: supported are 1 .. 256 (run zero-padded at width 64, 128 or 256)", who, d->hidden_size);
     GM_REQUIRE(d->num_layers <= 16, GM_ERR_UNSUPPORTED, "%s: num_layers=%d: at most 16", who, d->num_layers);
     GM_REQUIRE(d->edge_dim >= 1 && d->edge_dim <= 8, GM_ERR_UNSUPPORTED, "%s: edge_dim=%d unsupported (1..8)", who, d->edge_dim);
     GM_REQUIRE(d->node_dim >= 1 && d->node_dim <= 32, GM_ERR_UNSUPPORTED, "%s: node_dim=%d unsupported (1..32)", who, d->node_dim);
@@ -101,7 +101,11 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s, int w
         };
         auto head = [&](float rms) { prev = -1; head_rms = rms; };
         auto hh = [&](int ti, size_t& off) { lin(ti, Hv, 0, 0, Hv, H, H, Hv, H, H, true, Hv, off); };
-        auto hidden = [&](int base, size_t& off) { for (int l = 1; l <= NL; ++l) hh(base + 2 * l, off); };
+        // Linears 1 .. NL of an MLP that ends in a LayerNorm (the decoder's are queued one by one): the last one is packed centred
+        auto hidden = [&](int base, size_t& off) {
+            for (int l = 1; l <= NL; ++l) hh(base + 2 * l, off);
+            jobs.back().center = 1;
+        };
         auto proj = [&](int k, size_t& off) {   // P = h [W_i | W_j]^T + [b1 | 0] of processor step k: a chain of its own (input h)
             head(1.f);
             lin(b_edge(k), 3 * Hv, m->ci * Hv, m->cj * Hv, Hv, 2 * H, H, Hv, H, H, true, Hv, off);

@@ -253,11 +253,11 @@ class DstCsr:
 
 
 def padded_hidden(hidden):
-    """Width the kernels run a model of this hidden size at (gm_padded_hidden_size): multiples of 32 up to 256 are zero-padded
-    to 64 / 128 / 256; latent tensors handed to / returned by the standalone blocks have that row stride inside the library."""
+    """Width the kernels run a model of this hidden size at (gm_padded_hidden_size): sizes up to 256 are zero-padded to
+    64 / 128 / 256; latent tensors handed to / returned by the standalone blocks have that row stride inside the library."""
     w = int(lib().gm_padded_hidden_size(int(hidden)))
     if w <= 0:
-        raise ValueError(f"hidden size {hidden}: supported are the multiples of 32 up to 256")
+        raise ValueError(f"hidden size {hidden}: supported are 1 .. 256")
     return w
 
 

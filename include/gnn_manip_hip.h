@@ -163,7 +163,7 @@ int gm_rigid_transform(const float* rigid_init /*[Nr,3]*/, int64_t n_rigid, cons
  * ------------------------------------------------------------------------------------------ */
 typedef struct gm_model_desc {
     int32_t node_dim, edge_dim, out_dim;
-    int32_t hidden_size;   /* any multiple of 32 up to 256 (epd_gnn.py:13-14 takes any int); see gm_padded_hidden_size */
+    int32_t hidden_size;   /* 1 .. 256 (epd_gnn.py:13-14 takes any int); see gm_padded_hidden_size */
     int32_t num_layers;    /* >= 2: hidden layers per MLP (epd_gnn.py:26) */
     int32_t m_steps;       /* >= 1 */
     float ln_eps;          /* 1e-5 */
@@ -175,9 +175,10 @@ typedef struct gm_model_desc {
     int32_t node_agg_first; /* 0: phi_v(cat[h, agg]); 1: phi_v(cat[agg, h]) */
 } gm_model_desc;
 
-/* The kernels are instantiated for the widths 64, 128 and 256; a model of another hidden size h (multiple of 32) runs
+/* The kernels are instantiated for the widths 64, 128 and 256; a model of another hidden size h <= 256 runs
  * zero-padded at the next of them: weights, biases and LayerNorm vectors are padded with zeros when they are packed, LayerNorm
- * statistics are taken over the h features that exist, the padded features stay exactly zero.  Returns that width (0:
+ * statistics are taken over the h features that exist (the Linear in front of a LayerNorm is packed centred over its outputs,
+ * so the statistics are a mean square and zero padding adds nothing), the padded features stay exactly zero.  Returns that width (0:
  * unsupported).  It is the ROW STRIDE of every latent array that crosses this interface: h / e of
  * gm_graph_independent_forward and gm_interaction_network_forward (inputs zero-padded by the caller, outputs padded with
  * zeros); gm_epd_forward and the rollout entry points have no latent arguments.  Training entry points: hidden 64 / 128 / 256. */
