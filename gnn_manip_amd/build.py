@@ -16,7 +16,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-val
 # references; they add tile-crossing partial sums with float atomics, hence the extra flag for their file only)
 if os.environ.get("GM_DEV_KERNELS") == "1":
     FLAGS.append("-DGM_DEV_KERNELS")
-    EXTRA_FLAGS["mlp.hip"] = ["-munsafe-fp-atomics"]
+    SOURCES.append("mlp_dev_kernels.hip")   # not part of the product library
+    EXTRA_FLAGS["mlp_dev_kernels.hip"] = ["-munsafe-fp-atomics"]
 
 
 def source_digest():

@@ -101,6 +101,11 @@ constexpr int kB3StageFloats = 6144;
 int pack_linear_b3(const float* W, int ld, int col0, float* dst, hipStream_t s);
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
+#ifdef GM_DEV_KERNELS
+// development builds (mlp_dev_kernels.hip): the round-1 fp32 / bf16 x 6 kernels behind kernel choices 1 .. 4
+int launch_edge_dev(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
+int launch_node_dev(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
+#endif
 constexpr int kStageFloats = 4096;
 
 }  // namespace gm
