@@ -74,7 +74,7 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8];
 #define HEDGE_PRIO2 3
 #endif
 #ifndef EPI_SPLIT
-#define EPI_SPLIT 2   // row groups (of 8 rows) of a block's LayerNorm + e_out epilogue that role 1 keeps; role 2 takes the others
+#define EPI_SPLIT 1   // row groups (of 8 rows) of a block's LayerNorm + e_out epilogue that role 1 keeps; role 2 takes the others
 #endif
 #ifndef HEDGE_VAR
 #define HEDGE_VAR 0   // development builds: structural variants under A/B test (bit meanings at their use)

@@ -62,3 +62,15 @@ if ticks:
     arr = np.array([[st_all[r, t, 5] - st_all[2, t, 0] for r in range(3)] for t in ticks])
     rel = np.array([[st_all[r, t, 6] - st_all[2, t, 0] for r in range(3)] for t in ticks])
     print("barrier arrival after role 2's tick start (roles 0, 1, 2):", arr.mean(axis=0).round(0), " release:", rel.mean(axis=0).round(0))
+
+# per tick: which role's jb = 0 wave arrives last at the barrier, and by how much it trails the first one
+if ticks:
+    arr = np.array([[st_all[r, t, 5] - st_all[0, t, 0] for r in range(3)] for t in ticks])
+    dur = np.array([st_all[0, t + 1, 0] - st_all[0, t, 0] for t in ticks if t + 1 < 32 and st_all[0, t + 1, 0] > 0])
+    last = arr.argmax(axis=1)
+    print("last role per tick:", "".join(str(int(x)) for x in last))
+    print("spread (last - first arrival) per tick: mean %.0f  max %.0f;  tick duration: mean %.0f  std %.0f  min %.0f  max %.0f" % (
+        (arr.max(axis=1) - arr.min(axis=1)).mean(), (arr.max(axis=1) - arr.min(axis=1)).max(), dur.mean(), dur.std(), dur.min(), dur.max()))
+    for r in range(3):
+        a = arr[:, r]
+        print(f"role {r}: arrival after tick start mean {a.mean():.0f} std {a.std():.0f} min {a.min():.0f} max {a.max():.0f}")
