@@ -49,11 +49,16 @@ struct PackH3Job {
     const float* gamma;
     const float* beta;
     float* dst;        // h3_image_floats() floats
+    // encoder phi_e (launch_edge_sys_enc): W1 is [H][k1] with k1 raw features (k1 <= 16, leading dimension k1, W1_col0 = 0); its
+    // rows are scaled by their own power of two in the kernel, bounded by the image's cap (hmlp.h).  0: a processor step.
+    int enc_k1;
 };
 size_t h3_image_floats();
 int pack_h3(const PackH3Job* jobs, int n, hipStream_t s);
 
 int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s);
+// encoder phi_e in the same weight-stationary form: raw rows [E][4] in sorted order -> e [E][128] (LayerNorm output)
+int launch_edge_sys_enc(const EdgeArgs& a, hipStream_t s);
 // whether the kernel's 32-bit byte offsets cover a graph of this size (P < 4 GiB, agg + side buffer < 4 GiB: about 4M nodes at
 // hidden 128); larger launches take the streamed kernel
 bool edge_sys_fits(int64_t n_nodes, int64_t edge_capacity);

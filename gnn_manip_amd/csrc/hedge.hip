@@ -94,8 +94,8 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8];
 #ifndef HEDGE_ABL
 #define HEDGE_ABL 0   // development builds: timing ablations (1 no residual read, 2 P_j from the P_i row, 4 no e_out store, 8 no agg store, 16 no e read, 32 e_out rows folded onto 1024 rows)
 #endif
-constexpr int HW_HEADER_FLOATS = 4;            // T1, 1/T3, pad, pad
-constexpr int HW_VEC_FLOATS = 4 * H;           // b2*T2 | b3*T3 | gamma | beta
+constexpr int HW_HEADER_FLOATS = 4;            // T1, 1/T3, cap of the per-row input scale (encoder image), pad
+constexpr int HW_VEC_FLOATS = 5 * H;           // b2*T2 | b3*T3 | gamma | beta | b1*T1 (the encoder's; a processor step has b1 in P)
 constexpr int HW_IMAGE_HALF8 = 3 * 4 * 8 * 2 * 64;   // [layer][jb][ks][part][lane]
 
 
@@ -672,6 +672,196 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
 }
 
 // ------------------------------------------------------------------------------------------
+// Encoder phi_e in the same weight-stationary form (hidden 128, three Linears, 4 raw features per edge, rows in sorted order):
+//   e = LayerNorm(W3 relu(W2 relu(W1 x + b1) + b2) + b3)      (epd_gnn.py:30-33,72-84,88)
+// Role 0: scale of every raw row (its own power of two, hmlp.h), Linear 1 (one k-group: the B fragment is built in registers
+// from the 16-byte row), image X1; and -- it has 3 MFMAs per tick against the others' 24 -- the whole LayerNorm + store epilogue
+// of block x-3.  Role 1: Linear 2.  Role 2: Linear 3, statistics, raw accumulators to the Z tiles.  The row scales travel
+// through a ring in LDS (the biases of all three Linears and the LayerNorm's eps carry them).  Blocks are plain runs of 32 rows.
+// ------------------------------------------------------------------------------------------
+constexpr int LE_X1 = 0;
+constexpr int LE_X2 = LE_X1 + 2 * IMG_B;
+constexpr int LE_Z = LE_X2 + 2 * IMG_B;            // [2][4 jb] tiles
+constexpr int LE_ST = LE_Z + 8 * TILE_B;           // [2][4 jb][32 rows] floats
+constexpr int LE_KM = LE_ST + 2 * 4 * 32 * 4;      // [4 jb][32] floats: 1 / (T sigma) per row (role 0)
+constexpr int RS_SLOTS = 8;
+constexpr int LE_RS = LE_KM + 4 * 32 * 4;          // [RS_SLOTS][32] floats: power-of-two scale of every row of a block
+constexpr int LE_ZERO_END = LE_RS + RS_SLOTS * 32 * 4;
+constexpr int LE_VEC = LE_ZERO_END;                // 5 x 128 floats
+constexpr size_t ENC_LDS_BYTES = LE_VEC + 5 * H * 4;
+
+__global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader* a_hdr, const float* __restrict__ a_x, float* __restrict__ a_e_out,
+                                                                      const float* __restrict__ a_hw, int* a_flags, float a_eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, jb = wave & 3;
+    const int E = a_hdr->n_edges;
+    const int nblk = (E + BE - 1) / BE;
+    const int b0 = (int)((long long)blockIdx.x * nblk / gridDim.x), b1 = (int)((long long)(blockIdx.x + 1) * nblk / gridDim.x);
+    const int nb = b1 - b0;
+    if (nb <= 0) return;
+    const float inv_T = a_hw[1], cap = a_hw[2];
+    const float* hvec = a_hw + HW_HEADER_FLOATS;
+    const half8* wimg = reinterpret_cast<const half8*>(a_hw + HW_HEADER_FLOATS + HW_VEC_FLOATS);
+    half8 wh[8], wl[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {   // role 0 multiplies one k-group only (its image holds zeros beyond): it loads that one
+        const int kq = role == 0 ? 0 : ks;
+        wh[ks] = wimg[(((role * 4 + jb) * 8 + kq) * 2 + 0) * 64 + lane0];
+        wl[ks] = wimg[(((role * 4 + jb) * 8 + kq) * 2 + 1) * 64 + lane0];
+    }
+    for (int i = tid; i < LE_ZERO_END / 16; i += SYS_THREADS) LDS(uintx4, i * 16) = uintx4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < 5 * H; i += SYS_THREADS) LDS(float, LE_VEC + 4 * i) = hvec[i];
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    const int n = lane0 & 31, hi = lane0 >> 5, rr = lane0 >> 3, cq = lane0 & 7;
+    const int e0 = b0 * BE;                               // first row of the workgroup
+    const int rows_wg = (b1 * BE < E ? b1 * BE : E) - e0;  // its rows
+    std::integral_constant<int, 0> even;
+    std::integral_constant<int, 1> odd;
+    // bias of this role's Linear in accumulator layout (vec slot: role 0 -> b1 T1 (4), role 1 -> b2 T2 (0), role 2 -> b3' T3 (1))
+    floatx16 bv;
+    {
+        const int slot = role == 0 ? 4 : role - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 v = LDS(floatx4, LE_VEC + (slot * H + 32 * jb + 4 * hi + 8 * g) * 4);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) bv[4 * g + tt] = v[tt];
+        }
+    }
+    const unsigned rs_l = opaque(LE_RS + n * 4);   // + 128 slot
+    int rng = 0;
+    floatx16 acc;
+    auto scaled_bias = [&](float sc) {
+        floatx16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = bv[r] * sc;
+        return c;
+    };
+    if (role == 0) {
+        // raw rows: lane n of the lower half holds the 16-byte row n of the block; range-checked reads (rows past E read zeros)
+        const srd_t srd_x = make_srd(a_x + (size_t)e0 * 4, (unsigned)(rows_wg > 0 ? rows_wg : 0) * 16u);
+        float* const e_out_wg = a_e_out + (size_t)e0 * H;
+        const unsigned v_xoff = opaque(n * 16 + (hi ? 0x40000000u : 0u));   // the upper half reads nothing (out of range: zeros)
+        const unsigned v_eoff = opaque(rr * 512 + jb * 128 + cq * 16);
+        const unsigned x1_w = opaque(LE_X1 + 4 * jb * 1024 + lane0 * 16);
+        const unsigned st_r = opaque(LE_ST + n * 4);
+        const unsigned km_w = opaque(LE_KM + jb * 128 + n * 4), km_r = opaque(LE_KM + jb * 128 + rr * 4);
+        const unsigned z_r = opaque(LE_Z + jb * TILE_B + rr * TILE_ROW_B + cq * 16);
+        const floatx4 gm = LDS(floatx4, LE_VEC + (2 * H + 32 * jb + 4 * cq) * 4);
+        const floatx4 bt = LDS(floatx4, LE_VEC + (3 * H + 32 * jb + 4 * cq) * 4);
+        const float T3 = 1.0f / inv_T;
+        floatx4 xq = bld4(srd_x, v_xoff, 0);   // rows of block b0 - 2 + 2 ... the first tick's block (clamped below)
+        auto tick = [&](auto par_c, int t) {
+            constexpr int PAR = decltype(par_c)::value, P3 = 1 - PAR;
+            const int x = b0 + t;
+            // ---- this block's rows: scale, B fragment, bias
+            float mx = fmaxf(fmaxf(fabsf(xq[0]), fabsf(xq[1])), fmaxf(fabsf(xq[2]), fabsf(xq[3])));
+            float sc = cap;                        // zero (or non-finite) row: the bias alone, at the largest scale allowed
+            if (mx > 0.f && mx < 3.0e38f) {
+                int ex;
+                (void)frexpf(mx, &ex);             // mx = f 2^ex, f in [0.5, 1)  ->  mx 2^(7 - ex) in [2^6, 2^7)
+                sc = fminf(ldexpf(1.f, min(7 - ex, 100)), cap);
+            }
+            sc = lower_half_to_both(sc);           // both halves of the wave hold row n's scale
+            if (jb == 0 && hi == 0) LDS(float, rs_l + (x & (RS_SLOTS - 1)) * 128) = sc;
+            uintx2 h, l;
+            split4(xq[0] * sc, xq[1] * sc, xq[2] * sc, xq[3] * sc, h, l);   // upper half: zeros (features 4 .. 7 do not exist)
+            const half8 bh = __builtin_bit_cast(half8, uintx4{h[0], h[1], 0u, 0u}), bl = __builtin_bit_cast(half8, uintx4{l[0], l[1], 0u, 0u});
+            const floatx16 c0v = scaled_bias(sc);
+            // rows of the next block (clamped to the workgroup's range: the fill / drain ticks recompute a block, nothing is stored)
+            {
+                const int xn = x + 1 < b0 ? b0 : (x + 1 < b1 ? x + 1 : b1 - 1);
+                xq = bld4(srd_x, v_xoff, (unsigned)(xn - b0) * 512u);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[0], bh, c0v, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0], bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0], bh, acc, 0, 0, 0);
+            // ---- LayerNorm + store of block x-3 (its statistics and tiles were written a tick ago)
+            {
+                const float rs3 = LDS(float, rs_l + ((x - 3) & (RS_SLOTS - 1)) * 128);
+                const float q = (LDS(float, st_r + P3 * 512) + LDS(float, st_r + P3 * 512 + 128)) + (LDS(float, st_r + P3 * 512 + 256) + LDS(float, st_r + P3 * 512 + 384));
+                const float tt3 = T3 * rs3;        // the accumulators of Linear 3 carry T3 x the row's scale
+                const float v = fmaf(a_eps * tt3, tt3, q * (1.0f / 128.0f));
+                float r = __builtin_amdgcn_rsqf(v);
+                r = r * fmaf(-0.5f * v * r, r, 1.5f);
+                LDS(float, km_w) = r;
+                const int xb = x - 3;
+                const int cnt = (xb >= b0 && xb < b1) ? min(BE, E - xb * BE) : 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float kr = LDS(float, km_r + j * 32);
+                    const floatx4 zq = LDS(floatx4, z_r + P3 * 4 * TILE_B + j * 8 * TILE_ROW_B);
+                    floatx4 o;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(zq[tt] * kr, gm[tt], bt[tt]);
+                    bst4(make_srd(e_out_wg + (size_t)((xb - b0) * BE + 8 * j) * H, (unsigned)s_clamp0(cnt - 8 * j, 8) * 512u), v_eoff, 0, o);
+                }
+            }
+            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
+            GM_SB;
+            acc_to_image(acc, smem, x1_w + PAR * IMG_B);
+            lds_barrier();
+        };
+#pragma unroll 1
+        for (int t = -2; t <= nb + 2; t += 2) {
+            tick(even, t);
+            tick(odd, t + 1);
+        }
+    } else if (role == 1) {
+        const unsigned x_in = opaque(LE_X1 + lane0 * 16), x_out = opaque(LE_X2 + 4 * jb * 1024 + lane0 * 16);
+        auto nothing = [](int) {};
+        auto tick = [&](auto par_c, int t) {
+            constexpr int PAR = decltype(par_c)::value, P1 = 1 - PAR;
+            const int x = b0 + t;
+            const floatx16 c0v = scaled_bias(LDS(float, rs_l + ((x - 1) & (RS_SLOTS - 1)) * 128));
+            mlp_layer(acc, c0v, wh, wl, smem, x_in + P1 * IMG_B, x_in + P1 * IMG_B, nothing);
+            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
+            GM_SB;
+            acc_to_image(acc, smem, x_out + P1 * IMG_B);
+            lds_barrier();
+        };
+#pragma unroll 1
+        for (int t = -2; t <= nb + 2; t += 2) {
+            tick(even, t);
+            tick(odd, t + 1);
+        }
+    } else {
+        const unsigned x_in = opaque(LE_X2 + lane0 * 16);
+        const unsigned st_w = opaque(LE_ST + jb * 128 + n * 4);
+        const unsigned z_w = opaque(LE_Z + jb * TILE_B + n * TILE_ROW_B + hi * 16);
+        auto nothing = [](int) {};
+        auto tick = [&](auto par_c, int t) {
+            constexpr int PAR = decltype(par_c)::value, P2 = PAR;
+            const int x = b0 + t;
+            const floatx16 c0v = scaled_bias(LDS(float, rs_l + ((x - 2) & (RS_SLOTS - 1)) * 128));
+            mlp_layer(acc, c0v, wh, wl, smem, x_in + P2 * IMG_B, x_in + P2 * IMG_B, nothing);
+            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q = fmaf(acc[r], acc[r], q);
+            LDS(float, st_w + P2 * 512) = sum_of_halves(q);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                floatx4 z;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) z[tt] = acc[4 * g + tt];
+                LDS(floatx4, z_w + P2 * 4 * TILE_B + 32 * g) = z;
+            }
+            lds_barrier();
+        };
+#pragma unroll 1
+        for (int t = -2; t <= nb + 2; t += 2) {
+            tick(even, t);
+            tick(odd, t + 1);
+        }
+    }
+    if (rng && lane0 == 0 && a_flags) atomicOr(a_flags, ERRF_SPLIT_RANGE);
+}
+
+// ------------------------------------------------------------------------------------------
 // weight image: [T1, 1/T3, 0, 0 | b2 T2, b3 T3, gamma, beta | fp16 hi / lo fragments of t_l W_l]
 // One workgroup per processor step.  t_l: power of two from the Linear's gain (hmlp.h).
 // ------------------------------------------------------------------------------------------
@@ -687,6 +877,7 @@ struct PackH3Jobs {
     const float* gamma[kPackH3Max];
     const float* beta[kPackH3Max];
     float* dst[kPackH3Max];
+    int enc_k1[kPackH3Max];
 };
 
 constexpr int H3_PACK_THREADS = 1024;
@@ -708,22 +899,29 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
         cmean[H] = a * (1.0f / H);
     }
     __syncthreads();
-    const int ld[3] = {3 * H, H, H}, c0[3] = {J.c1[job], 0, 0};
+    const int k1 = J.enc_k1[job];          // > 0: encoder image (Linear 1 takes k1 raw features)
+    const bool enc = k1 > 0;
+    const int ld[3] = {enc ? k1 : 3 * H, H, H}, c0[3] = {J.c1[job], 0, 0};
     // Scales as in the streamed kernels (hmlp.h / pack_hm_kernel): m = estimated rms of the activations, a ReLU layer maps
     // m^2 -> gain^2 m^2 + rms(b)^2 / 2 with gain = ||W_l||_F / sqrt(out) / sqrt(2); U_l = power of two nearest kHmTargetRms / m_l,
     // t_l = U_l / U_(l-1).  Linear 1's pre-activation takes h_i and h_j too: its gain is that of the whole [H x 3H] matrix; its
     // inputs (h, e) are at their natural magnitude (m_0 = 1).
     const float* bl[3] = {J.b1[job], J.b2[job], J.b3[job]};
-    float m_est = 1.f, U_prev = 1.f;
+    // Encoder: the rows enter scaled by their own power of two (maximum in [2^6, 2^7): rms ~ kHmRawInputRms), the biases ride
+    // on that scale and are kept in range by the cap (pack_hm_kernel's rule), so they stay out of the estimate.
+    float m_est = enc ? kHmRawInputRms : 1.f, U_prev = 1.f;
+    if (tid == 0) tsc[3] = 0.f;
+    __shared__ float capv;
+    if (tid == 0) capv = 3.0e38f;
     for (int l = 0; l < 3; ++l) {
         float ss = 0.f, wm = 0.f;
-        const int cols = l == 0 ? 3 * H : H;
+        const int cols = l == 0 ? ld[0] : H;
         for (int i = tid; i < H * cols; i += H3_PACK_THREADS) {
             const int col = i % cols;
             float v = Wl[l][(size_t)(i / cols) * ld[l] + (l == 0 ? 0 : c0[l]) + col];
             if (l == 2) v -= cmean[col];
             ss = fmaf(v, v, ss);
-            if (l != 0 || (col >= c0[0] && col < c0[0] + H)) wm = fmaxf(wm, fabsf(v));   // the packed block
+            if (l != 0 || enc || (col >= c0[0] && col < c0[0] + H)) wm = fmaxf(wm, fabsf(v));   // the packed block
         }
         red[tid] = ss;
         __syncthreads();
@@ -741,13 +939,14 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
         }
         if (tid == 0) {
             const float wmax = red[0];
-            float bs = 0.f;
+            float bs = 0.f, bmax = 0.f;
             for (int o = 0; o < H; ++o) {
                 const float bv = bl[l][o] - (l == 2 ? cmean[H] : 0.f);
                 bs = fmaf(bv, bv, bs);
+                bmax = fmaxf(bmax, fabsf(bv));
             }
             const float g2 = ss_all / (float)H * 0.5f;
-            float m = sqrtf(fmaf(0.5f, bs / (float)H, g2 * m_est * m_est));
+            float m = sqrtf(fmaf(enc ? 0.f : 0.5f, bs / (float)H, g2 * m_est * m_est));
             if (!(m > 1.0e-30f) || !(m < 1.0e30f)) m = 1.f;
             auto pow2 = [](float want, bool nearest) {
                 if (!(want > 0.f) || !(want < 3.0e38f)) return 1.f;
@@ -764,6 +963,7 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
             }
             tsc[l] = t;
             tsc[3] = m;
+            if (enc && bmax > 0.f) capv = fminf(capv, pow2(4096.0f / (U_prev * t * bmax), false));   // no row scale may push a bias out of range
         }
         __syncthreads();
         m_est = tsc[3];
@@ -772,9 +972,10 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
     }
     const float T1 = tsc[0], T2 = T1 * tsc[1], T3 = T2 * tsc[2];
     float* dst = J.dst[job];
-    if (tid == 0) { dst[0] = T1; dst[1] = 1.0f / T3; dst[2] = 0.f; dst[3] = 0.f; }
+    if (tid == 0) { dst[0] = T1; dst[1] = 1.0f / T3; dst[2] = capv; dst[3] = 0.f; }
     float* vec = dst + HW_HEADER_FLOATS;
     for (int i = tid; i < H; i += H3_PACK_THREADS) {
+        vec[4 * H + i] = J.b1[job][i] * T1;
         vec[i] = J.b2[job][i] * T2;
         vec[H + i] = (J.b3[job][i] - cmean[H]) * T3;
         vec[2 * H + i] = J.gamma[job][i];
@@ -786,7 +987,8 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
         const int j = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 7, w = (idx >> 12) & 3, l = idx >> 14;
         const int i = lane & 31, kg = lane >> 5;
         const int kcol = 16 * ks + 8 * (j >> 2) + 4 * kg + (j & 3);
-        const float v = (Wl[l][(size_t)(32 * w + i) * ld[l] + c0[l] + kcol] - (l == 2 ? cmean[kcol] : 0.f)) * tsc[l];
+        const bool pad = l == 0 && enc && kcol >= k1;   // the encoder's first Linear: zero beyond its k1 inputs
+        const float v = pad ? 0.f : (Wl[l][(size_t)(32 * w + i) * ld[l] + c0[l] + kcol] - (l == 2 ? cmean[kcol] : 0.f)) * tsc[l];
         const _Float16 h = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)h);
         const size_t base = ((((size_t)(l * 4 + w) * 8 + ks) * 2) * 64 + lane) * 8 + j;
@@ -884,6 +1086,7 @@ int pack_h3(const PackH3Job* jobs, int n, hipStream_t s) {
             const PackH3Job& j = jobs[off + i];
             J.W1[i] = j.W1; J.c1[i] = j.W1_col0; J.W2[i] = j.W2; J.W3[i] = j.W3; J.b1[i] = j.b1; J.b2[i] = j.b2; J.b3[i] = j.b3; J.gamma[i] = j.gamma; J.beta[i] = j.beta;
             J.dst[i] = j.dst;
+            J.enc_k1[i] = j.enc_k1;
         }
         hipLaunchKernelGGL(pack_h3_kernel, dim3(J.n), dim3(H3_PACK_THREADS), 0, s, J);
         GM_LAUNCH_CHECK();
@@ -963,6 +1166,24 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
         hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
                            a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, (unsigned)(a.side - a.agg), (unsigned)agg_bytes,
                            (unsigned)((uint64_t)a.n_nodes_tab * 2 * H * 4), const_cast<int*>(&a.hdr->error_flags), a.eps, a.residual);
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_edge_sys_enc(const EdgeArgs& a, hipStream_t s) {
+    GM_REQUIRE(a.hdr && a.wstream_h3 && a.e_in && a.e_out && !a.eid && !a.eid_out && a.k1 == 4, GM_ERR_INVALID_ARGUMENT,
+               "launch_edge_sys_enc: unsupported argument combination");
+    static PerDeviceOnce attr_done;
+    const int rc_attr = attr_done.run([]() -> int {
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_enc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ENC_LDS_BYTES));
+        return GM_OK;
+    });
+    if (rc_attr != GM_OK) return rc_attr;
+    {
+        ProfScope prof(a.prof, PROF_ENC, s);
+        hipLaunchKernelGGL(sys_enc_kernel, dim3(device_cus()), dim3(SYS_THREADS), ENC_LDS_BYTES, s, a.hdr, a.e_in, a.e_out, a.wstream_h3,
+                           const_cast<int*>(&a.hdr->error_flags), a.eps);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;

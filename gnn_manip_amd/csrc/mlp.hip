@@ -159,6 +159,10 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     const bool sys_ok = H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && !enc && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
     if (sys_ok && (choice == EK_AUTO || choice == EK_SYS) && edge_sys_fits(a.n_nodes_tab, edge_capacity))
         return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), s);
+    // the encoder phi_e in the same weight-stationary form: 4 raw features per edge, rows in sorted order (the rollout path)
+    if (enc && H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && a.wstream_h3 && a.hdr && !a.eid && a.k1 == 4 &&
+        (choice == EK_AUTO || choice == EK_SYS))
+        return launch_edge_sys_enc(a, s);
     // the streamed fp16 x 3 kernels (hmlp.hip): every other case
     if (!fp32_forms && a.wstream_hm && hm_supported(H) && (enc || (a.edge_blocks && (a.side || !a.agg)))) {
         HmEdgeArgs h{};

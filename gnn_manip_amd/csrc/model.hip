@@ -287,17 +287,19 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s, int w
         }
     }
 #endif
-    if (m->packed_h3 && rc == GM_OK) {  // fp16 hi / lo image of the systolic processor edge kernel
-        std::vector<PackH3Job> jobs((size_t)M);
-        for (int k = 0; k < M; ++k) {
+    if (m->packed_h3 && rc == GM_OK) {  // fp16 hi / lo images of the systolic kernels: the M processor edge MLPs, then the edge encoder
+        std::vector<PackH3Job> jobs((size_t)M + 1);
+        for (int k = 0; k <= M; ++k) {
             PackH3Job& j = jobs[(size_t)k];
-            const int b = b_edge(k);
-            j.W1 = T[b]; j.W1_col0 = m->ce * H; j.W2 = T[b + 2]; j.W3 = T[b + 4];
+            const bool encj = k == M;
+            const int b = encj ? b_enc_edge : b_edge(k);
+            j.W1 = T[b]; j.W1_col0 = encj ? 0 : m->ce * H; j.W2 = T[b + 2]; j.W3 = T[b + 4];
             j.b1 = T[b + 1]; j.b2 = T[b + 3]; j.b3 = T[b + 5];
             j.gamma = T[b + 6]; j.beta = T[b + 7];
+            j.enc_k1 = encj ? m->d.edge_dim : 0;
             j.dst = m->packed_h3 + (size_t)k * h3_image_floats();
         }
-        rc = pack_h3(jobs.data(), M, s);
+        rc = pack_h3(jobs.data(), m->d.edge_dim <= 16 ? M + 1 : M, s);
     }
     return rc;
 }
@@ -470,7 +472,7 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
         return GM_ERR_HIP;
     }
 #endif
-    if (m->H == 128 && NL == 2 && hipMalloc(&m->packed_h3, (size_t)M * h3_image_floats() * sizeof(float)) != hipSuccess) {
+    if (m->H == 128 && NL == 2 && hipMalloc(&m->packed_h3, (size_t)(M + 1) * h3_image_floats() * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
         gm_model_destroy(m);
         return GM_ERR_HIP;
@@ -539,6 +541,7 @@ EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid
     a.wstream = m->packed ? m->packed + m->s_enc_edge : nullptr;
     a.wstream16 = m->packed16 ? m->packed16 + m->s16_enc_edge : nullptr;
     a.wstream_hm = m->packed_hm + m->hm_enc_edge;
+    a.wstream_h3 = m->packed_h3 ? m->packed_h3 + (size_t)m->M * h3_image_floats() : nullptr;   // the encoder's image follows the steps'
     a.kernel_choice = m->edge_kernel; a.prof = m->prof;
     const float* v = m->vec + m->v_enc_edge;
     a.bias = v; a.ln_g = v + (size_t)(m->NL + 1) * m->Hp; a.ln_b = v + (size_t)(m->NL + 2) * m->Hp; a.eps = m->d.ln_eps;
