@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         // LayerNorm gamma / beta of this lane's feature quad and the bias of Linear 2 in accumulator layout: constant over the launch
         const floatx4 gm = LDS(floatx4, L_VEC + (2 * H + 32 * jb + 4 * cq) * 4);
         const floatx4 bt = LDS(floatx4, L_VEC + (3 * H + 32 * jb + 4 * cq) * 4);
-        floatx16 b2v;   // b2 T2 in accumulator layout: read at the end of a tick for the next one (behind the barrier's LDS wait)
+        floatx16 b2v;   // b2 T2 in accumulator layout: constant over the launch (this role has the registers)
         auto init_acc = [&]() {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -440,6 +440,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             // 1 / (T sigma) of the rows of block x-3: lane n (both halves) -> this wave's table
             LDS(float, km_w) = ln_k(smem, st_r + P3 * 512, inv_T, a_eps);
             const int cnt_st = ok(x - 3) ? cnt_a : 0;   // rows of block x-3 that exist (none in the fill / drain ticks)
+            const int2 bi_n = a_blk[clampb(x)];         // requested now, used at the end of the tick: the barrier's wait for the
+                                                        // scalar-memory counter then finds it done
             const unsigned rel_a = (unsigned)(st_a - e0), rel_b = (unsigned)(st_b - e0);
             float kr;
             floatx4 zq;
@@ -469,8 +471,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 4);
             st_a = st_b; cnt_a = cnt_b;
             st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
-            bi_c = a_blk[clampb(x)];
-            init_acc();
+            bi_c = bi_n;
             SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);
@@ -515,7 +516,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         const unsigned x_in = opaque(L_X2 + lane0 * 16);
         const unsigned dr_r = opaque(L_DR + 64 * hi);
         const srd_t srd_agg = make_srd(reinterpret_cast<const char*>(a_agg) - L_ST, a_agg_bytes + L_ST);   // see v_aoff
-        floatx16 b3v;   // stays in LDS: read at the end of a tick for the next one (behind the barrier's LDS wait)
+        floatx16 b3v;   // stays in LDS: read at the top of every tick
         auto init_acc = [&]() {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -525,18 +526,22 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             }
         };
         init_acc();
-        auto fetch = [&](int x, int2 bi, int2 si, int& st, int& cnt, int& fl, unsigned& cont, unsigned& last, int& head) {
+        auto fetch = [&](int x, int2 bi, int2 si, int hd, int& st, int& cnt, int& fl, unsigned& cont, unsigned& last, int& head) {
             st = bi.x;
             if (!ok(x)) { cnt = 0; fl = 0; cont = 0; last = 0; return; }
             cnt = bi.y & 0xff;
             fl = bi.y >> 8;
             cont = (unsigned)si.x;
             last = (unsigned)si.y;
-            if (fl & 1) head = a_head[x >> 2];
+            if (fl & 1) head = hd;
         };
         auto tick = [&](auto par_c, int t) {
             constexpr int PAR = decltype(par_c)::value, P2 = PAR, P3 = 1 - PAR;   // parities of blocks x-2, x-3
             const int x = b0 + t;
+            // table entries of block x (decoded next tick): requested at the top, so that the barrier's scalar-memory wait finds them done
+            const int2 bn_n = a_blk[clampb(x)], sn_n = a_seg[clampb(x)];
+            const int hd_n = a_head[clampb(x - 1) >> 2];   // head of block x-1's group (used if that block opens its group)
+            init_acc();                                     // b3' T3 -> the first MFMA's C operand (lands under the statistics merge)
             const bool agg_on = ok(x - 3);
             SYS_STAMP(t, 0);
             // 1 / (T sigma) of the rows of block x-3 (lane = row) -> this wave's table, read back per register row below
@@ -654,10 +659,9 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             cnt_a = cnt_b; fl_a = fl_b; cont_a = cont_b; last_a = last_b;
             if (fl_b & 1) head_a = head_b;
             st_a = st_b;
-            fetch(x - 1, bn, sn, st_b, cnt_b, fl_b, cont_b, last_b, head_b);
-            bn = a_blk[clampb(x)];
-            sn = a_seg[clampb(x)];
-            init_acc();
+            fetch(x - 1, bn, sn, hd_n, st_b, cnt_b, fl_b, cont_b, last_b, head_b);
+            bn = bn_n;
+            sn = sn_n;
             SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);   // every wave of the workgroup has finished the tick
