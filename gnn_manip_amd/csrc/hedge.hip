@@ -359,6 +359,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             if (!HEDGE_PSPREAD) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) p_loads(j);
+                SYS_STAMP(t, 7);   // (development) the eight P requests issued
                 idx_loads();
             }
             const int2 be_next = a_blk[clampb(x + 3)];

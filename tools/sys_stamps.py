@@ -74,3 +74,10 @@ if ticks:
     for r in range(3):
         a = arr[:, r]
         print(f"role {r}: arrival after tick start mean {a.mean():.0f} std {a.std():.0f} min {a.min():.0f} max {a.max():.0f}")
+
+# role 0, sub-phase of the requests: stamp 7 = the eight P requests issued (after stamp 1)
+st = st_all[0]
+tk = [t for t in range(31) if st[t, 7] > st[t, 1] > 0]
+if tk:
+    print("role 0: P requests issued %.0f cycles after the staging tile; index requests + tile reads + stamp %.0f more" % (
+        np.mean([st[t, 7] - st[t, 1] for t in tk]), np.mean([st[t, 2] - st[t, 7] for t in tk])))
