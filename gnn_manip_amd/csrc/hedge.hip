@@ -319,14 +319,14 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pi[j] = floatx4{0.f, 0.f, 0.f, 0.f}; pj[j] = pi[j]; }
         int rng = 0;            // range check of the fp16 split: set once an accumulator row turns NaN
-        floatx4 eq[4];          // e rows of block x+1 on their way into the operand image E
+        floatx4 eq[4];          // e rows of block x+1 on their way into the operand image E (the first block's: requested here)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) eq[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) eq[j] = bld4(srd_ein, v_eoff, j * 4096);
         floatx16 acc, c0v;   // c0v: (P_i + P_j) T1 of the block, the first MFMA's C operand
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0v[r] = 0.f;
         intx4 di = bldi4(srd_dst, v_ioff, 0), si = bldi4(srd_src, v_ioff, 0);   // indices of the rows of block b0 ( = "x+1" of the first tick's requests)
-        int2 be = a_blk[b0];    // table entry of block x+2 (its .x = first edge): the rows and indices requested this tick
+        int2 be = a_blk[clampb(b0 + 1)];   // table entry of block x+2 (its .x = first edge): the rows and indices requested this tick
         auto tick = [&](auto par_c, int t) {
             constexpr int PAR = decltype(par_c)::value;   // parity of x: the images' double buffers are compile-time offsets
             const int x = b0 + t;
@@ -400,10 +400,13 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             lds_barrier();
             SYS_STAMP(t, 6);
         };
+        // Ticks -1 .. nb + 2: one tick of fill (the e rows and indices of the first block come from the prologue), nb ticks in
+        // which blocks enter, three that drain the pipeline: an even count (nb is a multiple of 4), taken as (odd, even) pairs --
+        // at N = 5k a workgroup has 12 blocks, and every fill / drain tick counts.
 #pragma unroll 1
-        for (int t = -2; t <= nb + 2; t += 2) {   // an even number of ticks (the last one drains like the one before it)
-            tick(even, t);
-            tick(odd, t + 1);
+        for (int t = -1; t <= nb + 1; t += 2) {
+            tick(odd, t);
+            tick(even, t + 1);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else if (role == 1) {
@@ -478,9 +481,9 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 6);
         };
 #pragma unroll 1
-        for (int t = -2; t <= nb + 2; t += 2) {
-            tick(even, t);
-            tick(odd, t + 1);
+        for (int t = -1; t <= nb + 1; t += 2) {
+            tick(odd, t);
+            tick(even, t + 1);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else {
@@ -668,9 +671,9 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 6);   // every wave of the workgroup has finished the tick
         };
 #pragma unroll 1
-        for (int t = -2; t <= nb + 2; t += 2) {
-            tick(even, t);
-            tick(odd, t + 1);
+        for (int t = -1; t <= nb + 1; t += 2) {
+            tick(odd, t);
+            tick(even, t + 1);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     }
@@ -758,7 +761,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader
         const floatx4 gm = LDS(floatx4, LE_VEC + (2 * H + 32 * jb + 4 * cq) * 4);
         const floatx4 bt = LDS(floatx4, LE_VEC + (3 * H + 32 * jb + 4 * cq) * 4);
         const float T3 = 1.0f / inv_T;
-        floatx4 xq = bld4(srd_x, v_xoff, 0);   // rows of block b0 - 2 + 2 ... the first tick's block (clamped below)
+        floatx4 xq = bld4(srd_x, v_xoff, 0);   // rows of the first tick's block
         auto tick = [&](auto par_c, int t) {
             constexpr int PAR = decltype(par_c)::value, P3 = 1 - PAR;
             const int x = b0 + t;
@@ -811,7 +814,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader
             lds_barrier();
         };
 #pragma unroll 1
-        for (int t = -2; t <= nb + 2; t += 2) {
+        for (int t = 0; t <= nb + 2; t += 2) {   // ticks 0 .. nb + 2 (one more when nb is even: it drains like the one before it)
             tick(even, t);
             tick(odd, t + 1);
         }
@@ -829,7 +832,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader
             lds_barrier();
         };
 #pragma unroll 1
-        for (int t = -2; t <= nb + 2; t += 2) {
+        for (int t = 0; t <= nb + 2; t += 2) {   // ticks 0 .. nb + 2 (one more when nb is even: it drains like the one before it)
             tick(even, t);
             tick(odd, t + 1);
         }
@@ -858,7 +861,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader
             lds_barrier();
         };
 #pragma unroll 1
-        for (int t = -2; t <= nb + 2; t += 2) {
+        for (int t = 0; t <= nb + 2; t += 2) {   // ticks 0 .. nb + 2 (one more when nb is even: it drains like the one before it)
             tick(even, t);
             tick(odd, t + 1);
         }
