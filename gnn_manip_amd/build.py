@@ -21,14 +21,14 @@ if os.environ.get("GM_DEV_KERNELS") == "1":
 
 
 def source_digest():
-    """sha256 (first 16 hex digits) over the kernel sources: profiles/<tag>_traffic.json records the digest of the build its PMC
+    """sha256 (first 16 hex digits) over the sources of the kernels whose HBM traffic is recorded: profiles/<tag>_traffic.json records the digest of the build its PMC
     passes ran, and bench.py reports the measured traffic only while it still matches the tree."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(CSRC, f), "rb").read())
+    # the processor edge kernels whose traffic is recorded, and what they include (host-side files do not change a kernel)
+    for f in ("common.h", "hedge.h", "hedge.hip", "hmlp.h", "hmlp.hip", "hmma_dev.h", "mlp.h"):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -828,7 +828,8 @@ int gm_rollout(const gm_model* m, float* obs, int64_t n, const gm_feature_desc* 
     gm::DevGuard dev_guard(obs);
     GM_REQUIRE(m && obs && fd && ws, GM_ERR_INVALID_ARGUMENT, "gm_rollout: null pointer");
     GM_REQUIRE(steps >= 0 && n_targets >= 0 && n_rigid >= 0, GM_ERR_INVALID_ARGUMENT, "gm_rollout: negative count");
-    GM_REQUIRE(rigid_targets || n_targets == 0, GM_ERR_INVALID_ARGUMENT, "gm_rollout: n_targets > 0 without rigid_targets");
+    // a scene without rigid rows has an empty trajectory ([steps, 0, 3]: a null pointer); the reference's loop runs on it unchanged
+    GM_REQUIRE(rigid_targets || n_targets == 0 || n_rigid == 0, GM_ERR_INVALID_ARGUMENT, "gm_rollout: n_targets > 0 without rigid_targets");
     GM_REQUIRE(!rigid_targets || rigid_rank, GM_ERR_INVALID_ARGUMENT, "gm_rollout: rigid_targets need rigid_rank");
     hipStream_t hs = (hipStream_t)stream;
     const size_t frame = (size_t)n * fd->data_dim;

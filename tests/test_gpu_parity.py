@@ -373,6 +373,24 @@ def test_rollout_vs_oracle_whole_state(dev):
     assert eng.status() > 0
 
 
+@pytest.mark.parametrize("n,side,seed", [(3, 0.01, 301), (40, 0.03, 302), (33, 0.4, 303), (1000, 0.35, 304), (777, 0.06, 305)])
+def test_rollout_small_and_ragged_scenes(dev, n, side, seed):
+    """The systolic kernels (edge encoder + processor edge MLP of the rollout path) on edge lists that are not whole blocks:
+    a handful of particles (one partial block, most workgroups idle), isolated particles (self edges only, every segment one
+    row long), a sparse scene, and a dense one whose last block is ragged -- two steps against the oracle's rollout."""
+    from gnn_manip_amd import RolloutEngine, scene
+    obs = scene.make_scene(n, seed=seed, side=side)
+    traj = scene.rigid_drift_trajectory(obs, 2)
+    params = orc.init_params(25, 4, 3, 128, 2, 3, seed)
+    m = _model(params, (25, 4, 3, 128, 2, 3), dev)
+    eng = RolloutEngine(m, _ga(), n, device=dev)
+    with torch.no_grad():
+        final = eng.rollout(_t(obs, dev), _t(traj, dev), horizon=2).cpu().numpy()
+    ref = orc.rollout(params, obs, traj, 2, STATS, BOUNDS, 0.015, CART, MAT, CTRL, 2, 3)
+    assert np.isfinite(final).all() and eng.status() >= n   # at least the self edges
+    np.testing.assert_allclose(final[:, :, 2:8], ref[:, :, 2:8], rtol=0, atol=5e-6)
+
+
 # ------------------------------------------------------------------ batches of scenes (candidates)
 def test_batched_radius_graph_is_block_diagonal(dev, golden):
     """collate_utils.py:68-87: a batch is the graphs side by side, indices offset by N*i -- no cross edges."""
