@@ -80,7 +80,7 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8];
 #define HEDGE_VAR 0   // development builds: structural variants under A/B test (bit meanings at their use)
 #endif
 #ifndef HEDGE_ROT0
-#define HEDGE_ROT0 0   // role 0 runs its MFMAs at the top of the tick and prepares the next block's accumulators behind them
+#define HEDGE_ROT0 1   // role 0 runs its MFMAs at the top of the tick and prepares the next block's accumulators behind them
 #endif
 #ifndef HEDGE_PSPREAD
 #define HEDGE_PSPREAD 0   // role 0 issues its P-row requests between its first MFMAs instead of before them
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         // ------------------------------------------------------------------ role 1
         floatx16 acc;
         int rng = 0;
-        floatx4 er[EPI_SPLIT];              // e rows (row-major quads, rows 8 j + rr) of block x-3 for the residual
+        floatx4 er[EPI_SPLIT + 1];          // e rows (row-major quads, rows 8 j + rr) of block x-3 for the residual
         int st_a = e0, cnt_a = 0, st_b = e0, cnt_b = 0;  // blocks x-3, x-2
         int2 bi_c = a_blk[b0];                          // raw table entry of block x-1 (decoded a tick after its load)
         const float res_w = a_residual ? 1.f : 0.f;
