@@ -122,8 +122,9 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(PackJobs J, float* __re
 }
 
 __global__ void __launch_bounds__(256) vec_batch_kernel(VecJobs J, float* __restrict__ base) {
-    const VecJob j = J.job[blockIdx.x];
-    for (int i = threadIdx.x; i < max(j.count, j.zero_to); i += blockDim.x) base[j.dst_off + i] = i < j.count ? j.src[i] : 0.f;
+    const VecJob j = J.job[blockIdx.x];   // blockIdx.y: slice of the tensor (a weight matrix is 16k .. 49k floats: not one workgroup's job)
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < max(j.count, j.zero_to); i += gridDim.y * blockDim.x)
+        base[j.dst_off + i] = i < j.count ? j.src[i] : 0.f;
 }
 
 int launch_pack_batch(const PackJobs& jobs, float* base32, float* base16, hipStream_t s) {
@@ -135,7 +136,7 @@ int launch_pack_batch(const PackJobs& jobs, float* base32, float* base16, hipStr
 
 int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s) {
     if (jobs.n <= 0) return GM_OK;
-    hipLaunchKernelGGL(vec_batch_kernel, dim3(jobs.n), dim3(256), 0, s, jobs, base);
+    hipLaunchKernelGGL(vec_batch_kernel, dim3(jobs.n, 16), dim3(256), 0, s, jobs, base);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
