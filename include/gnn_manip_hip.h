@@ -15,6 +15,11 @@
  *     synchronising, unless documented otherwise;
  *   - return value: GM_OK (0) or a negative gm_status; gm_last_error() returns a thread-local
  *     message for the last failure.  Nothing throws or aborts across this boundary.
+ *   - threading / streams: the stateless entry points are re-entrant.  A gm_model handle is NOT: it packs its inference
+ *     operand images lazily, on the stream of the first inference call after gm_model_create / gm_model_update, so one
+ *     handle is used from one thread and its update and inference calls go to ONE stream (or the caller orders the
+ *     streams itself); use one handle per thread / stream otherwise (the reference's callers are single-threaded on one
+ *     stream: rollout_utils.py:97-102, train_dyn.py:45-72).
  */
 #ifndef GNN_MANIP_HIP_H
 #define GNN_MANIP_HIP_H
