@@ -274,7 +274,9 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
         rec = {"value": world * candidates * steps / el, "unit": "rollout steps/s", "steps": steps, "warmup": warmup,
                "ms_per_step": el / steps * 1e3,
                "config": {"workload": wl["name"], "n_particles": wl["n"], "hidden": wl["hidden"], "edges_last_step": edges, "k_steps": 6,
-                          "candidates_per_gpu": candidates, "parallelism": f"candidate-parallel x{world}"},
+                          "candidates_per_gpu": candidates, "parallelism": f"candidate-parallel x{world}",
+                          "particle_ids": "random (scene.make_scene); the engine renumbers its working copy in grid-cell order per run() call, "
+                                          "inside the timed region" if eng.renumber else "random (scene.make_scene), used as given"},
                "roofline": roof, "breakdown": br, "collective_ms": coll * 1e3}
     return rec, (model, obs_np, stats, scene, ek)
 

@@ -391,6 +391,47 @@ def test_rollout_small_and_ragged_scenes(dev, n, side, seed):
     np.testing.assert_allclose(final[:, :, 2:8], ref[:, :, 2:8], rtol=0, atol=5e-6)
 
 
+def test_renumbered_rollout_matches_the_plain_one_and_the_oracle(dev):
+    """RolloutEngine(renumber=True) runs the rollout on a copy of the state in grid-cell order (default for large scenes) and
+    returns it in the caller's numbering: same graph every step (edge count), the rigid rows follow THEIR scripted poses, the
+    per-step record comes back row for row, and the result is the plain engine's up to the summation order of a node's
+    messages -- both within the oracle bound.  Scrambled particle ids, so the renumbering really moves every row; also as a
+    batch of candidates (each scene keeps its own block of rows) and bit-stable from run to run."""
+    from gnn_manip_amd import RolloutEngine, scene
+    n, steps, b = 1500, 3, 2
+    obs = scene.make_scene(n, seed=311, side=0.09)
+    order = np.random.Generator(np.random.PCG64(312)).permutation(n)
+    obs = np.ascontiguousarray(obs[:, order])                 # rigid rows scattered over the ids
+    rigid = obs[-1, :, 1] == 1
+    traj = scene.rigid_drift_trajectory(obs, steps, seed=313, step_size=3e-4)
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 314)
+    m = _model(params, (25, 4, 3, 128, 2, 10), dev)
+    with torch.no_grad():
+        plain = RolloutEngine(m, _ga(), n, device=dev, renumber=False)
+        f0, r0 = plain.rollout(_t(obs, dev), _t(traj, dev), horizon=steps, record=True)
+        e0 = plain.status()
+        ren = RolloutEngine(m, _ga(), n, device=dev, renumber=True)
+        f1, r1 = ren.rollout(_t(obs, dev), _t(traj, dev), horizon=steps, record=True)
+        e1 = ren.status()
+        f2, r2 = ren.rollout(_t(obs, dev), _t(traj, dev), horizon=steps, record=True)
+    assert ren._perm is not None and not torch.equal(ren._perm, torch.arange(n, device=dev)) and plain._perm is None
+    assert e0 == e1 and ren.n_rigid == plain.n_rigid == int(rigid.sum())
+    assert torch.equal(f1, f2) and torch.equal(r1, r2)
+    f0, r0, f1, r1 = (x.cpu().numpy() for x in (f0, r0, f1, r1))
+    np.testing.assert_array_equal(f1[:, :, :2], obs[:, :, :2])                       # ids and materials stay on their rows
+    np.testing.assert_array_equal(f1[-1, rigid, 2:5], traj[steps - 1])               # every rigid row got its own pose
+    np.testing.assert_allclose(f1[:, :, 2:8], f0[:, :, 2:8], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r1[:, :, 2:8], r0[:, :, 2:8], rtol=0, atol=2e-6)
+    ref = orc.rollout(params, obs, traj, steps, STATS, BOUNDS, 0.015, CART, MAT, CTRL)
+    np.testing.assert_allclose(f1[:, :, 2:8], ref[:, :, 2:8], rtol=0, atol=5e-6)
+    trajs = np.stack([traj, scene.rigid_drift_trajectory(obs, steps, seed=315, step_size=3e-4)])
+    with torch.no_grad():
+        out = RolloutEngine(m, _ga(), n, device=dev, candidates=b, renumber=True).rollout_candidates(_t(obs, dev), _t(trajs, dev)).cpu().numpy()
+        one = ren.rollout(_t(obs, dev), _t(trajs[1], dev), horizon=steps).cpu().numpy()
+    assert np.array_equal(out[0], f1) and np.array_equal(out[1], one)
+    assert RolloutEngine(m, _ga(), RolloutEngine.RENUMBER_MIN_NODES, device=dev).renumber and not RolloutEngine(m, _ga(), 5000, device=dev).renumber
+
+
 # ------------------------------------------------------------------ batches of scenes (candidates)
 def test_batched_radius_graph_is_block_diagonal(dev, golden):
     """collate_utils.py:68-87: a batch is the graphs side by side, indices offset by N*i -- no cross edges."""
