@@ -508,16 +508,27 @@ __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __rest
         if (sub == 0) cnt[qi] = -1;  // general kernel takes this query
         return;
     }
-    for (int a = sub; a < count; a += 8) {
-        const double da = ld[a];
-        const int ja = lj[a];
-        int rank = 0;
+    // rank = number of smaller (d2, index) keys.  A lane keeps four of its elements in registers and walks the list once for all
+    // of them (the list reads are the same address for the 8 lanes of the group: one broadcast per element)
+    for (int a0 = sub; a0 < count; a0 += 32) {
+        double da[4];
+        int ja[4], rank[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + 8 * u;
+            da[u] = a < count ? ld[a] : -1.0;   // d2 >= 0: nothing ranks below a filler, its rank is never used
+            ja[u] = a < count ? lj[a] : 0;
+            rank[u] = 0;
+        }
         for (int f = 0; f < count; ++f) {
             const double df = ld[f];
             const int jf = lj[f];
-            rank += (df < da || (df == da && jf < ja)) ? 1 : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rank[u] += (df < da[u] || (df == da[u] && jf < ja[u])) ? 1 : 0;
         }
-        if (rank < K) nbr[(int64_t)qi * K + rank] = ja;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (a0 + 8 * u < count && rank[u] < K) nbr[(int64_t)qi * K + rank[u]] = ja[u];
     }
     if (sub == 0) cnt[qi] = count < K ? count : K;
 }
@@ -626,18 +637,20 @@ __global__ void __launch_bounds__(256) csr_clear_kernel(CsrHeader* hdr, int* __r
 
 // mode 0: slots of the radius graph (source = query i, destination = neighbour)
 // flow 0: the aggregation node of edge (query i -> neighbour) is the neighbour (edge_index[1]); 1: the query (edge_index[0])
+// The counting pass hands every edge its arrival number within its destination's segment (`slot`), so the fill pass places the
+// edge with plain stores: one atomic per edge instead of two.  (The arrival order is arbitrary; segment_sort_kernel fixes the order.)
 __global__ void __launch_bounds__(256) indeg_graph_kernel(const int* __restrict__ cnt, const int* __restrict__ nbr,
-                                                           int64_t n, int K, int flow, int* __restrict__ indeg) {
+                                                           int64_t n, int K, int flow, int* __restrict__ indeg, int* __restrict__ slot) {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n * K) return;
     int64_t i = id / K;
     if ((int)(id - i * K) >= cnt[i]) return;
-    atomicAdd(&indeg[flow ? (int)i : nbr[id]], 1);
+    slot[id] = atomicAdd(&indeg[flow ? (int)i : nbr[id]], 1);
 }
 
 __global__ void __launch_bounds__(256) fill_graph_kernel(const int* __restrict__ cnt, const int* __restrict__ out_ptr,
                                                           const int* __restrict__ nbr, int64_t n, int K,
-                                                          const int* __restrict__ in_ptr, int* __restrict__ cursor,
+                                                          const int* __restrict__ in_ptr, const int* __restrict__ slot,
                                                           int64_t cap, int flow, int* __restrict__ dst, int* __restrict__ src,
                                                           int* __restrict__ eid, CsrHeader* hdr) {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -646,7 +659,7 @@ __global__ void __launch_bounds__(256) fill_graph_kernel(const int* __restrict__
     int s = (int)(id - i * K);
     if (s >= cnt[i]) return;
     const int d = flow ? (int)i : nbr[id];
-    int p = in_ptr[d] + atomicAdd(&cursor[d], 1);
+    int p = in_ptr[d] + slot[id];
     if (p >= cap) { atomicOr(&hdr->error_flags, ERRF_CAPACITY); return; }
     dst[p] = d;
     src[p] = flow ? nbr[id] : (int)i;
@@ -891,11 +904,12 @@ int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* c
     }
     if (n > 0) {
         unsigned nb = (unsigned)cdiv(cap, 256);
-        hipLaunchKernelGGL(indeg_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.nbr, n, K, flow, c.in_ptr);
+        int* slot = c.sort_tmp;   // [cap]: free until segment_sort_kernel (which runs after the fill) needs it for long segments
+        hipLaunchKernelGGL(indeg_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.nbr, n, K, flow, c.in_ptr, slot);
         int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s, nullptr);
         if (rc != GM_OK) return rc;
         hipLaunchKernelGGL(fill_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.out_ptr, g.nbr, n, K, c.in_ptr,
-                           c.cursor, cap, flow, c.dst, c.src, c.eid, c.hdr);
+                           slot, cap, flow, c.dst, c.src, c.eid, c.hdr);
         hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, pos, pos_stride, conn_r, edge_attr, flow, c.sort_tmp, c.sort_tmp + c.cap);
         GM_LAUNCH_CHECK();
     }

@@ -85,6 +85,9 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8];
 #ifndef HEDGE_PSPREAD
 #define HEDGE_PSPREAD 0   // role 0 issues its P-row requests between its first MFMAs instead of before them
 #endif
+#ifndef HEDGE_XCD
+#define HEDGE_XCD 1
+#endif
 #ifndef HEDGE_NT
 #define HEDGE_NT 0     // non-temporal hint on: 1 the e rows role 0 reads, 2 the residual re-read, 4 the e_out stores
 #endif
@@ -138,6 +141,15 @@ __device__ __forceinline__ intx4 bldi4(srd_t r, unsigned voff, unsigned soff) { 
 __device__ __forceinline__ void bst4(srd_t r, unsigned voff, unsigned soff, floatx4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), r, voff, soff, 0); }
 __device__ __forceinline__ void bst1(srd_t r, unsigned voff, unsigned soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0); }
 // scalar clamp to [0, hi]: written as SALU so that the values that feed a resource stay in scalar registers
+// Workgroups are dealt to the 8 XCDs in turn (workgroup i runs on XCD i % 8), each XCD with its own L2.  The systolic kernels give
+// workgroup i the i-th contiguous range of the destination-sorted edge list; numbered this way, the 32 workgroups of an XCD hold one
+// contiguous eighth of it, so that -- with particle ids in spatial order (RolloutEngine: grid cells, x fastest) -- the workgroups that
+// gather the same neighbouring P rows at the same time (ranges one layer of cells apart advance in step) share an L2.
+__device__ __forceinline__ int xcd_major_wg() {
+    const int g = (int)gridDim.x, i = (int)blockIdx.x;
+    return (HEDGE_XCD && (g & 7) == 0) ? (i & 7) * (g >> 3) + (i >> 3) : i;
+}
+
 __device__ __forceinline__ int s_clamp0(int v, int hi) {
     int r;
     asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, %2" : "=s"(r) : "s"(v), "s"(hi) : "scc");
@@ -261,8 +273,9 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
 #endif
     const int E = a_hdr->n_edges;
     const int nchunks = a_tab->n_groups;   // the workgroup takes a contiguous range of whole groups (4 blocks each)
-    const int c0 = (int)((long long)blockIdx.x * nchunks / gridDim.x);
-    const int c1 = (int)((long long)(blockIdx.x + 1) * nchunks / gridDim.x);
+    const int wg = xcd_major_wg();
+    const int c0 = (int)((long long)wg * nchunks / gridDim.x);
+    const int c1 = (int)((long long)(wg + 1) * nchunks / gridDim.x);
     if (c1 <= c0) return;
     const int b0 = 4 * c0, b1 = 4 * c1;
     const int nb = b1 - b0;
@@ -706,7 +719,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader
     const int role = wave >> 2, jb = wave & 3;
     const int E = a_hdr->n_edges;
     const int nblk = (E + BE - 1) / BE;
-    const int b0 = (int)((long long)blockIdx.x * nblk / gridDim.x), b1 = (int)((long long)(blockIdx.x + 1) * nblk / gridDim.x);
+    const int wg = xcd_major_wg();
+    const int b0 = (int)((long long)wg * nblk / gridDim.x), b1 = (int)((long long)(wg + 1) * nblk / gridDim.x);
     const int nb = b1 - b0;
     if (nb <= 0) return;
     const float inv_T = a_hw[1], cap = a_hw[2];

@@ -8,6 +8,7 @@ encode/process/decode -> Euler integration -> state_post, all enqueued on the cu
 by ``gm_rollout_step`` with no host synchronisation and no PCIe traffic.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -73,6 +74,8 @@ class RolloutEngine:
         self.ws = _ws(L.gm_rollout_workspace_bytes(C.byref(self.mdesc), self.n, self.max_neighbours), self.device)
         self.rigid_rank = None
         self.n_rigid = 0
+        if renumber == "auto" and os.environ.get("GM_RENUMBER") in ("0", "1"):   # A/B runs of the benchmark
+            renumber = os.environ["GM_RENUMBER"] == "1"
         self.renumber = (self.n_per >= self.RENUMBER_MIN_NODES) if renumber == "auto" else bool(renumber)
         self._perm = self._inv = self._rigid_rank_p = self._traj_sel = None
 
