@@ -77,7 +77,10 @@ int layer_stages_b3(int k, int out);      // stages of a Linear with k inputs an
 
 int train_kernels_init();
 int launch_train_fwd(int H, int kind, const TrainFwdArgs& a, hipStream_t s);
-int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s);
+struct WgradBatch;
+// wb != nullptr: the LayerNorm partial sums go to the batch's own region and are reduced by its next flush (one launch with the
+// weight-gradient reductions) instead of a launch of their own -- flush before the next backward chain is launched.
+int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s, WgradBatch* wb = nullptr);
 // Weight gradients: jobs are collected and run a batch per launch pair (GEMM over row chunks + fixed-order reduction).
 //   out[m][col0 + k] += sum_r dz[r][m] * X[xidx ? xidx[r] : r][k];  db[m] += sum_r dz[r][m] (db may be nullptr)
 // A job reads its operands when the batch is FLUSHED: flush before anything overwrites them.
@@ -95,13 +98,21 @@ constexpr int kWgJobsMax = 8;
 struct WgJobs {
     int n;
     WgJob job[kWgJobsMax];
+    // LayerNorm parameter gradients of the backward chain that ran since the last flush (ln_G = 0: none):
+    // dgamma[c] += sum_g ln_part[g][c], dbeta[c] += sum_g ln_part[g][H + c]
+    const float* ln_part;
+    int ln_G, ln_H;
+    float* dgamma;
+    float* dbeta;
 };
 struct WgradBatch {
     WgJobs jobs{};
-    float* part = nullptr;   // wgrad_partial_floats(H) floats
-    size_t cap = 0, used = 0;
+    float* part = nullptr;   // wgrad_partial_floats(H) floats: weight-gradient partials, then the LayerNorm region
+    size_t cap = 0;          // floats of the weight-gradient part
     hipStream_t stream = nullptr;
+    float* ln_region() const { return part + cap; }
 };
+void wgrad_batch_init(WgradBatch& b, float* part, int H, hipStream_t s);
 size_t wgrad_partial_floats(int H);
 int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X, int ldx, int K, const int* xidx, int64_t rows, float* out,
                   int ldw, int col0, float* db);

@@ -523,6 +523,9 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
 struct WgRaw {
     float a0[8], a1[8], b0[8], b1[8];
 };
+typedef __amdgpu_buffer_rsrc_t wg_srd_t;
+__device__ __forceinline__ wg_srd_t wg_make_srd(const void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000); }
+__device__ __forceinline__ float wg_ld(wg_srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
 
 template <bool HAS_IDX>
 __device__ __forceinline__ void wgrad_body(const WgJob& J, float* __restrict__ part) {
@@ -545,29 +548,43 @@ __device__ __forceinline__ void wgrad_body(const WgJob& J, float* __restrict__ p
     // columns past M / K read a clamped (valid) column: their products land in partial entries nobody reads
     const int mc0 = min(m0 + i, M - 1), mc1 = min(m0 + 32 + i, M - 1), kc0 = min(k0 + i, K - 1), kc1 = min(k0 + 32 + i, K - 1);
     float bs0 = 0.f, bs1 = 0.f;  // column sums of dz (bias gradient), kept by the waves of k-block 0
+    // Buffer addressing: a resource per operand that covers exactly the chunk's rows (a read past them returns 0: the chunk's last,
+    // partial step needs no masking), a lane-constant byte offset (row 8 hi of the step, column), and a SCALAR offset per row of
+    // the step -- no per-lane 64-bit address arithmetic in the loop (it was a quarter of the loop's vector instructions).
+    const int rows_c = r_end - r_begin;
+    const wg_srd_t srd_z = wg_make_srd(dz + (size_t)r_begin * ldz, (unsigned)rows_c * (unsigned)ldz * 4u);
+    const wg_srd_t srd_x = wg_make_srd(HAS_IDX ? X : X + (size_t)r_begin * ldx, HAS_IDX ? 0xffffffffu : (unsigned)rows_c * (unsigned)ldx * 4u);
+    const unsigned vz0 = (unsigned)(8 * hi * ldz + mc0) * 4u, vz1 = (unsigned)(8 * hi * ldz + mc1) * 4u;
+    const unsigned vx0 = (unsigned)(8 * hi * ldx + kc0) * 4u, vx1 = (unsigned)(8 * hi * ldx + kc1) * 4u;
     auto load = [&](WgRaw& o, int r0) {
-        int64_t rz[8], rx[8];
+        const unsigned rr = (unsigned)(r0 - r_begin);   // wave-uniform
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            rz[e] = min(r0 + 8 * hi + e, r_end - 1);
-            rx[e] = HAS_IDX ? xidx[rz[e]] : rz[e];
+            const unsigned sz = (rr + e) * (unsigned)ldz * 4u;
+            o.a0[e] = wg_ld(srd_z, vz0, sz);
+            o.a1[e] = wg_ld(srd_z, vz1, sz);
         }
+        if (HAS_IDX) {
+            // gathered X rows (encoder inputs in the caller's edge order): per-lane row, 32-bit byte offsets; a row past the chunk
+            // reads row index r_end - 1's -- its dz is zero
+            unsigned xo[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float* zr = dz + rz[e] * ldz;
-            const float* xr = X + rx[e] * ldx;
-            o.a0[e] = zr[mc0];
-            o.a1[e] = zr[mc1];
-            o.b0[e] = xr[kc0];
-            o.b1[e] = xr[kc1];
+            for (int e = 0; e < 8; ++e) xo[e] = (unsigned)xidx[min(r0 + 8 * hi + e, r_end - 1)] * (unsigned)ldx * 4u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o.b0[e] = wg_ld(srd_x, xo[e] + (unsigned)kc0 * 4u, 0);
+                o.b1[e] = wg_ld(srd_x, xo[e] + (unsigned)kc1 * 4u, 0);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned sx = (rr + e) * (unsigned)ldx * 4u;
+                o.b0[e] = wg_ld(srd_x, vx0, sx);
+                o.b1[e] = wg_ld(srd_x, vx1, sx);
+            }
         }
     };
-    auto fma = [&](WgRaw& o, int r0) {
-        if (r0 + 16 > r_end) {   // the chunk's last, partial step (wave-uniform; no loads inside): rows past the end count as zero
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (r0 + 8 * hi + e >= r_end) { o.a0[e] = 0.f; o.a1[e] = 0.f; }
-        }
+    auto fma = [&](WgRaw& o, int) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bs0 += o.a0[e]; bs1 += o.a1[e]; }
         const Bf3 a0 = split_bf3(o.a0), b0 = split_bf3(o.b0);
@@ -628,13 +645,41 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_kernel(WgJobs Js, float* __r
     else wgrad_body<false>(J, part);
 }
 
+// sum over g = g0, g0 + 8, g0 + 16, ... < G of p[g * stride]: four loads in flight (the reduction kernels are a chain of dependent
+// L2 round trips otherwise), four accumulators combined in a fixed order -- the result depends on G only, not on timing
+__device__ __forceinline__ float strided_sum4(const float* __restrict__ p, size_t stride, int g0, int G) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = g0;
+    for (; g + 24 < G; g += 32) {
+        const float v0 = p[(size_t)g * stride], v1 = p[(size_t)(g + 8) * stride], v2 = p[(size_t)(g + 16) * stride], v3 = p[(size_t)(g + 24) * stride];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; g < G; g += 8) s0 += p[(size_t)g * stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // out[m][col0 + k] += sum_g part[g][m][k]; db[m] += sum_g partb[g][m].  32 outputs x 8 partial groups per
 // workgroup, fixed summation order (deterministic).  grid (max outputs / 32, jobs)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgJobs Js, const float* __restrict__ part_all) {
-    const WgJob& J = Js.job[blockIdx.y];
     __shared__ float red[8][33];
     const int tid = threadIdx.x, i = tid & 31, gg = tid >> 5;
     const int o = blockIdx.x * 32 + i;
+    if ((int)blockIdx.y == Js.n) {   // the LayerNorm parameter gradients of the last backward chain (fixed order: deterministic)
+        const int H = Js.ln_H;
+        if ((int)blockIdx.x * 32 >= 2 * H) return;
+        const float s = o < 2 * H ? strided_sum4(Js.ln_part + o, (size_t)2 * H, gg, Js.ln_G) : 0.f;
+        red[gg][i] = s;
+        __syncthreads();
+        if (gg == 0 && o < 2 * H) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q][i];
+            if (o < H) Js.dgamma[o] += t;
+            else Js.dbeta[o - H] += t;
+        }
+        return;
+    }
+    const WgJob& J = Js.job[blockIdx.y];
     const int M = J.M, K = J.K, Mp = J.Mp, Kp = J.Kp, G = J.G;
     const int nw = M * K, total = nw + (J.db ? M : 0);
     if ((int)blockIdx.x * 32 >= total) return;
@@ -643,10 +688,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgJobs Js, const floa
     float s = 0.f;
     if (o < nw) {
         const int m = o / K, k = o % K;
-        for (int g = gg; g < G; g += 8) s += part[((size_t)g * Mp + m) * Kp + k];
+        s = strided_sum4(part + (size_t)m * Kp + k, (size_t)Mp * Kp, gg, G);
     } else if (o < total) {
-        const int m = o - nw;
-        for (int g = gg; g < G; g += 8) s += partb[(size_t)g * Mp + m];
+        s = strided_sum4(partb + (o - nw), (size_t)Mp, gg, G);
     }
     red[gg][i] = s;
     __syncthreads();
@@ -810,9 +854,15 @@ static int device_cus() {
 size_t train_bwd_ln_part_floats(int H) { return (size_t)2 * 1024 * 2 * H; }   // workgroups of a backward launch: <= 2 per CU
 
 template <int H>
-static int launch_train_bwd_h(int kind, const TrainBwdArgs& a, hipStream_t s) {
+static int launch_train_bwd_h(int kind, const TrainBwdArgs& a_in, hipStream_t s, WgradBatch* wb) {
     const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4 + (size_t)4 * 2 * H * 4;
-    int grid = grid_tiles(a.rows);
+    int grid = grid_tiles(a_in.rows);
+    TrainBwdArgs a = a_in;
+    const bool batched = wb && a.ln_part && a.dgamma && a.dbeta;
+    if (batched) {
+        GM_REQUIRE(wb->jobs.ln_G == 0 && wb->jobs.n == 0, GM_ERR_INVALID_ARGUMENT, "launch_train_bwd: flush the weight-gradient batch first");
+        a.ln_part = wb->ln_region();
+    }
     const bool ln = a.ln_part && (kind == TB_ENC || kind == TB_EDGE || kind == TB_NODE);
     if (ln) {
         // as many workgroups as are resident at once, each walking its tiles: one partial row of the LayerNorm parameter sums each
@@ -827,44 +877,67 @@ static int launch_train_bwd_h(int kind, const TrainBwdArgs& a, hipStream_t s) {
         case TB_PROJ: hipLaunchKernelGGL((train_bwd_kernel<H, TB_PROJ>), dim3(grid), dim3(THREADS), lds, s, a); break;
         default: hipLaunchKernelGGL((train_bwd_kernel<H, TB_DEC>), dim3(grid), dim3(THREADS), lds, s, a); break;
     }
-    if (ln && a.dgamma && a.dbeta) hipLaunchKernelGGL(ln_grads_reduce_kernel, dim3(2 * H / 32), dim3(256), 0, s, a.ln_part, grid, H, a.dgamma, a.dbeta);
+    if (ln && batched) {
+        wb->jobs.ln_part = a.ln_part; wb->jobs.ln_G = grid; wb->jobs.ln_H = H; wb->jobs.dgamma = a.dgamma; wb->jobs.dbeta = a.dbeta;
+    } else if (ln && a.dgamma && a.dbeta) {
+        hipLaunchKernelGGL(ln_grads_reduce_kernel, dim3(2 * H / 32), dim3(256), 0, s, a.ln_part, grid, H, a.dgamma, a.dbeta);
+    }
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
-int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s) {
+int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s, WgradBatch* wb) {
     if (a.rows <= 0) return GM_OK;
-    return H == 64 ? launch_train_bwd_h<64>(kind, a, s) : H == 128 ? launch_train_bwd_h<128>(kind, a, s) : launch_train_bwd_h<256>(kind, a, s);
+    return H == 64 ? launch_train_bwd_h<64>(kind, a, s, wb) : H == 128 ? launch_train_bwd_h<128>(kind, a, s, wb) : launch_train_bwd_h<256>(kind, a, s, wb);
 }
 
-// Workgroups per job: about 512 (two per CU) for the edge-sized ones; chunks are multiples of 16 rows (one MFMA step), at least 64 rows.
-static int wgrad_chunk(int64_t rows, int tiles) {
-    int64_t want = 512 / tiles;
-    if (want < 1) want = 1;
-    int64_t c = cdiv(rows, want);
-    if (c < 64) c = 64;
-    return (int)(cdiv(c, 16) * 16);
-}
+// Row chunks of a batch.  All jobs of a flush share one chunk length, chosen so that the whole batch is two rounds of resident
+// workgroups (two per CU at a time: 194 VGPRs): every workgroup does the same share of the batch's rows, and the partial tiles the
+// reduction reads are a third of what 512 chunks per job made them (measured at 2 x N = 5k: one round 99, two 102.4, three 101.8,
+// four 100.0, six 98.0 training steps/s).  Chunks are multiples of 16 rows (one MFMA step), at least 64 rows.
 static size_t wgrad_job_floats(int G, int Mp, int Kp) { return (size_t)G * Mp * Kp + (size_t)G * Mp; }
+constexpr int kWgSlotsMax = 1024;   // resident workgroups the sizing may assume (the partial buffer is sized for it)
 size_t wgrad_partial_floats(int H) {
-    // every job: G * tiles <= 512 + tiles, i.e. at most (512 + 4) 128 x 128 tiles + the bias partials; ln_grads shares the buffer
-    (void)H;
-    return (size_t)kWgJobsMax * ((size_t)(512 + 4) * 128 * 128 + (size_t)(512 + 4) * 256);
+    // a flush: sum over jobs of G * tiles <= kWgSlotsMax + kWgJobsMax * 4 tiles of 128 x 128 + the bias partials; then the LayerNorm region
+    return ((size_t)kWgSlotsMax + kWgJobsMax * 4) * (128 * 128 + 128) + train_bwd_ln_part_floats(H);
+}
+void wgrad_batch_init(WgradBatch& b, float* part, int H, hipStream_t s) {
+    b.part = part;
+    b.cap = wgrad_partial_floats(H) - train_bwd_ln_part_floats(H);
+    b.stream = s;
+    b.jobs.n = 0;
+    b.jobs.ln_G = 0;
 }
 
 int wgrad_flush(WgradBatch& b) {
-    if (b.jobs.n <= 0) return GM_OK;
-    int maxG = 1, maxT = 1, maxO = 1;
-    for (int q = 0; q < b.jobs.n; ++q) {
-        const WgJob& j = b.jobs.job[q];
-        maxG = j.G > maxG ? j.G : maxG;
-        maxT = j.tiles > maxT ? j.tiles : maxT;
-        const int total = j.M * j.K + (j.db ? j.M : 0);
-        maxO = total > maxO ? total : maxO;
+    if (b.jobs.n <= 0 && b.jobs.ln_G <= 0) return GM_OK;
+    int maxG = 1, maxT = 1, maxO = b.jobs.ln_G > 0 ? 2 * b.jobs.ln_H : 1;
+    if (b.jobs.n > 0) {
+        int slots = 4 * device_cus();
+        if (slots > kWgSlotsMax) slots = kWgSlotsMax;
+        int64_t work = 0;
+        for (int q = 0; q < b.jobs.n; ++q) work += (int64_t)b.jobs.job[q].rows * b.jobs.job[q].tiles;
+        int64_t chunk = cdiv(cdiv(work, slots), 16) * 16;
+        if (chunk < 64) chunk = 64;
+        auto total = [&](int64_t c) { int64_t t = 0; for (int q = 0; q < b.jobs.n; ++q) t += cdiv(b.jobs.job[q].rows, c) * b.jobs.job[q].tiles; return t; };
+        while (total(chunk) > slots) chunk += 16;    // the ceilings of the jobs' last chunks: a few steps at most
+        size_t used = 0;
+        for (int q = 0; q < b.jobs.n; ++q) {
+            WgJob& j = b.jobs.job[q];
+            j.chunk = (int)chunk;
+            j.G = (int)cdiv(j.rows, chunk);
+            j.part_off = used;
+            used += wgrad_job_floats(j.G, j.Mp, j.Kp);
+            maxG = j.G > maxG ? j.G : maxG;
+            maxT = j.tiles > maxT ? j.tiles : maxT;
+            const int outs = j.M * j.K + (j.db ? j.M : 0);
+            maxO = outs > maxO ? outs : maxO;
+        }
+        GM_REQUIRE(used <= b.cap, GM_ERR_WORKSPACE, "wgrad: partial buffer too small (%zu > %zu floats)", used, b.cap);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(maxG, maxT, b.jobs.n), dim3(THREADS), 0, b.stream, b.jobs, b.part);
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(maxG, maxT, b.jobs.n), dim3(THREADS), 0, b.stream, b.jobs, b.part);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(maxO, 32), b.jobs.n), dim3(256), 0, b.stream, b.jobs, b.part);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(maxO, 32), b.jobs.n + (b.jobs.ln_G > 0 ? 1 : 0)), dim3(256), 0, b.stream, b.jobs, b.part);
     b.jobs.n = 0;
-    b.used = 0;
+    b.jobs.ln_G = 0;
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -877,17 +950,12 @@ int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X
     j.ldz = ldz; j.M = M; j.ldx = ldx; j.K = K; j.rows = (int)rows; j.ldw = ldw; j.col0 = col0;
     j.Mp = (int)cdiv(M, 128) * 128; j.Kp = (int)cdiv(K, 128) * 128;
     j.KT = j.Kp / 128; j.tiles = (j.Mp / 128) * j.KT;
-    j.chunk = wgrad_chunk(rows, j.tiles);
-    j.G = (int)cdiv(rows, j.chunk);
-    const size_t need = wgrad_job_floats(j.G, j.Mp, j.Kp);
-    GM_REQUIRE(need <= b.cap, GM_ERR_WORKSPACE, "wgrad: partial buffer too small (%zu > %zu floats)", need, b.cap);
-    if (b.jobs.n == kWgJobsMax || b.used + need > b.cap) {
+    GM_REQUIRE(j.tiles <= 4, GM_ERR_UNSUPPORTED, "wgrad: a %d x %d weight block (at most 4 tiles of 128 x 128 per job)", M, K);
+    if (b.jobs.n == kWgJobsMax) {
         const int rc = wgrad_flush(b);
         if (rc != GM_OK) return rc;
     }
-    j.part_off = b.used;
-    b.used += need;
-    b.jobs.job[b.jobs.n++] = j;
+    b.jobs.job[b.jobs.n++] = j;   // chunk, G and the partial offset are set when the batch is flushed
     return GM_OK;
 }
 

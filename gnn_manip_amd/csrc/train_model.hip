@@ -272,7 +272,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands
-    wb.part = b.part; wb.cap = wgrad_partial_floats(H); wb.stream = s;
+    wgrad_batch_init(wb, b.part, H, s);
     CsrWs c = carve_csr(t.csr_dst, n, e);
     CsrWs c2 = carve_csr(t.csr_src, n, e);
     const int PM = tensors_per_normed_mlp(NL);
@@ -361,7 +361,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             a.tape = t.tn[k]; a.ln_g = ln_gamma(m->v_node[k]); a.wstream = b.packT + b.off_node[k];
             a.ln_part = b.part; a.dgamma = grads[b_node(k) + 2 * (NL + 1)]; a.dbeta = grads[b_node(k) + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
             rc = wgrad_flush(wb);
-        if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s, &wb);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_node(k), t.tn[k], n);
             wgrad(b.dzl(1), H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ch * H, grads[b_node(k) + 1]);
@@ -374,7 +374,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             a.tape = t.te[k]; a.ln_g = ln_gamma(m->v_edge[k]); a.wstream = b.packT + b.off_edge[k];
             a.ln_part = b.part; a.dgamma = grads[b_edge(k) + 2 * (NL + 1)]; a.dbeta = grads[b_edge(k) + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.de; a.residual = 1;
             rc = wgrad_flush(wb);
-        if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s, &wb);
             if (rc != GM_OK) return rc;
             normed_tail_grads(b_edge(k), t.te[k], e);
             wgrad(b.dzl(1), H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, m->ce * H, grads[b_edge(k) + 1]);
@@ -394,7 +394,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         a.wstream = b.packT + b.off_enc_node;
         a.ln_part = b.part; a.dgamma = grads[b_enc_node + 2 * (NL + 1)]; a.dbeta = grads[b_enc_node + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = wgrad_flush(wb);
-        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s, &wb);
         if (rc != GM_OK) return rc;
         normed_tail_grads(b_enc_node, t.en, n);
         wgrad(b.dzl(1), H, H, nodes, m->d.node_dim, m->d.node_dim, nullptr, n, grads[b_enc_node], m->d.node_dim, 0, grads[b_enc_node + 1]);
@@ -405,7 +405,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         a.rows = (int)e; a.dY = b.de; a.tape = t.ee; a.ln_g = ln_gamma(m->v_enc_edge); a.wstream = b.packT + b.off_enc_edge;
         a.ln_part = b.part; a.dgamma = grads[b_enc_edge + 2 * (NL + 1)]; a.dbeta = grads[b_enc_edge + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = wgrad_flush(wb);
-        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s, &wb);
         if (rc != GM_OK) return rc;
         normed_tail_grads(b_enc_edge, t.ee, e);
         wgrad(b.dzl(1), H, H, edge_attr, m->d.edge_dim, m->d.edge_dim, c.eid, e, grads[b_enc_edge], m->d.edge_dim, 0, grads[b_enc_edge + 1]);
@@ -479,7 +479,7 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands
-    wb.part = b.part; wb.cap = wgrad_partial_floats(H); wb.stream = s;
+    wgrad_batch_init(wb, b.part, H, s);
     const size_t U = (size_t)m->T_HH * kStageFloatsB3;
     PackTJobs jobs;
     jobs.n = 0;
@@ -507,7 +507,7 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
         a.dx_in = dxin; a.k1 = k1;
         a.ln_part = b.part; a.dgamma = grads[base + 2 * (NL + 1)]; a.dbeta = grads[base + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
         rc = wgrad_flush(wb);
-        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s, &wb);
         for (int l = NL; l >= 1 && rc == GM_OK; --l)
             rc = wgrad_enqueue(wb, b.dzl(l + 1), H, H, tp.a + (size_t)(l - 1) * rows * H, H, H, nullptr, rows, grads[base + 2 * l], H, 0,
                               grads[base + 2 * l + 1]);
@@ -595,7 +595,7 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands
-    wb.part = b.part; wb.cap = wgrad_partial_floats(H); wb.stream = s;
+    wgrad_batch_init(wb, b.part, H, s);
     CsrWs c = carve_csr(t.csr_dst, n, e);
     CsrWs c2 = carve_csr(t.csr_src, n, e);
     const size_t U = (size_t)m->T_HH * kStageFloatsB3;
@@ -627,7 +627,7 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         a.rows = (int)n; a.dY = dh_out; a.tape = t.tn; a.ln_g = m->vec + m->v_node[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_node[0];
         a.ln_part = b.part; a.dgamma = grads[bn + 2 * (NL + 1)]; a.dbeta = grads[bn + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = b.dh; a.dagg_out = b.dagg;
         rc = wgrad_flush(wb);
-        if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s, &wb);
         if (rc != GM_OK) return rc;
         for (int l = NL; l >= 1; --l) wgrad(b.dzl(l + 1), t.tn.a + (size_t)(l - 1) * n * H, n, grads[bn + 2 * l], H, 0, grads[bn + 2 * l + 1]);
         wgrad(b.dzl(1), h, n, grads[bn], 2 * H, m->ch * H, grads[bn + 1]);
@@ -640,7 +640,7 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         a.ln_g = m->vec + m->v_edge[k] + (size_t)(NL + 1) * H; a.wstream = b.packT + b.off_edge[0];
         a.ln_part = b.part; a.dgamma = grads[be + 2 * (NL + 1)]; a.dbeta = grads[be + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx = de_in; a.dxidx = c.eid; a.residual = 0;
         rc = wgrad_flush(wb);
-        if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s);
+        if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s, &wb);
         if (rc != GM_OK) return rc;
         for (int l = NL; l >= 1; --l) wgrad(b.dzl(l + 1), t.te.a + (size_t)(l - 1) * e * H, e, grads[be + 2 * l], H, 0, grads[be + 2 * l + 1]);
         if (rc == GM_OK) rc = wgrad_enqueue(wb, b.dzl(1), H, H, e_in, H, H, c.eid, e, grads[be], 3 * H, m->ce * H, grads[be + 1]);
