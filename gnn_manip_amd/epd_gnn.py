@@ -251,6 +251,20 @@ class DstCsr:
         check(lib().gm_csr_num_edges(ptr(self.ws), C.byref(e), current_stream()))
         return int(e.value)
 
+    def watch(self, pinned_row):
+        """Queue an asynchronous copy of the header (n_edges, error_flags, flow, pad) into a pinned int32 row behind the work
+        enqueued so far; ``poll`` then tells without blocking whether it has arrived and whether a flag is set."""
+        self._host = pinned_row
+        self._host.copy_(self.ws[:16].view(torch.int32), non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+
+    def poll(self):
+        """None: still in flight; False: finished clean; True: finished with an error flag (``validate`` raises it)."""
+        if not self._event.query():
+            return None
+        return int(self._host[1]) != 0
+
 
 def padded_hidden(hidden):
     """Width the kernels run a model of this hidden size at (gm_padded_hidden_size): sizes up to 256 are zero-padded to
@@ -518,12 +532,12 @@ class EncProcDecGNN(nn.Module):
             _check_edge_index(edge_index, n, e)
             return _EpdTrainFunction.apply(self, nodes, edge_attr, edge_index, *params)
         if self.auto_status:
-            # the PREVIOUS inference forward of this model: a device-side error of it (edge_index entry out of range, fp16
-            # split range exceeded) surfaces here at the latest -- a reference-style caller never calls status() itself.
-            # One header read-back; by now that forward has normally finished.  (model.auto_status = False opts out.)
-            prev, self._last_csr = getattr(self, "_last_csr", None), None
-            if prev is not None:
-                prev.validate()
+            # EARLIER inference forwards of this model: a device-side error (edge_index entry out of range, fp16 split range
+            # exceeded) of one that has FINISHED surfaces here -- a reference-style caller never calls status() itself.
+            # Nothing blocks: every forward leaves an asynchronous copy of its CSR header in pinned memory behind it, and
+            # this only looks at the copies that have arrived; a forward still in flight is looked at by a later call, or by
+            # status().  (A loop over forward() keeps queueing work ahead of the GPU.  model.auto_status = False opts out.)
+            self._reap_watched(block=False)
         h = self.device_handle(nodes.device)
         csr = DstCsr(edge_index, n, flow=self.convention[0])
         L = lib()
@@ -533,13 +547,45 @@ class EncProcDecGNN(nn.Module):
         check(L.gm_epd_forward(h, ptr(nodes), n, ptr(edge_attr), 0, ptr(csr.ws), e, ptr(out), ptr(fwd),
                                fwd.numel(), current_stream()))
         # no synchronisation here: an out-of-range edge_index entry is dropped by the destination sort and flagged in the
-        # CSR header, like a value outside the fp16 split range; status() -- or the next forward -- reports it
+        # CSR header, like a value outside the fp16 split range; status() -- or a later forward -- reports it
         self._last_csr = csr
+        if self.auto_status:
+            self._watch(csr)
         return out
+
+    _WATCH_SLOTS = 8
+
+    def _watch(self, csr):
+        w = self.__dict__.setdefault("_watched", [])
+        if "_watch_pin" not in self.__dict__ or self._watch_pin.device != torch.device("cpu"):
+            self._watch_pin, self._watch_next = torch.zeros((self._WATCH_SLOTS, 4), dtype=torch.int32).pin_memory(), 0
+        if len(w) >= self._WATCH_SLOTS:   # every pinned row in use: the oldest forward is waited for (a loop 8 forwards ahead of the GPU)
+            self._reap_watched(block=True, at_most=1)
+        csr.watch(self._watch_pin[self._watch_next])
+        self._watch_next = (self._watch_next + 1) % self._WATCH_SLOTS
+        w.append(csr)
+
+    def _reap_watched(self, block, at_most=None):
+        w = self.__dict__.get("_watched", [])
+        done = 0
+        while w and (at_most is None or done < at_most):
+            r = w[0].poll()
+            if r is None:
+                if not block:
+                    break
+                w[0]._event.synchronize()
+                r = w[0].poll()
+            csr = w.pop(0)
+            done += 1
+            if r:
+                if csr is getattr(self, "_last_csr", None):
+                    self._last_csr = None    # reported once
+                csr.validate()               # raises the library's message for the flag
 
     def status(self):
         """Checks the last inference forward (synchronises): raises GMError if its edge_index held an entry outside
         [0, n_nodes) -- such edges were left out --, else returns its edge count."""
+        self._reap_watched(block=True)       # earlier forwards first: the oldest error is the one reported
         csr = getattr(self, "_last_csr", None)
         if csr is None:
             return 0

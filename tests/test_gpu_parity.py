@@ -177,6 +177,18 @@ def test_bad_edge_index_raises(dev):
         m.forward(torch.zeros(3, 25, device=dev), torch.zeros(3, 4, device=dev), ei)
     with pytest.raises(GMError, match="out of range"):
         m.status()
+    # the check never blocks: a loop may run ahead of the GPU (more forwards than the engine has pinned header rows), and an
+    # error inside the loop is reported by a later forward or by status() at the latest
+    with torch.no_grad():
+        for _ in range(11):
+            m.forward(torch.zeros(3, 25, device=dev), torch.zeros(2, 4, device=dev), ei[:, :2].contiguous())
+    assert m.status() == 2 and not m._watched
+    with torch.no_grad(), pytest.raises(GMError, match="out of range"):
+        m.forward(torch.zeros(3, 25, device=dev), torch.zeros(3, 4, device=dev), ei)
+        for _ in range(11):
+            m.forward(torch.zeros(3, 25, device=dev), torch.zeros(2, 4, device=dev), ei[:, :2].contiguous())
+        m.status()
+    assert m.status() in (0, 2)     # reported once
     # opting out restores the fire-and-forget behaviour: nothing is checked until status()
     m.auto_status = False
     with torch.no_grad():
