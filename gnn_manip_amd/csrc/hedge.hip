@@ -59,11 +59,13 @@ constexpr int SYS_THREADS = 768;
 #ifdef HEDGE_STAMPS
 // development build only: s_memtime stamps of the three roles (workgroup 0, waves jb = 0, lane 0) at the phase boundaries of
 // ticks 16..47; read back with gm_debug_sys_stamps (tools/sys_stamps.py)
-__device__ unsigned long long g_sys_stamps[3 * 32 * 8];
+__device__ unsigned long long g_sys_stamps[3 * 32 * 8 + 32];   // + the 100 MHz s_memrealtime at the start of role 0's ticks
 #define SYS_STAMP(tick, slot)                                                                                         \
     do {                                                                                                              \
-        if (blockIdx.x == 0 && jb == 0 && lane0 == 0 && (tick) >= 16 && (tick) < 48)                                  \
+        if (blockIdx.x == 0 && jb == 0 && lane0 == 0 && (tick) >= 16 && (tick) < 48) {                                \
             g_sys_stamps[(role * 32 + (tick) - 16) * 8 + (slot)] = __builtin_readcyclecounter();                     \
+            if (role == 0 && (slot) == 0) g_sys_stamps[3 * 32 * 8 + (tick) - 16] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                             \
     } while (0)
 #else
 #define SYS_STAMP(tick, slot) do { } while (0)
@@ -1224,8 +1226,8 @@ int zero_edge_pad_rows(const CsrHeader* hdr, float* e, int row_floats, hipStream
 }
 
 #ifdef HEDGE_STAMPS
-extern "C" int gm_debug_sys_stamps(unsigned long long* out) {   // 3 roles x 32 ticks x 8 slots, development builds only
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sys_stamps), sizeof(unsigned long long) * 3 * 32 * 8) == hipSuccess ? 0 : -1;
+extern "C" int gm_debug_sys_stamps(unsigned long long* out) {   // 3 roles x 32 ticks x 8 slots + 32 real-time stamps, development builds only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sys_stamps), sizeof(unsigned long long) * (3 * 32 * 8 + 32)) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -35,9 +35,14 @@ L = _lib.lib()
 if not hasattr(L, "gm_debug_sys_stamps"):
     raise SystemExit("this library was not built with -DHEDGE_STAMPS")
 L.gm_debug_sys_stamps.restype = C.c_int
-buf = (C.c_ulonglong * (3 * 256))()
+buf = (C.c_ulonglong * (3 * 256 + 32))()
 assert L.gm_debug_sys_stamps(buf) == 0
-st_all = np.array(buf, dtype=np.int64).reshape(3, 32, 8)
+st_all = np.array(buf, dtype=np.int64)[:768].reshape(3, 32, 8)
+real = np.array(buf, dtype=np.int64)[768:]   # s_memrealtime (100 MHz) at the start of role 0's ticks 16 .. 47
+if real[0] > 0 and real[31] > real[0]:
+    cyc, sec = st_all[0, 31, 0] - st_all[0, 0, 0], (real[31] - real[0]) / 100e6
+    print(f"31 ticks: {cyc} s_memtime counts in {sec * 1e6:.2f} us of s_memrealtime -> {cyc / sec / 1e9:.3f} G counts/s "
+          f"({sec / 31 * 1e6:.3f} us per tick)")
 NAMES = [
     ["wait for the P rows + sum -> staging tile", "requests (P rows, indices) + tile -> accumulators", "24 MFMAs (Linear 1)",
      "ReLU + split -> image X1", "-", "wait at the tick barrier"],
