@@ -142,6 +142,9 @@ __device__ __forceinline__ void report_range(int bad, int* flags) {
 //   im : image of the wave's first row block at k-group 0, + lane  (row-block stride img_ksn * 128, k-group stride 128)
 // nrb: row blocks of this wave that hold rows (the others' MFMAs are skipped: the last tile of a workgroup's range may be partial;
 // a branch-free copy of the loop for full tiles was measured: -4 %, it costs registers the kernels do not have)
+#ifndef HM_SHORT_TILE_ROWS
+#define HM_SHORT_TILE_ROWS 1
+#endif
 #ifndef HM_RING4
 #define HM_RING4(RBW) ((RBW) == 1)
 #endif
@@ -638,8 +641,12 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
         const int nrb = (nbt - rg + C::NRG - 1) / C::NRG;           // ... of which this wave's row group holds (image slots rb < nrb)
         // first row of image slot rbg = RBW rg' + rb': tile block j = rb' NRG + rg'
         auto slot_row0 = [&](int rbg) { return 32 * (bt + (rbg % RBW) * C::NRG + rbg / RBW); };
+        // image slots of a short tile that hold no block (tile block j >= nbt) are filled from the tile's FIRST block instead of from
+        // the rows that follow the workgroup's range: same instructions (no branch around a load), but cache hits instead of HBM
+        // rows nobody uses -- the last, short tile of a workgroup then costs what its blocks cost
         auto row_of = [&](int rbg, int nn) -> long long {
-            const int r = slot_row0(rbg) + nn;
+            const int j = (rbg % RBW) * C::NRG + rbg / RBW;
+            const int r = (HM_SHORT_TILE_ROWS && j >= nbt ? 32 * bt : slot_row0(rbg)) + nn;
             return r < N ? r : N - 1;
         };
         __syncthreads();   // the previous tile's readers of the image are done
