@@ -40,8 +40,9 @@ class RolloutEngine:
     stats, bounds and the column indices, exactly like ``dataset.graph_attr`` in the reference.
     """
 
-    # run() renumbers the particles of scenes at least this large in grid-cell order (see set_scene)
+    # run() renumbers the particles of scenes at least this large in grid-cell order, again every RENUMBER_EVERY steps
     RENUMBER_MIN_NODES = 20000
+    RENUMBER_EVERY = 64
 
     def __init__(self, model, graph_attr, n_nodes, k_steps=6, data_dim=None, max_neighbours=20, device="cuda:0",
                  candidates=1, renumber="auto"):
@@ -50,8 +51,10 @@ class RolloutEngine:
         the offset rule of collate_utils.py:76), everything else is per node / per edge.
 
         renumber: True / False / "auto" (scenes of RENUMBER_MIN_NODES particles or more).  ``run`` then works on a copy of
-        the state whose rows are in grid-cell order, so that the per-edge gathers of neighbouring rows find each other
-        in cache, and writes the result back in the caller's numbering.  A radius graph does not depend on the numbering
+        the state whose rows are in grid-cell order (cells of edge conn_r, x fastest; particles of a cell in index order:
+        a stable sort, the same every time), so that the per-edge gathers of neighbouring rows find each other in cache,
+        re-sorts it every RENUMBER_EVERY steps (particles move a fraction of a cell per step) and writes the result back
+        in the caller's numbering.  A radius graph does not depend on the numbering
         (neighbours are ranked by distance; only an exact tie in distance falls back on the index) and every per-node /
         per-edge function is numbering-free, so what changes is the order in which a node's incoming messages are
         summed: float32 rounding, far inside the 1e-5 parity bound."""
@@ -77,7 +80,6 @@ class RolloutEngine:
         if renumber == "auto" and os.environ.get("GM_RENUMBER") in ("0", "1"):   # A/B runs of the benchmark
             renumber = os.environ["GM_RENUMBER"] == "1"
         self.renumber = (self.n_per >= self.RENUMBER_MIN_NODES) if renumber == "auto" else bool(renumber)
-        self._perm = self._inv = self._rigid_rank_p = self._traj_sel = None
 
     def _rank_rigid(self, obs):
         rank = torch.empty(self.n, dtype=torch.int32, device=self.device)
@@ -86,28 +88,22 @@ class RolloutEngine:
         return rank, cnt
 
     def set_scene(self, obs):
-        """Classify rigid rows (material == 1, rollout_utils.py:20) once per scene; with ``renumber`` also fix the
-        scene's grid-cell order (cells of edge conn_r, x fastest; particles of a cell in index order -- a stable sort,
-        the same every time) from the last frame.  Particles move a fraction of a cell per step, so the order chosen
-        here serves the whole rollout."""
+        """Classify rigid rows (material == 1, rollout_utils.py:20) once per scene."""
         _need_cuda(obs, "obs")
         assert obs.shape == (self.k, self.n, self.data_dim) and obs.dtype == torch.float32 and obs.is_contiguous()
         self.rigid_rank, cnt = self._rank_rigid(obs)
         self.n_rigid = int(cnt.item())
-        self._perm = None
-        if self.renumber and self.n > 0:
-            c0 = self.graph_attr.cartesian_idx[0]
-            pos = torch.nan_to_num(obs[-1, :, c0:c0 + 3], nan=0.0, posinf=0.0, neginf=0.0)
-            cell = torch.floor((pos - pos.amin(0)) / float(self.graph_attr.conn_r)).clamp_(0, 1023).long()
-            key = (cell[:, 2] * 1024 + cell[:, 1]) * 1024 + cell[:, 0]
-            key += (torch.arange(self.n, device=self.device) // self.n_per) << 30     # scenes of a batch stay apart, in order
-            self._perm = torch.argsort(key, stable=True)
-            self._inv = torch.empty_like(self._perm)
-            self._inv[self._perm] = torch.arange(self.n, device=self.device)
-            self._rigid_rank_p, _ = self._rank_rigid(obs.index_select(1, self._perm))
-            r = self.rigid_rank.long()[self._perm]
-            self._traj_sel = r[r >= 0]        # renumbered rigid row j follows the caller's scripted pose _traj_sel[j]
         return self.n_rigid
+
+    def _cell_order(self, state):
+        """Permutation that puts the rows of ``state`` [k, N, D] in grid-cell order of its last frame (scenes of a batch stay
+        apart, in order); a stable sort of integer keys: the same state gives the same order every time."""
+        c0 = self.graph_attr.cartesian_idx[0]
+        pos = torch.nan_to_num(state[-1, :, c0:c0 + 3], nan=0.0, posinf=0.0, neginf=0.0)
+        cell = torch.floor((pos - pos.amin(0)) / float(self.graph_attr.conn_r)).clamp_(0, 1023).long()
+        key = (cell[:, 2] * 1024 + cell[:, 1]) * 1024 + cell[:, 0]
+        key += (torch.arange(self.n, device=self.device) // self.n_per) << 30
+        return torch.argsort(key, stable=True)
 
     def _check_state(self, obs, rigid_target, pred_out, use_rigid):
         """The C entry takes raw pointers: shapes, dtypes and devices are checked here."""
@@ -155,17 +151,34 @@ class RolloutEngine:
                 raise ValueError(f"trajectory must be contiguous float32 [T, {self.n_rigid}, 3] on {self.device}, got {tuple(trajectory.shape)}")
         recs = torch.empty((steps, self.n, self.data_dim), dtype=torch.float32, device=self.device) if record else None
         handle = self.model.device_handle(self.device)  # resolved once per rollout
-        state, rank, traj = obs, self.rigid_rank, trajectory
-        if self._perm is not None:   # the rollout runs on the renumbered copy (set_scene)
-            state = obs.index_select(1, self._perm)
-            rank = self._rigid_rank_p
-            traj = None if trajectory is None else trajectory.index_select(1, self._traj_sel)
-        check(lib().gm_rollout(handle, ptr(state), self.n, C.byref(self.fdesc), self.max_neighbours, ptr(rank),
-                               ptr(traj), T, self.n_rigid, steps, ptr(recs), ptr(self.ws), self.ws.numel(), current_stream()))
-        if self._perm is not None:
-            torch.index_select(state, 1, self._inv, out=obs)
-            if recs is not None:
-                recs = recs.index_select(1, self._inv)
+        L = lib()
+        if not (self.renumber and self.n > 0 and steps > 0):
+            check(L.gm_rollout(handle, ptr(obs), self.n, C.byref(self.fdesc), self.max_neighbours, ptr(self.rigid_rank),
+                               ptr(trajectory), T, self.n_rigid, steps, ptr(recs), ptr(self.ws), self.ws.numel(), current_stream()))
+            return recs
+        # renumbered: chunks of RENUMBER_EVERY steps on a copy in cell order; `total` maps its rows to the caller's
+        state, total = obs, None
+        for s0 in range(0, steps, self.RENUMBER_EVERY):
+            k = min(self.RENUMBER_EVERY, steps - s0)
+            q = self._cell_order(state)
+            state = state.index_select(1, q)
+            total = q if total is None else total.index_select(0, q)
+            rank, _ = self._rank_rigid(state)
+            t_k = max(0, min(T, s0 + k) - s0)
+            traj = None
+            if t_k > 0:
+                r = self.rigid_rank.long().index_select(0, total)
+                traj = trajectory[s0:s0 + t_k].index_select(1, r[r >= 0])   # renumbered rigid row j follows the caller's pose r[j]
+            rec_k = None if recs is None else recs[s0:s0 + k]
+            check(L.gm_rollout(handle, ptr(state), self.n, C.byref(self.fdesc), self.max_neighbours, ptr(rank),
+                               ptr(traj), t_k, self.n_rigid, k, ptr(rec_k), ptr(self.ws), self.ws.numel(), current_stream()))
+            if rec_k is not None:
+                inv = torch.empty_like(total)
+                inv[total] = torch.arange(self.n, device=self.device)
+                rec_k.copy_(rec_k.index_select(1, inv))
+        inv = torch.empty_like(total)
+        inv[total] = torch.arange(self.n, device=self.device)
+        torch.index_select(state, 1, inv, out=obs)
         return recs
 
     def rollout_candidates(self, obs0, trajectories, horizon=None):

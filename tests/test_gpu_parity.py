@@ -404,8 +404,8 @@ def test_rollout_small_and_ragged_scenes(dev, n, side, seed):
 
 
 def test_renumbered_rollout_matches_the_plain_one_and_the_oracle(dev):
-    """RolloutEngine(renumber=True) runs the rollout on a copy of the state in grid-cell order (default for large scenes) and
-    returns it in the caller's numbering: same graph every step (edge count), the rigid rows follow THEIR scripted poses, the
+    """RolloutEngine(renumber=True) runs the rollout on a copy of the state in grid-cell order (default for large scenes), re-sorted
+    every RENUMBER_EVERY steps, and returns it in the caller's numbering: same graph every step (edge count), the rigid rows follow THEIR scripted poses, the
     per-step record comes back row for row, and the result is the plain engine's up to the summation order of a node's
     messages -- both within the oracle bound.  Scrambled particle ids, so the renumbering really moves every row; also as a
     batch of candidates (each scene keeps its own block of rows) and bit-stable from run to run."""
@@ -423,10 +423,12 @@ def test_renumbered_rollout_matches_the_plain_one_and_the_oracle(dev):
         f0, r0 = plain.rollout(_t(obs, dev), _t(traj, dev), horizon=steps, record=True)
         e0 = plain.status()
         ren = RolloutEngine(m, _ga(), n, device=dev, renumber=True)
+        ren.RENUMBER_EVERY = 2                                # three steps = a chunk of two and one of one: the re-sort path too
         f1, r1 = ren.rollout(_t(obs, dev), _t(traj, dev), horizon=steps, record=True)
         e1 = ren.status()
         f2, r2 = ren.rollout(_t(obs, dev), _t(traj, dev), horizon=steps, record=True)
-    assert ren._perm is not None and not torch.equal(ren._perm, torch.arange(n, device=dev)) and plain._perm is None
+    assert ren.renumber and not plain.renumber
+    assert not torch.equal(ren._cell_order(_t(obs, dev)), torch.arange(n, device=dev))
     assert e0 == e1 and ren.n_rigid == plain.n_rigid == int(rigid.sum())
     assert torch.equal(f1, f2) and torch.equal(r1, r2)
     f0, r0, f1, r1 = (x.cpu().numpy() for x in (f0, r0, f1, r1))
@@ -438,8 +440,14 @@ def test_renumbered_rollout_matches_the_plain_one_and_the_oracle(dev):
     np.testing.assert_allclose(f1[:, :, 2:8], ref[:, :, 2:8], rtol=0, atol=5e-6)
     trajs = np.stack([traj, scene.rigid_drift_trajectory(obs, steps, seed=315, step_size=3e-4)])
     with torch.no_grad():
-        out = RolloutEngine(m, _ga(), n, device=dev, candidates=b, renumber=True).rollout_candidates(_t(obs, dev), _t(trajs, dev)).cpu().numpy()
+        eng_b = RolloutEngine(m, _ga(), n, device=dev, candidates=b, renumber=True)
+        eng_b.RENUMBER_EVERY = 2
+        out = eng_b.rollout_candidates(_t(obs, dev), _t(trajs, dev)).cpu().numpy()
         one = ren.rollout(_t(obs, dev), _t(trajs[1], dev), horizon=steps).cpu().numpy()
+        # a horizon beyond the scripted poses (the rigid body then stays where it is: traj_utils.py:126-134), cut by a chunk boundary
+        long_p = plain.rollout(_t(obs, dev), _t(traj[:1], dev), horizon=steps).cpu().numpy()
+        long_r = ren.rollout(_t(obs, dev), _t(traj[:1], dev), horizon=steps).cpu().numpy()
+    np.testing.assert_allclose(long_r[:, :, 2:8], long_p[:, :, 2:8], rtol=0, atol=2e-6)
     assert np.array_equal(out[0], f1) and np.array_equal(out[1], one)
     assert RolloutEngine(m, _ga(), RolloutEngine.RENUMBER_MIN_NODES, device=dev).renumber and not RolloutEngine(m, _ga(), 5000, device=dev).renumber
 
