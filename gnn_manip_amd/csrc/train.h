@@ -121,6 +121,9 @@ size_t train_bwd_ln_part_floats(int H);   // size of TrainBwdArgs.ln_part
 int launch_pack_b3_batch(const PackTJobs& jobs, float* base, hipStream_t s);
 int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows, const float* scale, const float* shift, float* out,
                        int64_t n, hipStream_t s);
+// two segment sums over the same rows in one launch (out2 = sums over ptr2 / perm2; scale / shift apply to both)
+int launch_segment_sum_pair(int H, const int* ptr, const int* perm, const int* ptr2, const int* perm2, const float* rows, const float* scale,
+                            const float* shift, float* out, float* out2, int64_t n, hipStream_t s);
 int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_t s);
 
 enum : int { TK_ENC_EDGE = 0, TK_ENC_NODE = 1, TK_PROC_EDGE = 2, TK_PROC_NODE = 3, TK_DEC = 4, TK_PROJ = 5 };   // TK_PROJ: out [N][2H] = h [W_i | W_j]^T + [b1 | 0]

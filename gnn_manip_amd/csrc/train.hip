@@ -762,7 +762,10 @@ __global__ void __launch_bounds__(256) pack_b3_batch_kernel(PackTJobs J, float* 
 template <int W>
 __global__ void __launch_bounds__(256) segment_sum_kernel(const int* __restrict__ ptr, const int* __restrict__ perm,
                                                            const float* __restrict__ rows, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, float* __restrict__ out, int n) {
+                                                           const float* __restrict__ shift, float* __restrict__ out, int n,
+                                                           const int* __restrict__ ptr2, const int* __restrict__ perm2, float* __restrict__ out2) {
+    // blockIdx.y = 1: the second sum of a pair over the same rows (the per-destination and per-source sums of dz1: one launch)
+    if (blockIdx.y) { ptr = ptr2; perm = perm2; out = out2; }
     // One wave per node.  A row is read as 16-byte pieces (H / 4 lanes per row, so a wave step covers 64 / (H / 4) rows and every
     // request is a whole line), two steps in flight; the partial sums of the row slots are added in a fixed order at the end
     // (round 4: the 8-byte-per-lane form ran at 0.6 of this rate).  One order of additions: bit-reproducible.
@@ -971,15 +974,19 @@ int launch_pack_b3_batch(const PackTJobs& jobs, float* base, hipStream_t s) {
     return GM_OK;
 }
 
-int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows, const float* scale, const float* shift, float* out,
-                       int64_t n, hipStream_t s) {
+int launch_segment_sum_pair(int H, const int* ptr, const int* perm, const int* ptr2, const int* perm2, const float* rows, const float* scale,
+                            const float* shift, float* out, float* out2, int64_t n, hipStream_t s) {
     if (n <= 0) return GM_OK;
-    const unsigned grid = (unsigned)cdiv(n, 4);
-    if (H == 64) hipLaunchKernelGGL((segment_sum_kernel<1>), dim3(grid), dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n);
-    else if (H == 128) hipLaunchKernelGGL((segment_sum_kernel<2>), dim3(grid), dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n);
-    else hipLaunchKernelGGL((segment_sum_kernel<4>), dim3(grid), dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n);
+    const dim3 grid((unsigned)cdiv(n, 4), out2 ? 2 : 1);
+    if (H == 64) hipLaunchKernelGGL((segment_sum_kernel<1>), grid, dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n, ptr2, perm2, out2);
+    else if (H == 128) hipLaunchKernelGGL((segment_sum_kernel<2>), grid, dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n, ptr2, perm2, out2);
+    else hipLaunchKernelGGL((segment_sum_kernel<4>), grid, dim3(256), 0, s, ptr, perm, rows, scale, shift, out, (int)n, ptr2, perm2, out2);
     GM_LAUNCH_CHECK();
     return GM_OK;
+}
+int launch_segment_sum(int H, const int* ptr, const int* perm, const float* rows, const float* scale, const float* shift, float* out,
+                       int64_t n, hipStream_t s) {
+    return launch_segment_sum_pair(H, ptr, perm, nullptr, nullptr, rows, scale, shift, out, nullptr, n, s);
 }
 
 int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_t s) {

@@ -380,8 +380,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             wgrad(b.dzl(1), H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, m->ce * H, grads[b_edge(k) + 1]);
             if (rc != GM_OK) return rc;
             // node-level sums of dz1: everything the factorised layer 1 needs
-            rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dzl(1), nullptr, nullptr, b.Gi, n, s);
-            if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dzl(1), nullptr, nullptr, b.Gj, n, s);
+            rc = launch_segment_sum_pair(H, c.in_ptr, nullptr, c2.in_ptr, c2.eid, b.dzl(1), nullptr, nullptr, b.Gi, b.Gj, n, s);
             wgrad(b.Gi, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, m->ci * H, nullptr);
             wgrad(b.Gj, H, H, t.h[k], H, H, nullptr, n, grads[b_edge(k)], 3 * H, m->cj * H, nullptr);
             if (rc != GM_OK) return rc;
@@ -646,8 +645,7 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
         if (rc == GM_OK) rc = wgrad_enqueue(wb, b.dzl(1), H, H, e_in, H, H, c.eid, e, grads[be], 3 * H, m->ce * H, grads[be + 1]);
         if (rc != GM_OK) return rc;
     }
-    rc = launch_segment_sum(H, c.in_ptr, nullptr, b.dzl(1), nullptr, nullptr, b.Gi, n, s);
-    if (rc == GM_OK) rc = launch_segment_sum(H, c2.in_ptr, c2.eid, b.dzl(1), nullptr, nullptr, b.Gj, n, s);
+    rc = launch_segment_sum_pair(H, c.in_ptr, nullptr, c2.in_ptr, c2.eid, b.dzl(1), nullptr, nullptr, b.Gi, b.Gj, n, s);
     wgrad(b.Gi, h, n, grads[be], 3 * H, m->ci * H, nullptr);
     wgrad(b.Gj, h, n, grads[be], 3 * H, m->cj * H, nullptr);
     if (rc != GM_OK) return rc;
