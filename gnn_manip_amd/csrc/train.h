@@ -31,6 +31,10 @@ struct TrainFwdArgs {
     float* out;            // [rows][H]; decoder: [rows][out_dim]
     int residual;          // processor: out = y + x_in
     int out_dim;
+    // node MLPs (encoder, processor): tail that projects the new h for the NEXT edge step's factorised layer 1,
+    // P_out [N][2H] = [h W_i^T + proj_bias | h W_j^T]; its two H x H images follow the MLP's in `wstream`.  nullptr: no tail.
+    float* P_out;
+    const float* proj_bias;
 };
 
 struct TrainBwdArgs {

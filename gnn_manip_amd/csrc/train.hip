@@ -285,10 +285,11 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
     WStream ws;
     ws.base = A.wstream;
     ws.ring = ring;
+    const bool proj_tail = (KIND == TK_ENC_NODE || KIND == TK_PROC_NODE) && A.P_out != nullptr;
     ws.total = KIND == TK_ENC_EDGE ? 1 + NL * SL
-             : KIND == TK_ENC_NODE ? (2 * NJB + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS + NL * SL
+             : KIND == TK_ENC_NODE ? (2 * NJB + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS + NL * SL + (proj_tail ? 2 * SL : 0)
              : KIND == TK_PROC_EDGE ? (NL + 1) * SL
-             : KIND == TK_PROC_NODE ? (NL + 2) * SL
+             : KIND == TK_PROC_NODE ? (NL + 2) * SL + (proj_tail ? 2 * SL : 0)
              : KIND == TK_PROJ ? 2 * SL
                                    : NL * SL + (H / 16 + B3_STAGE_GROUPS - 1) / B3_STAGE_GROUPS;
     ws.cur = 0;
@@ -368,6 +369,18 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
             const int64_t orow = KIND == TK_PROC_EDGE && A.rowidx ? (int64_t)A.rowidx[pc] : pc;
             if ((KIND == TK_PROC_EDGE || KIND == TK_PROC_NODE) && A.residual) add_feat(acc, A.x_in + orow * H, hi);
             if (valid) store_feat(acc, A.out + orow * H, hi);
+            if ((KIND == TK_ENC_NODE || KIND == TK_PROC_NODE) && proj_tail) {
+                // the next edge step's factorised layer 1 on the rows still in registers: P = [h W_i^T + b1 | h W_j^T]
+                // (what the inference node kernels' tail does; it was a launch of its own that re-read h)
+#pragma unroll
+                for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
+                load_feat(acc, A.proj_bias, hi);
+                run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
+                if (valid) store_feat(acc, A.P_out + pc * (2 * H), hi);
+                zero_feat(acc);
+                run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
+                if (valid) store_feat(acc, A.P_out + pc * (2 * H) + H, hi);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -205,19 +205,12 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
         a.rows = (int)n; a.x_in = nodes; a.k1 = m->d.node_dim; a.wstream = m->packed_t3 + m->t_enc_node;
         normed(a, m->v_enc_node);
         a.tape = t.en; a.out = t.h[0];
+        // tail: P = h_0 [W_i | W_j]^T (+ b1) of the first edge step -- the projection section that follows this MLP in its stream
+        a.P_out = t.P; a.proj_bias = m->vec + m->v_edge[0];
         rc = launch_train_fwd(H, TK_ENC_NODE, a, s);
         if (rc != GM_OK) return rc;
     }
     for (int k = 0; k < M; ++k) {
-        // P = h_k [W_i | W_j]^T (+ b1): the projection section of the preceding node stream
-        {
-            TrainFwdArgs pa{};   // P = [h W_i^T + b1 | h W_j^T] of this step's edge MLP
-            pa.rows = (int)n; pa.x_in = t.h[k]; pa.bias = m->vec + m->v_edge[k]; pa.out = t.P; pa.nl = NL;
-            pa.wstream = k == 0 ? m->packed_t3 + m->t_enc_node + (size_t)(m->T_n0 + NL * m->T_HH) * kStageFloatsB3
-                                : m->packed_t3 + m->t_node[k - 1] + (size_t)(NL + 2) * U;
-            rc = launch_train_fwd(H, TK_PROJ, pa, s);
-        }
-        if (rc != GM_OK) return rc;
         const float* ve = mlp_vec(m, m->v_edge[k]);
         {
             TrainFwdArgs a{};
@@ -235,6 +228,7 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
             a.rows = (int)n; a.x_in = t.h[k]; a.agg = t.agg[k]; a.wstream = m->packed_t3 + m->t_node[k];
             normed(a, m->v_node[k]);
             a.tape = t.tn[k]; a.out = t.h[k + 1]; a.residual = 1;
+            if (k + 1 < M) { a.P_out = t.P; a.proj_bias = m->vec + m->v_edge[k + 1]; }   // tail: the next edge step's P (after the decoder's h_M: none)
             rc = launch_train_fwd(H, TK_PROC_NODE, a, s);
             if (rc != GM_OK) return rc;
         }
