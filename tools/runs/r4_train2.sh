@@ -1,5 +1,5 @@
 #!/bin/bash
-for sl in 512 1024 1536 2048 3072 512 1536; do
+for sl in 512 640 768 1024 512 768 1024; do
 GM_WGRAD_SLOTS=$sl python - <<'PY'
 import os, torch, sys
 sys.path.insert(0, "/root/repo")
