@@ -56,6 +56,7 @@ PROTOTYPES = {
     "gm_csr_from_graph_flow": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp]),
     "gm_csr_from_edge_index_flow": (_i32, [_vp, _i64, _i64, _i32, _vp, _sz, _vp]),
     "gm_csr_num_edges": (_i32, [_vp, C.POINTER(_i64), _vp]),
+    "gm_csr_header_status": (_i32, [_vp, C.POINTER(_i64)]),
     "gm_edge_features": (_i32, [_vp, _i64, _vp, _vp, _i64, _f32, _vp, _vp]),
     "gm_edge_features_csr": (_i32, [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp]),
     "gm_node_features": (_i32, [_vp, _i64, _FD, _vp, _vp]),

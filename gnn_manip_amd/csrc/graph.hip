@@ -679,11 +679,20 @@ __global__ void __launch_bounds__(256) indeg_ei_kernel(const int64_t* __restrict
 __global__ void __launch_bounds__(256) fill_ei_kernel(const int64_t* __restrict__ ei, int64_t n, int64_t e, int flow,
                                                        const int* __restrict__ in_ptr, int* __restrict__ cursor,
                                                        int* __restrict__ dst, int* __restrict__ src,
-                                                       int* __restrict__ eid) {
+                                                       int* __restrict__ eid, CsrHeader* hdr) {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= e) return;
     int64_t s = ei[flow ? e + id : id], d = ei[flow ? id : e + id];
-    if (s < 0 || s >= n || d < 0 || d >= n) return;
+    if (s < 0 || s >= n || d < 0 || d >= n) {
+        // An edge with an index out of range is left out (flagged by the counting pass).  Its place is one of the slots past the
+        // E valid edges: it gets VALID indices there (node 0, its own edge id), so that a caller that walks all `e` slots with its
+        // host-side count -- the training kernels -- stays inside every array; what it computes for a flagged forward is not used.
+        const int p = (int)e - 1 - atomicAdd(&hdr->pad, 1);
+        dst[p] = 0;
+        src[p] = 0;
+        eid[p] = (int)id;
+        return;
+    }
     int p = in_ptr[d] + atomicAdd(&cursor[d], 1);
     dst[p] = (int)d;
     src[p] = (int)s;
@@ -942,12 +951,25 @@ int gm_csr_from_edge_index_flow(const int64_t* ei, int64_t n, int64_t e, int flo
         hipLaunchKernelGGL(indeg_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, flow, c.in_ptr, c.hdr);
         int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s, nullptr);
         if (rc != GM_OK) return rc;
-        hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, flow, c.in_ptr, c.cursor, c.dst, c.src, c.eid);
+        hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, flow, c.in_ptr, c.cursor, c.dst, c.src, c.eid, c.hdr);
     }
     if (n > 0)
         hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0, c.sort_tmp, c.sort_tmp + c.cap);
     GM_LAUNCH_CHECK();
     return build_edge_blocks(c.in_ptr, c.dst, n, e, nullptr, (int)n, carve_edge_blocks(c.blocks, n, e), s);
+}
+
+int gm_csr_header_status(const int32_t* header_host, int64_t* n_edges_host) {
+    GM_REQUIRE(header_host, GM_ERR_INVALID_ARGUMENT, "gm_csr_header_status: null pointer");
+    CsrHeader h;
+    memcpy(&h, header_host, sizeof(h));
+    if (n_edges_host) *n_edges_host = h.n_edges;
+    GM_REQUIRE(!(h.error_flags & ERRF_BAD_EDGE_INDEX), GM_ERR_DATA, "edge_index entry out of range [0, n_nodes)");
+    GM_REQUIRE(!(h.error_flags & ERRF_CAPACITY), GM_ERR_DATA, "edge capacity exceeded");
+    GM_REQUIRE(!(h.error_flags & ERRF_SPLIT_RANGE), GM_ERR_DATA,
+               "fp16 split range exceeded: a feature, latent or hidden activation of the last forward over this edge structure reached "
+               "|x| >= 65504 in a matrix-pipe operand image (include/gnn_manip_hip.h, numeric domain); its results are not valid");
+    return GM_OK;
 }
 
 int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream) {
@@ -956,13 +978,7 @@ int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream) {
     CsrHeader h;
     GM_HIP_CHECK(hipMemcpyAsync(&h, csr_ws, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
     GM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    *n_edges_host = h.n_edges;
-    GM_REQUIRE(!(h.error_flags & ERRF_BAD_EDGE_INDEX), GM_ERR_DATA, "edge_index entry out of range [0, n_nodes)");
-    GM_REQUIRE(!(h.error_flags & ERRF_CAPACITY), GM_ERR_DATA, "edge capacity exceeded");
-    GM_REQUIRE(!(h.error_flags & ERRF_SPLIT_RANGE), GM_ERR_DATA,
-               "fp16 split range exceeded: a feature, latent or hidden activation of the last forward over this edge structure reached "
-               "|x| >= 65504 in a matrix-pipe operand image (include/gnn_manip_hip.h, numeric domain); its results are not valid");
-    return GM_OK;
+    return gm_csr_header_status(reinterpret_cast<const int32_t*>(&h), n_edges_host);
 }
 
 }  // extern "C"

@@ -148,11 +148,11 @@ def _wants_grad(params, *inputs):
     return torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(t.requires_grad for t in inputs))
 
 
-def _check_edge_index(edge_index, n, e):
+def _check_edge_index(edge_index, n, e, ranges=True):
     _need_cuda(edge_index, "edge_index")
     if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.shape[1] != e:
         raise ValueError("edge_index must be int64 [2, E]")
-    if e and (int(edge_index.min()) < 0 or int(edge_index.max()) >= n):
+    if ranges and e and (int(edge_index.min()) < 0 or int(edge_index.max()) >= n):   # two blocking reductions
         raise ValueError("edge_index entry out of range [0, n_nodes)")
 
 
@@ -251,19 +251,31 @@ class DstCsr:
         check(lib().gm_csr_num_edges(ptr(self.ws), C.byref(e), current_stream()))
         return int(e.value)
 
-    def watch(self, pinned_row):
-        """Queue an asynchronous copy of the header (n_edges, error_flags, flow, pad) into a pinned int32 row behind the work
-        enqueued so far; ``poll`` then tells without blocking whether it has arrived and whether a flag is set."""
+
+
+class _HeaderWatch:
+    """Asynchronous look at the 16-byte header (n_edges, error flags, flow, left-out edges) at the start of a csr workspace -- or of a
+    training tape, which begins with one: the copy into a pinned int32 row is queued behind the work enqueued so far, ``poll``
+    tells without blocking whether it has arrived and whether a flag is set, ``check`` raises the library's message for it
+    (gm_csr_header_status: no device access).  The workspace itself is not kept alive."""
+
+    def __init__(self, ws, pinned_row):
         self._host = pinned_row
-        self._host.copy_(self.ws[:16].view(torch.int32), non_blocking=True)
+        self._host.copy_(ws[:16].view(torch.int32), non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
 
     def poll(self):
-        """None: still in flight; False: finished clean; True: finished with an error flag (``validate`` raises it)."""
+        """None: still in flight; False: finished clean; True: finished with an error flag."""
         if not self._event.query():
             return None
         return int(self._host[1]) != 0
+
+    def wait(self):
+        self._event.synchronize()
+
+    def check(self):
+        check(lib().gm_csr_header_status(C.c_void_p(self._host.data_ptr()), None))
 
 
 def padded_hidden(hidden):
@@ -416,6 +428,8 @@ class _EpdTrainFunction(torch.autograd.Function):
                                      current_stream()))
         ctx.module, ctx.handle, ctx.desc, ctx.tape = module, h, d, tape
         ctx.sizes = (n, e)
+        if module.auto_status:
+            module._watch(tape)    # the tape begins with the forward's csr workspace: its header carries the edge_index verdict
         ctx.save_for_backward(nodes, edge_attr, *params)
         return out
 
@@ -529,7 +543,12 @@ class EncProcDecGNN(nn.Module):
             if nodes.requires_grad or edge_attr.requires_grad:
                 raise NotImplementedError("EncProcDecGNN: gradients w.r.t. nodes / edge_attr are not produced "
                                           "(they are data in train_dyn.py); detach them")
-            _check_edge_index(edge_index, n, e)
+            # edge_index entries outside [0, n) are flagged on the device by the forward's destination sort (and left out; the
+            # kernels stay inside their arrays): no blocking range check here -- a training loop queues its steps ahead of the GPU.
+            # The flag surfaces as GMError at a later forward (auto_status) or at status(), like the inference path's.
+            _check_edge_index(edge_index, n, e, ranges=False)
+            if self.auto_status:
+                self._reap_watched(block=False)
             return _EpdTrainFunction.apply(self, nodes, edge_attr, edge_index, *params)
         if self.auto_status:
             # EARLIER inference forwards of this model: a device-side error (edge_index entry out of range, fp16 split range
@@ -561,26 +580,26 @@ class EncProcDecGNN(nn.Module):
             self._watch_pin, self._watch_next = torch.zeros((self._WATCH_SLOTS, 4), dtype=torch.int32).pin_memory(), 0
         if len(w) >= self._WATCH_SLOTS:   # every pinned row in use: the oldest forward is waited for (a loop 8 forwards ahead of the GPU)
             self._reap_watched(block=True, at_most=1)
-        csr.watch(self._watch_pin[self._watch_next])
+        is_csr = isinstance(csr, DstCsr)   # else: a training tape (it begins with the forward's csr workspace); not kept alive here
+        w.append((_HeaderWatch(csr.ws if is_csr else csr, self._watch_pin[self._watch_next]), csr if is_csr else None))
         self._watch_next = (self._watch_next + 1) % self._WATCH_SLOTS
-        w.append(csr)
 
     def _reap_watched(self, block, at_most=None):
         w = self.__dict__.get("_watched", [])
         done = 0
         while w and (at_most is None or done < at_most):
-            r = w[0].poll()
+            r = w[0][0].poll()
             if r is None:
                 if not block:
                     break
-                w[0]._event.synchronize()
-                r = w[0].poll()
-            csr = w.pop(0)
+                w[0][0].wait()
+                r = w[0][0].poll()
+            watch, csr = w.pop(0)
             done += 1
             if r:
                 if csr is getattr(self, "_last_csr", None):
                     self._last_csr = None    # reported once
-                csr.validate()               # raises the library's message for the flag
+                watch.check()                # raises the library's message for the flag
 
     def status(self):
         """Checks the last inference forward (synchronises): raises GMError if its edge_index held an entry outside

@@ -88,6 +88,11 @@ int gm_csr_from_edge_index_flow(const int64_t* edge_index, int64_t n_nodes, int6
                                 void* csr_ws, size_t csr_ws_bytes, void* stream);
 /* Synchronises; copies E and error flags to the host. */
 int gm_csr_num_edges(const void* csr_ws, int64_t* n_edges_host, void* stream);
+/* The same verdict from a HOST copy of the workspace's first 16 bytes (its header: n_edges, error flags, flow, pad) -- for callers
+ * that copy the header asynchronously behind their work and poll for it instead of synchronising.  No device access.  The tape of
+ * gm_epd_forward_train and of gm_interaction_network_forward_train begins with the csr workspace of that forward: the same
+ * 16 bytes tell whether its edge_index held an entry outside [0, n_nodes) (such edges are left out). */
+int gm_csr_header_status(const int32_t* header_host /*[4]*/, int64_t* n_edges_host /* may be NULL */);
 
 /* ------------------------------------------------------------------------------------------
  * Features.

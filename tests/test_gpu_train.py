@@ -230,3 +230,34 @@ def test_graph_independent_input_gradients(dev):
     for got, ref in ((x.grad, x64.grad), (a.grad, a64.grad)):
         ref = ref.numpy()
         assert np.abs(got.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_training_forward_flags_a_bad_edge_index_without_blocking(dev):
+    """The training forward makes no blocking range check of edge_index (a training loop queues its steps ahead of the GPU): an
+    entry outside [0, n_nodes) is flagged and left out by the destination sort on the device, the slots past the valid edges get
+    valid indices (the kernels walk all E slots with the host-side count and must stay inside their arrays), and the flag
+    surfaces as GMError at a later forward or at status() -- the step itself completes (its numbers are not used)."""
+    from gnn_manip_amd import EncProcDecGNN
+    from gnn_manip_amd._lib import GMError
+    torch.manual_seed(3)
+    n, e = 300, 4000
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 2).to(dev)
+    x, ea = torch.randn(n, 25, device=dev), torch.randn(e, 4, device=dev)
+    ei = torch.randint(0, n, (2, e), device=dev)
+    bad = ei.clone()
+    bad[1, 17] = n + 5
+    bad[0, 3000] = -2
+    out = m.forward(x, ea, bad)
+    out.abs().sum().backward()                       # the backward walks the same slots
+    torch.cuda.synchronize()
+    assert all(p.grad is not None for p in m.parameters())
+    with pytest.raises(GMError, match="out of range"):
+        m.status()
+    m.zero_grad()
+    out = m.forward(x, ea, ei)                       # a clean step afterwards: nothing pending, gradients finite
+    out.abs().sum().backward()
+    assert m.status() == 0 and all(torch.isfinite(p.grad).all() for p in m.parameters())
+    m.forward(x, ea, bad).sum().backward()
+    torch.cuda.synchronize()
+    with pytest.raises(GMError, match="out of range"):
+        m.forward(x, ea, ei)                         # ... or at the next forward, for a caller that never asks
