@@ -82,8 +82,8 @@ int layer_stages_b3(int k, int out);      // stages of a Linear with k inputs an
 int train_kernels_init();
 int launch_train_fwd(int H, int kind, const TrainFwdArgs& a, hipStream_t s);
 struct WgradBatch;
-// wb != nullptr: the LayerNorm partial sums go to the batch's own region and are reduced by its next flush (one launch with the
-// weight-gradient reductions) instead of a launch of their own -- flush before the next backward chain is launched.
+// wb != nullptr: the LayerNorm partial sums go to one of the batch's own regions and are reduced by its next flush (one launch with
+// the weight-gradient reductions) instead of a launch of their own -- at most kWgLnMax chains between two flushes.
 int launch_train_bwd(int H, int kind, const TrainBwdArgs& a, hipStream_t s, WgradBatch* wb = nullptr);
 // Weight gradients: jobs are collected and run a batch per launch pair (GEMM over row chunks + fixed-order reduction).
 //   out[m][col0 + k] += sum_r dz[r][m] * X[xidx ? xidx[r] : r][k];  db[m] += sum_r dz[r][m] (db may be nullptr)
@@ -98,23 +98,27 @@ struct WgJob {
     int Mp, Kp, KT, tiles, chunk, G;
     size_t part_off;   // floats from the partial buffer: [G][Mp][Kp] tiles, then [G][Mp] bias partials
 };
-constexpr int kWgJobsMax = 8;
-struct WgJobs {
-    int n;
-    WgJob job[kWgJobsMax];
-    // LayerNorm parameter gradients of the backward chain that ran since the last flush (ln_G = 0: none):
-    // dgamma[c] += sum_g ln_part[g][c], dbeta[c] += sum_g ln_part[g][H + c]
-    const float* ln_part;
-    int ln_G, ln_H;
+constexpr int kWgJobsMax = 12;
+constexpr int kWgLnMax = 2;   // backward chains whose LayerNorm partials may wait for one flush (a node chain and the edge chain after it)
+struct WgLnJob {              // dgamma[c] += sum_g part[g][c], dbeta[c] += sum_g part[g][H + c]
+    const float* part;
+    int G, H;
     float* dgamma;
     float* dbeta;
 };
+struct WgJobs {
+    int n;
+    WgJob job[kWgJobsMax];
+    int n_ln;                 // LayerNorm parameter gradients of the backward chains that ran since the last flush
+    WgLnJob ln[kWgLnMax];
+};
 struct WgradBatch {
     WgJobs jobs{};
-    float* part = nullptr;   // wgrad_partial_floats(H) floats: weight-gradient partials, then the LayerNorm region
+    float* part = nullptr;   // wgrad_partial_floats(H) floats: weight-gradient partials, then kWgLnMax LayerNorm regions
     size_t cap = 0;          // floats of the weight-gradient part
+    size_t ln_floats = 0;    // floats of one LayerNorm region
     hipStream_t stream = nullptr;
-    float* ln_region() const { return part + cap; }
+    float* ln_region(int slot) const { return part + cap + (size_t)slot * ln_floats; }
 };
 void wgrad_batch_init(WgradBatch& b, float* part, int H, hipStream_t s);
 size_t wgrad_partial_floats(int H);

@@ -677,18 +677,19 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgJobs Js, const floa
     __shared__ float red[8][33];
     const int tid = threadIdx.x, i = tid & 31, gg = tid >> 5;
     const int o = blockIdx.x * 32 + i;
-    if ((int)blockIdx.y == Js.n) {   // the LayerNorm parameter gradients of the last backward chain (fixed order: deterministic)
-        const int H = Js.ln_H;
+    if ((int)blockIdx.y >= Js.n) {   // the LayerNorm parameter gradients of a backward chain since the last flush (fixed order: deterministic)
+        const WgLnJob& Lj = Js.ln[blockIdx.y - Js.n];
+        const int H = Lj.H;
         if ((int)blockIdx.x * 32 >= 2 * H) return;
-        const float s = o < 2 * H ? strided_sum4(Js.ln_part + o, (size_t)2 * H, gg, Js.ln_G) : 0.f;
+        const float s = o < 2 * H ? strided_sum4(Lj.part + o, (size_t)2 * H, gg, Lj.G) : 0.f;
         red[gg][i] = s;
         __syncthreads();
         if (gg == 0 && o < 2 * H) {
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) t += red[q][i];
-            if (o < H) Js.dgamma[o] += t;
-            else Js.dbeta[o - H] += t;
+            if (o < H) Lj.dgamma[o] += t;
+            else Lj.dbeta[o - H] += t;
         }
         return;
     }
@@ -876,8 +877,8 @@ static int launch_train_bwd_h(int kind, const TrainBwdArgs& a_in, hipStream_t s,
     TrainBwdArgs a = a_in;
     const bool batched = wb && a.ln_part && a.dgamma && a.dbeta;
     if (batched) {
-        GM_REQUIRE(wb->jobs.ln_G == 0 && wb->jobs.n == 0, GM_ERR_INVALID_ARGUMENT, "launch_train_bwd: flush the weight-gradient batch first");
-        a.ln_part = wb->ln_region();
+        GM_REQUIRE(wb->jobs.n_ln < kWgLnMax, GM_ERR_INVALID_ARGUMENT, "launch_train_bwd: flush the weight-gradient batch first");
+        a.ln_part = wb->ln_region(wb->jobs.n_ln);
     }
     const bool ln = a.ln_part && (kind == TB_ENC || kind == TB_EDGE || kind == TB_NODE);
     if (ln) {
@@ -894,7 +895,8 @@ static int launch_train_bwd_h(int kind, const TrainBwdArgs& a_in, hipStream_t s,
         default: hipLaunchKernelGGL((train_bwd_kernel<H, TB_DEC>), dim3(grid), dim3(THREADS), lds, s, a); break;
     }
     if (ln && batched) {
-        wb->jobs.ln_part = a.ln_part; wb->jobs.ln_G = grid; wb->jobs.ln_H = H; wb->jobs.dgamma = a.dgamma; wb->jobs.dbeta = a.dbeta;
+        WgLnJob& Lj = wb->jobs.ln[wb->jobs.n_ln++];
+        Lj.part = a.ln_part; Lj.G = grid; Lj.H = H; Lj.dgamma = a.dgamma; Lj.dbeta = a.dbeta;
     } else if (ln && a.dgamma && a.dbeta) {
         hipLaunchKernelGGL(ln_grads_reduce_kernel, dim3(2 * H / 32), dim3(256), 0, s, a.ln_part, grid, H, a.dgamma, a.dbeta);
     }
@@ -914,19 +916,21 @@ static size_t wgrad_job_floats(int G, int Mp, int Kp) { return (size_t)G * Mp * 
 constexpr int kWgSlotsMax = 1024;   // resident workgroups the sizing may assume (the partial buffer is sized for it)
 size_t wgrad_partial_floats(int H) {
     // a flush: sum over jobs of G * tiles <= kWgSlotsMax + kWgJobsMax * 4 tiles of 128 x 128 + the bias partials; then the LayerNorm region
-    return ((size_t)kWgSlotsMax + kWgJobsMax * 4) * (128 * 128 + 128) + train_bwd_ln_part_floats(H);
+    return ((size_t)kWgSlotsMax + kWgJobsMax * 4) * (128 * 128 + 128) + kWgLnMax * train_bwd_ln_part_floats(H);
 }
 void wgrad_batch_init(WgradBatch& b, float* part, int H, hipStream_t s) {
     b.part = part;
-    b.cap = wgrad_partial_floats(H) - train_bwd_ln_part_floats(H);
+    b.ln_floats = train_bwd_ln_part_floats(H);
+    b.cap = wgrad_partial_floats(H) - kWgLnMax * b.ln_floats;
     b.stream = s;
     b.jobs.n = 0;
-    b.jobs.ln_G = 0;
+    b.jobs.n_ln = 0;
 }
 
 int wgrad_flush(WgradBatch& b) {
-    if (b.jobs.n <= 0 && b.jobs.ln_G <= 0) return GM_OK;
-    int maxG = 1, maxT = 1, maxO = b.jobs.ln_G > 0 ? 2 * b.jobs.ln_H : 1;
+    if (b.jobs.n <= 0 && b.jobs.n_ln <= 0) return GM_OK;
+    int maxG = 1, maxT = 1, maxO = 1;
+    for (int q = 0; q < b.jobs.n_ln; ++q) maxO = 2 * b.jobs.ln[q].H > maxO ? 2 * b.jobs.ln[q].H : maxO;
     if (b.jobs.n > 0) {
         int slots = 4 * device_cus();
         if (slots > kWgSlotsMax) slots = kWgSlotsMax;
@@ -951,9 +955,9 @@ int wgrad_flush(WgradBatch& b) {
         GM_REQUIRE(used <= b.cap, GM_ERR_WORKSPACE, "wgrad: partial buffer too small (%zu > %zu floats)", used, b.cap);
         hipLaunchKernelGGL(wgrad_kernel, dim3(maxG, maxT, b.jobs.n), dim3(THREADS), 0, b.stream, b.jobs, b.part);
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(maxO, 32), b.jobs.n + (b.jobs.ln_G > 0 ? 1 : 0)), dim3(256), 0, b.stream, b.jobs, b.part);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(maxO, 32), b.jobs.n + b.jobs.n_ln), dim3(256), 0, b.stream, b.jobs, b.part);
     b.jobs.n = 0;
-    b.jobs.ln_G = 0;
+    b.jobs.n_ln = 0;
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -967,10 +971,7 @@ int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X
     j.Mp = (int)cdiv(M, 128) * 128; j.Kp = (int)cdiv(K, 128) * 128;
     j.KT = j.Kp / 128; j.tiles = (j.Mp / 128) * j.KT;
     GM_REQUIRE(j.tiles <= 4, GM_ERR_UNSUPPORTED, "wgrad: a %d x %d weight block (at most 4 tiles of 128 x 128 per job)", M, K);
-    if (b.jobs.n == kWgJobsMax) {
-        const int rc = wgrad_flush(b);
-        if (rc != GM_OK) return rc;
-    }
+    GM_REQUIRE(b.jobs.n < kWgJobsMax, GM_ERR_INVALID_ARGUMENT, "wgrad: more than %d jobs between two flushes", kWgJobsMax);
     b.jobs.job[b.jobs.n++] = j;   // chunk, G and the partial offset are set when the batch is flushed
     return GM_OK;
 }

@@ -62,9 +62,13 @@ Tape carve_tape(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
 }
 
 struct BwdWs {
-    float *packT, *dz, *de, *dh, *dagg, *Gi, *Gj, *part;
+    float *packT, *dz, *dzn, *de, *dh, *dagg, *Gi, *Gj, *part;
     size_t dz_stride;   // floats between dz_l and dz_(l+1) (l = 1 .. NL + 1)
     float* dzl(int l) const { return dz + (size_t)(l - 1) * dz_stride; }
+    // the node-sized chains of the model backward (node MLPs, node encoder) leave their dz in a set of their own, so that the
+    // weight-gradient jobs over an edge chain's dz and those over the node chain's that follows run as ONE batch
+    size_t dzn_stride;
+    float* dznl(int l) const { return dzn + (size_t)(l - 1) * dzn_stride; }
     size_t off_dec, off_enc_edge, off_enc_node;
     std::vector<size_t> off_edge, off_node;
     size_t bytes;
@@ -90,6 +94,8 @@ BwdWs carve_bwd(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
     const int64_t R = n > e ? n : e;
     b.dz_stride = align_up((size_t)R * H, 64);
     b.dz = c.take<float>((size_t)(NL + 1) * b.dz_stride);
+    b.dzn_stride = align_up((size_t)n * H, 64);
+    b.dzn = c.take<float>((size_t)(NL + 1) * b.dzn_stride);
     b.de = c.take<float>((size_t)e * H);
     b.dh = c.take<float>((size_t)n * H);
     b.dagg = c.take<float>((size_t)n * H);
@@ -324,9 +330,12 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     // W3 (+ b3), W2 (+ b2) and the LayerNorm gradients of a normed MLP whose chain kernel has just run over `rows`
     // (b1 comes with the first-layer weight gradient at the call site)
     auto act = [&](const TapePtr& tp, int l, int64_t rows) { return tp.a + (size_t)(l - 1) * rows * H; };   // a_l
-    auto normed_tail_grads = [&](int base, const TapePtr& tp, int64_t rows) {
+    // `node_set`: the chain left its dz in the node-sized set (BwdWs::dzn) -- the node MLPs and the node encoder, so that their
+    // jobs and those of the edge chain before them (edge-sized set) wait in one batch: a flush only before each EDGE chain
+    auto dz_of = [&](bool node_set, int l) { return node_set ? b.dznl(l) : b.dzl(l); };
+    auto normed_tail_grads = [&](int base, const TapePtr& tp, int64_t rows, bool node_set) {
         for (int l = NL; l >= 1; --l)   // Linear l + 1: dW = dz_(l+1)^T a_l
-            wgrad(b.dzl(l + 1), H, H, act(tp, l, rows), H, H, nullptr, rows, grads[base + 2 * l], H, 0, grads[base + 2 * l + 1]);
+            wgrad(dz_of(node_set, l + 1), H, H, act(tp, l, rows), H, H, nullptr, rows, grads[base + 2 * l], H, 0, grads[base + 2 * l + 1]);
     };
     auto chain = [&](TrainBwdArgs& a) { a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; };
     // (the LayerNorm parameter gradients are summed inside the chain kernels: TrainBwdArgs.ln_part / dgamma / dbeta)
@@ -353,13 +362,13 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             TrainBwdArgs a{};
             a.rows = (int)n; a.dY = b.dh; a.Gi = has_next ? b.Gi : nullptr; a.Gj = has_next ? b.Gj : nullptr;
             a.tape = t.tn[k]; a.ln_g = ln_gamma(m->v_node[k]); a.wstream = b.packT + b.off_node[k];
-            a.ln_part = b.part; a.dgamma = grads[b_node(k) + 2 * (NL + 1)]; a.dbeta = grads[b_node(k) + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
-            rc = wgrad_flush(wb);
-        if (rc == GM_OK) rc = launch_train_bwd(H, TB_NODE, a, s, &wb);
+            a.ln_part = b.part; a.dgamma = grads[b_node(k) + 2 * (NL + 1)]; a.dbeta = grads[b_node(k) + 2 * (NL + 1) + 1]; a.dz = b.dzn; a.dz_stride = b.dzn_stride; a.nl = NL; a.dx_resid = b.dh; a.dx = b.dh; a.dagg_out = b.dagg;
+            // no flush: the waiting jobs read the edge-sized dz set, Gi / Gj and tapes -- nothing this chain writes
+            rc = launch_train_bwd(H, TB_NODE, a, s, &wb);
             if (rc != GM_OK) return rc;
-            normed_tail_grads(b_node(k), t.tn[k], n);
-            wgrad(b.dzl(1), H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ch * H, grads[b_node(k) + 1]);
-            wgrad(b.dzl(1), H, H, t.agg[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ca * H, nullptr);
+            normed_tail_grads(b_node(k), t.tn[k], n, true);
+            wgrad(b.dznl(1), H, H, t.h[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ch * H, grads[b_node(k) + 1]);
+            wgrad(b.dznl(1), H, H, t.agg[k], H, H, nullptr, n, grads[b_node(k)], 2 * H, m->ca * H, nullptr);
             if (rc != GM_OK) return rc;
         }
         {
@@ -370,7 +379,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
             rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_EDGE, a, s, &wb);
             if (rc != GM_OK) return rc;
-            normed_tail_grads(b_edge(k), t.te[k], e);
+            normed_tail_grads(b_edge(k), t.te[k], e, false);
             wgrad(b.dzl(1), H, H, t.e[k], H, H, nullptr, e, grads[b_edge(k)], 3 * H, m->ce * H, grads[b_edge(k) + 1]);
             if (rc != GM_OK) return rc;
             // node-level sums of dz1: everything the factorised layer 1 needs
@@ -385,12 +394,11 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         TrainBwdArgs a{};
         a.rows = (int)n; a.dY = b.dh; a.Gi = b.Gi; a.Gj = b.Gj; a.tape = t.en; a.ln_g = ln_gamma(m->v_enc_node);
         a.wstream = b.packT + b.off_enc_node;
-        a.ln_part = b.part; a.dgamma = grads[b_enc_node + 2 * (NL + 1)]; a.dbeta = grads[b_enc_node + 2 * (NL + 1) + 1]; a.dz = b.dz; a.dz_stride = b.dz_stride; a.nl = NL;
-        rc = wgrad_flush(wb);
-        if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s, &wb);
+        a.ln_part = b.part; a.dgamma = grads[b_enc_node + 2 * (NL + 1)]; a.dbeta = grads[b_enc_node + 2 * (NL + 1) + 1]; a.dz = b.dzn; a.dz_stride = b.dzn_stride; a.nl = NL;
+        rc = launch_train_bwd(H, TB_ENC, a, s, &wb);   // no flush: as the node MLPs
         if (rc != GM_OK) return rc;
-        normed_tail_grads(b_enc_node, t.en, n);
-        wgrad(b.dzl(1), H, H, nodes, m->d.node_dim, m->d.node_dim, nullptr, n, grads[b_enc_node], m->d.node_dim, 0, grads[b_enc_node + 1]);
+        normed_tail_grads(b_enc_node, t.en, n, true);
+        wgrad(b.dznl(1), H, H, nodes, m->d.node_dim, m->d.node_dim, nullptr, n, grads[b_enc_node], m->d.node_dim, 0, grads[b_enc_node + 1]);
         if (rc != GM_OK) return rc;
     }
     if (e > 0) {
@@ -400,7 +408,7 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
         rc = wgrad_flush(wb);
         if (rc == GM_OK) rc = launch_train_bwd(H, TB_ENC, a, s, &wb);
         if (rc != GM_OK) return rc;
-        normed_tail_grads(b_enc_edge, t.ee, e);
+        normed_tail_grads(b_enc_edge, t.ee, e, false);
         wgrad(b.dzl(1), H, H, edge_attr, m->d.edge_dim, m->d.edge_dim, c.eid, e, grads[b_enc_edge], m->d.edge_dim, 0, grads[b_enc_edge + 1]);
         if (rc != GM_OK) return rc;
     }
