@@ -168,6 +168,8 @@ int rollout_integrate_post(float* obs, int64_t n, const gm_feature_desc* d, cons
 // destination sort of the radius graph with the edge features computed in the same pass (graph.hip)
 int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, const float* pos,
                                  int64_t pos_stride, float conn_r, float* edge_attr, int flow, hipStream_t s);
+// destination-sorted structure of an edge_index; with_blocks = false leaves the inference kernels' block tables out (training)
+int csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, int flow, void* csr_ws, size_t csr_ws_bytes, bool with_blocks, hipStream_t stream);
 
 int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s, int* total_out);
 size_t scan_tmp_ints(int64_t n_max);

@@ -934,6 +934,15 @@ int gm_csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, void* csr_ws
 }
 
 int gm_csr_from_edge_index_flow(const int64_t* ei, int64_t n, int64_t e, int flow, void* csr_ws, size_t csr_ws_bytes, void* stream) {
+    return gm::csr_from_edge_index(ei, n, e, flow, csr_ws, csr_ws_bytes, true, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace gm {
+// with_blocks = false: the sorted lists and in_ptr only, without the 32-edge block tables of the inference edge kernels (the training
+// kernels walk rows: five launches fewer per structure)
+int csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, int flow, void* csr_ws, size_t csr_ws_bytes, bool with_blocks, hipStream_t stream) {
     gm::DevGuard dev_guard(csr_ws);
     GM_REQUIRE(flow == 0 || flow == 1, GM_ERR_INVALID_ARGUMENT, "gm_csr_from_edge_index: flow must be 0 or 1");
     GM_REQUIRE(csr_ws && (ei || e == 0), GM_ERR_INVALID_ARGUMENT, "gm_csr_from_edge_index: null pointer");
@@ -956,8 +965,12 @@ int gm_csr_from_edge_index_flow(const int64_t* ei, int64_t n, int64_t e, int flo
     if (n > 0)
         hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0, c.sort_tmp, c.sort_tmp + c.cap);
     GM_LAUNCH_CHECK();
+    if (!with_blocks) return GM_OK;
     return build_edge_blocks(c.in_ptr, c.dst, n, e, nullptr, (int)n, carve_edge_blocks(c.blocks, n, e), s);
 }
+}  // namespace gm
+
+extern "C" {
 
 int gm_csr_header_status(const int32_t* header_host, int64_t* n_edges_host) {
     GM_REQUIRE(header_host, GM_ERR_INVALID_ARGUMENT, "gm_csr_header_status: null pointer");

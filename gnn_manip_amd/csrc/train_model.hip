@@ -185,12 +185,12 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     // destination-sorted edges (aggregation index i = edge_index[1]) and the source-grouped view of the sorted list
-    rc = gm_csr_from_edge_index_flow(edge_index, n, e, m->d.flow, t.csr_dst, t.csr_bytes, stream);
+    rc = gm::csr_from_edge_index(edge_index, n, e, m->d.flow, t.csr_dst, t.csr_bytes, false, (hipStream_t)stream);
     if (rc != GM_OK) return rc;
     CsrWs c = carve_csr(t.csr_dst, n, e);
     rc = launch_swap_index(c.src, e, t.ei2, s);
     if (rc != GM_OK) return rc;
-    rc = gm_csr_from_edge_index(t.ei2, n, e, t.csr_src, t.csr_bytes, stream);
+    rc = gm::csr_from_edge_index(t.ei2, n, e, 0, t.csr_src, t.csr_bytes, false, (hipStream_t)stream);
     if (rc != GM_OK) return rc;
 
     const size_t U = (size_t)m->T_HH * kStageFloatsB3;
@@ -534,12 +534,12 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
     rc = train_kernels_init();
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    rc = gm_csr_from_edge_index_flow(edge_index, n, e, m->d.flow, t.csr_dst, t.csr_bytes, stream);
+    rc = gm::csr_from_edge_index(edge_index, n, e, m->d.flow, t.csr_dst, t.csr_bytes, false, (hipStream_t)stream);
     if (rc != GM_OK) return rc;
     CsrWs c = carve_csr(t.csr_dst, n, e);
     rc = launch_swap_index(c.src, e, t.ei2, s);
     if (rc != GM_OK) return rc;
-    rc = gm_csr_from_edge_index(t.ei2, n, e, t.csr_src, t.csr_bytes, stream);
+    rc = gm::csr_from_edge_index(t.ei2, n, e, 0, t.csr_src, t.csr_bytes, false, (hipStream_t)stream);
     if (rc != GM_OK) return rc;
     const size_t U = (size_t)m->T_HH * kStageFloatsB3;
     {
