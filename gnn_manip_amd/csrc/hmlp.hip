@@ -302,9 +302,12 @@ __device__ __forceinline__ void agg_rows_to_image(const float* __restrict__ agg,
             const int rowhalf = u % (2 * C::NRB), kspair = u / (2 * C::NRB);
             const int rbg = rowhalf >> 1, nn = 16 * (rowhalf & 1) + (lane & 15), c = lane >> 4, ks = 2 * kspair + (c >> 1), kg = c & 1;
             if (SC) {
-                const float keep = gs[q] >= 0 ? 1.f : 0.f;
+                // rows without a head partial read side row 0 for nothing: dropped by a SELECT, not by a multiplication with zero --
+                // that row belongs to no group (group 0 never has a head partial) and holds whatever the workspace held: NaN x 0
+                // is NaN, and a NaN operand is then flushed to zero by the ReLU (a wrong, finite result)
+                const bool has = gs[q] >= 0;
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) { v0[q][tt] = fmaf(s0[q][tt], keep, v0[q][tt]); v1[q][tt] = fmaf(s1[q][tt], keep, v1[q][tt]); }
+                for (int tt = 0; tt < 4; ++tt) { v0[q][tt] += has ? s0[q][tt] : 0.f; v1[q][tt] += has ? s1[q][tt] : 0.f; }
                 if (gs[q] >= 0 && (gs[q] & 1)) {
                     int g = (gs[q] >> 1) + 1;
                     do {

@@ -149,3 +149,53 @@ def test_deep_mlp_scales_stay_in_range(dev, graph):
         out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
     assert m.status() == ei.shape[1]
     assert _rel(out, ref) <= 2e-5, _rel(out, ref)
+
+
+def _poison(dev, pattern):
+    """Fill the caching allocator's free blocks: what torch.empty hands out next (the library's workspaces) holds `pattern`."""
+    junk = [torch.full((n,), pattern, device=dev) for n in (1 << 24, 1 << 22, 1 << 20, 3 << 18, 5 << 16, 7 << 12, 65536 * 3, 257)]
+    junk += [torch.full((n,), 0x7fc00000, dtype=torch.int32, device=dev) for n in (1 << 22, 1 << 20, 1 << 18, 4096)]
+    del junk
+
+
+@pytest.mark.parametrize("pattern", [float("nan"), float("inf"), 3e38])
+def test_results_do_not_depend_on_what_the_workspaces_held(dev, pattern):
+    """Every workspace the library is given is uninitialised memory.  A row that is read for nothing must be dropped by a select,
+    never by a multiplication with zero (NaN x 0 = NaN, and a NaN operand is flushed to zero by the next ReLU: a wrong, FINITE
+    result -- found in the node kernel's stitch of head partials, where rows without one read side row 0).  Each entry point, run
+    after the allocator's free blocks were filled with NaN / inf / huge values, must return bit for bit what it returns on clean memory:
+    the standalone blocks, the fused forward on both kernel families, a rollout, a training step."""
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, RolloutEngine, scene
+    torch.manual_seed(5)
+    obs = scene.make_scene(900, seed=77, side=0.08)
+    ga = GraphBoundedMultimaterialControl(0.015, STATS, CART, MAT, CTRL, BOUNDS)
+    with torch.no_grad():
+        nodes, ea, ei, _ = ga.process_collate([(torch.from_numpy(obs).to(dev), torch.zeros(obs.shape[1], 3, device=dev))])
+    traj = torch.from_numpy(scene.rigid_drift_trajectory(obs, 2)).to(dev)
+
+    def runs():
+        out = {}
+        for hid in (128, 64):
+            torch.manual_seed(hid)
+            m = EncProcDecGNN(25, 4, 3, hid, 2, 3).to(dev)
+            with torch.no_grad():
+                out[f"forward{hid}"] = m.forward(nodes, ea, ei).clone()
+                h0, e0, _ = m.encoder(nodes, ea, ei)
+                h1, e1, _ = m.processor[0](h0, e0, ei)
+                out[f"block{hid}"] = torch.cat((h1.flatten(), e1.flatten())).clone()
+                if hid == 128:
+                    eng = RolloutEngine(m, ga, obs.shape[1], device=dev)
+                    out["rollout"] = eng.rollout(torch.from_numpy(obs).to(dev), traj, horizon=2).clone()
+            m.zero_grad()
+            m.forward(nodes, ea, ei).square().sum().backward()
+            out[f"grads{hid}"] = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+            m.status()
+        torch.cuda.synchronize()
+        return out
+
+    clean = runs()
+    _poison(dev, pattern)
+    dirty = runs()
+    for k in clean:
+        assert torch.isfinite(clean[k]).all(), k
+        assert torch.equal(clean[k], dirty[k]), (k, float((clean[k] - dirty[k]).abs().max()))
