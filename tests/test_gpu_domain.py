@@ -192,6 +192,11 @@ def test_results_do_not_depend_on_what_the_workspaces_held(dev, pattern):
             m.forward(nodes, ea, ei).square().sum().backward()
             out[f"grads{hid}"] = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
             m.status()
+        from gnn_manip_amd.losses import SamplesLoss
+        g = np.random.Generator(np.random.PCG64(9))
+        x = torch.from_numpy(g.random((700, 3), dtype=np.float32)).to(dev)
+        y = torch.from_numpy(g.random((650, 3), dtype=np.float32) + np.float32(0.1)).to(dev)
+        out["sinkhorn"] = SamplesLoss(loss="sinkhorn", p=2, blur=.05)(x, y).reshape(1).clone()
         torch.cuda.synchronize()
         return out
 
