@@ -133,6 +133,15 @@ __device__ __forceinline__ void check_rows(int& bad, const floatx16 (&acc)[RBW])
     for (int rb = 0; rb < RBW; ++rb) nan |= acc[rb][0] != acc[rb][0];
     bad |= __any(nan) ? 1 : 0;
 }
+// Encoder forms (raw feature rows in; the standalone GraphIndependent entry point has no header to flag): a row whose accumulators
+// went NaN in ANY Linear -- a non-finite input, or a range violation further on -- must come out NaN, but the ReLU flushes a NaN
+// operand to zero.  pois[rb] stays 0 for a clean row and turns NaN for good (x - x: 0 for finite x, NaN for NaN / inf); it joins
+// the LayerNorm's additive term.
+template <int RBW>
+__device__ __forceinline__ void mark_rows(float (&pois)[RBW], const floatx16 (&acc)[RBW]) {
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) pois[rb] += acc[rb][0] - acc[rb][0];
+}
 __device__ __forceinline__ void report_range(int bad, int* flags) {
     if (flags && bad && (threadIdx.x & 63) == 0) atomicOr(flags, ERRF_SPLIT_RANGE);
 }
@@ -488,6 +497,8 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
         HM_STAMP_E(iter, 2);   // P gather issued (accumulators initialised: waits land in the GEMM)
         gemm(acc, L.frag + (size_t)jb * KS0 * 128 + lane, imgh + (size_t)(4 * rg) * KS0 * 128 + lane, KS0, KS0);
         check_rows(rng, acc);
+        float pois[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ENC) mark_rows(pois, acc);
         wp += lin0;
         HM_STAMP_E(iter, 3);   // GEMM 1
 #pragma unroll 1
@@ -501,6 +512,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             else init_bias(acc, L.bias, jb, hi);
             gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(4 * rg) * C::KS * 128 + lane, C::KS, C::KS);
             check_rows(rng, acc);
+            if (ENC) mark_rows(pois, acc);
             wp += linh;
         }
         HM_STAMP_E(iter, 4);   // hidden Linears
@@ -520,6 +532,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
             const int cnt = sb[rbg].y;
             float k, m;
             ln_merge<H>(ST, rbg, n, L.u * rs[rb], A.eps, A.h_valid, k, m);
+            if (ENC) m += pois[rb];
             const bool valid = n < cnt;
             const int p = pe[rb];
             const long long orow = A.eid_out ? A.eid_out[p] : p;
@@ -663,9 +676,9 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
         }
         floatx16 acc[RBW];
         Lin L;
-        float rs[RBW];
+        float rs[RBW], pois[RBW];   // pois: MODE 0 only (mark_rows)
 #pragma unroll
-        for (int rb = 0; rb < RBW; ++rb) rs[rb] = 1.f;
+        for (int rb = 0; rb < RBW; ++rb) { rs[rb] = 1.f; pois[rb] = 0.f; }
         if (MODE == 0) narrow_rows_to_image<H, RBW, 2>(A.x_in, A.k1, img, RS, A.w[3], tid, row_of);
         else rows_to_image<H, RBW, 2 * RBW>(A.x_in, img, wave, lane, row_of, [](long long, int, floatx4&, floatx4&) {});
         __syncthreads();
@@ -683,6 +696,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             if (MODE == 0) {
                 gemm(acc, L.frag + (size_t)jb * 2 * 128 + lane, imgh + (size_t)(RBW * rg) * 2 * 128 + lane, 2, 2, nrb);
                 check_rows(rng, acc);
+                mark_rows(pois, acc);
             } else {
                 int sc_head = -2;
                 const int ng = stitched ? A.tab->n_groups : 0;
@@ -716,6 +730,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                 else init_bias(acc, L.bias, jb, hi);
                 gemm(acc, L.frag + (size_t)jb * C::KS * 128 + lane, imgh + (size_t)(RBW * rg) * C::KS * 128 + lane, C::KS, C::KS, nrb);
                 check_rows(rng, acc);
+                if (MODE == 0) mark_rows(pois, acc);
                 wp += linh;
             }
             HM_STAMP(tile_i, 5);   // hidden Linears
@@ -728,6 +743,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                 const int rbg = RBW * rg + rb;
                 float k, m;
                 ln_merge<H>(ST, rbg, n, L.u * rs[rb], A.eps, A.h_valid, k, m);
+                if (MODE == 0) m += pois[rb];
                 const int r = slot_row0(rbg) + n;
                 const bool valid = rb < nrb && r < N;
                 const size_t off = (size_t)(r < N ? r : N - 1) * H + 32 * jb + 4 * hi;

@@ -233,7 +233,9 @@ int gm_epd_forward(const gm_model* m, const float* nodes /*[N,node_dim]*/, int64
  * `block` = -1: encoder; 0..m_steps-1: processor block.  Outputs in the caller's edge order.
  * Range violations of the fp16 split (see "Numeric domain" above): gm_interaction_network_forward flags them in the header of
  * its csr workspace like the fused forward (gm_csr_num_edges returns GM_ERR_DATA).  gm_graph_independent_forward has no such
- * header: there a violating row -- a non-finite input included -- comes out as NaN in every feature, which is how the caller sees it. */
+ * header: there a violating row -- a non-finite input feature, or a range violation further on -- comes out as NaN in every
+ * feature (the kernels carry a per-row poison term from every Linear's accumulators into the LayerNorm), which is how the caller
+ * sees it; the other rows are unaffected. */
 int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n_nodes, const float* edge_attr,
                                  int64_t n_edges, float* h_out, float* e_out, void* stream);
 int gm_interaction_network_forward(const gm_model* m, int block, const float* h, int64_t n_nodes,

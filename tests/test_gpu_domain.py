@@ -206,3 +206,29 @@ def test_results_do_not_depend_on_what_the_workspaces_held(dev, pattern):
     for k in clean:
         assert torch.isfinite(clean[k]).all(), k
         assert torch.equal(clean[k], dirty[k]), (k, float((clean[k] - dirty[k]).abs().max()))
+
+
+@pytest.mark.parametrize("hid", [128, 64, 100])
+def test_standalone_encoder_turns_a_non_finite_input_row_into_a_nan_row(dev, hid):
+    """gm_graph_independent_forward has no header to flag (include/gnn_manip_hip.h): a row with a NaN / inf feature must come out
+    NaN in every feature -- the one-instruction ReLU flushes a NaN operand to zero, so the kernels carry a per-row poison term
+    from every Linear's accumulators into the LayerNorm -- and every other row must be untouched, bit for bit.  A huge but finite
+    feature (1e30) is inside the numeric domain and stays finite."""
+    from gnn_manip_amd import EncProcDecGNN
+    torch.manual_seed(hid)
+    m = EncProcDecGNN(25, 4, 3, hid, 2, 2).to(dev)
+    n, e = 300, 2000
+    x, ea = torch.randn(n, 25, device=dev), torch.randn(e, 4, device=dev)
+    ei = torch.randint(0, n, (2, e), device=dev)
+    with torch.no_grad():
+        h0, e0, _ = m.encoder(x, ea, ei)
+        xb, eb = x.clone(), ea.clone()
+        xb[7, 3] = float("nan"); xb[100, 24] = float("inf"); xb[299, 0] = float("-inf"); xb[20, 0] = 1e30
+        eb[11, 1] = float("inf"); eb[1999, 3] = float("nan"); eb[64, 0] = -1e30
+        h1, e1, _ = m.encoder(xb, eb, ei)
+    bad_n, bad_e = [7, 100, 299], [11, 1999]
+    assert torch.isnan(h1[bad_n]).all() and torch.isnan(e1[bad_e]).all()
+    keep_n = torch.ones(n, dtype=torch.bool, device=dev); keep_n[bad_n + [20]] = False
+    keep_e = torch.ones(e, dtype=torch.bool, device=dev); keep_e[bad_e + [64]] = False
+    assert torch.equal(h1[keep_n], h0[keep_n]) and torch.equal(e1[keep_e], e0[keep_e])
+    assert torch.isfinite(h1[20]).all() and torch.isfinite(e1[64]).all()
