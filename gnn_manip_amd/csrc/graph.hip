@@ -778,7 +778,7 @@ extern "C" {
 
 const char* gm_last_error(void) { return gm::last_error(); }
 
-int gm_abi_version(void) { return 4; }
+int gm_abi_version(void) { return 5; }
 
 size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours) {
     if (n_nodes < 0 || max_neighbours < 1) return 0;
