@@ -232,3 +232,40 @@ def test_standalone_encoder_turns_a_non_finite_input_row_into_a_nan_row(dev, hid
     keep_e = torch.ones(e, dtype=torch.bool, device=dev); keep_e[bad_e + [64]] = False
     assert torch.equal(h1[keep_n], h0[keep_n]) and torch.equal(e1[keep_e], e0[keep_e])
     assert torch.isfinite(h1[20]).all() and torch.isfinite(e1[64]).all()
+
+
+def test_entry_points_follow_the_callers_stream(dev):
+    """Everything is enqueued on the stream the caller passes (torch's current stream in the host layer): a forward, a rollout and
+    a training step issued on a side stream -- with the default stream kept busy by unrelated work -- return the bits of the same
+    calls on the default stream."""
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, RolloutEngine, scene
+    obs = scene.make_scene(1200, seed=78, side=0.085)
+    ga = GraphBoundedMultimaterialControl(0.015, STATS, CART, MAT, CTRL, BOUNDS)
+    with torch.no_grad():
+        nodes, ea, ei, _ = ga.process_collate([(torch.from_numpy(obs).to(dev), torch.zeros(obs.shape[1], 3, device=dev))])
+    traj = torch.from_numpy(scene.rigid_drift_trajectory(obs, 2)).to(dev)
+
+    def runs():
+        torch.manual_seed(11)
+        m = EncProcDecGNN(25, 4, 3, 128, 2, 3).to(dev)
+        out = {}
+        with torch.no_grad():
+            out["forward"] = m.forward(nodes, ea, ei).clone()
+            out["rollout"] = RolloutEngine(m, ga, obs.shape[1], device=dev).rollout(torch.from_numpy(obs).to(dev), traj, horizon=2).clone()
+        m.forward(nodes, ea, ei).square().sum().backward()
+        out["grads"] = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+        return out
+
+    ref = runs()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    busy = torch.randn(4096, 4096, device=dev)
+    for _ in range(20):
+        busy = busy @ busy * 1e-3          # the default stream has work queued while the side stream runs
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = runs()
+    side.synchronize()
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), (k, float((ref[k] - got[k]).abs().max()))
