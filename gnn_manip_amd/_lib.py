@@ -88,7 +88,8 @@ PROTOTYPES = {
     "gm_sinkhorn_divergence": (_i32, [_vp, _i64, _vp, _i64, _f32, _f32, _vp, _vp, _sz, _vp]),
     "gm_rollout_workspace_bytes": (_sz, [_MD, _i64, _i32]),
     "gm_rollout_step": (_i32, [_vp, _vp, _i64, _FD, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "gm_rollout": (_i32, [_vp, _vp, _i64, _FD, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "gm_rollout_renumber_workspace_bytes": (_sz, [_FD, _i64]),
+    "gm_rollout": (_i32, [_vp, _vp, _i64, _FD, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _sz, _vp, _sz, _vp]),
     "gm_rollout_status": (_i32, [_vp, _MD, _i64, _i32, C.POINTER(_i64), _vp]),
     "gm_model_profile": (_i32, [_vp, _i32]),
     "gm_model_set_edge_kernel": (_i32, [_vp, _i32]),

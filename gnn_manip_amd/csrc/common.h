@@ -101,6 +101,7 @@ struct GraphHeader {  // lives at the start of the graph workspace (device memor
     int n_per_graph;   // nodes per graph of a batch of equal-sized graphs (= n for a single graph)
     int ncells_local;  // cells of one graph's grid; graph b owns cells [b*ncells_local, (b+1)*ncells_local)
     int ticket;        // blocks of the bounding-box kernel that have finished (the last one derives the grid)
+    int order_skip;    // cell_order(): a cell held more rows than its ranking loop takes -- the order is the identity this time
 };
 
 struct GraphWs {
@@ -165,12 +166,23 @@ int rollout_pre_features(float* obs, int64_t n, const gm_feature_desc* d, const 
                          hipStream_t s);
 int rollout_integrate_post(float* obs, int64_t n, const gm_feature_desc* d, const float* pred, const int* rank,
                            const float* target, float* pred_out, hipStream_t s);
+// renumbered rollout (features.hip): out[t][j] = in[t][src(j)] over the k frames, src = perm (or the identity when the order was
+// skipped: GraphHeader::order_skip of graph_ws); total_out[j] = total_in ? total_in[src] : src; rank_out[j] = rank_caller[total_out[j]]
+int renumber_gather(const float* in, float* out, int k, int64_t n, int D, const int* perm, const void* graph_ws, const int* total_in,
+                    int* total_out, const int* rank_caller, int* rank_out, hipStream_t s);
+// out[t][total[j]] = in[t][j] over `frames` frames
+int renumber_scatter(const float* in, float* out, int frames, int64_t n, int D, const int* total, hipStream_t s);
 // destination sort of the radius graph with the edge features computed in the same pass (graph.hip)
 int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, const float* pos,
                                  int64_t pos_stride, float conn_r, float* edge_attr, int flow, hipStream_t s);
 // destination-sorted structure of an edge_index; with_blocks = false leaves the inference kernels' block tables out (training)
 int csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, int flow, void* csr_ws, size_t csr_ws_bytes, bool with_blocks, hipStream_t stream);
 
+// Order of the rows by (grid cell of the radius-graph grid over `pos`, row index) -- graphs of a batch stay apart, in order: the
+// deterministic form of the build's own cell sort (graph.hip).  perm[j] = row that comes j-th.  Uses graph_ws as scratch (the
+// next build clears it); hdr->order_skip tells the consumers (launched after this) that perm is to be read as the identity.
+int cell_order(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K, void* graph_ws, size_t graph_ws_bytes,
+               int* perm, hipStream_t s);
 int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s, int* total_out);
 size_t scan_tmp_ints(int64_t n_max);
 

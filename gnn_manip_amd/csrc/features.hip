@@ -280,6 +280,48 @@ __global__ void __launch_bounds__(256) rigid_transform_kernel(const float* __res
     out[id * 3 + 1] = p2;
 }
 
+// ---- renumbered rollout: rows of the [k, N, D] state move as whole rows (D floats), one thread per (frame, row)
+__global__ void __launch_bounds__(256) renumber_gather_kernel(const float* __restrict__ in, float* __restrict__ out, int k, int64_t n, int D,
+                                                               const int* __restrict__ perm, const GraphHeader* __restrict__ ghdr,
+                                                               const int* __restrict__ total_in, int* __restrict__ total_out,
+                                                               const int* __restrict__ rank_caller, int* __restrict__ rank_out) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t)k * n) return;
+    const int64_t t = id / n, j = id - t * n;
+    const int64_t src = ghdr->order_skip ? j : (int64_t)perm[j];
+    const float* a = in + (t * n + src) * D;
+    float* b = out + (t * n + j) * D;
+    for (int d = 0; d < D; ++d) b[d] = a[d];
+    if (t == 0) {
+        const int tot = total_in ? total_in[src] : (int)src;
+        total_out[j] = tot;
+        if (rank_out) rank_out[j] = rank_caller[tot];
+    }
+}
+__global__ void __launch_bounds__(256) renumber_scatter_kernel(const float* __restrict__ in, float* __restrict__ out, int frames, int64_t n, int D,
+                                                                const int* __restrict__ total) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t)frames * n) return;
+    const int64_t t = id / n, j = id - t * n;
+    const float* a = in + (t * n + j) * D;
+    float* b = out + (t * n + (int64_t)total[j]) * D;
+    for (int d = 0; d < D; ++d) b[d] = a[d];
+}
+int renumber_gather(const float* in, float* out, int k, int64_t n, int D, const int* perm, const void* graph_ws, const int* total_in,
+                    int* total_out, const int* rank_caller, int* rank_out, hipStream_t s) {
+    if (n <= 0 || k <= 0) return GM_OK;
+    hipLaunchKernelGGL(renumber_gather_kernel, dim3((unsigned)cdiv((int64_t)k * n, 256)), dim3(256), 0, s, in, out, k, n, D, perm,
+                       static_cast<const GraphHeader*>(graph_ws), total_in, total_out, rank_caller, rank_out);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+int renumber_scatter(const float* in, float* out, int frames, int64_t n, int D, const int* total, hipStream_t s) {
+    if (n <= 0 || frames <= 0) return GM_OK;
+    hipLaunchKernelGGL(renumber_scatter_kernel, dim3((unsigned)cdiv((int64_t)frames * n, 256)), dim3(256), 0, s, in, out, frames, n, D, total);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
 int rollout_pre_features(float* obs, int64_t n, const gm_feature_desc* d, const int* rank, const float* target, float* out,
                          hipStream_t s) {
     FeatParams P;

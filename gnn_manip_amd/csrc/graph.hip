@@ -298,6 +298,7 @@ __global__ void __launch_bounds__(256) graph_clear_kernel(GraphHeader* hdr, int*
         hdr->n_per_graph = 1;
         hdr->ncells_local = 1;
         hdr->ticket = 0;
+        hdr->order_skip = 0;
     }
 }
 
@@ -434,6 +435,28 @@ __global__ void __launch_bounds__(256) cell_fill_kernel(const float* __restrict_
     int c = cell_of[i];
     int p = cell_start[c] + atomicAdd(&cell_cursor[c], 1);
     sorted[p] = make_float4(pos[i * stride], pos[i * stride + 1], pos[i * stride + 2], __int_as_float((int)i));
+}
+
+// Rows in (cell, index) order: slot p of `sorted` holds row i of cell c; it comes (rows of c with a smaller index) places after the
+// cell's first slot.  cell_fill_kernel places rows with an atomic cursor, so the order inside a cell differs from run to run; this
+// ranking does not.  Cells of a dense scene hold ~5 rows; a cell beyond kCellOrderCap rows (a degenerate scene) would make the
+// loop quadratic, so it raises order_skip instead and the caller keeps the rows where they are (the order only buys locality).
+constexpr int kCellOrderCap = 1024;
+__global__ void __launch_bounds__(256) cell_order_kernel(const float4* __restrict__ sorted, const int* __restrict__ cell_of,
+                                                          const int* __restrict__ cell_start, GraphHeader* hdr, int64_t n,
+                                                          int* __restrict__ perm) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = __float_as_int(sorted[p].w);
+    const int c = cell_of[i];
+    const int lo = cell_start[c], hi = cell_start[c + 1];
+    if (hi - lo > kCellOrderCap) {
+        if (p == lo) atomicOr(&hdr->order_skip, 1);
+        return;
+    }
+    int before = 0;
+    for (int q = lo; q < hi; ++q) before += __float_as_int(sorted[q].w) < i ? 1 : 0;
+    perm[lo + before] = i;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -770,6 +793,25 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
     }
 }
 
+int cell_order(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K, void* graph_ws, size_t graph_ws_bytes,
+               int* perm, hipStream_t s) {
+    GM_REQUIRE(pos && graph_ws && perm && n > 0 && pos_stride >= 3 && conn_r > 0.0, GM_ERR_INVALID_ARGUMENT, "cell_order: bad argument");
+    GraphWs g = carve_graph(graph_ws, n, K);
+    GM_REQUIRE(graph_ws_bytes >= g.bytes, GM_ERR_WORKSPACE, "cell_order: workspace %zu < %zu", graph_ws_bytes, g.bytes);
+    const int64_t work = (int64_t)g.max_cells + 1;
+    const int cb = (int)cdiv(work, 256), nb = (int)cdiv(n, 256);
+    hipLaunchKernelGGL(graph_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, g.hdr, g.cell_start, (int64_t)g.max_cells + 1,
+                       g.cell_cursor, (int64_t)g.max_cells, g.cnt, (int64_t)0);
+    hipLaunchKernelGGL(bbox_kernel, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, pos, pos_stride, n, g.hdr, conn_r, g.max_cells, n_per);
+    hipLaunchKernelGGL(cell_assign_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.hdr, g.cell_of, g.cell_start);
+    const int rc = exclusive_scan_i32(g.cell_start, g.cell_start, (int64_t)g.max_cells + 1, nullptr, g.scan_tmp, s, nullptr);
+    if (rc != GM_OK) return rc;
+    hipLaunchKernelGGL(cell_fill_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.cell_of, g.cell_start, g.cell_cursor, g.sorted);
+    hipLaunchKernelGGL(cell_order_kernel, dim3(nb), dim3(256), 0, s, g.sorted, g.cell_of, g.cell_start, g.hdr, n, perm);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
 }  // namespace gm
 
 using namespace gm;
@@ -778,7 +820,7 @@ extern "C" {
 
 const char* gm_last_error(void) { return gm::last_error(); }
 
-int gm_abi_version(void) { return 5; }
+int gm_abi_version(void) { return 6; }
 
 size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours) {
     if (n_nodes < 0 || max_neighbours < 1) return 0;

@@ -185,6 +185,27 @@ __device__ __forceinline__ void acc_to_image(const floatx16& a, char* smem, unsi
 // after each MFMA with the instruction order pinned.  B fragments are fetched one k-group (hi part) / two MFMAs (lo part) ahead.  a0 / a1: byte address of this
 // lane's slot in fragment (0, hi part) for the even / odd k-groups (they differ in the swizzled image E only); c0: initial
 // accumulators (the first MFMA's C operand).
+#ifndef HEDGE_MFMA16
+#define HEDGE_MFMA16 0   // development builds, TIMING ONLY (results invalid): every 32x32x16 MFMA issued as two 16x16x32 on the same registers
+#endif
+typedef float floatx4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_step(floatx16& acc, const half8& a, const half8& b, const floatx16& c, int which) {
+#if HEDGE_MFMA16
+    // two quarter tiles per issue slot of the 32x32 form: the same operands, FLOPs and register traffic, not the same numbers
+    floatx4v q0, q1;
+    const int i0 = (2 * which) & 3, i1 = (2 * which + 1) & 3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { q0[t] = c[4 * i0 + t]; q1[t] = c[4 * i1 + t]; }
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q1, 0, 0, 0);
+    if (&acc != &c) acc = c;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[4 * i0 + t] = q0[t]; acc[4 * i1 + t] = q1[t]; }
+#else
+    (void)which;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
 template <class F>
 __device__ __forceinline__ void mlp_layer(floatx16& acc, const floatx16& c0, const half8 (&wh)[8], const half8 (&wl)[8], char* smem, unsigned a0, unsigned a1, F&& side) {
     half8 bh = LDS(half8, a0), bl = LDS(half8, a0 + 1024);
@@ -193,17 +214,17 @@ __device__ __forceinline__ void mlp_layer(floatx16& acc, const floatx16& c0, con
         half8 nh = bh;
         const unsigned an = (((ks + 1) & 1) ? a1 : a0) + (ks + 1) * 2048;
         GM_SB;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], bh, ks == 0 ? c0 : acc, 0, 0, 0);
+        if (ks == 0) mfma_step(acc, wl[ks], bh, c0, 3 * ks); else mfma_step(acc, wl[ks], bh, acc, 3 * ks);
         GM_SB;
         if (ks + 1 < 8) nh = LDS(half8, an);
         side(3 * ks);
         GM_SB;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bl, acc, 0, 0, 0);
+        mfma_step(acc, wh[ks], bl, acc, 3 * ks + 1);
         GM_SB;
         if (ks + 1 < 8) bl = LDS(half8, an + 1024);   // the low part is read by the middle MFMA only: its registers are free again
         side(3 * ks + 1);
         GM_SB;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bh, acc, 0, 0, 0);
+        mfma_step(acc, wh[ks], bh, acc, 3 * ks + 2);
         GM_SB;
         side(3 * ks + 2);
         bh = nh;

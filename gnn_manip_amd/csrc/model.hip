@@ -737,6 +737,27 @@ RolloutWs carve_rollout(void* ws, const gm_model_desc* d, int64_t n, int K) {
     r.bytes = c.used();
     return r;
 }
+// scratch of a renumbered rollout (gm_rollout, renumber_every > 0): two copies of the state (a re-ordering reads one and writes the
+// other), the row maps that go with them, the order and the rigid ranks of the current copy
+struct RenumberWs {
+    float* state[2];
+    int* total[2];
+    int *perm, *rank;
+    size_t bytes;
+};
+RenumberWs carve_renumber(void* ws, const gm_feature_desc* fd, int64_t n) {
+    RenumberWs w;
+    Carver c(ws);
+    const size_t st = (size_t)fd->k_steps * n * fd->data_dim;
+    w.state[0] = c.take<float>(st);
+    w.state[1] = c.take<float>(st);
+    w.total[0] = c.take<int>(n);
+    w.total[1] = c.take<int>(n);
+    w.perm = c.take<int>(n);
+    w.rank = c.take<int>(n);
+    w.bytes = c.used();
+    return w;
+}
 }  // namespace
 
 extern "C" {
@@ -822,29 +843,70 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
     return gm::rollout_integrate_post(obs, n, fd, r.pred, rigid_rank, rigid_target, pred_acc_out, hs);
 }
 
+size_t gm_rollout_renumber_workspace_bytes(const gm_feature_desc* fd, int64_t n) {
+    if (!fd || n < 0 || fd->k_steps < 1 || fd->data_dim < 1) return 0;
+    return carve_renumber(nullptr, fd, n).bytes;
+}
+
 int gm_rollout(const gm_model* m, float* obs, int64_t n, const gm_feature_desc* fd, int K, const int32_t* rigid_rank,
-               const float* rigid_targets, int64_t n_targets, int64_t n_rigid, int64_t steps, float* record_last, void* ws,
-               size_t ws_bytes, void* stream) {
+               const float* rigid_targets, int64_t n_targets, int64_t n_rigid, int64_t steps, float* record_last,
+               int64_t renumber_every, void* renumber_ws, size_t renumber_ws_bytes, void* ws, size_t ws_bytes, void* stream) {
     gm::DevGuard dev_guard(obs);
     GM_REQUIRE(m && obs && fd && ws, GM_ERR_INVALID_ARGUMENT, "gm_rollout: null pointer");
-    GM_REQUIRE(steps >= 0 && n_targets >= 0 && n_rigid >= 0, GM_ERR_INVALID_ARGUMENT, "gm_rollout: negative count");
+    GM_REQUIRE(steps >= 0 && n_targets >= 0 && n_rigid >= 0 && renumber_every >= 0, GM_ERR_INVALID_ARGUMENT, "gm_rollout: negative count");
     // a scene without rigid rows has an empty trajectory ([steps, 0, 3]: a null pointer); the reference's loop runs on it unchanged
     GM_REQUIRE(rigid_targets || n_targets == 0 || n_rigid == 0, GM_ERR_INVALID_ARGUMENT, "gm_rollout: n_targets > 0 without rigid_targets");
     GM_REQUIRE(!rigid_targets || rigid_rank, GM_ERR_INVALID_ARGUMENT, "gm_rollout: rigid_targets need rigid_rank");
     hipStream_t hs = (hipStream_t)stream;
     const size_t frame = (size_t)n * fd->data_dim;
-    float* last = obs + (size_t)(fd->k_steps - 1) * frame;
+    const bool renum = renumber_every > 0 && n > 0 && steps > 0;
+    RenumberWs rw{};
+    RolloutWs r{};
+    if (renum) {
+        GM_REQUIRE(renumber_ws, GM_ERR_INVALID_ARGUMENT, "gm_rollout: renumber_every > 0 needs renumber_ws (gm_rollout_renumber_workspace_bytes)");
+        rw = carve_renumber(renumber_ws, fd, n);
+        GM_REQUIRE(renumber_ws_bytes >= rw.bytes, GM_ERR_WORKSPACE, "gm_rollout: renumber workspace %zu < %zu", renumber_ws_bytes, rw.bytes);
+        GM_REQUIRE(n < ((int64_t)1 << 31) / (K > 0 ? K : 1), GM_ERR_UNSUPPORTED, "gm_rollout: n*max_neighbours overflows int32");
+        r = carve_rollout(ws, &m->d, n, K);
+        GM_REQUIRE(ws_bytes >= r.bytes, GM_ERR_WORKSPACE, "gm_rollout: workspace %zu < %zu", ws_bytes, r.bytes);
+    }
+    // The renumbered rollout works on a copy of the state whose rows are in grid-cell order (gm::cell_order: the radius graph's own
+    // grid; scenes of a batch stay apart), re-ordered every `renumber_every` steps: state[j] is the caller's row total[j], its rigid
+    // rank is the caller's (rank values only index the pose arrays: any order does), records and the final state go back through
+    // `total`.  A radius graph does not depend on the numbering and every per-node / per-edge function is numbering-free, so what
+    // changes is the order in which a node's incoming messages are summed: float32 rounding (tests: 2e-6 of the plain engine).
+    float* state = obs;            // the array the steps run on
+    const int* rank = rigid_rank;
+    const int* total = nullptr;    // row of the caller's state that row j of `state` is (nullptr: the identity)
+    int flip = 0;
     for (int64_t i = 0; i < steps; ++i) {
+        if (renum && i % renumber_every == 0) {
+            const float* last_pos = state + (size_t)(fd->k_steps - 1) * frame + fd->cart_col;
+            int rc = gm::cell_order(last_pos, fd->data_dim, n, fd->nodes_per_graph > 0 ? fd->nodes_per_graph : n, fd->conn_r, K, r.graph,
+                                    r.graph_bytes, rw.perm, hs);
+            if (rc != GM_OK) return rc;
+            rc = gm::renumber_gather(state, rw.state[flip], fd->k_steps, n, fd->data_dim, rw.perm, r.graph, total, rw.total[flip],
+                                     rigid_rank, rigid_rank ? rw.rank : nullptr, hs);
+            if (rc != GM_OK) return rc;
+            state = rw.state[flip];
+            total = rw.total[flip];
+            rank = rigid_rank ? rw.rank : nullptr;
+            flip ^= 1;
+        }
+        float* last = state + (size_t)(fd->k_steps - 1) * frame;
         // traj_utils.py:126-134: steps past the scripted trajectory keep the rigid body where it is (control = 0 displacement)
         const float* target = i < n_targets ? rigid_targets + (size_t)i * n_rigid * 3 : nullptr;
         if (record_last) {  // the reference records the last frame after the control overwrite (rollout_utils.py:49, traj_utils.py:137)
-            int rc = gm_state_pre(obs, n, fd, rigid_rank, target, stream);
+            int rc = gm_state_pre(state, n, fd, rank, target, stream);
             if (rc != GM_OK) return rc;
-            GM_HIP_CHECK(hipMemcpyAsync(record_last + (size_t)i * frame, last, frame * sizeof(float), hipMemcpyDeviceToDevice, hs));
+            if (total) rc = gm::renumber_scatter(last, record_last + (size_t)i * frame, 1, n, fd->data_dim, total, hs);
+            else GM_HIP_CHECK(hipMemcpyAsync(record_last + (size_t)i * frame, last, frame * sizeof(float), hipMemcpyDeviceToDevice, hs));
+            if (rc != GM_OK) return rc;
         }
-        int rc = gm_rollout_step(m, obs, n, fd, K, rigid_rank, target, nullptr, ws, ws_bytes, stream);
+        int rc = gm_rollout_step(m, state, n, fd, K, rank, target, nullptr, ws, ws_bytes, stream);
         if (rc != GM_OK) return rc;
     }
+    if (total) return gm::renumber_scatter(state, obs, fd->k_steps, n, fd->data_dim, total, hs);
     return GM_OK;
 }
 

@@ -971,7 +971,17 @@ int wgrad_enqueue(WgradBatch& b, const float* dz, int ldz, int M, const float* X
     j.Mp = (int)cdiv(M, 128) * 128; j.Kp = (int)cdiv(K, 128) * 128;
     j.KT = j.Kp / 128; j.tiles = (j.Mp / 128) * j.KT;
     GM_REQUIRE(j.tiles <= 4, GM_ERR_UNSUPPORTED, "wgrad: a %d x %d weight block (at most 4 tiles of 128 x 128 per job)", M, K);
-    GM_REQUIRE(b.jobs.n < kWgJobsMax, GM_ERR_INVALID_ARGUMENT, "wgrad: more than %d jobs between two flushes", kWgJobsMax);
+    // Indexed X rows are addressed with 32-bit byte offsets from the array's base (buffer addressing, wgrad_body): every row a
+    // valid index can name must lie below 4 GiB.  xidx values are rows of X < `rows` for every caller (an edge permutation).
+    GM_REQUIRE(!xidx || (uint64_t)rows * (uint64_t)ldx * 4u < (1ull << 32), GM_ERR_UNSUPPORTED,
+               "wgrad: an indexed operand of %lld rows x %d floats exceeds the 4 GiB its 32-bit row offsets cover", (long long)rows, ldx);
+    // A full batch is flushed first: the jobs it holds read operands that are still valid (they were produced by launches already
+    // on the stream), so an early flush is always safe -- deep MLPs (num_layers >= 4) put more than kWgJobsMax jobs between the
+    // model's own flush points.
+    if (b.jobs.n >= kWgJobsMax) {
+        const int rc = wgrad_flush(b);
+        if (rc != GM_OK) return rc;
+    }
     b.jobs.job[b.jobs.n++] = j;   // chunk, G and the partial offset are set when the batch is flushed
     return GM_OK;
 }

@@ -63,6 +63,7 @@ Tape carve_tape(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
 
 struct BwdWs {
     float *packT, *dz, *dzn, *de, *dh, *dagg, *Gi, *Gj, *part;
+    float* go;          // the upstream gradient as the chains read it: zero when the forward's edge_index was flagged (gate_grad_out_kernel)
     size_t dz_stride;   // floats between dz_l and dz_(l+1) (l = 1 .. NL + 1)
     float* dzl(int l) const { return dz + (size_t)(l - 1) * dz_stride; }
     // the node-sized chains of the model backward (node MLPs, node encoder) leave their dz in a set of their own, so that the
@@ -102,8 +103,26 @@ BwdWs carve_bwd(void* ws, const gm_model_desc* d, int64_t n, int64_t e) {
     b.Gi = c.take<float>((size_t)n * H);
     b.Gj = c.take<float>((size_t)n * H);
     b.part = c.take<float>(wgrad_partial_floats(H));
+    b.go = c.take<float>((size_t)n * (d->out_dim > 0 ? d->out_dim : 1));
     b.bytes = c.used();
     return b;
+}
+
+// A training forward does not synchronise: an edge_index entry outside [0, n) is flagged by the destination sort in the tape's CSR
+// headers and reported at a later forward / status() (epd_gnn.py).  Until then the step must not do damage: the flagged forward's
+// output is NaN (the loss shows it) and its backward produces exactly zero gradients (the upstream gradient is gated to zero), so
+// the optimiser step that runs before the error surfaces leaves the weights where a raise at the forward would have left them.
+__global__ void __launch_bounds__(256) poison_if_flagged_kernel(const CsrHeader* a, const CsrHeader* b, float* out, size_t count) {
+    if (!((a->error_flags | b->error_flags) & ERRF_BAD_EDGE_INDEX)) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) out[i] = __builtin_nanf("");
+}
+__global__ void __launch_bounds__(256) gate_grad_out_kernel(const CsrHeader* a, const CsrHeader* b, const float* g, float* out, size_t count) {
+    const bool bad = ((a->error_flags | b->error_flags) & ERRF_BAD_EDGE_INDEX) != 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) out[i] = bad ? 0.f : g[i];
+}
+unsigned small_grid(size_t count) {
+    const size_t g = (count + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 512 ? 512 : g));
 }
 
 int check_sizes(const gm_model* m, int64_t n, int64_t e, const char* who) {
@@ -248,6 +267,11 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
         rc = launch_train_fwd(H, TK_DEC, a, s);
         if (rc != GM_OK) return rc;
     }
+    {   // a flagged edge_index: the prediction is NaN, not a plausible number computed on a different graph
+        const size_t cnt = (size_t)n * m->d.out_dim;
+        hipLaunchKernelGGL(poison_if_flagged_kernel, dim3(small_grid(cnt)), dim3(256), 0, s, c.hdr, carve_csr(t.csr_src, n, e).hdr, out, cnt);
+        GM_LAUNCH_CHECK();
+    }
     return GM_OK;
 }
 
@@ -341,6 +365,13 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     // (the LayerNorm parameter gradients are summed inside the chain kernels: TrainBwdArgs.ln_part / dgamma / dbeta)
     auto ln_gamma = [&](size_t voff) { return m->vec + voff + (size_t)(NL + 1) * H; };
 
+    // ---- the upstream gradient as the chains see it: zero for a forward whose edge_index was flagged (see gate_grad_out_kernel)
+    {
+        const size_t cnt = (size_t)n * OD;
+        hipLaunchKernelGGL(gate_grad_out_kernel, dim3(small_grid(cnt)), dim3(256), 0, s, c.hdr, c2.hdr, grad_out, b.go, cnt);
+        GM_LAUNCH_CHECK();
+        grad_out = b.go;
+    }
     // ---- decoder
     {
         TrainBwdArgs a{};

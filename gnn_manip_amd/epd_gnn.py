@@ -261,9 +261,13 @@ class _HeaderWatch:
 
     def __init__(self, ws, pinned_row):
         self._host = pinned_row
-        self._host.copy_(ws[:16].view(torch.int32), non_blocking=True)
-        self._event = torch.cuda.Event()
-        self._event.record()
+        self._host.zero_()     # a recycled row must not show an earlier forward's verdict while this copy is in flight
+        # the copy and the event go on the stream the library's work for `ws` runs on: the current stream of ws's device, which
+        # need not be the current device (_lib.current_stream / DevGuard support tensors on another device)
+        with torch.cuda.device(ws.device):
+            self._host.copy_(ws[:16].view(torch.int32), non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record(torch.cuda.current_stream(ws.device))
 
     def poll(self):
         """None: still in flight; False: finished clean; True: finished with an error flag."""
@@ -428,8 +432,9 @@ class _EpdTrainFunction(torch.autograd.Function):
                                      current_stream()))
         ctx.module, ctx.handle, ctx.desc, ctx.tape = module, h, d, tape
         ctx.sizes = (n, e)
-        if module.auto_status:
-            module._watch(tape)    # the tape begins with the forward's csr workspace: its header carries the edge_index verdict
+        # the tape begins with the forward's csr workspace: its header carries the edge_index verdict.  Watched whatever
+        # auto_status says (that switch only decides whether a later forward looks at it unasked): status() must see it.
+        module._watch(tape)
         ctx.save_for_backward(nodes, edge_attr, *params)
         return out
 
@@ -545,7 +550,10 @@ class EncProcDecGNN(nn.Module):
                                           "(they are data in train_dyn.py); detach them")
             # edge_index entries outside [0, n) are flagged on the device by the forward's destination sort (and left out; the
             # kernels stay inside their arrays): no blocking range check here -- a training loop queues its steps ahead of the GPU.
-            # The flag surfaces as GMError at a later forward (auto_status) or at status(), like the inference path's.
+            # The flag surfaces as GMError at a later forward (auto_status) or at status(), like the inference path's.  Until it
+            # does, the flagged step is harmless by construction: its prediction is NaN and its backward returns zero gradients
+            # (csrc/train_model.hip: poison_if_flagged_kernel / gate_grad_out_kernel), so the optimiser steps that run before the
+            # error is raised leave the weights where a raise at the forward (the reference's behaviour) would have left them.
             _check_edge_index(edge_index, n, e, ranges=False)
             if self.auto_status:
                 self._reap_watched(block=False)

@@ -50,11 +50,11 @@ class RolloutEngine:
         node axis ([k, candidates*n_nodes, D]); the radius graph never links two scenes (block-diagonal batch,
         the offset rule of collate_utils.py:76), everything else is per node / per edge.
 
-        renumber: True / False / "auto" (scenes of RENUMBER_MIN_NODES particles or more).  ``run`` then works on a copy of
-        the state whose rows are in grid-cell order (cells of edge conn_r, x fastest; particles of a cell in index order:
-        a stable sort, the same every time), so that the per-edge gathers of neighbouring rows find each other in cache,
-        re-sorts it every RENUMBER_EVERY steps (particles move a fraction of a cell per step) and writes the result back
-        in the caller's numbering.  A radius graph does not depend on the numbering
+        renumber: True / False / "auto" (scenes of RENUMBER_MIN_NODES particles or more).  ``run`` then asks the library
+        (gm_rollout, renumber_every = RENUMBER_EVERY) to work on a copy of the state whose rows are in grid-cell order (the
+        radius graph's own grid, x fastest; particles of a cell in index order: the same every time), so that the per-edge
+        gathers of neighbouring rows find each other in cache, re-ordered every RENUMBER_EVERY steps (particles move a
+        fraction of a cell per step), and to write the result back in the caller's numbering.  A radius graph does not depend on the numbering
         (neighbours are ranked by distance; only an exact tie in distance falls back on the index) and every per-node /
         per-edge function is numbering-free, so what changes is the order in which a node's incoming messages are
         summed: float32 rounding, far inside the 1e-5 parity bound."""
@@ -80,6 +80,7 @@ class RolloutEngine:
         if renumber == "auto" and os.environ.get("GM_RENUMBER") in ("0", "1"):   # A/B runs of the benchmark
             renumber = os.environ["GM_RENUMBER"] == "1"
         self.renumber = (self.n_per >= self.RENUMBER_MIN_NODES) if renumber == "auto" else bool(renumber)
+        self._renumber_ws = None
 
     def _rank_rigid(self, obs):
         rank = torch.empty(self.n, dtype=torch.int32, device=self.device)
@@ -94,16 +95,6 @@ class RolloutEngine:
         self.rigid_rank, cnt = self._rank_rigid(obs)
         self.n_rigid = int(cnt.item())
         return self.n_rigid
-
-    def _cell_order(self, state):
-        """Permutation that puts the rows of ``state`` [k, N, D] in grid-cell order of its last frame (scenes of a batch stay
-        apart, in order); a stable sort of integer keys: the same state gives the same order every time."""
-        c0 = self.graph_attr.cartesian_idx[0]
-        pos = torch.nan_to_num(state[-1, :, c0:c0 + 3], nan=0.0, posinf=0.0, neginf=0.0)
-        cell = torch.floor((pos - pos.amin(0)) / float(self.graph_attr.conn_r)).clamp_(0, 1023).long()
-        key = (cell[:, 2] * 1024 + cell[:, 1]) * 1024 + cell[:, 0]
-        key += (torch.arange(self.n, device=self.device) // self.n_per) << 30
-        return torch.argsort(key, stable=True)
 
     def _check_state(self, obs, rigid_target, pred_out, use_rigid):
         """The C entry takes raw pointers: shapes, dtypes and devices are checked here."""
@@ -152,33 +143,17 @@ class RolloutEngine:
         recs = torch.empty((steps, self.n, self.data_dim), dtype=torch.float32, device=self.device) if record else None
         handle = self.model.device_handle(self.device)  # resolved once per rollout
         L = lib()
-        if not (self.renumber and self.n > 0 and steps > 0):
-            check(L.gm_rollout(handle, ptr(obs), self.n, C.byref(self.fdesc), self.max_neighbours, ptr(self.rigid_rank),
-                               ptr(trajectory), T, self.n_rigid, steps, ptr(recs), ptr(self.ws), self.ws.numel(), current_stream()))
-            return recs
-        # renumbered: chunks of RENUMBER_EVERY steps on a copy in cell order; `total` maps its rows to the caller's
-        state, total = obs, None
-        for s0 in range(0, steps, self.RENUMBER_EVERY):
-            k = min(self.RENUMBER_EVERY, steps - s0)
-            q = self._cell_order(state)
-            state = state.index_select(1, q)
-            total = q if total is None else total.index_select(0, q)
-            rank, _ = self._rank_rigid(state)
-            t_k = max(0, min(T, s0 + k) - s0)
-            traj = None
-            if t_k > 0:
-                r = self.rigid_rank.long().index_select(0, total)
-                traj = trajectory[s0:s0 + t_k].index_select(1, r[r >= 0])   # renumbered rigid row j follows the caller's pose r[j]
-            rec_k = None if recs is None else recs[s0:s0 + k]
-            check(L.gm_rollout(handle, ptr(state), self.n, C.byref(self.fdesc), self.max_neighbours, ptr(rank),
-                               ptr(traj), t_k, self.n_rigid, k, ptr(rec_k), ptr(self.ws), self.ws.numel(), current_stream()))
-            if rec_k is not None:
-                inv = torch.empty_like(total)
-                inv[total] = torch.arange(self.n, device=self.device)
-                rec_k.copy_(rec_k.index_select(1, inv))
-        inv = torch.empty_like(total)
-        inv[total] = torch.arange(self.n, device=self.device)
-        torch.index_select(state, 1, inv, out=obs)
+        every, rws = 0, None
+        if self.renumber and self.n > 0 and steps > 0:
+            # rows in grid-cell order inside the library (gm_rollout, renumber_every): order, row maps, gathers and the write-back
+            # are device kernels of the same call -- nothing is sorted or synchronised here
+            every = self.RENUMBER_EVERY
+            if self._renumber_ws is None:
+                self._renumber_ws = _ws(L.gm_rollout_renumber_workspace_bytes(C.byref(self.fdesc), self.n), self.device)
+            rws = self._renumber_ws
+        check(L.gm_rollout(handle, ptr(obs), self.n, C.byref(self.fdesc), self.max_neighbours, ptr(self.rigid_rank),
+                           ptr(trajectory), T, self.n_rigid, steps, ptr(recs), every, ptr(rws), 0 if rws is None else rws.numel(),
+                           ptr(self.ws), self.ws.numel(), current_stream()))
         return recs
 
     def rollout_candidates(self, obs0, trajectories, horizon=None):

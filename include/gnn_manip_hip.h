@@ -313,11 +313,24 @@ int gm_rollout_step(const gm_model* m, float* obs /*[k,N,D] in/out*/, int64_t n_
  * == cma_objective's (traj_utils.py:123-152).  rigid_targets: [n_targets, n_rigid, 3] scripted poses, step i uses pose i;
  * steps beyond n_targets keep the rigid body in place (traj_utils.py:130-131); NULL / 0: no scripted poses.
  * record_last: [steps, N, D] or NULL -- the last frame of the window after the control overwrite of every step, i.e. what
- * the reference appends to `prediction` / `positions` (rollout_utils.py:49, traj_utils.py:137).  No host synchronisation. */
+ * the reference appends to `prediction` / `positions` (rollout_utils.py:49, traj_utils.py:137).  No host synchronisation.
+ *
+ * renumber_every > 0 (ABI 6): the loop runs on a copy of the state whose rows are in grid-cell order -- the radius graph's own
+ * cell grid over the last frame, rows of a cell by index, graphs of a batch apart and in order -- re-ordered every
+ * `renumber_every` steps (particles move a fraction of a cell per step; 64 is what RolloutEngine uses), so that the per-edge
+ * gathers of neighbouring rows share cache lines whatever numbering the caller's simulator emits.  obs, record_last,
+ * rigid_rank and rigid_targets stay in the CALLER's numbering: the result is written back through the row map, the records
+ * too, and a renumbered rigid row keeps the caller's rank (ranks only index the pose arrays).  The order is computed on the
+ * device (a ranking inside the graph build's cells: deterministic, no sort library, no host synchronisation).  A radius graph
+ * does not depend on the numbering and every per-node / per-edge function is numbering-free: what changes is the order in
+ * which a node's incoming messages are summed (float32 rounding, <= 2e-6 of the plain loop in the tests); the same state
+ * gives the same bits every time.  renumber_ws: gm_rollout_renumber_workspace_bytes(fdesc, n_nodes) bytes (two copies of the
+ * state + row maps); NULL / 0 with renumber_every == 0, which is the plain loop of ABI 5. */
+size_t gm_rollout_renumber_workspace_bytes(const gm_feature_desc* fdesc, int64_t n_nodes);
 int gm_rollout(const gm_model* m, float* obs /*[k,N,D] in/out*/, int64_t n_nodes, const gm_feature_desc* fdesc,
                int max_neighbours, const int32_t* rigid_rank, const float* rigid_targets, int64_t n_targets,
-               int64_t n_rigid, int64_t steps, float* record_last, void* rollout_ws, size_t rollout_ws_bytes,
-               void* stream);
+               int64_t n_rigid, int64_t steps, float* record_last, int64_t renumber_every, void* renumber_ws,
+               size_t renumber_ws_bytes, void* rollout_ws, size_t rollout_ws_bytes, void* stream);
 /* Error flags / edge count of the last step (synchronises). */
 int gm_rollout_status(const void* rollout_ws, const gm_model_desc* desc, int64_t n_nodes,
                       int max_neighbours, int64_t* n_edges_host, void* stream);

@@ -428,7 +428,7 @@ def test_renumbered_rollout_matches_the_plain_one_and_the_oracle(dev):
         e1 = ren.status()
         f2, r2 = ren.rollout(_t(obs, dev), _t(traj, dev), horizon=steps, record=True)
     assert ren.renumber and not plain.renumber
-    assert not torch.equal(ren._cell_order(_t(obs, dev)), torch.arange(n, device=dev))
+    assert not torch.equal(f1, f0)       # the rows really moved: another summation order somewhere, not the plain loop again
     assert e0 == e1 and ren.n_rigid == plain.n_rigid == int(rigid.sum())
     assert torch.equal(f1, f2) and torch.equal(r1, r2)
     f0, r0, f1, r1 = (x.cpu().numpy() for x in (f0, r0, f1, r1))
@@ -450,6 +450,54 @@ def test_renumbered_rollout_matches_the_plain_one_and_the_oracle(dev):
     np.testing.assert_allclose(long_r[:, :, 2:8], long_p[:, :, 2:8], rtol=0, atol=2e-6)
     assert np.array_equal(out[0], f1) and np.array_equal(out[1], one)
     assert RolloutEngine(m, _ga(), RolloutEngine.RENUMBER_MIN_NODES, device=dev).renumber and not RolloutEngine(m, _ga(), 5000, device=dev).renumber
+
+
+def test_gm_rollout_renumbers_behind_the_c_abi(dev):
+    """gm_rollout(..., renumber_every, renumber_ws, ...) driven raw through ctypes -- pointers, sizes and a stream, no RolloutEngine --
+    gives the bits of RolloutEngine(renumber=True): the cell order, the row maps, the gathers and the write-back in the caller's
+    numbering are all behind the C ABI (include/gnn_manip_hip.h; the loop it replaces: rollout_utils.py:38-61).  With
+    renumber_every = 0 and no renumber workspace the same entry point is the plain loop."""
+    import ctypes as C
+    from gnn_manip_amd import RolloutEngine, scene
+    from gnn_manip_amd._lib import ModelDesc, check, lib
+    n, steps, every = 1500, 5, 2
+    obs = scene.make_scene(n, seed=321, side=0.09)
+    obs = np.ascontiguousarray(obs[:, np.random.Generator(np.random.PCG64(322)).permutation(n)])
+    traj = scene.rigid_drift_trajectory(obs, steps, seed=323, step_size=3e-4)
+    params = orc.init_params(25, 4, 3, 128, 2, 3, 324)
+    m = _model(params, (25, 4, 3, 128, 2, 3), dev)
+    with torch.no_grad():
+        ren = RolloutEngine(m, _ga(), n, device=dev, renumber=True)
+        ren.RENUMBER_EVERY = every
+        want, want_rec = ren.rollout(_t(obs, dev), _t(traj, dev), horizon=steps, record=True)
+        plain = RolloutEngine(m, _ga(), n, device=dev, renumber=False)
+        want_plain = plain.rollout(_t(obs, dev), _t(traj, dev), horizon=steps)
+    L = lib()
+    fdesc, mdesc = ren.fdesc, ModelDesc(*m.model_desc())
+    handle = m.device_handle(dev)
+    u8 = lambda nbytes: torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    ws = u8(L.gm_rollout_workspace_bytes(C.byref(mdesc), n, 20))
+    rws = u8(L.gm_rollout_renumber_workspace_bytes(C.byref(fdesc), n))
+    rws.fill_(0xff)                       # whatever the scratch held
+    state, t_dev = _t(obs, dev).clone(), _t(traj, dev)
+    rank = torch.empty(n, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    check(L.gm_rigid_rank(p(state), n, C.byref(fdesc), p(rank), p(cnt), stream))
+    n_rigid = int(cnt.item())
+    rec = torch.empty((steps, n, obs.shape[2]), dtype=torch.float32, device=dev)
+    check(L.gm_rollout(handle, p(state), n, C.byref(fdesc), 20, p(rank), p(t_dev), steps, n_rigid, steps, p(rec), every, p(rws), rws.numel(),
+                       p(ws), ws.numel(), stream))
+    torch.cuda.synchronize()
+    assert torch.equal(state, want) and torch.equal(rec, want_rec)
+    state2 = _t(obs, dev).clone()
+    check(L.gm_rollout(handle, p(state2), n, C.byref(fdesc), 20, p(rank), p(t_dev), steps, n_rigid, steps, None, 0, None, 0, p(ws), ws.numel(), stream))
+    torch.cuda.synchronize()
+    assert torch.equal(state2, want_plain) and not torch.equal(state2, state)
+    # argument errors come back as status codes, before any launch
+    assert L.gm_rollout(handle, p(state2), n, C.byref(fdesc), 20, p(rank), p(t_dev), steps, n_rigid, steps, None, every, None, 0, p(ws), ws.numel(), stream) != 0
+    assert L.gm_rollout(handle, p(state2), n, C.byref(fdesc), 20, p(rank), p(t_dev), steps, n_rigid, steps, None, every, p(rws), 16, p(ws), ws.numel(), stream) != 0
 
 
 # ------------------------------------------------------------------ batches of scenes (candidates)
