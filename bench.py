@@ -167,17 +167,15 @@ def roofline_record(model, ek, hidden, edges, n_nodes, workload_key):
     alg = edge_kernel_alg_flops(edges, hidden)
     issued = edge_kernel_issued_flops(edges, hidden)
     # MFMA utilisation is priced on the flops the kernel ISSUES (3 HxH products per edge; SURVEY.md 8d "utilisation uses
-    # F_issued"); the split-operand kernels issue 3 (fp16 two-way split) or 6 (bf16 three-way split) matrix-pipe product
-    # blocks per fp32-equivalent block and are priced against the 16-bit pipe.
-    mult = {"sys": 3, "hm": 3, "b3": 6, "b3p": 6}.get(ek, 1)
-    peak = MFMA_16BIT_PEAK_TFLOPS if mult > 1 else MFMA_F32_PEAK_TFLOPS
+    # F_issued"); the split-operand kernels issue 3 matrix-pipe product blocks (fp16 two-way split) per fp32-equivalent block
+    # and are priced against the 16-bit pipe.
+    mult = 3
+    peak = MFMA_16BIT_PEAK_TFLOPS
     achieved = issued * mult / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-    kname = {"16": "edge_kernel16<2,1>", "classic": f"edge_kernel<{hidden},2,1>", "b3": "edge_kernel_b3<2,1>", "b3p": "edge_kernel_b3p<2,1>",
-             "sys": "sys_edge_kernel", "hm": f"hm_edge_kernel<{hidden},false>"}[ek]
+    kname = {"sys": "sys_edge_kernel", "hm": f"hm_edge_kernel<{hidden},false>"}[ek]
     alg_bytes = edge_kernel_alg_bytes(edges, n_nodes, hidden)
     hbm = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    pipe = {"sys": "fp16 MFMA (2.5 PF dense)", "hm": "fp16 MFMA (2.5 PF dense)", "b3": "bf16 MFMA (2.5 PF dense)",
-            "b3p": "bf16 MFMA (2.5 PF dense)"}.get(ek, "fp32 MFMA")
+    pipe = "fp16 MFMA (2.5 PF dense)"
     mfma = {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "pipe": pipe,
             "floor_ms": issued * mult / (peak * 1e12) * 1e3}
     hbmr = {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "floor_ms": alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3}
@@ -350,7 +348,7 @@ def run_c5(dev, rank, world, dist, cdev, args):
                        "parallelism": f"candidate-parallel x{world}"},
             # rank 0's wall time inside the generation's broadcast + all-gather calls (the all-gather includes the wait for the
             # slowest rank): what is not rollout or loss work when the 1 -> N curve falls short
-            "collective_ms": ev.collective_s * 1e3}
+            "collective_ms": ev.collective_s * 1e3, "collective_backend": dist.get_backend() if dist else None}
 
 
 def extra_c5_1gpu(dev, args):
@@ -470,9 +468,12 @@ def main():
                     help="candidate rollouts batched per GPU (block-diagonal); value counts candidates x steps")
     ap.add_argument("--candidates-total", type=int, default=64, help="c5: CMA-ES population size")
     ap.add_argument("--batch", type=int, default=8, help="c5: candidates per block-diagonal batch")
+    ap.add_argument("--collectives", default="auto", choices=["auto", "always"],
+                    help="always: initialise torch.distributed (nccl = RCCL) and run the per-generation broadcast / all-gather even "
+                         "with ONE rank -- the multi-GPU code path, device-resident payloads included, on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C3 / C4 sub-records")
-    ap.add_argument("--edge-kernel", default="auto", choices=["auto", "16", "classic", "b3", "b3p", "sys", "hm"],
+    ap.add_argument("--edge-kernel", default="auto", choices=["auto", "sys", "hm"],
                     help="processor edge kernel (per-model option): auto = systolic fp16 x 3 kernel for hidden 128 (DESIGN.md 5.1)")
     args = ap.parse_args()
 
@@ -493,8 +494,17 @@ def main():
     dev = torch.device("cuda:0" if rehearse else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.collectives == "always":
         import torch.distributed as dist
+        if world == 1:   # a single rank has no launcher around it: rendezvous with itself on the loopback interface
+            import socket
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -516,17 +526,14 @@ def main():
                    "value": rec["value"], "unit": "rollout steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
                    "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                    "dtype": "f32",
-                   "arithmetic": {"sys": "fp32 operands as two-way fp16 splits, three exact fp16 x fp16 partial products per multiply on the fp16 "
-                                         "MFMA pipe, fp32 accumulation (1e-6 vs float64 through the model, like plain fp32)",
-                                  "hm": "fp32 operands as two-way fp16 splits, three exact fp16 x fp16 partial products per multiply on the fp16 "
-                                        "MFMA pipe, fp32 accumulation (1e-6 vs float64 through the model, like plain fp32)",
-                                  "b3": "six exact bf16 x bf16 partial products of three-way operand splits, fp32 accumulation",
-                                  "b3p": "six exact bf16 x bf16 partial products of three-way operand splits, fp32 accumulation"}.get(ek, "fp32 MFMA"),
+                   "arithmetic": "fp32 operands as two-way fp16 splits, three exact fp16 x fp16 partial products per multiply on the fp16 "
+                                 "MFMA pipe, fp32 accumulation (1e-6 vs float64 through the model, like plain fp32)",
                    "data": "synthetic (seeded dense scene; random-init weights, decoder output layer scaled 1e-5 so the pile stays dense "
                            "over the rollout)",
                    "config": rec["config"], "roofline": rec["roofline"], "breakdown": rec["breakdown"]}
-            if world > 1:
+            if dist:
                 out["collective_ms"] = rec["collective_ms"]   # rank 0: broadcast + all-gather (incl. waiting for the slowest rank)
+                out["collective_backend"] = dist.get_backend()
             if world == 1 and not args.no_extra and args.workload == "target" and args.candidates == 1:
                 extra = {}
                 for key in ("c2", "c3", "c4"):

@@ -12,12 +12,6 @@ SOURCES = ["graph.hip", "features.hip", "mlp.hip", "hedge.hip", "hmlp.hip", "mod
 # hedge.hip: packed fp32 VALU (SLP-vectorised v_pk_fma_f32) returned wrong low lanes next to its LDS / MFMA traffic on gfx950
 EXTRA_FLAGS = {"hedge.hip": ["-fno-slp-vectorize"] + os.environ.get("GM_HEDGE_FLAGS", "").split(), "hmlp.hip": ["-fno-slp-vectorize"] + os.environ.get("GM_HM_FLAGS", "").split()}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
-# GM_DEV_KERNELS=1: development build that also contains the round-1 fp32 / bf16 x 6 inference kernels (A/B and accuracy
-# references; they add tile-crossing partial sums with float atomics, hence the extra flag for their file only)
-if os.environ.get("GM_DEV_KERNELS") == "1":
-    FLAGS.append("-DGM_DEV_KERNELS")
-    SOURCES.append("mlp_dev_kernels.hip")   # not part of the product library
-    EXTRA_FLAGS["mlp_dev_kernels.hip"] = ["-munsafe-fp-atomics"]
 
 
 def source_digest():

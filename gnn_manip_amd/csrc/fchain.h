@@ -1,6 +1,6 @@
-// Device building blocks of the fused MLP kernels (mlp.hip, train.hip): packed weight stream, the
-// transposed MFMA layer, register <-> feature-row helpers, LayerNorm in registers.  See mlp.hip for the
-// formulation.
+// Device building blocks of the training kernels' chains (train.hip): LDS-DMA weight stream, the transposed MFMA layer on the 32 x 32
+// accumulator layout, register <-> feature-row helpers.  (Round 1's fp32 inference kernels were built from the same pieces; they
+// were removed in round 5.)
 #pragma once
 #include "common.h"
 #include "mlp.h"
@@ -170,65 +170,6 @@ __device__ __forceinline__ void relu_to(floatx16 (&dst)[NKB], const floatx16 (&s
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[kb][r] = fmaxf(src[kb][r], 0.f);
-}
-
-// LayerNorm over the H = 32*NJB features of each lane pair (n, hi=0/1); two-pass, float32.
-template <int NJB>
-__device__ __forceinline__ void layer_norm_regs(floatx16 (&acc)[NJB], const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, float eps, int hi) {
-    constexpr float INV_H = 1.0f / (32 * NJB);
-    float s = 0.f;
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[jb][r];
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * INV_H;
-    float q = 0.f;
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = acc[jb][r] - mean;
-            q += d * d;
-        }
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * INV_H + eps);
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb) {
-        // compiler-level memory barrier: keeps the gamma / beta loads of block jb from being hoisted
-        // above block jb-1 (all 128 values in flight at once cost 128 VGPRs and spill the accumulators)
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const floatx4 gm = *reinterpret_cast<const floatx4*>(gamma + 32 * jb + 8 * g + 4 * hi);
-            const floatx4 bt = *reinterpret_cast<const floatx4*>(beta + 32 * jb + 8 * g + 4 * hi);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[jb][4 * g + t] = (acc[jb][4 * g + t] - mean) * rstd * gm[t] + bt[t];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Two workgroups share a CU (two waves per SIMD).  The matrix pipe is the shared resource; everything
-// else a tile does (index / gather issue, LayerNorm, LDS staging, segmented reduction, stores) is a
-// latency-bound chain of few instructions.  Those phases run at raised priority so that they are never
-// starved by the partner workgroup's MFMA stream (measured: at equal or lower priority a workgroup's
-// epilogue stretches from ~12 us to ~27 us while its partner is in its MFMA phase); the MFMA phases
-// run at priority 0 and take whatever issue slots are left, which is all the pipe needs.
-__device__ __forceinline__ void prio_latency_phase() { __builtin_amdgcn_s_setprio(3); }
-__device__ __forceinline__ void prio_mfma_phase() { __builtin_amdgcn_s_setprio(0); }
-
-// hidden layers 2..NL and the output layer of an MLP whose layer 1 has just been accumulated
-template <int H, int NL>
-__device__ __forceinline__ void mlp_tail_layers(floatx16 (&acc)[H / 32], floatx16 (&act)[H / 32], const float* __restrict__ bias,
-                                                WStream& ws, bool more_tiles, int hi) {
-#pragma unroll
-    for (int l = 1; l <= NL; ++l) {
-        relu_to(act, acc);
-        load_feat(acc, bias + (l - 1) * H, hi);
-        run_layer<H / 8, H / 32, H / 32>(acc, act, ws, more_tiles);
-    }
 }
 
 }  // namespace gm

@@ -99,6 +99,9 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8 + 32];   // + the 100 MHz 
 #ifndef HEDGE_ABL
 #define HEDGE_ABL 0   // development builds: timing ablations (1 no residual read, 2 P_j from the P_i row, 4 no e_out store, 8 no agg store, 16 no e read, 32 e_out rows folded onto 1024 rows)
 #endif
+#ifndef HEDGE_SC1
+#define HEDGE_SC1 12   // sc1 (write-through, the line is not kept in L2) on: 1 the e rows role 0 reads, 2 the residual re-read, 4 the e_out stores, 8 the agg stores; 16: sc0 on the e_out stores too
+#endif
 constexpr int HW_HEADER_FLOATS = 4;            // T1, 1/T3, cap of the per-row input scale (encoder image), pad
 constexpr int HW_VEC_FLOATS = 5 * H;           // b2*T2 | b3*T3 | gamma | beta | b1*T1 (the encoder's; a processor step has b1 in P)
 constexpr int HW_IMAGE_HALF8 = 3 * 4 * 8 * 2 * 64;   // [layer][jb][ks][part][lane]
@@ -135,13 +138,13 @@ typedef __amdgpu_buffer_rsrc_t srd_t;
 __device__ __forceinline__ srd_t make_srd(const void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000); }
 __device__ __forceinline__ floatx4 bld4(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
 // the same with the non-temporal hint (aux bit 1): rows that are read once per launch
+template <int NT>   // NT: cache-policy bits of the instruction (2 = nt, 16 = sc1: served by L2, not kept in the CU's L1)
+__device__ __forceinline__ floatx4 bld4s(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, NT)); }
 template <int NT>
-__device__ __forceinline__ floatx4 bld4s(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, NT ? 2 : 0)); }
-template <int NT>
-__device__ __forceinline__ void bst4s(srd_t r, unsigned voff, unsigned soff, floatx4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), r, voff, soff, NT ? 2 : 0); }
+__device__ __forceinline__ void bst4s(srd_t r, unsigned voff, unsigned soff, floatx4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), r, voff, soff, NT); }
 __device__ __forceinline__ intx4 bldi4(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(intx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
 __device__ __forceinline__ void bst4(srd_t r, unsigned voff, unsigned soff, floatx4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), r, voff, soff, 0); }
-__device__ __forceinline__ void bst1(srd_t r, unsigned voff, unsigned soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0); }
+__device__ __forceinline__ void bst1(srd_t r, unsigned voff, unsigned soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, (HEDGE_SC1 & 8) ? 16 : 0); }
 // scalar clamp to [0, hi]: written as SALU so that the values that feed a resource stay in scalar registers
 // Workgroups are dealt to the 8 XCDs in turn (workgroup i runs on XCD i % 8), each XCD with its own L2.  The systolic kernels give
 // workgroup i the i-th contiguous range of the destination-sorted edge list; numbered this way, the 32 workgroups of an XCD hold one
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     if (slot == 7) idx_loads();
                 } else if (slot == 8) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (!(HEDGE_ABL & 16)) eq[j] = bld4s<(HEDGE_NT & 1)>(srd_ein, v_eoff, rel * 512 + j * 4096);
+                    for (int j = 0; j < 4; ++j) if (!(HEDGE_ABL & 16)) eq[j] = bld4s<((HEDGE_NT & 1) ? 2 : 0) | ((HEDGE_SC1 & 1) ? 16 : 0)>(srd_ein, v_eoff, rel * 512 + j * 4096);
                     be = be_next;
                 }
             };
@@ -497,8 +500,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(er[j][tt], res_w, fmaf(zq[tt] * kr, gm[tt], bt[tt]));
                     // rows past the block's end (and every row of a fill / drain tick) lie beyond the resource's byte count: dropped
                     // (the block's position is in the resource's base: gfx9 subtracts a scalar offset from the byte count)
-                    if (!(HEDGE_ABL & 4)) bst4s<(HEDGE_NT & 4)>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
-                    if (!(HEDGE_ABL & 1)) er[j] = bld4s<(HEDGE_NT & 2)>(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
+                    if (!(HEDGE_ABL & 4)) bst4s<((HEDGE_NT & 4) ? 2 : 0) | ((HEDGE_SC1 & 4) ? 16 : 0) | ((HEDGE_SC1 & 16) ? 1 : 0)>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
+                    if (!(HEDGE_ABL & 1)) er[j] = bld4s<((HEDGE_NT & 2) ? 2 : 0) | ((HEDGE_SC1 & 2) ? 16 : 0)>(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
                 }
             };
             SYS_STAMP(t, 1);
@@ -635,8 +638,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                             floatx4 o;
 #pragma unroll
                             for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(er[j - EPI_SPLIT][tt], res_w, fmaf(ezq[tt] * ek, gmq[tt], btq[tt]));
-                            if (!(HEDGE_ABL & 4)) bst4s<(HEDGE_NT & 4)>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
-                            if (!(HEDGE_ABL & 1)) er[j - EPI_SPLIT] = bld4s<(HEDGE_NT & 2)>(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
+                            if (!(HEDGE_ABL & 4)) bst4s<((HEDGE_NT & 4) ? 2 : 0) | ((HEDGE_SC1 & 4) ? 16 : 0) | ((HEDGE_SC1 & 16) ? 1 : 0)>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
+                            if (!(HEDGE_ABL & 1)) er[j - EPI_SPLIT] = bld4s<((HEDGE_NT & 2) ? 2 : 0) | ((HEDGE_SC1 & 2) ? 16 : 0)>(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
                         }
                     }
                 }
@@ -842,7 +845,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader
                     floatx4 o;
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(zq[tt] * kr, gm[tt], bt[tt]);
-                    bst4(make_srd(e_out_wg + (size_t)((xb - b0) * BE + 8 * j) * H, (unsigned)s_clamp0(cnt - 8 * j, 8) * 512u), v_eoff, 0, o);
+                    bst4s<((HEDGE_SC1 & 32) ? 16 : 0)>(make_srd(e_out_wg + (size_t)((xb - b0) * BE + 8 * j) * H, (unsigned)s_clamp0(cnt - 8 * j, 8) * 512u), v_eoff, 0, o);
                 }
             }
             rng |= __any(acc[0] != acc[0]) ? 1 : 0;

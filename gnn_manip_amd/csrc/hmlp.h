@@ -79,7 +79,6 @@ struct HmNodeArgs {
     const float* x_in;    // mode 0: [N][k1]; mode 1 / 2: h [N][H]
     int k1;
     const float* agg;
-    float* agg_clear;
     float* h_out;
     int residual;
     const float* w;       // L0 | .. | L_NL

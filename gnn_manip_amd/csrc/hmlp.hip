@@ -764,10 +764,6 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) acc[rb][4 * g + tt] = y[tt];
                 }
-                if (A.agg_clear && valid) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) *reinterpret_cast<floatx4*>(A.agg_clear + off + 8 * g) = floatx4{0.f, 0.f, 0.f, 0.f};
-                }
             }
             HM_STAMP(tile_i, 7);   // epilogue: residual read, h stores
             if (A.tail == 0) continue;

@@ -16,15 +16,12 @@ struct EdgeArgs {
     float* e_out;          // [E][H]
     float* agg;            // [N][H] pre-zeroed, or nullptr
     float* side;           // [n_groups][H] head partials of the scatter-add (hedge.h), sys / hm kernels
-    const float* wstream;  // packed weights (32x32x2 operand image), stage 0
-    const float* wstream16;  // same layers in the 16x16x4 operand image, or nullptr
-    const float* wstream_b3; // same layers as three bf16 parts for v_mfma_f32_32x32x16_bf16 (H = 128), or nullptr
     const float* wstream_h3; // fp16 hi / lo image of the systolic kernel (hedge.h), or nullptr
     const float* wstream_hm; // fp16 hi / lo Linear images of this MLP for the streamed kernels (hmlp.h), or nullptr
     const int* edge_blocks;  // block / chunk tables of the edge list (carve_edge_blocks), or nullptr
     int64_t n_nodes_tab;     // n_nodes the tables were carved for
     ProfState* prof;         // timing of this launch (gm_model_profile), or nullptr
-    int kernel_choice;       // 0 automatic, 1 fp32 16x16x4, 2 fp32 32x32x2, 3 / 4 bf16 x 6, 5 systolic fp16 x 3, 6 streamed fp16 x 3
+    int kernel_choice;       // 0 automatic, 5 systolic fp16 x 3, 6 streamed fp16 x 3
     const float* bias;     // processor: biases of layers 2..; encoder: biases of layers 1..
     const float* ln_g;
     const float* ln_b;
@@ -32,8 +29,6 @@ struct EdgeArgs {
     int residual;          // e_out = e' + e_in
     int k1;                // encoder: edge_dim
     int h_valid;           // the model's hidden_size (<= the width H the kernel runs at; LayerNorm statistics are over these features)
-    int debug;             // timing-ablation bits of the fp32 kernels; launch_edge always passes 0 (no run-time switch)
-    unsigned long long* stamps;  // diagnostic build only: per-tile s_memrealtime stamps, or nullptr
 };
 
 struct NodeArgs {
@@ -41,7 +36,6 @@ struct NodeArgs {
     const float* x_in;     // mode 0: raw node features [N][k1]; mode 1/2: h [N][H]
     int k1;
     const float* agg;      // mode 1: [N][H]
-    float* agg_clear;      // mode 1: same buffer, zeroed row by row after it is read (the fp32 edge kernels add into it atomically), or nullptr
     const int* edge_blocks;  // mode 1: block tables whose stitch / head lists say which side-buffer rows to add to agg (hedge.h), or nullptr
     int64_t n_nodes_tab, edge_capacity_tab;
     const float* side;
@@ -49,11 +43,10 @@ struct NodeArgs {
     int h_valid;           // the model's hidden_size (<= the width H the kernel runs at)
     float* h_out;          // [N][H] (may alias x_in)
     int residual;
-    const float* wstream;
     const float* wstream_hm;  // fp16 hi / lo Linear images of this MLP (hmlp.h), or nullptr
     const float* tail_hm;     // images of the tail
     ProfState* prof;
-    int kernel_choice;        // 1..4: the fp32 kernels; otherwise the streamed fp16 x 3 kernel when its images are present
+    int kernel_choice;        // as EdgeArgs (the node MLPs always take the streamed fp16 x 3 kernel)
     const float* bias;     // [NL+1][H]
     const float* ln_g;
     const float* ln_b;
@@ -66,23 +59,6 @@ struct NodeArgs {
     int out_dim;
 };
 
-int layer_stages(int k, int out);
-int layer_stages16(int k, int out);
-int pack_linear16(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s);
-int pack_linear(const float* W, int out_rows, int ld, int col0, int kvalid, float* dst, hipStream_t s);
-int pack_linear_t(const float* W, int w_rows, int ld, int col0, int ksub, float* dst, hipStream_t s);
-// Batched (device-resident weights): many Linears / vectors per launch.
-struct PackJob {
-    const float* W;   // row-major [rows][ld]
-    int out_rows, ld, col0, kvalid;
-    int layout;       // 0: 32x32x2 operand image, 1: 16x16x4
-    size_t dst_off;   // floats from the base passed to launch_pack_batch (per layout)
-};
-constexpr int kPackJobsMax = 80;
-struct PackJobs {
-    int n;
-    PackJob job[kPackJobsMax];
-};
 struct VecJob {
     const float* src;
     size_t dst_off;
@@ -94,18 +70,8 @@ struct VecJobs {
     int n;
     VecJob job[kVecJobsMax];
 };
-int launch_pack_batch(const PackJobs& jobs, float* base32, float* base16, hipStream_t s);
 int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s);
-// three-part bf16 image of an H x H (H = 128) Linear: 4 stages of 24 KiB (kB3StageFloats floats) per layer
-constexpr int kB3StageFloats = 6144;
-int pack_linear_b3(const float* W, int ld, int col0, float* dst, hipStream_t s);
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
-#ifdef GM_DEV_KERNELS
-// development builds (mlp_dev_kernels.hip): the round-1 fp32 / bf16 x 6 kernels behind kernel choices 1 .. 4
-int launch_edge_dev(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
-int launch_node_dev(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
-#endif
-constexpr int kStageFloats = 4096;
 
 }  // namespace gm

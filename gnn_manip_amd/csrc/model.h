@@ -11,10 +11,6 @@ struct gm_model {
     int Hp = 0;                   // the width the inference kernels run at: H zero-padded to 64 / 128 / 256 (hm_padded_hidden)
     int ci = 0, cj = 1, ce = 2;   // column block of phi_e's first Linear that multiplies h_i, h_j, e (gm_model_desc.col_*)
     int ch = 0, ca = 1;           // column block of phi_v's first Linear for h, agg (gm_model_desc.node_agg_first)
-    float* packed = nullptr;  // operand image of every Linear, stage-aligned streams
-    float* packed16 = nullptr;  // 16x16x4 operand image of the edge MLPs (hidden 128)
-    size_t packed16_floats = 0, s16_enc_edge = 0;
-    float* packed_b3 = nullptr;  // bf16 x 3 operand image of the processor edge MLPs (hidden 128): [M][3 layers][4 stages]
     float* packed_h3 = nullptr;  // fp16 hi / lo image of the processor edge MLPs for the systolic kernel (hedge.h): [M][h3_image_floats]
     float* packed_hm = nullptr;  // fp16 hi / lo image of every Linear (hmlp.h)
     std::vector<gm::PackHmJob> hm_jobs;   // the pack job list of the last weight load (host copy of hm_jobs_dev)
@@ -23,21 +19,15 @@ struct gm_model {
     size_t hm_jobs_cap = 0;
     size_t hm_floats = 0, hm_enc_edge = 0, hm_enc_node = 0, hm_enc_node_tail = 0;
     std::vector<size_t> hm_edge, hm_node, hm_node_tail;
-    bool legacy = false;         // hidden 64 / 128 / 256: the fp32 images (packed) of the training kernels exist
-    bool dev_forms = false;      // hidden 128 / 256 with num_layers 2: the round-1 forward kernels can be selected (development builds)
+    bool legacy = false;         // hidden 64 / 128 / 256: the bf16 x 3 streams (packed_t3) of the training kernels exist
     gm::ProfState* prof = nullptr;  // gm_model_profile
-    int edge_kernel = 0;         // processor edge kernel of this model: 0 automatic, 1..5 see gm_model_set_edge_kernel
-    std::vector<size_t> s16_edge;
+    int edge_kernel = 0;         // processor edge kernel of this model: 0 automatic, 5 / 6 see gm_model_set_edge_kernel
     float* vec = nullptr;     // per-MLP contiguous [bias_0..bias_NL, ln_gamma, ln_beta]
-    size_t packed_floats = 0, vec_floats = 0;
-    // stream offsets (floats) into packed
-    size_t s_enc_edge, s_enc_node;
-    std::vector<size_t> s_edge, s_node;
+    size_t vec_floats = 0;
     // vec offsets (floats): start of MLP block
     size_t v_enc_edge, v_enc_node, v_dec;
     std::vector<size_t> v_edge, v_node;
-    int S_HH, S_e0, S_n0, S_out;
-    // bf16 x 3 weight streams of the training kernels (train.hip): same MLP order as `packed`, stages of kStageFloatsB3
+    // bf16 x 3 weight streams of the training kernels (train.hip): MLP after MLP, stages of kStageFloatsB3
     float* packed_t3 = nullptr;
     size_t packed_t3_floats = 0;
     size_t t_enc_edge = 0, t_enc_node = 0;
@@ -51,8 +41,15 @@ struct gm_model {
     size_t raw_floats = 0;
     bool infer_stale = true;
     std::mutex lazy_mu;
+    // Every copy / pack of the weights is queued on the stream of the call that triggered it; `ready` is recorded behind the last
+    // one.  An entry point that runs on ANOTHER stream waits for it there (weights_ready_on), so a model may be loaded on one
+    // stream and used on others.  (The other direction -- a weight update while a forward on another stream still reads the old
+    // images -- is the caller's to order, like any write to memory a queued kernel reads.)
+    hipEvent_t ready = nullptr;
+    hipStream_t ready_stream = nullptr;
 };
 int ensure_inference_images(const gm_model* m, hipStream_t s);   // model.hip; called by every inference entry point
+int weights_ready_on(const gm_model* m, hipStream_t s);          // model.hip; called by every entry point that reads the packed weights
 
 namespace gm {
 inline int tensors_per_normed_mlp(int NL) { return 2 * (NL + 1) + 2; }

@@ -215,78 +215,8 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s, int w
         flush_t();
         if (rc != GM_OK) return rc;
     }
-    if (m->packed) {
-    // fp32 operand images of the selectable round-1 forward kernels (development builds)
-    PackJobs pj;
-    pj.n = 0;
-    auto flush_pack = [&]() {
-        if (rc == GM_OK && pj.n > 0) rc = launch_pack_batch(pj, m->packed, m->packed16, s);
-        pj.n = 0;
-    };
-    auto queue_pack = [&](int ti, int out_rows, int ld, int col0, int k, size_t off, int layout) {
-        if (pj.n == kPackJobsMax) flush_pack();
-        PackJob& j = pj.job[pj.n++];
-        j.W = T[ti]; j.out_rows = out_rows; j.ld = ld; j.col0 = col0; j.kvalid = k; j.layout = layout; j.dst_off = off;
-    };
-    auto pack = [&](int ti, int out_rows, int ld, int col0, int k, size_t& off) {
-        queue_pack(ti, out_rows, ld, col0, k, off, 0);
-        off += (size_t)layer_stages(k, out_rows) * kStageFloats;
-    };
-    auto hidden = [&](int base, size_t& off) {  // Linear 1..NL of an MLP (HxH)
-        for (int l = 1; l <= NL; ++l) pack(base + 2 * l, H, H, 0, H, off);
-    };
-    size_t off = m->s_enc_edge;
-    pack(b_enc_edge, H, m->d.edge_dim, 0, m->d.edge_dim, off);
-    hidden(b_enc_edge, off);
-    off = m->s_enc_node;
-    pack(b_enc_node, H, m->d.node_dim, 0, m->d.node_dim, off);
-    hidden(b_enc_node, off);
-    pack(b_edge(0), H, 3 * H, m->ci * H, H, off);  // W_i of processor 0
-    pack(b_edge(0), H, 3 * H, m->cj * H, H, off);  // W_j
-    for (int k = 0; k < M; ++k) {
-        off = m->s_edge[k];
-        pack(b_edge(k), H, 3 * H, m->ce * H, H, off);  // W_e
-        hidden(b_edge(k), off);
-        off = m->s_node[k];
-        pack(b_node(k), H, 2 * H, m->ch * H, H, off);  // W_h
-        pack(b_node(k), H, 2 * H, m->ca * H, H, off);  // W_agg
-        hidden(b_node(k), off);
-        if (k + 1 < M) {
-            pack(b_edge(k + 1), H, 3 * H, m->ci * H, H, off);
-            pack(b_edge(k + 1), H, 3 * H, m->cj * H, H, off);
-        } else {
-            for (int l = 0; l < NL; ++l) pack(b_dec + 2 * l, H, H, 0, H, off);
-            pack(b_dec + 2 * NL, m->d.out_dim, H, 0, H, off);
-        }
-    }
-    if (m->packed16) {  // 16x16x4 image of the edge MLPs
-        auto pack16 = [&](int ti, int out_rows, int ld, int col0, int k, size_t& o16) {
-            queue_pack(ti, out_rows, ld, col0, k, o16, 1);
-            o16 += (size_t)layer_stages16(k, out_rows) * kStageFloats;
-        };
-        size_t o16 = m->s16_enc_edge;
-        pack16(b_enc_edge, H, m->d.edge_dim, 0, m->d.edge_dim, o16);
-        for (int l = 1; l <= NL; ++l) pack16(b_enc_edge + 2 * l, H, H, 0, H, o16);
-        for (int k = 0; k < M; ++k) {
-            o16 = m->s16_edge[k];
-            pack16(b_edge(k), H, 3 * H, m->ce * H, H, o16);
-            for (int l = 1; l <= NL; ++l) pack16(b_edge(k) + 2 * l, H, H, 0, H, o16);
-        }
-    }
-    flush_pack();
-    }
     }   // kPackCommon
     if (!(what & kPackInference)) return rc;
-#ifdef GM_DEV_KERNELS
-    if (m->packed_b3) {  // three-part bf16 image of the processor edge MLPs
-        for (int k = 0; k < M && rc == GM_OK; ++k) {
-            float* base = m->packed_b3 + (size_t)k * 3 * 4 * kB3StageFloats;
-            rc = pack_linear_b3(T[b_edge(k)], 3 * H, m->ce * H, base, s);
-            for (int l = 1; l <= NL && rc == GM_OK; ++l)
-                rc = pack_linear_b3(T[b_edge(k) + 2 * l], H, 0, base + (size_t)l * 4 * kB3StageFloats, s);
-        }
-    }
-#endif
     if (m->packed_h3 && rc == GM_OK) {  // fp16 hi / lo images of the systolic kernels: the M processor edge MLPs, then the edge encoder
         std::vector<PackH3Job> jobs((size_t)M + 1);
         for (int k = 0; k <= M; ++k) {
@@ -302,6 +232,14 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s, int w
         rc = pack_h3(jobs.data(), m->d.edge_dim <= 16 ? M + 1 : M, s);
     }
     return rc;
+}
+
+// `ready` = everything queued for the model's images so far, on stream s (model.h)
+int mark_ready(gm_model* m, hipStream_t s) {
+    if (!m->ready) GM_HIP_CHECK(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming));
+    GM_HIP_CHECK(hipEventRecord(m->ready, s));
+    m->ready_stream = s;
+    return GM_OK;
 }
 
 // The raw tensors are first copied into the model's own device buffer (host- or device-resident callers alike), then the cheap
@@ -341,7 +279,9 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
     std::vector<const float*> D((size_t)nt);
     for (int i = 0; i < nt; ++i) D[(size_t)i] = m->raw + m->raw_off[(size_t)i];
     m->infer_stale = true;
-    return load_weights_device(m, D.data(), s, kPackCommon);
+    rc = load_weights_device(m, D.data(), s, kPackCommon);
+    if (rc == GM_OK) rc = mark_ready(m, s);
+    return rc;
 }
 
 }  // namespace
@@ -349,14 +289,24 @@ int load_weights(gm_model* m, const float* const* T, int nt, bool on_device, hip
 int ensure_inference_images(const gm_model* cm, hipStream_t s) {
     gm_model* m = const_cast<gm_model*>(cm);
     std::lock_guard<std::mutex> guard(m->lazy_mu);
+    // the copy / common pack (and an earlier inference pack) may have been queued on another stream: this one waits for them
+    if (m->ready && s != m->ready_stream) GM_HIP_CHECK(hipStreamWaitEvent(s, m->ready, 0));
     if (!m->infer_stale) return GM_OK;
     GM_REQUIRE(m->raw, GM_ERR_INVALID_ARGUMENT, "model: no weights loaded");
     const size_t nt = m->raw_off.size();
     std::vector<const float*> D(nt);
     for (size_t i = 0; i < nt; ++i) D[i] = m->raw + m->raw_off[i];
-    const int rc = load_weights_device(m, D.data(), s, kPackInference);
+    int rc = load_weights_device(m, D.data(), s, kPackInference);
+    if (rc == GM_OK) rc = mark_ready(m, s);   // the images are complete once THIS lands: other streams wait for it
     if (rc == GM_OK) m->infer_stale = false;
     return rc;
+}
+
+int weights_ready_on(const gm_model* cm, hipStream_t s) {
+    gm_model* m = const_cast<gm_model*>(cm);
+    std::lock_guard<std::mutex> guard(m->lazy_mu);
+    if (m->ready && s != m->ready_stream) GM_HIP_CHECK(hipStreamWaitEvent(s, m->ready, 0));
+    return GM_OK;
 }
 
 extern "C" {
@@ -382,22 +332,7 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
     if (desc->col_i || desc->col_j || desc->col_e) { m->ci = desc->col_i; m->cj = desc->col_j; m->ce = desc->col_e; }
     if (desc->node_agg_first) { m->ch = 1; m->ca = 0; }
     m->legacy = m->H == 64 || m->H == 128 || m->H == 256;   // widths the fp32 training kernels (and their operand images) exist for
-    m->dev_forms = (m->H == 128 || m->H == 256) && NL == 2;  // sizes of the selectable round-1 forward kernels (development builds)
-    m->S_HH = layer_stages(H, H);
-    m->S_e0 = layer_stages(desc->edge_dim, H);
-    m->S_n0 = layer_stages(desc->node_dim, H);
-    m->S_out = layer_stages(H, desc->out_dim);
-    size_t st = 0;
-    m->s_enc_edge = st * kStageFloats; st += m->S_e0 + NL * m->S_HH;
-    m->s_enc_node = st * kStageFloats; st += m->S_n0 + NL * m->S_HH + 2 * m->S_HH;
-    m->s_edge.resize(M);
-    m->s_node.resize(M);
-    for (int k = 0; k < M; ++k) {
-        m->s_edge[k] = st * kStageFloats; st += (NL + 1) * m->S_HH;
-        m->s_node[k] = st * kStageFloats; st += (NL + 2) * m->S_HH + (k + 1 < M ? 2 * m->S_HH : NL * m->S_HH + m->S_out);
-    }
-    m->packed_floats = st * kStageFloats;
-    {   // the same sequence as bf16 x 3 streams (training kernels)
+    {   // bf16 x 3 streams of the training kernels, one MLP after the other
         m->T_HH = layer_stages_b3(H, H);
         m->T_e0 = layer_stages_b3(desc->edge_dim, H);
         m->T_n0 = layer_stages_b3(desc->node_dim, H);
@@ -449,41 +384,13 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             return GM_ERR_HIP;
         }
     }
-#ifdef GM_DEV_KERNELS   // operand images of the round-1 inference kernels (development builds)
-    if (m->dev_forms && H == 128 && desc->edge_dim <= 16) {
-        size_t st16 = 0;
-        m->s16_enc_edge = 0;
-        st16 += layer_stages16(desc->edge_dim, H) + NL * layer_stages16(H, H);
-        m->s16_edge.resize(M);
-        for (int k = 0; k < M; ++k) {
-            m->s16_edge[k] = st16 * kStageFloats;
-            st16 += (NL + 1) * layer_stages16(H, H);
-        }
-        m->packed16_floats = st16 * kStageFloats;
-        if (hipMalloc(&m->packed16, m->packed16_floats * sizeof(float)) != hipSuccess) {
-            gm::set_error("gm_model_create: hipMalloc failed");
-            gm_model_destroy(m);
-            return GM_ERR_HIP;
-        }
-    }
-    if (m->dev_forms && H == 128 && hipMalloc(&m->packed_b3, (size_t)M * 3 * 4 * kB3StageFloats * sizeof(float)) != hipSuccess) {
-        gm::set_error("gm_model_create: hipMalloc failed");
-        gm_model_destroy(m);
-        return GM_ERR_HIP;
-    }
-#endif
     if (m->H == 128 && NL == 2 && hipMalloc(&m->packed_h3, (size_t)(M + 1) * h3_image_floats() * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
         gm_model_destroy(m);
         return GM_ERR_HIP;
     }
     m->edge_kernel = 0;   // automatic; gm_model_set_edge_kernel changes it per handle (no process-wide switch)
-    bool fp32_images = false;   // operand images of the round-1 fp32 forward kernels
-#ifdef GM_DEV_KERNELS
-    fp32_images = m->dev_forms;
-#endif
-    if ((fp32_images && hipMalloc(&m->packed, m->packed_floats * sizeof(float)) != hipSuccess) ||
-        (m->legacy && hipMalloc(&m->packed_t3, m->packed_t3_floats * sizeof(float)) != hipSuccess) ||
+    if ((m->legacy && hipMalloc(&m->packed_t3, m->packed_t3_floats * sizeof(float)) != hipSuccess) ||
         hipMalloc(&m->vec, m->vec_floats * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
         gm_model_destroy(m);
@@ -506,16 +413,14 @@ int gm_model_update(gm_model* m, const float* const* tensors, int n_tensors, int
 
 void gm_model_destroy(gm_model* m) {
     if (!m) return;
-    if (m->packed) hipFree(m->packed);
     if (m->packed_t3) hipFree(m->packed_t3);
-    if (m->packed16) hipFree(m->packed16);
-    if (m->packed_b3) hipFree(m->packed_b3);
     if (m->packed_h3) hipFree(m->packed_h3);
     if (m->packed_hm) hipFree(m->packed_hm);
     if (m->hm_jobs_dev) hipFree(m->hm_jobs_dev);
     if (m->hm_stats) hipFree(m->hm_stats);
     if (m->vec) hipFree(m->vec);
     if (m->raw) hipFree(m->raw);
+    if (m->ready) (void)hipEventDestroy(m->ready);
     delete m->prof;
     delete m;
 }
@@ -538,8 +443,6 @@ EdgeArgs enc_edge_args(const gm_model* m, const float* edge_attr, const int* eid
     EdgeArgs a{};
     a.hdr = hdr; a.n_edges_host = e_host; a.eid = eid;
     a.e_in = edge_attr; a.e_out = e_out; a.k1 = m->d.edge_dim;
-    a.wstream = m->packed ? m->packed + m->s_enc_edge : nullptr;
-    a.wstream16 = m->packed16 ? m->packed16 + m->s16_enc_edge : nullptr;
     a.wstream_hm = m->packed_hm + m->hm_enc_edge;
     a.wstream_h3 = m->packed_h3 ? m->packed_h3 + (size_t)m->M * h3_image_floats() : nullptr;   // the encoder's image follows the steps'
     a.kernel_choice = m->edge_kernel; a.prof = m->prof;
@@ -553,10 +456,7 @@ EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, int64_t n, con
     EdgeArgs a{};
     a.hdr = hdr; a.n_edges_host = e_host; a.dst = c.dst; a.src = c.src; a.eid = eid; a.eid_out = eid;
     a.P = P; a.e_in = e_in; a.e_out = e_out; a.agg = agg; a.side = side; a.residual = residual;
-    a.wstream = m->packed ? m->packed + m->s_edge[k] : nullptr;
-    a.wstream16 = m->packed16 ? m->packed16 + m->s16_edge[k] : nullptr;
     a.wstream_hm = m->packed_hm + m->hm_edge[k];
-    a.wstream_b3 = m->packed_b3 ? m->packed_b3 + (size_t)k * 3 * 4 * kB3StageFloats : nullptr;
     a.wstream_h3 = m->packed_h3 ? m->packed_h3 + (size_t)k * h3_image_floats() : nullptr;
     a.edge_blocks = c.blocks;
     a.n_nodes_tab = n;
@@ -609,7 +509,6 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     NodeArgs na{};
     na.h_valid = m->H;
     na.n_nodes = (int)n; na.x_in = nodes; na.k1 = m->d.node_dim; na.h_out = f.h;
-    na.wstream = m->packed ? m->packed + m->s_enc_node : nullptr;
     na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel; na.prof = m->prof;
     na.err_flags = &c.hdr->error_flags;
     const float* v = m->vec + m->v_enc_node;
@@ -617,8 +516,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     set_tail(m, na, 0, f.P, out);
     rc = launch_node(H, NL, 0, na, s);
     if (rc != GM_OK) return rc;
-    const bool legacy_kernels = m->edge_kernel >= 1 && m->edge_kernel <= 4;
-    // agg is zeroed once (nodes without in-edges read zeros)
+    // agg is zeroed once (nodes without in-edges read zeros; rows with in-edges are stored whole by every edge launch)
     GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
     for (int k = 0; k < M; ++k) {
         rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, f.side, 1), cap, s);
@@ -626,12 +524,8 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
         NodeArgs a{};
         a.h_valid = m->H;
         a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.h_out = f.h; a.residual = 1;
-        // the fp32 edge kernels add into agg atomically, so the rows consumed here are cleared for the next step; the
-        // sys / hm kernels store every row with in-edges whole (rows without keep the zeros of the memset above)
-        a.agg_clear = (legacy_kernels && k + 1 < M) ? f.agg : nullptr;
         a.edge_blocks = c.blocks; a.n_nodes_tab = n; a.edge_capacity_tab = cap; a.side = f.side;
         a.err_flags = &c.hdr->error_flags;
-        a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
         a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel; a.prof = m->prof;
         const float* vn = m->vec + m->v_node[k];
         a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
@@ -656,7 +550,6 @@ int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n, c
     NodeArgs na{};
     na.h_valid = m->H;
     na.n_nodes = (int)n; na.x_in = x; na.k1 = m->d.node_dim; na.h_out = h_out;
-    na.wstream = m->packed ? m->packed + m->s_enc_node : nullptr;
     na.wstream_hm = m->packed_hm + m->hm_enc_node; na.kernel_choice = m->edge_kernel; na.prof = m->prof;
     const float* v = m->vec + m->v_enc_node;
     na.bias = v; na.ln_g = v + (size_t)(m->NL + 1) * m->Hp; na.ln_b = v + (size_t)(m->NL + 2) * m->Hp; na.eps = m->d.ln_eps;
@@ -686,9 +579,6 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     NodeArgs pa{};
     pa.h_valid = m->H;
     pa.n_nodes = (int)n; pa.x_in = h;
-    pa.wstream = !m->packed ? nullptr
-                 : k == 0   ? m->packed + m->s_enc_node + (size_t)(m->S_n0 + NL * m->S_HH) * kStageFloats
-                            : m->packed + m->s_node[k - 1] + (size_t)((NL + 2) * m->S_HH) * kStageFloats;
     pa.kernel_choice = m->edge_kernel; pa.prof = m->prof;
     pa.err_flags = &c.hdr->error_flags;
     set_tail(m, pa, k, f.P, nullptr);
@@ -702,7 +592,6 @@ int gm_interaction_network_forward(const gm_model* m, int k, const float* h, int
     a.n_nodes = (int)n; a.x_in = h; a.agg = f.agg; a.h_out = h_out; a.residual = 0;
     a.edge_blocks = c.blocks; a.n_nodes_tab = n; a.edge_capacity_tab = cap; a.side = f.side;
     a.err_flags = &c.hdr->error_flags;
-    a.wstream = m->packed ? m->packed + m->s_node[k] : nullptr;
     a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel; a.prof = m->prof;
     const float* vn = m->vec + m->v_node[k];
     a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
@@ -765,13 +654,9 @@ extern "C" {
 int gm_model_set_edge_kernel(gm_model* m, int choice) {
     GM_REQUIRE(m, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: null model");
     GM_REQUIRE(choice >= 0 && choice <= 6, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: choice %d out of range", choice);
-#ifndef GM_DEV_KERNELS
     GM_REQUIRE(choice == 0 || choice >= 5, GM_ERR_UNSUPPORTED,
-               "gm_model_set_edge_kernel: choices 1..4 (the round-1 fp32 / bf16 x 6 kernels) exist in development builds of the library only");
-#endif
+               "gm_model_set_edge_kernel: choices 1..4 (the round-1 fp32 / bf16 x 6 kernels) were removed from the library (round 5)");
     GM_REQUIRE(choice != 5 || m->packed_h3, GM_ERR_UNSUPPORTED, "gm_model_set_edge_kernel: the systolic kernel is for hidden_size 128, num_layers 2");
-    GM_REQUIRE(m->dev_forms || choice == 0 || choice == 6, GM_ERR_UNSUPPORTED,
-               "gm_model_set_edge_kernel: hidden_size=%d num_layers=%d has the streamed fp16-split kernels only (0 / 6)", m->H, m->NL);
     m->edge_kernel = choice;
     return GM_OK;
 }

@@ -21,7 +21,7 @@
 #include <vector>
 #include "common.h"
 #include "mlp.h"
-#include "mlp_dev.h"
+#include "fchain.h"
 #include "train.h"
 
 namespace gm {
@@ -91,7 +91,7 @@ __device__ __forceinline__ void issue_stage3(const WStream& ws, int stage, int b
 }
 
 // One Linear: acc[jb] += W(block jb) . act.  NKG = K / 16 k-groups, NJB = OUT / 32 blocks, act in the accumulator layout.
-// more / PEND: as run_layer (mlp_dev.h).
+// more / PEND: as run_layer (fchain.h).
 template <int NKG, int NJB, int NKB, int PEND = 0>
 __device__ __forceinline__ void run_layer_b3(floatx16 (&acc)[NJB], const floatx16 (&act)[NKB], WStream& ws, bool more_tiles) {
     constexpr int NG = NKG * NJB;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void run_layer_b3(floatx16 (&acc)[NJB], const floatx1
 }
 
 // ------------------------------------------------------------------------------------------
-// small register helpers on the 32x32 feature layout (see mlp_dev.h)
+// small register helpers on the 32x32 feature layout (see fchain.h)
 // ------------------------------------------------------------------------------------------
 template <int NKB>
 __device__ __forceinline__ void zero_feat(floatx16 (&v)[NKB]) {

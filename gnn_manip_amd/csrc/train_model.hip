@@ -202,6 +202,8 @@ int gm_epd_forward_train(const gm_model* m, const float* nodes, int64_t n, const
     GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_epd_forward_train: tape %zu < %zu", tape_bytes, t.bytes);
     rc = train_kernels_init();
     if (rc != GM_OK) return rc;
+    rc = weights_ready_on(m, (hipStream_t)stream);   // the weight streams may have been packed on another stream (model.h)
+    if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     // destination-sorted edges (aggregation index i = edge_index[1]) and the source-grouped view of the sorted list
     rc = gm::csr_from_edge_index(edge_index, n, e, m->d.flow, t.csr_dst, t.csr_bytes, false, (hipStream_t)stream);
@@ -293,6 +295,8 @@ int gm_epd_backward(const gm_model* m, const float* const* T, int n_tensors, con
     BwdWs b = carve_bwd(ws, &m->d, n, e);
     GM_REQUIRE(ws_bytes >= b.bytes, GM_ERR_WORKSPACE, "gm_epd_backward: workspace %zu < %zu", ws_bytes, b.bytes);
     rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    rc = weights_ready_on(m, (hipStream_t)stream);   // the weight streams may have been packed on another stream (model.h)
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands
@@ -472,6 +476,8 @@ int gm_graph_independent_forward_train(const gm_model* m, const float* x, int64_
     GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_graph_independent_forward_train: tape %zu < %zu", tape_bytes, t.bytes);
     rc = train_kernels_init();
     if (rc != GM_OK) return rc;
+    rc = weights_ready_on(m, (hipStream_t)stream);   // the weight streams may have been packed on another stream (model.h)
+    if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     auto normed = [&](TrainFwdArgs& a, size_t voff) {
         const float* v = mlp_vec(m, voff);
@@ -508,6 +514,8 @@ int gm_graph_independent_backward(const gm_model* m, const float* const* T, int 
     BwdWs b = carve_block_bwd(ws, &m->d, n, e);
     GM_REQUIRE(ws_bytes >= b.bytes, GM_ERR_WORKSPACE, "gm_graph_independent_backward: workspace %zu < %zu", ws_bytes, b.bytes);
     rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    rc = weights_ready_on(m, (hipStream_t)stream);   // the weight streams may have been packed on another stream (model.h)
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands
@@ -563,6 +571,8 @@ int gm_interaction_network_forward_train(const gm_model* m, int k, const float* 
     InTape t = carve_in_tape(tape, H, NL, n, e);
     GM_REQUIRE(tape_bytes >= t.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_forward_train: tape %zu < %zu", tape_bytes, t.bytes);
     rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    rc = weights_ready_on(m, (hipStream_t)stream);   // the weight streams may have been packed on another stream (model.h)
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     rc = gm::csr_from_edge_index(edge_index, n, e, m->d.flow, t.csr_dst, t.csr_bytes, false, (hipStream_t)stream);
@@ -624,6 +634,8 @@ int gm_interaction_network_backward(const gm_model* m, int k, const float* const
     BwdWs b = carve_block_bwd(ws, &m->d, n, e);
     GM_REQUIRE(ws_bytes >= b.bytes, GM_ERR_WORKSPACE, "gm_interaction_network_backward: workspace %zu < %zu", ws_bytes, b.bytes);
     rc = train_kernels_init();
+    if (rc != GM_OK) return rc;
+    rc = weights_ready_on(m, (hipStream_t)stream);   // the weight streams may have been packed on another stream (model.h)
     if (rc != GM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     WgradBatch wb;   // weight-gradient jobs run a batch per launch; flushed before anything overwrites their operands

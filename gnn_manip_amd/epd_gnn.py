@@ -509,7 +509,7 @@ class EncProcDecGNN(nn.Module):
 
     auto_status = True   # check the previous inference forward's device-side error flags at the start of the next one
 
-    EDGE_KERNELS = {"auto": 0, "16": 1, "classic": 2, "b3": 3, "b3p": 4, "sys": 5, "hm": 6}
+    EDGE_KERNELS = {"auto": 0, "sys": 5, "hm": 6}   # 1 .. 4 were the round-1 fp32 / bf16 x 6 kernels (removed in round 5)
 
     def profile(self, kind_mask):
         """HIP-event timing of this model's launches (gm_model_profile; bit 0 processor edge kernel, 1 processor node
@@ -527,9 +527,7 @@ class EncProcDecGNN(nn.Module):
 
     def set_edge_kernel(self, choice):
         """Processor edge kernel of this model (diagnostics / A-B measurements; no reference counterpart): 'auto', 'sys'
-        (systolic fp16 x 3, hidden 128 / num_layers 2), 'hm' (streamed fp16 x 3).  'b3' / 'b3p' (bf16 x 6) and '16' /
-        'classic' (fp32 MFMA) exist in development builds of the library only (GM_DEV_KERNELS=1) and raise otherwise.
-        See include/gnn_manip_hip.h."""
+        (systolic fp16 x 3, hidden 128 / num_layers 2), 'hm' (streamed fp16 x 3).  See include/gnn_manip_hip.h."""
         self._handle.set_edge_kernel(self.EDGE_KERNELS.get(choice, choice))
 
     def forward(self, nodes, edge_attr, edge_index):

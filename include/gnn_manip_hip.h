@@ -207,12 +207,9 @@ void gm_model_destroy(gm_model* m);
 
 /* Processor edge kernel of THIS model (no reference counterpart; diagnostics / A-B measurements).  0 = automatic
  * (the systolic fp16 x 3 kernel for hidden 128 / num_layers 2 in the fused forward, else the
- * kernels below); 1 = fp32 MFMA 16x16x4; 2 = fp32 MFMA 32x32x2; 3 / 4 = bf16 matrix pipe, six partial products,
- * 128- / 64-edge tiles; 5 = systolic fp16 x 3 where it applies, else 6; 6 = streamed fp16 x 3 (hmlp.hip; every MLP of
- * the model, any supported size).  1..4 (the round-1 kernels; they add tile-crossing partial sums with float atomics) exist
- * in development builds of the library only (GM_DEV_KERNELS=1 at build time), for hidden 128 / 256 with num_layers 2;
- * the product library returns GM_ERR_UNSUPPORTED for them.  No environment variable is read: the choice belongs to the
- * handle. */
+ * streamed one); 5 = systolic fp16 x 3 where it applies, else 6; 6 = streamed fp16 x 3 (hmlp.hip; every MLP of the
+ * model, any supported size).  1..4 were round 1's fp32 / bf16 x 6 kernels: removed from the library in round 5
+ * (GM_ERR_UNSUPPORTED).  No environment variable is read: the choice belongs to the handle. */
 int gm_model_set_edge_kernel(gm_model* m, int choice);
 
 size_t gm_forward_workspace_bytes(const gm_model_desc* desc, int64_t n_nodes, int64_t edge_capacity);

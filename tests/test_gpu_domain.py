@@ -269,3 +269,38 @@ def test_entry_points_follow_the_callers_stream(dev):
     torch.cuda.synchronize()
     for k in ref:
         assert torch.equal(ref[k], got[k]), (k, float((ref[k] - got[k]).abs().max()))
+
+
+def test_model_loaded_on_one_stream_is_usable_from_others(dev):
+    """A handle's weight copy and its operand images are queued on the stream of the call that triggers them; a call on ANOTHER
+    stream waits for them through an event recorded behind the last pack (csrc/model.h: `ready`), not through luck.  The weights
+    are loaded (training forward) on the default stream behind a long queue of unrelated work, the first inference -- which packs
+    the inference images -- runs on a side stream, a second inference on a third stream right after it, none of them synchronised
+    with the others: all three must return the bits of the same calls made one after the other on one stream."""
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, scene
+    obs = scene.make_scene(900, seed=79, side=0.08)
+    ga = GraphBoundedMultimaterialControl(0.015, STATS, CART, MAT, CTRL, BOUNDS)
+    with torch.no_grad():
+        nodes, ea, ei, _ = ga.process_collate([(torch.from_numpy(obs).to(dev), torch.zeros(obs.shape[1], 3, device=dev))])
+
+    def model():
+        torch.manual_seed(12)
+        return EncProcDecGNN(25, 4, 3, 128, 2, 3).to(dev)
+
+    m = model()
+    ref_t = m.forward(nodes, ea, ei).detach().clone()
+    with torch.no_grad():
+        ref_i = m.forward(nodes, ea, ei).clone()
+    torch.cuda.synchronize()
+    m = model()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    busy = torch.randn(4096, 4096, device=dev)
+    for _ in range(30):
+        busy = busy @ busy * 1e-3                      # the weight copy + training pack queue up behind this
+    got_t = m.forward(nodes, ea, ei).detach()          # default stream: loads the weights, packs the training streams
+    with torch.cuda.stream(s1), torch.no_grad():
+        got_1 = m.forward(nodes, ea, ei)               # side stream: must wait for the load, then packs the inference images
+    with torch.cuda.stream(s2), torch.no_grad():
+        got_2 = m.forward(nodes, ea, ei)               # third stream: must wait for s1's pack
+    torch.cuda.synchronize()
+    assert torch.equal(got_t, ref_t) and torch.equal(got_1, ref_i) and torch.equal(got_2, ref_i)

@@ -33,6 +33,20 @@ def test_sinkhorn_kernel_vs_oracle(dev, n, m, seed):
     assert abs(got - ref) <= 1e-4 * abs(ref) + 1e-9
 
 
+@pytest.mark.parametrize("n,m,seed,blur", [(400, 350, 11, 0.05), (1500, 1500, 12, 0.05), (900, 1100, 13, 0.02)])
+def test_sinkhorn_kernel_vs_float64_dense_log_domain(dev, n, m, seed, blur):
+    """The float32 device kernels (distances recomputed per pair, two-pass log-sum-exp per row) against a dense float64 log-domain
+    evaluation of the same schedule (oracle.sinkhorn_divergence: full N x M cost matrices in float64): 1e-5 relative on the
+    divergence, which is itself a difference of potentials two orders of magnitude larger."""
+    from gnn_manip_amd.losses import SamplesLoss
+    rng = np.random.default_rng(seed)
+    x = (0.5 + 0.05 * rng.standard_normal((n, 3))).astype(np.float32)
+    y = (0.52 + 0.06 * rng.standard_normal((m, 3))).astype(np.float32)
+    got = float(SamplesLoss(loss="sinkhorn", p=2, blur=blur)(_t(x, dev), _t(y, dev)).item())
+    ref = orc.sinkhorn_divergence(x, y, blur=blur)
+    assert abs(got - ref) <= 1e-5 * abs(ref), (got, ref, abs(got - ref) / abs(ref))
+
+
 def test_sinkhorn_kernel_known_answers(dev):
     from gnn_manip_amd.losses import SamplesLoss
     rng = np.random.default_rng(5)
@@ -241,6 +255,31 @@ def test_bench_launches_its_own_ranks(dev):
         assert len(lines) == 1
         rec = json.loads(lines[0])
         assert rec["n_gpus"] == 2 and rec["scaling"] == scaling and rec["value"] > 0 and rec["unit"] == "rollout steps/s"
+
+
+def test_bench_collectives_run_through_rccl_on_one_rank(dev):
+    """The multi-GPU code path of bench.py on the one card the test box has: `--collectives always` initialises the `nccl` backend
+    (= RCCL on ROCm) with WORLD_SIZE = 1 in a fresh child process and runs the per-generation exchange of SURVEY 8e /
+    traj_utils.py:247-259 -- broadcast of the candidate matrix / scripted poses, all-gather of the results, barrier, MAX all-reduce
+    of the time -- on DEVICE-resident payloads, for the C5 shape (through planner.CandidateEvaluator) and for the default
+    workload.  (Two ranks on one device is what RCCL refuses; the gloo rehearsals above cover rank > 0.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GM_BENCH_REHEARSE"):
+        env.pop(k, None)
+    for extra, scaling in ((["--workload", "c5", "--candidates-total", "4", "--batch", "2", "--steps", "3"], "strong"),
+                           (["--workload", "c2", "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline"], "weak")):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--collectives", "always"] + extra, env=env, capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace")
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        rec = json.loads(lines[0])
+        assert rec["collective_backend"] == "nccl" and rec["n_gpus"] == 1 and rec["scaling"] == scaling
+        assert rec["value"] > 0 and rec["collective_ms"] >= 0.0
 
 
 def test_bench_launcher_reports_a_failed_rank(dev):
