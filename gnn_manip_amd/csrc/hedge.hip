@@ -99,6 +99,18 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8 + 32];   // + the 100 MHz 
 #ifndef HEDGE_ABL
 #define HEDGE_ABL 0   // development builds: timing ablations (1 no residual read, 2 P_j from the P_i row, 4 no e_out store, 8 no agg store, 16 no e read, 32 e_out rows folded onto 1024 rows)
 #endif
+#ifndef HEDGE_DEFER
+#define HEDGE_DEFER 0   // roles 0 / 1 run the ReLU + split -> image of a block in the MFMA gaps of the NEXT tick (two register sets per wave
+                        // change places: accumulators of the block in flight <-> previous results, then the next initial accumulators)
+#endif
+#ifndef HEDGE_EIMG1
+#define HEDGE_EIMG1 0   // 1: role 1 (not role 0) requests the e rows and writes the operand image E: four requests, 24 vector instructions,
+                        // eight LDS stores and 16 registers leave the role that is last at the barrier most often
+#endif
+#ifndef HEDGE_TAIL0
+#define HEDGE_TAIL0 11   // MFMA slots (of 24) in which the two halves of a deferred tail run
+#define HEDGE_TAIL1 15
+#endif
 #ifndef HEDGE_SC1
 #define HEDGE_SC1 12   // sc1 (write-through, the line is not kept in L2) on: 1 the e rows role 0 reads, 2 the residual re-read, 4 the e_out stores, 8 the agg stores; 16: sc0 on the e_out stores too
 #endif
@@ -182,6 +194,15 @@ __device__ __forceinline__ void acc_to_image(const floatx16& a, char* smem, unsi
         LDS(uintx4, addr + (q * 2 + 0) * 1024) = uintx4{h0[0], h0[1], h1[0], h1[1]};
         LDS(uintx4, addr + (q * 2 + 1) * 1024) = uintx4{l0[0], l0[1], l1[0], l1[1]};
     }
+}
+
+// the same, one fragment (registers 8q .. 8q+7) per call: for the MFMA gaps of the next tick (HEDGE_DEFER)
+__device__ __forceinline__ void tail_piece(const floatx16& a, char* smem, unsigned addr, int q) {
+    uintx2 h0, l0, h1, l1;
+    split4(relu(a[8 * q]), relu(a[8 * q + 1]), relu(a[8 * q + 2]), relu(a[8 * q + 3]), h0, l0);
+    split4(relu(a[8 * q + 4]), relu(a[8 * q + 5]), relu(a[8 * q + 6]), relu(a[8 * q + 7]), h1, l1);
+    LDS(uintx4, addr + (q * 2 + 0) * 1024) = uintx4{h0[0], h0[1], h1[0], h1[1]};
+    LDS(uintx4, addr + (q * 2 + 1) * 1024) = uintx4{l0[0], l0[1], l1[0], l1[1]};
 }
 
 // One Linear for this wave's 32 output features: 8 k-groups x 3 MFMAs (lo*hi, hi*lo, hi*hi).  side(slot), slot = 0..23, runs
@@ -360,15 +381,20 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         int rng = 0;            // range check of the fp16 split: set once an accumulator row turns NaN
         floatx4 eq[4];          // e rows of block x+1 on their way into the operand image E (the first block's: requested here)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) eq[j] = bld4(srd_ein, v_eoff, j * 4096);
-        floatx16 acc, c0v;   // c0v: (P_i + P_j) T1 of the block, the first MFMA's C operand
+        for (int j = 0; j < 4; ++j) eq[j] = HEDGE_EIMG1 ? floatx4{0.f, 0.f, 0.f, 0.f} : bld4(srd_ein, v_eoff, j * 4096);
+        // Two register sets.  Plain form: `acc` = the block's accumulators, c0v = (P_i + P_j) T1 of the next block (the first MFMA's C
+        // operand).  HEDGE_DEFER: the sets change places every tick -- `cur` arrives holding the block's initial accumulators and is
+        // accumulated in place, `prv` holds the previous block's results until their ReLU + split has run in this tick's MFMA gaps and
+        // then receives the next block's initial accumulators.
+        floatx16 acc, c0v;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c0v[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { c0v[r] = 0.f; acc[r] = 0.f; }
         intx4 di = bldi4(srd_dst, v_ioff, 0), si = bldi4(srd_src, v_ioff, 0);   // indices of the rows of block b0 ( = "x+1" of the first tick's requests)
         int2 be = a_blk[clampb(b0 + 1)];   // table entry of block x+2 (its .x = first edge): the rows and indices requested this tick
-        auto tick = [&](auto par_c, int t) {
+        auto tick = [&](auto par_c, int t, floatx16& cur, floatx16& prv) {
             constexpr int PAR = decltype(par_c)::value;   // parity of x: the images' double buffers are compile-time offsets
             const int x = b0 + t;
+            floatx16& c0v = HEDGE_DEFER ? prv : cur;      // where prepare() leaves the next block's initial accumulators
             SYS_STAMP(t, 0);
             auto prepare = [&]() {   // accumulator = (P_i[dst] + P_j[src]) * T1: row-major sum -> tile -> accumulator layout
 #pragma unroll
@@ -405,7 +431,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             // e of block x+1 -> operand image E (this role reads it next tick), one row group per call, between the MFMAs;
             // then the rows of block x+2 are requested into the same registers
             auto side = [&](int slot) {
-                if (slot < 8 && !(slot & 1)) {
+                if (!HEDGE_EIMG1 && slot < 8 && !(slot & 1)) {
                     const int j = slot >> 1;
                     uintx2 h, l;
                     split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
@@ -418,18 +444,25 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     if (slot == 7) idx_loads();
                 } else if (slot == 8) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (!(HEDGE_ABL & 16)) eq[j] = bld4s<((HEDGE_NT & 1) ? 2 : 0) | ((HEDGE_SC1 & 1) ? 16 : 0)>(srd_ein, v_eoff, rel * 512 + j * 4096);
+                    for (int j = 0; j < 4; ++j) if (!(HEDGE_ABL & 16) && !HEDGE_EIMG1) eq[j] = bld4s<((HEDGE_NT & 1) ? 2 : 0) | ((HEDGE_SC1 & 1) ? 16 : 0)>(srd_ein, v_eoff, rel * 512 + j * 4096);
                     be = be_next;
+                } else if (HEDGE_DEFER && slot == 9) {
+                    rng |= __any(prv[0] != prv[0]) ? 1 : 0;   // range check of block x-1 (see below), ahead of the asm readers
+                } else if (HEDGE_DEFER && (slot == HEDGE_TAIL0 || slot == HEDGE_TAIL1)) {
+                    tail_piece(prv, smem, x1_w + (1 - PAR) * IMG_B, slot == HEDGE_TAIL1);   // image X1 of block x-1
                 }
             };
             SYS_STAMP(t, 2);
-            mlp_layer(acc, c0v, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
+            if (HEDGE_DEFER) mlp_layer(cur, cur, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
+            else mlp_layer(prv, cur, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
             SYS_STAMP(t, 3);
             // range check of the fp16 split: a value that does not fit an operand image is (inf, -inf) as a pair and turns every
             // accumulator of its row into NaN (hmlp.hip: check_rows) -- one comparison per tick, wave-uniform verdict
-            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
-            GM_SB;
-            acc_to_image(acc, smem, x1_w + PAR * IMG_B);
+            if (!HEDGE_DEFER) {
+                rng |= __any(prv[0] != prv[0]) ? 1 : 0;
+                GM_SB;
+                acc_to_image(prv, smem, x1_w + PAR * IMG_B);
+            }
             SYS_STAMP(t, 4);
             // Rotated tick (HEDGE_ROT0): this wave's MFMAs open the tick -- while roles 1 and 2 merge statistics -- and the
             // accumulators of block x+1 (rows requested at the top of this tick) are prepared here, behind them, and cross the
@@ -441,34 +474,42 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         };
         // Ticks -1 .. nb + 2: one tick of fill (the e rows and indices of the first block come from the prologue), nb ticks in
         // which blocks enter, three that drain the pipeline: an even count (nb is a multiple of 4), taken as (odd, even) pairs --
-        // at N = 5k a workgroup has 12 blocks, and every fill / drain tick counts.
+        // at N = 5k a workgroup has 12 blocks, and every fill / drain tick counts.  (HEDGE_DEFER: two more, the two hand-offs take a
+        // tick longer each.)  Plain form: (cur, prv) = (c0v, acc) every tick; deferred form: the two sets change places.
 #pragma unroll 1
-        for (int t = -1; t <= nb + 1; t += 2) {
-            tick(odd, t);
-            tick(even, t + 1);
+        for (int t = -1; t <= nb + 1 + 2 * HEDGE_DEFER; t += 2) {
+            tick(odd, t, c0v, acc);
+            if (HEDGE_DEFER) tick(even, t + 1, acc, c0v);
+            else tick(even, t + 1, c0v, acc);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else if (role == 1) {
         // ------------------------------------------------------------------ role 1
-        floatx16 acc;
+        // Plain form: this role runs Linear 2 of block x-1 and its share of the epilogue of block x-3.  HEDGE_DEFER: role 0's image
+        // arrives a tick later and this role's own goes out a tick later (ReLU + split in the next tick's MFMA gaps): Linear 2 of block
+        // x-2, image X2 of block x-3, epilogue of block x-5 (D = 2 ticks behind the plain schedule).
+        constexpr int D = 2 * HEDGE_DEFER;
+        floatx16 acc, acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
         int rng = 0;
-        floatx4 er[EPI_SPLIT + 1];          // e rows (row-major quads, rows 8 j + rr) of block x-3 for the residual
-        int st_a = e0, cnt_a = 0, st_b = e0, cnt_b = 0;  // blocks x-3, x-2
-        int2 bi_c = a_blk[b0];                          // raw table entry of block x-1 (decoded a tick after its load)
+        floatx4 er[EPI_SPLIT + 1];          // e rows (row-major quads, rows 8 j + rr) of block x-3-D for the residual
+        int st_a = e0, cnt_a = 0, st_b = e0, cnt_b = 0;  // blocks x-3-D, x-2-D
+        int2 bi_c = a_blk[b0];                          // raw table entry of block x-1-D (decoded a tick after its load)
         const float res_w = a_residual ? 1.f : 0.f;
         // LayerNorm gamma / beta of this lane's feature quad and the bias of Linear 2 in accumulator layout: constant over the launch
         const floatx4 gm = LDS(floatx4, L_VEC + (2 * H + 32 * jb + 4 * cq) * 4);
         const floatx4 bt = LDS(floatx4, L_VEC + (3 * H + 32 * jb + 4 * cq) * 4);
-        floatx16 b2v;   // b2 T2 in accumulator layout: constant over the launch (this role has the registers)
-        auto init_acc = [&]() {
+        floatx16 b2v;   // b2 T2 in accumulator layout: constant over the launch (plain form: this role has the registers)
+        auto init_acc = [&](floatx16& dstv) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const floatx4 v = LDS(floatx4, L_VEC + (32 * jb + 4 * hi + 8 * g) * 4);
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) b2v[4 * g + tt] = v[tt];
+                for (int tt = 0; tt < 4; ++tt) dstv[4 * g + tt] = v[tt];
             }
         };
-        init_acc();
+        if (!HEDGE_DEFER) init_acc(b2v);
         const unsigned st_r = opaque(L_ST + n * 4);
         const unsigned km_w = opaque(L_KM + jb * 128 + n * 4), km_r = opaque(L_KM + jb * 128 + rr * 4);
         const unsigned z_r = opaque(L_Z + jb * TILE_B + rr * TILE_ROW_B + cq * 16);
@@ -476,19 +517,44 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         float* const e_out_wg = a_e_out + (size_t)e0 * H;
 #pragma unroll
         for (int j = 0; j < EPI_SPLIT; ++j) er[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        auto tick = [&](auto par_c, int t) {
-            constexpr int PAR = decltype(par_c)::value, P1 = 1 - PAR, P3 = 1 - PAR;   // parities of blocks x, x-1, x-3
+        // HEDGE_EIMG1: the e rows of block x+1 on their way into the operand image E that role 0 multiplies next tick (row 8 j + rr,
+        // this wave's 128-byte slab; the first block's are requested here), written between this role's MFMAs
+        const int kg1 = cq & 1, ksb1 = cq >> 2, half1 = (cq >> 1) & 1;
+        const unsigned e_w = opaque(L_E + ((2 * jb + ksb1) * 2 * 64 + ((rr ^ (2 * (ksb1 + 2 * kg1))) + 32 * kg1)) * 16 + half1 * 8);   // + 128 j, + 1024: lo part
+        floatx4 eq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) eq[j] = HEDGE_EIMG1 ? bld4(srd_ein, v_eoff, j * 4096) : floatx4{0.f, 0.f, 0.f, 0.f};
+        int2 be = a_blk[clampb(b0 + 1)];   // table entry of block x+2: the rows requested this tick
+        auto tick = [&](auto par_c, int t, floatx16& cur, floatx16& prv) {
+            constexpr int PAR = decltype(par_c)::value, P1 = HEDGE_DEFER ? PAR : 1 - PAR, P3 = 1 - PAR;   // parities of blocks x, this Linear's (x-1 / x-2), x-3-D
             const int x = b0 + t;
             SYS_STAMP(t, 0);
-            // 1 / (T sigma) of the rows of block x-3: lane n (both halves) -> this wave's table
+            // 1 / (T sigma) of the rows of block x-3-D: lane n (both halves) -> this wave's table
             LDS(float, km_w) = ln_k(smem, st_r + P3 * 512, inv_T, a_eps);
-            const int cnt_st = ok(x - 3) ? cnt_a : 0;   // rows of block x-3 that exist (none in the fill / drain ticks)
-            const int2 bi_n = a_blk[clampb(x)];         // requested now, used at the end of the tick: the barrier's wait for the
+            const int cnt_st = ok(x - 3 - D) ? cnt_a : 0;   // rows of block x-3-D that exist (none in the fill / drain ticks)
+            const int2 bi_n = a_blk[clampb(x - D)];     // requested now, used at the end of the tick: the barrier's wait for the
                                                         // scalar-memory counter then finds it done
+            if (HEDGE_DEFER) init_acc(cur);   // b2 T2 -> the first MFMA's C operand (from LDS: both register sets are in use), accumulated in place
             const unsigned rel_a = (unsigned)(st_a - e0), rel_b = (unsigned)(st_b - e0);
             float kr;
             floatx4 zq;
-            auto side = [&](int slot) {   // LayerNorm + e_out of block x-3, row group slot / SIDE_STRIDE
+            const int2 be_next = a_blk[clampb(x + 3)];
+            const unsigned rel_e = (unsigned)(be.x - e0);
+            auto side = [&](int slot) {   // LayerNorm + e_out of block x-3-D, row group slot / SIDE_STRIDE
+                if (HEDGE_EIMG1 && slot >= 3 && slot <= 9 && (slot & 1)) {   // e of block x+1 -> image E, one row group per call
+                    const int j = (slot - 3) >> 1;
+                    uintx2 h, l;
+                    split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
+                    LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128) = h;
+                    LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128 + 1024) = l;
+                }
+                if (HEDGE_EIMG1 && slot == 10) {   // ... then the rows of block x+2 are requested into the same registers
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) eq[j] = bld4(srd_ein, v_eoff, rel_e * 512 + j * 4096);
+                    be = be_next;
+                }
+                if (HEDGE_DEFER && slot == 9) rng |= __any(prv[0] != prv[0]) ? 1 : 0;   // range check of block x-3, ahead of the asm readers
+                if (HEDGE_DEFER && (slot == HEDGE_TAIL0 || slot == HEDGE_TAIL1)) tail_piece(prv, smem, x_out + (1 - PAR) * IMG_B, slot == HEDGE_TAIL1);
                 if (slot >= EPI_SPLIT * SIDE_STRIDE) return;   // the other row groups are role 2's (balance of the roles' ticks)
                 const int j = slot / SIDE_STRIDE;
                 if (slot % SIDE_STRIDE == 0) {
@@ -506,11 +572,15 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             };
             SYS_STAMP(t, 1);
             SYS_STAMP(t, 2);
-            mlp_layer(acc, b2v, wh, wl, smem, x_in + P1 * IMG_B, x_in + P1 * IMG_B, side);
+            if (HEDGE_DEFER) {
+                mlp_layer(cur, cur, wh, wl, smem, x_in + P1 * IMG_B, x_in + P1 * IMG_B, side);
+            } else {
+                mlp_layer(cur, b2v, wh, wl, smem, x_in + P1 * IMG_B, x_in + P1 * IMG_B, side);
+                rng |= __any(cur[0] != cur[0]) ? 1 : 0;
+                GM_SB;
+                acc_to_image(cur, smem, x_out + P1 * IMG_B);
+            }
             SYS_STAMP(t, 3);
-            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
-            GM_SB;
-            acc_to_image(acc, smem, x_out + P1 * IMG_B);
             SYS_STAMP(t, 4);
             st_a = st_b; cnt_a = cnt_b;
             st_b = bi_c.x; cnt_b = bi_c.y & 0xff;
@@ -520,9 +590,10 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 6);
         };
 #pragma unroll 1
-        for (int t = -1; t <= nb + 1; t += 2) {
-            tick(odd, t);
-            tick(even, t + 1);
+        for (int t = -1; t <= nb + 1 + 2 * HEDGE_DEFER; t += 2) {
+            tick(odd, t, acc, acc2);
+            if (HEDGE_DEFER) tick(even, t + 1, acc2, acc);
+            else tick(even, t + 1, acc, acc2);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else {
@@ -580,7 +651,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         };
         auto tick = [&](auto par_c, int t) {
             constexpr int PAR = decltype(par_c)::value, P2 = PAR, P3 = 1 - PAR;   // parities of blocks x-2, x-3
-            const int x = b0 + t;
+            const int x = b0 + t - 2 * HEDGE_DEFER;   // HEDGE_DEFER: the images reach this role two ticks later (same parities)
             // table entries of block x (decoded next tick): requested at the top, so that the barrier's scalar-memory wait finds them done
             const int2 bn_n = a_blk[clampb(x)], sn_n = a_seg[clampb(x)];
             const int hd_n = a_head[clampb(x - 1) >> 2];   // head of block x-1's group (used if that block opens its group)
@@ -710,7 +781,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 6);   // every wave of the workgroup has finished the tick
         };
 #pragma unroll 1
-        for (int t = -1; t <= nb + 1; t += 2) {
+        for (int t = -1; t <= nb + 1 + 2 * HEDGE_DEFER; t += 2) {
             tick(odd, t);
             tick(even, t + 1);
         }
