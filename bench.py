@@ -59,9 +59,10 @@ def edge_kernel_issued_flops(E, H=128, num_layers=2):
     return E * 2.0 * (H * H * (num_layers + 1))
 
 
-def edge_kernel_alg_bytes(E, N, H=128):
-    """Compulsory HBM bytes of one launch: read e, write e', P (2H per node), agg (H per node), indices."""
-    return E * H * 4 * 2 + N * H * 4 * 3 + E * 12
+def edge_kernel_alg_bytes(E, N, H=128, m_steps=10):
+    """Compulsory HBM bytes of one launch: read e, write e', P (2H per node), agg (H per node), indices -- averaged
+    over the m_steps launches of a forward, the last of which writes no e' (nobody reads it: the decoder takes h, epd_gnn.py:96)."""
+    return E * H * 4 * (2 - 1.0 / m_steps) + N * H * 4 * 3 + E * 12
 
 
 def cpu_model_name():

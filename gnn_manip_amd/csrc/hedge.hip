@@ -305,6 +305,10 @@ __device__ __forceinline__ void scan3(float& ya, float& yb, float& yc, float ypr
     }
 }
 
+// WRITE_E = false: the launch whose e_out nobody reads (the last message-passing step of a forward: the decoder takes h only,
+// epd_gnn.py:96) -- LayerNorm statistics and the scatter-add run as always, the row-major epilogue (residual read, e + e', store)
+// does not exist: 1 GB less written and 1 GB less re-read at the target.
+template <bool WRITE_E>
 __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeader* a_hdr, const int* __restrict__ a_dst, const int* __restrict__ a_src, const float* __restrict__ a_P,
                                                                        const float* a_e_in, float* a_e_out, float* __restrict__ a_agg, const float* __restrict__ a_hw,
                                                                        const int2* __restrict__ a_blk, const int2* __restrict__ a_seg, const int* __restrict__ a_head,
@@ -327,7 +331,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
     const int b0 = 4 * c0, b1 = 4 * c1;
     const int nb = b1 - b0;
     if (nb <= 0) return;
-    const float T1 = a_hw[0], inv_T = a_hw[1];
+    const float inv_T = a_hw[1];
     const float* hvec = a_hw + HW_HEADER_FLOATS;
     const half8* wimg = reinterpret_cast<const half8*>(a_hw + HW_HEADER_FLOATS + HW_VEC_FLOATS);
 
@@ -398,7 +402,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 0);
             auto prepare = [&]() {   // accumulator = (P_i[dst] + P_j[src]) * T1: row-major sum -> tile -> accumulator layout
 #pragma unroll
-                for (int j = 0; j < 4; ++j) LDS(floatx4, ps_w + j * TILE_ROW_B) = (pi[j] + pj[j]) * T1;
+                for (int j = 0; j < 4; ++j) LDS(floatx4, ps_w + j * TILE_ROW_B) = pi[j] + pj[j];   // P arrives times T1 (NodeArgs::p_scale)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const floatx4 v = LDS(floatx4, ps_r + 32 * g);
@@ -530,7 +534,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             const int x = b0 + t;
             SYS_STAMP(t, 0);
             // 1 / (T sigma) of the rows of block x-3-D: lane n (both halves) -> this wave's table
-            LDS(float, km_w) = ln_k(smem, st_r + P3 * 512, inv_T, a_eps);
+            if (WRITE_E) LDS(float, km_w) = ln_k(smem, st_r + P3 * 512, inv_T, a_eps);
             const int cnt_st = ok(x - 3 - D) ? cnt_a : 0;   // rows of block x-3-D that exist (none in the fill / drain ticks)
             const int2 bi_n = a_blk[clampb(x - D)];     // requested now, used at the end of the tick: the barrier's wait for the
                                                         // scalar-memory counter then finds it done
@@ -555,7 +559,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 }
                 if (HEDGE_DEFER && slot == 9) rng |= __any(prv[0] != prv[0]) ? 1 : 0;   // range check of block x-3, ahead of the asm readers
                 if (HEDGE_DEFER && (slot == HEDGE_TAIL0 || slot == HEDGE_TAIL1)) tail_piece(prv, smem, x_out + (1 - PAR) * IMG_B, slot == HEDGE_TAIL1);
-                if (slot >= EPI_SPLIT * SIDE_STRIDE) return;   // the other row groups are role 2's (balance of the roles' ticks)
+                if (!WRITE_E || slot >= EPI_SPLIT * SIDE_STRIDE) return;   // the other row groups are role 2's (balance of the roles' ticks)
                 const int j = slot / SIDE_STRIDE;
                 if (slot % SIDE_STRIDE == 0) {
                     kr = LDS(float, km_r + j * 32);
@@ -696,7 +700,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     const float from0 = lower_half_to_both(open0);
                     const float c1v = (cont & 0x10000u) ? from0 : 0.f;
                     cpend = hi ? c1v : c0v;
-                } else if (EPI_SPLIT < 4 && slot >= 14 && slot < 14 + 2 * (4 - EPI_SPLIT)) {
+                } else if (WRITE_E && EPI_SPLIT < 4 && slot >= 14 && slot < 14 + 2 * (4 - EPI_SPLIT)) {
                     // this role's share of the e_out epilogue: row group j, loads at an even slot, arithmetic + store at the next
                     {
                         const int j = EPI_SPLIT + ((slot - 14) >> 1);
@@ -1268,13 +1272,15 @@ bool edge_sys_fits(int64_t n_nodes, int64_t edge_capacity) {
 
 int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
     GM_REQUIRE(a.hdr && a.wstream_h3 && a.agg && a.side && !a.eid && !a.eid_out, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: unsupported argument combination");
+    GM_REQUIRE(a.P_prescaled, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: P must carry the weight scale of this step (NodeArgs::p_scale = edge_sys_p_scale(image))");
     // the scatter-add addresses agg rows and side rows with 32-bit byte offsets from agg (carve_fwd puts them in one workspace)
     const uint64_t agg_bytes = ((uint64_t)(a.side - a.agg) + (uint64_t)(t.max_blocks / 4 + 1) * H) * 4;
     GM_REQUIRE(a.side >= a.agg && agg_bytes < (1ull << 32) && (uint64_t)a.n_nodes_tab * 2 * H * 4 < (1ull << 32), GM_ERR_INVALID_ARGUMENT,
                "launch_edge_sys: P and agg + side buffer must each stay below 4 GiB (edge_sys_fits)");
     static PerDeviceOnce attr_done;
     const int rc_attr = attr_done.run([]() -> int {
-        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
         return GM_OK;
     });
     if (rc_attr != GM_OK) return rc_attr;
@@ -1282,9 +1288,14 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
         ProfScope prof(a.prof, PROF_EDGE, s);
         // pointers as separate __restrict__ parameters (e_in / e_out may be the same array): the table reads are then provably
         // unclobbered and become scalar loads
-        hipLaunchKernelGGL(sys_edge_kernel, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
-                           a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, (unsigned)(a.side - a.agg), (unsigned)agg_bytes,
-                           (unsigned)((uint64_t)a.n_nodes_tab * 2 * H * 4), const_cast<int*>(&a.hdr->error_flags), a.eps, a.residual);
+        if (a.discard_e_out)
+            hipLaunchKernelGGL(sys_edge_kernel<false>, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
+                               a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, (unsigned)(a.side - a.agg), (unsigned)agg_bytes,
+                               (unsigned)((uint64_t)a.n_nodes_tab * 2 * H * 4), const_cast<int*>(&a.hdr->error_flags), a.eps, a.residual);
+        else
+            hipLaunchKernelGGL(sys_edge_kernel<true>, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
+                               a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, (unsigned)(a.side - a.agg), (unsigned)agg_bytes,
+                               (unsigned)((uint64_t)a.n_nodes_tab * 2 * H * 4), const_cast<int*>(&a.hdr->error_flags), a.eps, a.residual);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;

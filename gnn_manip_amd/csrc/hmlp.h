@@ -63,6 +63,7 @@ struct HmEdgeArgs {
     const float* ln_b;
     float eps;
     int residual;
+    int discard_e_out;    // processor with scatter-add: e_out is not read after this launch and may stay unwritten
     int k1;
     int nl;               // num_layers: nl + 1 Linears
     int h_valid;          // features that exist (<= H): the rest of the width is zero padding
@@ -90,6 +91,7 @@ struct HmNodeArgs {
     int tail;             // 0 none, 1 projection P = h [W_i | W_j]^T (+ b1), 2 decoder
     const float* w_tail;  // tail 1: one Linear image (2H outputs); tail 2: nl images H -> H, then H -> 32 (zero-padded)
     float* P_out;
+    const float* p_scale; // tail 1: P is written times *p_scale (a power of two: the consuming systolic edge kernel's weight scale), or nullptr
     float* dec_out;
     int out_dim;
     const int* stitch;    // mode 1: stitch / head lists + side buffer of the edge kernel's head partials (hedge.h), or nullptr

@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                     const floatx4 gm4 = *reinterpret_cast<const floatx4*>(gamp + 8 * g), bt4 = *reinterpret_cast<const floatx4*>(betp + 8 * g);
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) y[tt] = fmaf(fmaf(acc[rb][4 * g + tt], k, m), gm4[tt], bt4[tt]);
-                    if (valid) {
+                    if (valid && !A.discard_e_out) {   // (the last step of a forward: nobody reads its e + e')
                         floatx4 eo = floatx4{y[0], y[1], y[2], y[3]};
                         if (A.residual) {
                             const floatx4 e0 = *reinterpret_cast<const floatx4*>(outp + 8 * g);
@@ -775,6 +775,9 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
         }
         if (A.tail == 1 || MODE == 2) {
             const Lin LP = lin_at(A.w_tail, 2 * H);
+            // P leaves at the scale its consumer multiplies at: the systolic edge kernel adds P_i + P_j straight into accumulators that
+            // carry its first Linear's power-of-two weight scale (exact: a power of two commutes with every rounding on the way)
+            const float p_out_scale = LP.inv_u * (A.p_scale ? *A.p_scale : 1.f);
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
                 const int jbv = jb + half * C::NJB;
@@ -790,7 +793,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
                         for (int g = 0; g < 4; ++g) {
                             floatx4 v;
 #pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) v[tt] = acc[rb][4 * g + tt] * LP.inv_u;
+                            for (int tt = 0; tt < 4; ++tt) v[tt] = acc[rb][4 * g + tt] * p_out_scale;
                             *reinterpret_cast<floatx4*>(pp + 8 * g) = v;
                         }
                     }

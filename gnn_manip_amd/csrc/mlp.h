@@ -27,6 +27,8 @@ struct EdgeArgs {
     const float* ln_b;
     float eps;
     int residual;          // e_out = e' + e_in
+    int discard_e_out;     // nobody reads e_out after this launch (the last step of a forward): a kernel may leave it unwritten
+    int P_prescaled;       // P was written times the systolic kernel's weight scale T1 (NodeArgs::p_scale): only that kernel may take the launch
     int k1;                // encoder: edge_dim
     int h_valid;           // the model's hidden_size (<= the width H the kernel runs at; LayerNorm statistics are over these features)
 };
@@ -54,6 +56,7 @@ struct NodeArgs {
     int tail;              // 0 none, 1 projection, 2 decoder
     const float* proj_bias;  // [H] layer-1 bias of the next edge MLP
     float* P_out;            // [N][2H]
+    const float* p_scale;    // device pointer to the power of two P_out is multiplied with (edge_sys_p_scale), or nullptr
     const float* dec_bias;   // [NL][H] then [32] (out bias zero-padded)
     float* dec_out;          // [N][out_dim]
     int out_dim;
@@ -72,6 +75,8 @@ struct VecJobs {
 };
 int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s);
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a, int64_t edge_capacity, hipStream_t s);
+// whether launch_edge hands this processor launch to the systolic kernel (which then expects P pre-scaled: NodeArgs::p_scale)
+bool edge_launch_is_sys(int H, int NL, const EdgeArgs& a, int64_t edge_capacity);
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s);
 
 }  // namespace gm

@@ -35,15 +35,21 @@ int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s) {
 enum : int { EK_AUTO = 0, EK_SYS = 5, EK_HM = 6 };   // gm_model_set_edge_kernel (1 .. 4 were the removed round-1 kernels)
 
 
+// the systolic fp16 x 3 kernel (hedge.hip): processor step of the fused forward (rows in sorted order, device-side edge count, block
+// tables present), hidden 128 / num_layers 2
+bool edge_launch_is_sys(int H, int NL, const EdgeArgs& a, int64_t edge_capacity) {
+    const int choice = a.kernel_choice;
+    const bool sys_ok = H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
+    return edge_capacity > 0 && sys_ok && (choice == EK_AUTO || choice == EK_SYS) && edge_sys_fits(a.n_nodes_tab, edge_capacity);
+}
+
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capacity, hipStream_t s) {
     if (edge_capacity <= 0) return GM_OK;
     const EdgeArgs& a = a_in;
     const int choice = a.kernel_choice;
-    // the systolic fp16 x 3 kernel (hedge.hip): processor step of the fused forward (rows in sorted order, device-side
-    // edge count, block tables present), hidden 128 / num_layers 2
-    const bool sys_ok = H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && !enc && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
-    if (sys_ok && (choice == EK_AUTO || choice == EK_SYS) && edge_sys_fits(a.n_nodes_tab, edge_capacity))
+    if (!enc && edge_launch_is_sys(H, NL, a, edge_capacity))
         return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), s);
+    GM_REQUIRE(enc || !a.P_prescaled, GM_ERR_INVALID_ARGUMENT, "edge kernel: P carries the systolic kernel's scale, but the launch is not its");
     // the encoder phi_e in the same weight-stationary form: 4 raw features per edge, rows in sorted order (the rollout path)
     if (enc && H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && a.wstream_h3 && a.hdr && !a.eid && a.k1 == 4 &&
         (choice == EK_AUTO || choice == EK_SYS))
@@ -53,7 +59,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
         HmEdgeArgs h{};
         h.hdr = a.hdr; h.n_edges_host = a.n_edges_host; h.dst = a.dst; h.src = a.src; h.eid = a.eid; h.eid_out = a.eid_out;
         h.P = a.P; h.e_in = a.e_in; h.e_out = a.e_out; h.agg = a.agg; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b;
-        h.eps = a.eps; h.residual = a.residual; h.k1 = a.k1; h.nl = NL; h.prof = a.prof;
+        h.eps = a.eps; h.residual = a.residual; h.discard_e_out = a.discard_e_out; h.k1 = a.k1; h.nl = NL; h.prof = a.prof;
         h.h_valid = a.h_valid > 0 ? a.h_valid : H;
         h.flags = a.hdr ? const_cast<int*>(&a.hdr->error_flags) : nullptr;
         if (!enc) {
@@ -71,7 +77,7 @@ int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
         HmNodeArgs h{};
         h.n_nodes = a.n_nodes; h.x_in = a.x_in; h.k1 = a.k1; h.agg = a.agg; h.h_out = a.h_out;
         h.residual = a.residual; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b; h.eps = a.eps; h.nl = NL;
-        h.tail = mode == 2 ? 1 : a.tail; h.w_tail = a.tail_hm; h.P_out = a.P_out; h.dec_out = a.dec_out; h.out_dim = a.out_dim; h.prof = a.prof;
+        h.tail = mode == 2 ? 1 : a.tail; h.w_tail = a.tail_hm; h.P_out = a.P_out; h.p_scale = a.p_scale; h.dec_out = a.dec_out; h.out_dim = a.out_dim; h.prof = a.prof;
         h.flags = a.err_flags;
         h.h_valid = a.h_valid > 0 ? a.h_valid : H;
         if (mode == 1 && a.edge_blocks && a.side) {   // lists + side buffer of the edge kernel's head partials (hedge.h)

@@ -467,8 +467,10 @@ EdgeArgs proc_edge_args(const gm_model* m, int k, const CsrWs& c, int64_t n, con
     a.h_valid = m->H;
     return a;
 }
-void set_tail(const gm_model* m, NodeArgs& a, int next_edge_step /* -1: none, M: decoder */, float* P, float* out) {
+void set_tail(const gm_model* m, NodeArgs& a, int next_edge_step /* -1: none, M: decoder */, float* P, float* out, bool sys_edge = false) {
     if (next_edge_step < 0) { a.tail = 0; return; }
+    // P for a step the systolic edge kernel takes leaves the node kernel at that kernel's weight scale
+    a.p_scale = (sys_edge && next_edge_step < m->M && m->packed_h3) ? edge_sys_p_scale(m->packed_h3 + (size_t)next_edge_step * h3_image_floats()) : nullptr;
     a.tail_hm = m->packed_hm + (next_edge_step == 0 ? m->hm_enc_node_tail : m->hm_node_tail[next_edge_step - 1]);
     if (next_edge_step < m->M) {
         a.tail = 1;
@@ -513,13 +515,18 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     na.err_flags = &c.hdr->error_flags;
     const float* v = m->vec + m->v_enc_node;
     na.bias = v; na.ln_g = v + (size_t)(NL + 1) * H; na.ln_b = v + (size_t)(NL + 2) * H; na.eps = m->d.ln_eps;
-    set_tail(m, na, 0, f.P, out);
+    // which kernel the processor edge launches of this forward take (the same for every step: it depends on sizes and the handle's choice)
+    const bool sys_edge = cap > 0 && edge_launch_is_sys(H, NL, proc_edge_args(m, 0, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, f.side, 1), cap);
+    set_tail(m, na, 0, f.P, out, sys_edge);
     rc = launch_node(H, NL, 0, na, s);
     if (rc != GM_OK) return rc;
     // agg is zeroed once (nodes without in-edges read zeros; rows with in-edges are stored whole by every edge launch)
     GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
     for (int k = 0; k < M; ++k) {
-        rc = launch_edge(H, NL, false, proc_edge_args(m, k, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, f.side, 1), cap, s);
+        EdgeArgs ea = proc_edge_args(m, k, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, f.side, 1);
+        ea.discard_e_out = k + 1 == M;   // the decoder reads h only (epd_gnn.py:96): the last step's e + e' is never looked at
+        ea.P_prescaled = sys_edge;
+        rc = launch_edge(H, NL, false, ea, cap, s);
         if (rc != GM_OK) return rc;
         NodeArgs a{};
         a.h_valid = m->H;
@@ -529,7 +536,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
         a.wstream_hm = m->packed_hm + m->hm_node[k]; a.kernel_choice = m->edge_kernel; a.prof = m->prof;
         const float* vn = m->vec + m->v_node[k];
         a.bias = vn; a.ln_g = vn + (size_t)(NL + 1) * H; a.ln_b = vn + (size_t)(NL + 2) * H; a.eps = m->d.ln_eps;
-        set_tail(m, a, k + 1, f.P, out);
+        set_tail(m, a, k + 1, f.P, out, sys_edge);
         rc = launch_node(H, NL, 1, a, s);
         if (rc != GM_OK) return rc;
     }
