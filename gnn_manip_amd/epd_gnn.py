@@ -417,14 +417,16 @@ def _run_block(handle, desc, k, x, edge_attr, edge_index, csr=None):
 class _EpdTrainFunction(torch.autograd.Function):
     """``EncProcDecGNN.forward`` under autograd (examples/train_dyn.py:45-72): the forward records the
     activation tape in one device buffer, the backward is gm_epd_backward.  Gradients are produced for the
-    parameters only; nodes / edge_attr / edge_index are data."""
+    parameters only; nodes / edge_attr / edge_index are data.  `spec` = (model descriptor tuple, _Handle): the module's own, or
+    -- for a hidden size between the training kernels' widths -- the zero-padded model's (EncProcDecGNN._padded_training)."""
 
     @staticmethod
-    def forward(ctx, module, nodes, edge_attr, edge_index, *params):
+    def forward(ctx, module, spec, nodes, edge_attr, edge_index, *params):
         L = lib()
         n, e = int(nodes.shape[0]), int(edge_attr.shape[0])
-        h = module.device_handle(nodes.device)
-        d = ModelDesc(*module.model_desc())
+        desc_tuple, handle = spec
+        h = handle.get(desc_tuple, list(params), nodes.device)
+        d = ModelDesc(*desc_tuple)
         tape = _ws(L.gm_train_tape_bytes(C.byref(d), n, e), nodes.device)
         out = torch.empty((n, module.dims[2]), dtype=torch.float32, device=nodes.device)
         ei = edge_index.contiguous()
@@ -450,7 +452,10 @@ class _EpdTrainFunction(torch.autograd.Function):
         check(L.gm_epd_backward(ctx.handle, t_arr, len(tensors), ptr(nodes), ptr(edge_attr), n, e, ptr(grad_out), g_arr,
                                 ptr(ctx.tape), ctx.tape.numel(), ptr(ws), ws.numel(), current_stream()))
         ctx.tape = None
-        return (None, None, None, None) + tuple(views)
+        return (None, None, None, None, None) + tuple(views)
+
+
+TRAIN_WIDTHS = (64, 128, 256)   # hidden sizes the training kernels are instantiated for (csrc/train.hip)
 
 
 class EncProcDecGNN(nn.Module):
@@ -507,6 +512,60 @@ class EncProcDecGNN(nn.Module):
         """gm_model* for the current parameters on `device` (packed once, re-packed on change)."""
         return self._handle.get(self.model_desc(), list(self.parameters()), device)
 
+    def _padded_training(self, params):
+        """Training at a hidden size between the kernels' widths (train_dyn.py:237-238 takes any int): the model runs zero-padded
+        at the next width, as the inference kernels do.  The padded parameters are built from the real ones by differentiable torch
+        operations, so autograd carries the gradients back through them:
+          * every hidden dimension is zero-padded (input blocks of the processors' first Linears each to the padded width);
+          * the Linear in front of a LayerNorm is centred over its outputs (W - mean_rows(W), b - mean(b)): its outputs have zero
+            mean over the features that exist, the padded ones are exactly zero, and a LayerNorm over the padded width Hp with
+            eps' = eps Hv / Hp and gamma' = gamma sqrt(Hv / Hp) is the LayerNorm over the Hv real features:
+            x / sqrt(Q / Hp + eps') * gamma' = x / sqrt(Q / Hv + eps) * gamma  (Q = sum of squares); beta is padded with zeros, so
+            padded features leave every LayerNorm as zeros again.
+        Returns ((descriptor tuple of the padded model, its handle), padded parameter tensors)."""
+        node_dim, edge_dim, out_dim, hv, nl, m_steps = self.dims
+        hp = padded_hidden(hv)
+        if hp not in TRAIN_WIDTHS:
+            raise NotImplementedError(f"training at hidden_size={hv}: supported are 1 .. {TRAIN_WIDTHS[-1]}")
+        pad = torch.nn.functional.pad
+        scale = (hv / hp) ** 0.5
+        it = iter(params)
+
+        def mlp(in_blocks, normed, out_rows):
+            # in_blocks: widths of the column blocks of the first Linear that are hidden-sized (padded each) or raw (kept)
+            out = []
+            for l in range(nl + 1):
+                w, b = next(it), next(it)
+                last = l == nl
+                if last and normed:
+                    w, b = w - w.mean(dim=0, keepdim=True), b - b.mean()
+                if l == 0:
+                    cols, c0 = [], 0
+                    for width, hidden_block in in_blocks:
+                        blk = w[:, c0:c0 + width]
+                        cols.append(pad(blk, (0, hp - width)) if hidden_block else blk)
+                        c0 += width
+                    w = torch.cat(cols, dim=1)
+                else:
+                    w = pad(w, (0, hp - hv))
+                if not last or normed:   # a hidden-sized output (all but the decoder's last Linear): padded rows / bias entries are zero
+                    w, b = pad(w, (0, 0, 0, hp - hv)), pad(b, (0, hp - hv))
+                out += [w.contiguous(), b.contiguous()]
+            if normed:
+                g, bt = next(it), next(it)
+                out += [pad(g * scale, (0, hp - hv)), pad(bt, (0, hp - hv))]
+            return out
+
+        padded = mlp([(edge_dim, False)], True, hv) + mlp([(node_dim, False)], True, hv)
+        for _ in range(m_steps):
+            padded += mlp([(hv, True)] * 3, True, hv) + mlp([(hv, True)] * 2, True, hv)
+        padded += mlp([(hv, True)], False, out_dim)
+        eps = float(self.encoder.phi_edge[-1].eps) * hv / hp
+        desc = (int(node_dim), int(edge_dim), int(out_dim), hp, int(nl), int(m_steps), eps) + self.convention
+        if "_pad_handle" not in self.__dict__:
+            self.__dict__["_pad_handle"] = _Handle()
+        return (desc, self._pad_handle), padded
+
     auto_status = True   # check the previous inference forward's device-side error flags at the start of the next one
 
     EDGE_KERNELS = {"auto": 0, "sys": 5, "hm": 6}   # 1 .. 4 were the round-1 fp32 / bf16 x 6 kernels (removed in round 5)
@@ -555,7 +614,11 @@ class EncProcDecGNN(nn.Module):
             _check_edge_index(edge_index, n, e, ranges=False)
             if self.auto_status:
                 self._reap_watched(block=False)
-            return _EpdTrainFunction.apply(self, nodes, edge_attr, edge_index, *params)
+            hidden = self.dims[3]
+            if hidden in TRAIN_WIDTHS:
+                return _EpdTrainFunction.apply(self, (self.model_desc(), self._handle), nodes, edge_attr, edge_index, *params)
+            spec, padded = self._padded_training(params)
+            return _EpdTrainFunction.apply(self, spec, nodes, edge_attr, edge_index, *padded)
         if self.auto_status:
             # EARLIER inference forwards of this model: a device-side error (edge_index entry out of range, fp16 split range
             # exceeded) of one that has FINISHED surfaces here -- a reference-style caller never calls status() itself.

@@ -112,6 +112,25 @@ def test_backward_other_widths_and_depths(dev, hidden, num_layers, m_steps, seed
     _check(m, params, nodes, ea, ei, dims, dev, seed)
 
 
+@pytest.mark.parametrize("hidden,num_layers,m_steps,seed", [(100, 2, 2, 140), (40, 3, 2, 141), (200, 2, 1, 142)])
+def test_backward_at_hidden_sizes_between_the_kernel_widths(dev, hidden, num_layers, m_steps, seed):
+    """train_dyn.py:237-238 takes any hidden size.  Sizes between the training kernels' widths (64 / 128 / 256) train zero-padded
+    at the next width: the padded parameters are differentiable functions of the real ones (EncProcDecGNN._padded_training: zero
+    padding; the Linear in front of every LayerNorm centred over its outputs; eps and gamma rescaled so that the LayerNorm over the
+    padded width is the one over the features that exist), so every parameter gradient comes back in the caller's shapes -- held to
+    the same float64 yardstick as the native widths, forward 1e-5."""
+    dims = (25, 4, 3, hidden, num_layers, m_steps)
+    params = orc.init_params(*dims, seed)
+    m = _model(params, dims, dev)
+    nodes, ea, ei = _graph(600, 0.07, seed)
+    _check(m, params, nodes, ea, ei, dims, dev, seed)
+    # the fused inference path of the same module (native zero-padded kernels) agrees with the training forward
+    with torch.no_grad():
+        out_inf = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
+    out_train = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).detach()
+    assert (out_train - out_inf).abs().max() <= 1e-5 * max(float(out_inf.abs().max()), 0.1)
+
+
 def test_backward_over_many_seeds(dev):
     """The single-seed tests above use seeds on which no pre-activation sits within rounding distance of zero.  Over a run of
     seeds that cannot hold: a ReLU whose sign differs between two float32-accurate evaluations moves the gradients by ~1e-4 ..
