@@ -267,9 +267,10 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
         model.profile(0)
         roof, k_ms = roofline_record(model, ek, wl["hidden"], edges, wl["n"] * candidates, wl_key)
         br = {"edge_kernel_ms_per_step": k_ms * 10}
-        for name, (kind, calls) in {"node_kernel": (1, 10), "graph_build": (2, 1), "encoder_kernels": (3, 2)}.items():
-            n_k, ms_k = model.profile_query(kind)
-            br[name + "_ms_per_step"] = ms_k / max(n_k, 1) * calls
+        for name, kind in {"node_kernel": 1, "graph_build": 2, "encoder_kernels": 3}.items():
+            n_k, ms_k = model.profile_query(kind)   # totals over the profiled steps (a step's node side is several launches)
+            br[name + "_ms_per_step"] = ms_k / max(steps, 1)
+            br[name + "_launches_per_step"] = n_k / max(steps, 1)
         rec = {"value": world * candidates * steps / el, "unit": "rollout steps/s", "steps": steps, "warmup": warmup,
                "ms_per_step": el / steps * 1e3,
                "config": {"workload": wl["name"], "n_particles": wl["n"], "hidden": wl["hidden"], "edges_last_step": edges, "k_steps": 6,

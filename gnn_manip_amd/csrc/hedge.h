@@ -41,6 +41,7 @@ constexpr int kPackH3Max = 16;
 struct PackH3Job {
     const float* W1;   // Linear 1 weight [H][3H]: the block that multiplies e is packed (W_i, W_j live in P)
     int W1_col0;       // first column of that block (2H with the default concat order)
+    int W1_ld;         // leading dimension of W1 (0: 3H, phi_e); a node MLP's image packs the agg block of its [H][2H] first Linear
     const float* W2;   // [H][H]
     const float* W3;   // [H][H]
     const float* b1;   // Linear 1 bias (applied through P; here only for the scale estimate)
@@ -60,6 +61,38 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s);
 // device address of the power of two the systolic kernel's accumulators carry through its first Linear (T1 of the step's weight
 // image): the node kernel that writes P for that step multiplies it in (NodeArgs::p_scale), the edge kernel then adds P_i + P_j as is
 inline const float* edge_sys_p_scale(const float* h3_image) { return h3_image; }
+
+// ---- processor node MLP and the next step's projections in the weight-stationary form (hedge.hip: sys_node_kernel, sys_proj_kernel)
+struct NodeSysArgs {
+    const float* h;        // [N][128] (residual input)
+    const float* agg;      // [N][128], head partials already added (launch_agg_stitch)
+    const float* Q;        // [N][128] = (h W_h^T + b1) T1 of this step's image (launch_proj_sys)
+    float* h_out;          // [N][128], may be h
+    const float* image;    // pack_h3 image of [W_agg | W2 | W3] of this node MLP
+    int n;
+    int* flags;
+    float eps;
+    ProfState* prof;
+};
+int launch_node_sys(const NodeSysArgs& a, hipStream_t s);
+struct ProjSysArgs {
+    const float* h;        // [N][128]
+    float* P;              // [N][256] = h [W_i | W_j]^T + [b1 | 0], times *scale_p
+    float* Q;              // [N][128] = h W_h^T + b1 of the next node MLP, times *scale_q
+    const float* img_p;    // hmlp.h Linear images (256 / 128 outputs, 128 inputs)
+    const float* img_q;
+    const float* scale_p;  // device pointers (edge_sys_p_scale of the consuming kernels' images) or nullptr
+    const float* scale_q;
+    int n;
+    int* flags;
+    ProfState* prof;
+};
+int launch_proj_sys(const ProjSysArgs& a, hipStream_t s);
+int launch_agg_stitch(float* agg, const float* side, const EdgeBlocks& t, int64_t n, ProfState* prof, hipStream_t s);
+#ifndef GM_SYS_NODE_MIN_NODES
+#define GM_SYS_NODE_MIN_NODES (32 * 256 * 6)
+#endif
+constexpr int64_t kSysNodeMinNodes = GM_SYS_NODE_MIN_NODES;   // graphs from this size take the systolic node path (a workgroup needs blocks to pipeline)
 // encoder phi_e in the same weight-stationary form: raw rows [E][4] in sorted order -> e [E][128] (LayerNorm output)
 int launch_edge_sys_enc(const EdgeArgs& a, hipStream_t s);
 // whether the kernel's 32-bit byte offsets cover a graph of this size (P < 4 GiB, agg + side buffer < 4 GiB: about 4M nodes at

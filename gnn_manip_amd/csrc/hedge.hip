@@ -91,7 +91,8 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8 + 32];   // + the 100 MHz 
 #define HEDGE_XCD 1
 #endif
 #ifndef HEDGE_NT
-#define HEDGE_NT 0     // non-temporal hint on: 1 the e rows role 0 reads, 2 the residual re-read, 4 the e_out stores
+#define HEDGE_NT 4     // non-temporal hint on: 1 the e rows role 0 reads, 2 the residual re-read, 4 the e_out stores (with sc1: written
+                       // through and kept out of L2 / the Infinity Cache, which then hold h, P and agg for the kernels that follow)
 #endif
 #ifndef HEDGE_ROT2
 #define HEDGE_ROT2 0   // role 2 runs the scatter-add of block x-3 before its MFMAs instead of between them
@@ -110,6 +111,9 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8 + 32];   // + the 100 MHz 
 #ifndef HEDGE_TAIL0
 #define HEDGE_TAIL0 11   // MFMA slots (of 24) in which the two halves of a deferred tail run
 #define HEDGE_TAIL1 15
+#endif
+#ifndef HENC_ST_AUX
+#define HENC_ST_AUX 0    // cache policy of the edge encoder's e stores (2 = nt, 16 = sc1)
 #endif
 #ifndef HEDGE_SC1
 #define HEDGE_SC1 12   // sc1 (write-through, the line is not kept in L2) on: 1 the e rows role 0 reads, 2 the residual re-read, 4 the e_out stores, 8 the agg stores; 16: sc0 on the e_out stores too
@@ -920,7 +924,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader
                     floatx4 o;
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(zq[tt] * kr, gm[tt], bt[tt]);
-                    bst4s<((HEDGE_SC1 & 32) ? 16 : 0)>(make_srd(e_out_wg + (size_t)((xb - b0) * BE + 8 * j) * H, (unsigned)s_clamp0(cnt - 8 * j, 8) * 512u), v_eoff, 0, o);
+                    bst4s<HENC_ST_AUX>(make_srd(e_out_wg + (size_t)((xb - b0) * BE + 8 * j) * H, (unsigned)s_clamp0(cnt - 8 * j, 8) * 512u), v_eoff, 0, o);
                 }
             }
             rng |= __any(acc[0] != acc[0]) ? 1 : 0;
@@ -985,6 +989,349 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader
 }
 
 // ------------------------------------------------------------------------------------------
+// Processor node MLP in the same weight-stationary form (hidden 128, three Linears):
+//   h' = h + LayerNorm(W3 relu(W2 relu(W1 [h, agg] + b1) + b2) + b3)          (epd_gnn.py:38,44-45,100-105)
+// A node MLP's first Linear has 2H inputs: 128 KB of fp16 hi / lo weights, twice what a role's four waves hold.  Its h half is
+// therefore taken out the way phi_e's node terms are: the kernel that projects a step's h (sys_proj_kernel: P for the next edge
+// step) also writes Q = (W_h h + b1) T1 for the next node step, and Q enters Linear 1 here as the initial accumulator -- 3 H x H
+// products per node in this kernel, the roles of the edge encoder's kernel:
+//   role 0: Q rows of block x+1 and agg rows of block x+2 requested; agg of block x+1 -> operand image E (between the MFMAs);
+//           Linear 1 on E from c0 = Q, ReLU, image X1; Q of block x+1 -> staging tile -> accumulator layout (behind the MFMAs);
+//   role 1: Linear 2 (X1 -> X2) and row groups 0 / 1 of the epilogue of block x-3: LayerNorm, h + ., store (whole 128-byte lines);
+//   role 2: Linear 3 (X2 -> raw accumulators Z + sums of squares) and row groups 2 / 3 of that epilogue.
+// Blocks are plain runs of 32 rows.  agg arrives with the scatter-add's head partials already added (agg_stitch_kernel).  h may be
+// updated in place: a block's residual rows are read (role 1 / 2, a tick ahead of their use) before the same waves store them.
+// ------------------------------------------------------------------------------------------
+constexpr int LN_E = 0;                            // [2] images of agg rows (eslot() order)
+constexpr int LN_X1 = LN_E + 2 * IMG_B;
+constexpr int LN_X2 = LN_X1 + 2 * IMG_B;
+constexpr int LN_Z = LN_X2 + 2 * IMG_B;            // [2][4 jb] tiles
+constexpr int LN_PS = LN_Z + 8 * TILE_B;           // [4 jb] tiles: role-0 staging of Q
+constexpr int LN_ST = LN_PS + 4 * TILE_B;          // [2][4 jb][32 rows] floats
+constexpr int LN_KM = LN_ST + 2 * 4 * 32 * 4;      // [2 roles][4 jb][32] floats: 1 / (T sigma) per row
+constexpr int LN_ZERO_END = LN_KM + 2 * 4 * 32 * 4;
+constexpr int LN_VEC = LN_ZERO_END;                // 4 x 128 floats: b2 T2 | b3' T3 | gamma | beta
+constexpr size_t NODE_LDS_BYTES = LN_VEC + 4 * H * 4;
+static_assert(NODE_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+__global__ void __launch_bounds__(SYS_THREADS, 1) sys_node_kernel(const float* a_h, const float* __restrict__ a_agg, const float* __restrict__ a_Q,
+                                                                       float* a_h_out, const float* __restrict__ a_hw, int a_n, int* a_flags, float a_eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, jb = wave & 3;
+    const int N = a_n;
+    const int nblk = (N + BE - 1) / BE;
+    const int wg = (int)blockIdx.x;
+    const int b0 = (int)((long long)wg * nblk / gridDim.x), b1 = (int)((long long)(wg + 1) * nblk / gridDim.x);
+    const int nb = b1 - b0;
+    if (nb <= 0) return;
+    const float inv_T = a_hw[1];
+    const float* hvec = a_hw + HW_HEADER_FLOATS;
+    const half8* wimg = reinterpret_cast<const half8*>(a_hw + HW_HEADER_FLOATS + HW_VEC_FLOATS);
+    half8 wh[8], wl[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        wh[ks] = wimg[(((role * 4 + jb) * 8 + ks) * 2 + 0) * 64 + lane0];
+        wl[ks] = wimg[(((role * 4 + jb) * 8 + ks) * 2 + 1) * 64 + lane0];
+    }
+    for (int i = tid; i < LN_ZERO_END / 16; i += SYS_THREADS) LDS(uintx4, i * 16) = uintx4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < 4 * H; i += SYS_THREADS) LDS(float, LN_VEC + 4 * i) = hvec[i];
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    const int n = lane0 & 31, hi = lane0 >> 5, rr = lane0 >> 3, cq = lane0 & 7;
+    const int r0 = b0 * BE;                                 // first row of the workgroup
+    const int rows_wg = (b1 * BE < N ? b1 * BE : N) - r0;   // its rows
+    const unsigned wg_bytes = (unsigned)(rows_wg > 0 ? rows_wg : 0) * 512u;   // reads past them return zeros, stores are dropped
+    std::integral_constant<int, 0> even;
+    std::integral_constant<int, 1> odd;
+    const unsigned v_eoff = opaque(rr * 512 + jb * 128 + cq * 16);   // row 8 j + rr of a block, this wave's 128-byte slab: + 4096 j
+    int rng = 0;
+    if (role == 2) __builtin_amdgcn_s_setprio(HEDGE_PRIO2);
+    else if (role == 0) __builtin_amdgcn_s_setprio(HEDGE_PRIO0);
+    else __builtin_amdgcn_s_setprio(HEDGE_PRIO1);
+    if (role == 0) {
+        const srd_t srd_q = make_srd(a_Q + (size_t)r0 * H, wg_bytes), srd_a = make_srd(a_agg + (size_t)r0 * H, wg_bytes);
+        const unsigned v_qoff = opaque(rr * 2048 + jb * 128 + cq * 16);   // row 4 rr + j: + 512 j
+        const unsigned ps_w = opaque(LN_PS + jb * TILE_B + 4 * rr * TILE_ROW_B + cq * 16);   // + j rows
+        const unsigned ps_r = opaque(LN_PS + jb * TILE_B + n * TILE_ROW_B + hi * 16);        // + 32 g
+        const int kg = cq & 1, ksb = cq >> 2, half = (cq >> 1) & 1;
+        const unsigned e_w = opaque(LN_E + ((2 * jb + ksb) * 2 * 64 + ((rr ^ (2 * (ksb + 2 * kg))) + 32 * kg)) * 16 + half * 8);   // + 128 j, + 1024: lo part
+        const unsigned e_r0 = opaque(LN_E + eslot(n, hi, 0) * 16), e_r1 = opaque(LN_E + eslot(n, hi, 1) * 16);
+        const unsigned x1_w = opaque(LN_X1 + 4 * jb * 1024 + lane0 * 16);
+        floatx4 qv[4], eq[4];   // Q rows of block x+1 (rows 4 rr + j); agg rows of block x+1 (rows 8 j + rr) on their way into E
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { qv[j] = floatx4{0.f, 0.f, 0.f, 0.f}; eq[j] = bld4(srd_a, v_eoff, j * 4096); }
+        floatx16 acc, c0v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0v[r] = 0.f;
+        auto clampb = [&](int x) { return x < b0 ? b0 : (x < b1 ? x : b1 - 1); };
+        auto tick = [&](auto par_c, int t) {
+            constexpr int PAR = decltype(par_c)::value;
+            const int x = b0 + t;
+            const unsigned rel1 = (unsigned)(clampb(x + 1) - b0) * (BE * 512u), rel2 = (unsigned)(clampb(x + 2) - b0) * (BE * 512u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qv[j] = bld4(srd_q, v_qoff, rel1 + j * 512);
+            auto side = [&](int slot) {
+                if (slot < 8 && !(slot & 1)) {
+                    const int j = slot >> 1;
+                    uintx2 h, l;
+                    split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
+                    LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128) = h;
+                    LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128 + 1024) = l;
+                } else if (slot == 8) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) eq[j] = bld4(srd_a, v_eoff, rel2 + j * 4096);
+                }
+            };
+            mlp_layer(acc, c0v, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
+            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
+            GM_SB;
+            acc_to_image(acc, smem, x1_w + PAR * IMG_B);
+            // initial accumulators of block x+1: Q rows (already at this kernel's weight scale) row-major -> tile -> accumulator layout
+#pragma unroll
+            for (int j = 0; j < 4; ++j) LDS(floatx4, ps_w + j * TILE_ROW_B) = qv[j];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 v = LDS(floatx4, ps_r + 32 * g);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) c0v[4 * g + tt] = v[tt];
+            }
+            lds_barrier();
+        };
+#pragma unroll 1
+        for (int t = -1; t <= nb + 2; t += 2) {   // one tick of fill, nb blocks, three (four when nb is odd) that drain the pipeline
+            tick(odd, t);
+            tick(even, t + 1);
+        }
+    } else {
+        // roles 1 / 2: Linear 2 of block x-1 / Linear 3 of block x-2; each runs two row groups of the epilogue of block x-3
+        const bool r2 = role == 2;
+        const int eg0 = r2 ? 2 : 0;                       // first of this role's two epilogue row groups
+        const srd_t srd_h = make_srd(a_h + (size_t)r0 * H, wg_bytes);
+        float* const h_out_wg = a_h_out + (size_t)r0 * H;
+        const floatx4 gm = LDS(floatx4, LN_VEC + (2 * H + 32 * jb + 4 * cq) * 4);
+        const floatx4 bt = LDS(floatx4, LN_VEC + (3 * H + 32 * jb + 4 * cq) * 4);
+        floatx16 bv;   // bias of this role's Linear in accumulator layout
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 v = LDS(floatx4, LN_VEC + ((r2 ? H : 0) + 32 * jb + 4 * hi + 8 * g) * 4);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) bv[4 * g + tt] = v[tt];
+        }
+        const unsigned st_r = opaque(LN_ST + n * 4);
+        const unsigned km_w = opaque(LN_KM + (r2 ? 512 : 0) + jb * 128 + n * 4), km_r = opaque(LN_KM + (r2 ? 512 : 0) + jb * 128 + rr * 4);
+        const unsigned z_r = opaque(LN_Z + jb * TILE_B + rr * TILE_ROW_B + cq * 16);
+        const unsigned x_in = opaque((r2 ? LN_X2 : LN_X1) + lane0 * 16), x_out = opaque(LN_X2 + 4 * jb * 1024 + lane0 * 16);
+        const unsigned st_w = opaque(LN_ST + jb * 128 + n * 4);
+        const unsigned z_w = opaque(LN_Z + jb * TILE_B + n * TILE_ROW_B + hi * 16);
+        floatx4 er[2];   // residual rows (h, row-major quads) of block x-3, this role's two row groups
+        er[0] = er[1] = floatx4{0.f, 0.f, 0.f, 0.f};
+        floatx16 acc;
+        auto tick = [&](auto par_c, int t) {
+            constexpr int PAR = decltype(par_c)::value, PIN = 1 - PAR, P3 = 1 - PAR;   // role 1: X1 of block x-1; role 2: X2 of block x-2 (PAR)
+            const int x = b0 + t;
+            LDS(float, km_w) = ln_k(smem, st_r + P3 * 512, inv_T, a_eps);   // 1 / (T sigma) of the rows of block x-3
+            const int xb = x - 3;
+            const int cnt = (xb >= b0 && xb < b1) ? min(BE, N - xb * BE) : 0;   // rows of block x-3 that exist
+            const unsigned rel_a = (unsigned)((xb < b0 ? b0 : xb) - b0) * BE;   // its first row, relative to the workgroup's
+            const int xr = x - 2 < b0 ? b0 : (x - 2 < b1 ? x - 2 : b1 - 1);
+            const unsigned rel_b = (unsigned)(xr - b0) * (BE * 512u);           // block x-2: the residual rows requested this tick
+            float kr;
+            floatx4 zq;
+            auto side = [&](int slot) {   // LayerNorm + h + . of block x-3, row groups eg0 (slots 0 / 2) and eg0 + 1 (slots 6 / 8)
+                if (slot != 0 && slot != 2 && slot != 6 && slot != 8) return;
+                const int jj = slot >= 6, j = eg0 + jj;
+                if (slot == 0 || slot == 6) {
+                    kr = LDS(float, km_r + j * 32);
+                    zq = LDS(floatx4, z_r + P3 * 4 * TILE_B + j * 8 * TILE_ROW_B);
+                } else {
+                    floatx4 o;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) o[tt] = er[jj][tt] + fmaf(zq[tt] * kr, gm[tt], bt[tt]);
+                    bst4(make_srd(h_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt - 8 * j, 8) * 512u), v_eoff, 0, o);
+                    er[jj] = bld4(srd_h, v_eoff, rel_b + j * 4096);   // residual rows of block x-2: a whole tick to arrive
+                }
+            };
+            if (!r2) {
+                mlp_layer(acc, bv, wh, wl, smem, x_in + PIN * IMG_B, x_in + PIN * IMG_B, side);
+                rng |= __any(acc[0] != acc[0]) ? 1 : 0;
+                GM_SB;
+                acc_to_image(acc, smem, x_out + PIN * IMG_B);
+            } else {
+                mlp_layer(acc, bv, wh, wl, smem, x_in + PAR * IMG_B, x_in + PAR * IMG_B, side);
+                rng |= __any(acc[0] != acc[0]) ? 1 : 0;
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q = fmaf(acc[r], acc[r], q);
+                LDS(float, st_w + PAR * 512) = sum_of_halves(q);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 z;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) z[tt] = acc[4 * g + tt];
+                    LDS(floatx4, z_w + PAR * 4 * TILE_B + 32 * g) = z;
+                }
+            }
+            lds_barrier();
+        };
+#pragma unroll 1
+        for (int t = -1; t <= nb + 2; t += 2) {
+            tick(odd, t);
+            tick(even, t + 1);
+        }
+    }
+    if (rng && lane0 == 0 && a_flags) atomicOr(a_flags, ERRF_SPLIT_RANGE);
+}
+
+// ------------------------------------------------------------------------------------------
+// Projections of a step's h for the NEXT step, weight-stationary: twelve waves, wave w = output block w of
+//   [ P_i | P_j | Q ] = h [ W_i | W_j | W_h ]^T + [ b1(phi_e) | 0 | b1(phi_v) ]      (3 x 128 outputs, 128 inputs)
+// P leaves at the scale of the edge kernel that adds it into its accumulators, Q at the node kernel's (NodeArgs::p_scale).  One
+// block of 32 rows per tick and ONE barrier: rows of block x+2 requested, rows of block x+1 -> operand image (waves 0 .. 7, two
+// (row group, slab) units each), 24 MFMAs on the image of block x, accumulators -> the wave's own tile -> whole 128-byte lines.
+// ------------------------------------------------------------------------------------------
+#ifndef HPROJ_Q_AUX
+#define HPROJ_Q_AUX 16   // cache policy of the Q stores (16 = sc1)
+#endif
+constexpr int LP_E = 0;                             // [2] images of h rows
+constexpr int LP_T = LP_E + 2 * IMG_B;              // [12 waves] output tiles
+constexpr size_t PROJ_LDS_BYTES = LP_T + 12 * TILE_B;
+
+__global__ void __launch_bounds__(SYS_THREADS, 1) sys_proj_kernel(const float* __restrict__ a_h, float* __restrict__ a_P, float* __restrict__ a_Q,
+                                                                       const float* __restrict__ a_wp, const float* __restrict__ a_wq,
+                                                                       const float* __restrict__ a_sp, const float* __restrict__ a_sq, int a_n, int* a_flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a_n;
+    const int nblk = (N + BE - 1) / BE;
+    const int b0 = (int)((long long)blockIdx.x * nblk / gridDim.x), b1 = (int)((long long)(blockIdx.x + 1) * nblk / gridDim.x);
+    const int nb = b1 - b0;
+    if (nb <= 0) return;
+    // Linear images of hmlp.h: [t, 1/U, U, cap | bias U (out_pad floats) | fragments [out / 32][K / 16][2][64 lanes] half8]
+    const bool isq = wave >= 8;
+    const float* img = isq ? a_wq : a_wp;
+    const int ob = isq ? wave - 8 : wave;                 // output block inside its image
+    const int out_pad = isq ? H : 2 * H;
+    const float out_scale = img[1] * (isq ? (a_sq ? *a_sq : 1.f) : (a_sp ? *a_sp : 1.f));
+    const half8* frag = reinterpret_cast<const half8*>(img + 4 + out_pad);
+    half8 wh[8], wl[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        wh[ks] = frag[((size_t)(ob * 8 + ks) * 2 + 0) * 64 + lane0];
+        wl[ks] = frag[((size_t)(ob * 8 + ks) * 2 + 1) * 64 + lane0];
+    }
+    const int n = lane0 & 31, hi = lane0 >> 5, rr = lane0 >> 3, cq = lane0 & 7;
+    floatx16 bv;   // bias (times U) of this wave's 32 outputs in accumulator layout
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const floatx4 v = *reinterpret_cast<const floatx4*>(img + 4 + 32 * ob + 8 * g + 4 * hi);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) bv[4 * g + tt] = v[tt];
+    }
+    for (int i = tid; i < 2 * IMG_B / 16; i += SYS_THREADS) LDS(uintx4, LP_E + i * 16) = uintx4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    const int r0 = b0 * BE;
+    const int rows_wg = (b1 * BE < N ? b1 * BE : N) - r0;
+    const unsigned wg_bytes = (unsigned)(rows_wg > 0 ? rows_wg : 0) * 512u;
+    const srd_t srd_h = make_srd(a_h + (size_t)r0 * H, wg_bytes);
+    // image production: waves 0 .. 7 take units u = 2 wave, 2 wave + 1 of the 16 (row group j = u >> 2, slab sb = u & 3) units of a block
+    const bool producer = wave < 8;
+    unsigned v_in[2], e_w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = 2 * (wave & 7) + i, j = u >> 2, sb = u & 3;
+        const int kg = cq & 1, ksb = cq >> 2, half = (cq >> 1) & 1;
+        v_in[i] = opaque((unsigned)((8 * j + rr) * 512 + sb * 128 + cq * 16));
+        e_w[i] = opaque((unsigned)(LP_E + ((2 * sb + ksb) * 2 * 64 + ((rr ^ (2 * (ksb + 2 * kg))) + 32 * kg)) * 16 + half * 8 + j * 128));
+    }
+    const unsigned e_r0 = opaque(LP_E + eslot(n, hi, 0) * 16), e_r1 = opaque(LP_E + eslot(n, hi, 1) * 16);
+    const unsigned t_w = opaque(LP_T + wave * TILE_B + n * TILE_ROW_B + hi * 16);        // + 32 g: accumulator layout
+    const unsigned t_r = opaque(LP_T + wave * TILE_B + rr * TILE_ROW_B + cq * 16);       // + 8 j rows: row-major
+    float* const out_wg = isq ? a_Q + (size_t)r0 * H + 32 * ob : a_P + (size_t)r0 * 2 * H + 32 * ob;
+    const unsigned out_row_b = isq ? 512u : 1024u;
+    const unsigned v_out = opaque((unsigned)(rr * out_row_b + cq * 16));                  // row 8 j + rr: + 8 j rows by the resource's base
+    std::integral_constant<int, 0> even;
+    std::integral_constant<int, 1> odd;
+    auto clampb = [&](int x) { return x < b0 ? b0 : (x < b1 ? x : b1 - 1); };
+    floatx4 hq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) hq[i] = producer ? bld4(srd_h, v_in[i], 0) : floatx4{0.f, 0.f, 0.f, 0.f};   // rows of block b0 ("x+1" of the fill tick)
+    int rng = 0;
+    floatx16 acc;
+    auto tick = [&](auto par_c, int t) {
+        constexpr int PAR = decltype(par_c)::value;
+        const int x = b0 + t;
+        const unsigned rel2 = (unsigned)(clampb(x + 2) - b0) * (BE * 512u);
+        const int cnt = (x >= b0 && x < b1) ? min(BE, N - x * BE) : 0;
+        auto side = [&](int slot) {
+            if (producer && (slot == 0 || slot == 2)) {   // rows of block x+1 -> image
+                const int i = slot >> 1;
+                uintx2 h, l;
+                split4(hq[i][0], hq[i][1], hq[i][2], hq[i][3], h, l);
+                LDS(uintx2, e_w[i] + (1 - PAR) * IMG_B) = h;
+                LDS(uintx2, e_w[i] + (1 - PAR) * IMG_B + 1024) = l;
+            } else if (producer && slot == 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) hq[i] = bld4(srd_h, v_in[i], rel2);
+            }
+        };
+        mlp_layer(acc, bv, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
+        rng |= __any(acc[0] != acc[0]) ? 1 : 0;
+        // outputs of block x: accumulator layout -> the wave's own tile -> row-major, whole 128-byte lines (rows that do not exist
+        // lie beyond the resource's byte count)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            floatx4 z;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) z[tt] = acc[4 * g + tt] * out_scale;
+            LDS(floatx4, t_w + 32 * g) = z;
+        }
+        const unsigned rowx = (unsigned)((x < b0 ? b0 : x) - b0) * BE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const floatx4 o = LDS(floatx4, t_r + j * 8 * TILE_ROW_B);
+            // Q is read once, by the node kernel behind the next edge launch (2 GB of streaming later): written through, not kept in L2;
+            // P is gathered by that edge launch: default policy
+            if (isq) bst4s<HPROJ_Q_AUX>(make_srd(out_wg + (size_t)(rowx + 8 * j) * (out_row_b / 4), (unsigned)s_clamp0(cnt - 8 * j, 8) * out_row_b), v_out, 0, o);
+            else bst4(make_srd(out_wg + (size_t)(rowx + 8 * j) * (out_row_b / 4), (unsigned)s_clamp0(cnt - 8 * j, 8) * out_row_b), v_out, 0, o);
+        }
+        lds_barrier();
+    };
+#pragma unroll 1
+    for (int t = -1; t <= nb; t += 2) {   // one tick of fill, nb blocks (one more when nb is even: it recomputes the last block, stores nothing)
+        tick(odd, t);
+        tick(even, t + 1);
+    }
+    if (rng && lane0 == 0 && a_flags) atomicOr(a_flags, ERRF_SPLIT_RANGE);
+}
+
+// agg rows of the nodes whose in-edge segment crosses groups of the scatter-add: + the head partials the later groups hold, in
+// group order (hedge.h: stitch / head lists) -- what hm_node_kernel does while it reads agg; the systolic node kernel reads plain rows.
+__global__ void __launch_bounds__(256) agg_stitch_kernel(float* __restrict__ agg, const float* __restrict__ side, const int* __restrict__ stitch,
+                                                          const int* __restrict__ head, const EdgeBlockHeader* __restrict__ tab, int n) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int v = id >> 3, c = id & 7;   // eight threads per node: most nodes have nothing to add and leave at once
+    if (v >= n) return;
+    const int ng = tab->n_groups;
+    const int g0 = stitch[v];
+    if (g0 < 0 || g0 >= ng || head[g0] != v) return;
+    floatx4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<floatx4*>(agg + (size_t)v * H + 16 * c + 4 * q);
+    int g = g0;
+    do {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += *reinterpret_cast<const floatx4*>(side + (size_t)g * H + 16 * c + 4 * q);
+        ++g;
+    } while (g < ng && head[g] == v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<floatx4*>(agg + (size_t)v * H + 16 * c + 4 * q) = a[q];
+}
+
+// ------------------------------------------------------------------------------------------
 // weight image: [T1, 1/T3, 0, 0 | b2 T2, b3 T3, gamma, beta | fp16 hi / lo fragments of t_l W_l]
 // One workgroup per processor step.  t_l: power of two from the Linear's gain (hmlp.h).
 // ------------------------------------------------------------------------------------------
@@ -1001,6 +1348,7 @@ struct PackH3Jobs {
     const float* beta[kPackH3Max];
     float* dst[kPackH3Max];
     int enc_k1[kPackH3Max];
+    int ld1[kPackH3Max];
 };
 
 constexpr int H3_PACK_THREADS = 1024;
@@ -1024,7 +1372,7 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
     __syncthreads();
     const int k1 = J.enc_k1[job];          // > 0: encoder image (Linear 1 takes k1 raw features)
     const bool enc = k1 > 0;
-    const int ld[3] = {enc ? k1 : 3 * H, H, H}, c0[3] = {J.c1[job], 0, 0};
+    const int ld[3] = {enc ? k1 : (J.ld1[job] > 0 ? J.ld1[job] : 3 * H), H, H}, c0[3] = {J.c1[job], 0, 0};
     // Scales as in the streamed kernels (hmlp.h / pack_hm_kernel): m = estimated rms of the activations, a ReLU layer maps
     // m^2 -> gain^2 m^2 + rms(b)^2 / 2 with gain = ||W_l||_F / sqrt(out) / sqrt(2); U_l = power of two nearest kHmTargetRms / m_l,
     // t_l = U_l / U_(l-1).  Linear 1's pre-activation takes h_i and h_j too: its gain is that of the whole [H x 3H] matrix; its
@@ -1210,6 +1558,7 @@ int pack_h3(const PackH3Job* jobs, int n, hipStream_t s) {
             J.W1[i] = j.W1; J.c1[i] = j.W1_col0; J.W2[i] = j.W2; J.W3[i] = j.W3; J.b1[i] = j.b1; J.b2[i] = j.b2; J.b3[i] = j.b3; J.gamma[i] = j.gamma; J.beta[i] = j.beta;
             J.dst[i] = j.dst;
             J.enc_k1[i] = j.enc_k1;
+            J.ld1[i] = j.W1_ld;
         }
         hipLaunchKernelGGL(pack_h3_kernel, dim3(J.n), dim3(H3_PACK_THREADS), 0, s, J);
         GM_LAUNCH_CHECK();
@@ -1314,6 +1663,48 @@ int launch_edge_sys_enc(const EdgeArgs& a, hipStream_t s) {
         ProfScope prof(a.prof, PROF_ENC, s);
         hipLaunchKernelGGL(sys_enc_kernel, dim3(device_cus()), dim3(SYS_THREADS), ENC_LDS_BYTES, s, a.hdr, a.e_in, a.e_out, a.wstream_h3,
                            const_cast<int*>(&a.hdr->error_flags), a.eps);
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_node_sys(const NodeSysArgs& a, hipStream_t s) {
+    GM_REQUIRE(a.h && a.agg && a.Q && a.h_out && a.image && a.n > 0, GM_ERR_INVALID_ARGUMENT, "launch_node_sys: bad argument");
+    static PerDeviceOnce attr_done;
+    const int rc_attr = attr_done.run([]() -> int {
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_node_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NODE_LDS_BYTES));
+        return GM_OK;
+    });
+    if (rc_attr != GM_OK) return rc_attr;
+    {
+        ProfScope prof(a.prof, PROF_NODE, s);
+        hipLaunchKernelGGL(sys_node_kernel, dim3(device_cus()), dim3(SYS_THREADS), NODE_LDS_BYTES, s, a.h, a.agg, a.Q, a.h_out, a.image, a.n, a.flags, a.eps);
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_proj_sys(const ProjSysArgs& a, hipStream_t s) {
+    GM_REQUIRE(a.h && a.P && a.Q && a.img_p && a.img_q && a.n > 0, GM_ERR_INVALID_ARGUMENT, "launch_proj_sys: bad argument");
+    static PerDeviceOnce attr_done;
+    const int rc_attr = attr_done.run([]() -> int {
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PROJ_LDS_BYTES));
+        return GM_OK;
+    });
+    if (rc_attr != GM_OK) return rc_attr;
+    {
+        ProfScope prof(a.prof, PROF_NODE, s);
+        hipLaunchKernelGGL(sys_proj_kernel, dim3(device_cus()), dim3(SYS_THREADS), PROJ_LDS_BYTES, s, a.h, a.P, a.Q, a.img_p, a.img_q, a.scale_p, a.scale_q, a.n, a.flags);
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+int launch_agg_stitch(float* agg, const float* side, const EdgeBlocks& t, int64_t n, ProfState* prof_state, hipStream_t s) {
+    if (n <= 0) return GM_OK;
+    {
+        ProfScope prof(prof_state, PROF_NODE, s);
+        hipLaunchKernelGGL(agg_stitch_kernel, dim3((unsigned)cdiv(n * 8, 256)), dim3(256), 0, s, agg, side, t.stitch, t.head, t.hdr, (int)n);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;

@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_node_kernel(HmNodeArgs A) {
             __syncthreads();
             HM_STAMP(tile_i, 8);   // h in the image
         }
-        if (A.tail == 1 || MODE == 2) {
+        if (A.tail == 1) {   // (MODE 2 launches carry tail 1 = projection only, or tail 2 = decoder only)
             const Lin LP = lin_at(A.w_tail, 2 * H);
             // P leaves at the scale its consumer multiplies at: the systolic edge kernel adds P_i + P_j straight into accumulators that
             // carry its first Linear's power-of-two weight scale (exact: a power of two commutes with every rounding on the way)
@@ -1110,7 +1110,8 @@ int launch_node_hm(int H, int mode, const HmNodeArgs& a, hipStream_t s) {
     GM_REQUIRE(mode != 1 || a.agg, GM_ERR_INVALID_ARGUMENT, "launch_node_hm: processor step needs agg");
     GM_REQUIRE(mode != 0 || (a.k1 >= 1 && a.k1 <= 32), GM_ERR_UNSUPPORTED, "launch_node_hm: node_dim %d unsupported (1..32)", a.k1);
     GM_REQUIRE((a.tail == 0 && mode != 2) || a.w_tail, GM_ERR_INVALID_ARGUMENT, "launch_node_hm: tail without weights");
-    GM_REQUIRE(!(a.tail == 1 || mode == 2) || a.P_out, GM_ERR_INVALID_ARGUMENT, "launch_node_hm: projection without P_out");
+    GM_REQUIRE(a.tail != 1 || a.P_out, GM_ERR_INVALID_ARGUMENT, "launch_node_hm: projection without P_out");
+    GM_REQUIRE(mode != 2 || a.tail == 1 || a.tail == 2, GM_ERR_INVALID_ARGUMENT, "launch_node_hm: mode 2 runs a tail only (1 projection, 2 decoder)");
     GM_REQUIRE(a.tail != 2 || (a.dec_out && a.out_dim >= 1 && a.out_dim <= 4), GM_ERR_INVALID_ARGUMENT, "launch_node_hm: decoder tail arguments");
     if (a.n_nodes <= 0) return GM_OK;
     int rc;

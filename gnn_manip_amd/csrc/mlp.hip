@@ -32,7 +32,7 @@ int launch_vec_batch(const VecJobs& jobs, float* base, hipStream_t s) {
 // launchers
 // ------------------------------------------------------------------------------------------
 
-enum : int { EK_AUTO = 0, EK_SYS = 5, EK_HM = 6 };   // gm_model_set_edge_kernel (1 .. 4 were the removed round-1 kernels)
+enum : int { EK_AUTO = 0, EK_SYS = 5, EK_HM = 6, EK_SYS_ALL = 7 };   // gm_model_set_edge_kernel (1 .. 4 were the removed round-1 kernels)
 
 
 // the systolic fp16 x 3 kernel (hedge.hip): processor step of the fused forward (rows in sorted order, device-side edge count, block
@@ -40,7 +40,7 @@ enum : int { EK_AUTO = 0, EK_SYS = 5, EK_HM = 6 };   // gm_model_set_edge_kernel
 bool edge_launch_is_sys(int H, int NL, const EdgeArgs& a, int64_t edge_capacity) {
     const int choice = a.kernel_choice;
     const bool sys_ok = H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && a.wstream_h3 && a.edge_blocks && a.hdr && a.agg && !a.eid && !a.eid_out;
-    return edge_capacity > 0 && sys_ok && (choice == EK_AUTO || choice == EK_SYS) && edge_sys_fits(a.n_nodes_tab, edge_capacity);
+    return edge_capacity > 0 && sys_ok && (choice == EK_AUTO || choice == EK_SYS || choice == EK_SYS_ALL) && edge_sys_fits(a.n_nodes_tab, edge_capacity);
 }
 
 int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capacity, hipStream_t s) {
@@ -52,7 +52,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     GM_REQUIRE(enc || !a.P_prescaled, GM_ERR_INVALID_ARGUMENT, "edge kernel: P carries the systolic kernel's scale, but the launch is not its");
     // the encoder phi_e in the same weight-stationary form: 4 raw features per edge, rows in sorted order (the rollout path)
     if (enc && H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && a.wstream_h3 && a.hdr && !a.eid && a.k1 == 4 &&
-        (choice == EK_AUTO || choice == EK_SYS))
+        (choice == EK_AUTO || choice == EK_SYS || choice == EK_SYS_ALL))
         return launch_edge_sys_enc(a, s);
     // the streamed fp16 x 3 kernels (hmlp.hip): every other case
     if (a.wstream_hm && hm_supported(H) && (enc || (a.edge_blocks && (a.side || !a.agg)))) {
@@ -73,18 +73,19 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
 
 int launch_node(int H, int NL, int mode, const NodeArgs& a, hipStream_t s) {
     if (a.n_nodes <= 0) return GM_OK;
-    if (hm_supported(H) && (mode == 2 ? a.tail_hm != nullptr : a.wstream_hm != nullptr)) {
+    // mode 3: the decoder alone on h (the tail of a step whose node MLP ran in the systolic kernel)
+    if (hm_supported(H) && (mode >= 2 ? a.tail_hm != nullptr : a.wstream_hm != nullptr)) {
         HmNodeArgs h{};
         h.n_nodes = a.n_nodes; h.x_in = a.x_in; h.k1 = a.k1; h.agg = a.agg; h.h_out = a.h_out;
         h.residual = a.residual; h.w = a.wstream_hm; h.ln_g = a.ln_g; h.ln_b = a.ln_b; h.eps = a.eps; h.nl = NL;
-        h.tail = mode == 2 ? 1 : a.tail; h.w_tail = a.tail_hm; h.P_out = a.P_out; h.p_scale = a.p_scale; h.dec_out = a.dec_out; h.out_dim = a.out_dim; h.prof = a.prof;
+        h.tail = mode == 2 ? 1 : (mode == 3 ? 2 : a.tail); h.w_tail = a.tail_hm; h.P_out = a.P_out; h.p_scale = a.p_scale; h.dec_out = a.dec_out; h.out_dim = a.out_dim; h.prof = a.prof;
         h.flags = a.err_flags;
         h.h_valid = a.h_valid > 0 ? a.h_valid : H;
         if (mode == 1 && a.edge_blocks && a.side) {   // lists + side buffer of the edge kernel's head partials (hedge.h)
             const EdgeBlocks t = carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, a.edge_capacity_tab);
             h.stitch = t.stitch; h.head = t.head; h.side = a.side; h.tab = t.hdr;
         }
-        return launch_node_hm(H, mode, h, s);
+        return launch_node_hm(H, mode == 3 ? 2 : mode, h, s);
     }
     (void)NL;
     GM_REQUIRE(false, GM_ERR_UNSUPPORTED, "node kernel: hidden_size=%d, kernel choice %d: no kernel of this library takes this launch", H, a.kernel_choice);

@@ -11,7 +11,8 @@ struct gm_model {
     int Hp = 0;                   // the width the inference kernels run at: H zero-padded to 64 / 128 / 256 (hm_padded_hidden)
     int ci = 0, cj = 1, ce = 2;   // column block of phi_e's first Linear that multiplies h_i, h_j, e (gm_model_desc.col_*)
     int ch = 0, ca = 1;           // column block of phi_v's first Linear for h, agg (gm_model_desc.node_agg_first)
-    float* packed_h3 = nullptr;  // fp16 hi / lo image of the processor edge MLPs for the systolic kernel (hedge.h): [M][h3_image_floats]
+    float* packed_h3 = nullptr;  // fp16 hi / lo images of the systolic kernels (hedge.h), h3_image_floats() each: the M processor edge MLPs, the
+                                 // edge encoder, then the M processor node MLPs (agg block of Linear 1 | Linear 2 | Linear 3)
     float* packed_hm = nullptr;  // fp16 hi / lo image of every Linear (hmlp.h)
     std::vector<gm::PackHmJob> hm_jobs;   // the pack job list of the last weight load (host copy of hm_jobs_dev)
     void* hm_jobs_dev = nullptr;
@@ -19,6 +20,7 @@ struct gm_model {
     size_t hm_jobs_cap = 0;
     size_t hm_floats = 0, hm_enc_edge = 0, hm_enc_node = 0, hm_enc_node_tail = 0;
     std::vector<size_t> hm_edge, hm_node, hm_node_tail;
+    std::vector<size_t> hm_node_q;   // Linear image of Q = h W_h^T + b1 of node step k (systolic node path: hedge.h)
     bool legacy = false;         // hidden 64 / 128 / 256: the bf16 x 3 streams (packed_t3) of the training kernels exist
     gm::ProfState* prof = nullptr;  // gm_model_profile
     int edge_kernel = 0;         // processor edge kernel of this model: 0 automatic, 5 / 6 see gm_model_set_edge_kernel

@@ -37,6 +37,7 @@ int check_desc(const gm_model_desc* d, const char* who) {
 
 struct FwdWs {
     float *h, *P, *agg, *side, *e;
+    float* Q;   // [N][H]: the h half of the next node MLP's first Linear (systolic node path)
     size_t bytes;
 };
 // cap_e: rows of the latent edge array held here (0: the caller's); cap_side: edge capacity the side buffer of the
@@ -49,6 +50,7 @@ FwdWs carve_fwd(void* ws, int H, int64_t n, int64_t cap_e, int64_t cap_side) {
     f.agg = c.take<float>((size_t)n * H);
     f.side = c.take<float>(edge_groups_max(n, cap_side) * H);
     f.e = c.take<float>((size_t)(cap_e > 0 ? cap_e + kEdgePadRows : 0) * H);   // + zero rows behind the list (hedge.h)
+    f.Q = c.take<float>((size_t)n * H);
     f.bytes = c.used();
     return f;
 }
@@ -135,6 +137,11 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s, int w
                 for (int l = 0; l < NL; ++l) hh(b_dec + 2 * l, off);
                 lin(b_dec + 2 * NL, Hv, 0, 0, m->d.out_dim, 32, 32, Hv, H, H, true, m->d.out_dim, off);
             }
+        }
+        for (int k = 0; k < M; ++k) {   // Q = h W_h^T + b1 of node step k (systolic node path): a chain of its own, input h
+            off = m->hm_node_q[k];
+            head(1.f);
+            lin(b_node(k), 2 * Hv, m->ch * Hv, 0, Hv, H, H, Hv, H, H, true, Hv, off);
         }
         GM_REQUIRE(jobs.size() <= m->hm_jobs_cap, GM_ERR_INVALID_ARGUMENT, "model: %zu pack jobs, room for %zu", jobs.size(), m->hm_jobs_cap);
         rc = pack_hm(jobs.data(), (int)jobs.size(), static_cast<PackHmJob*>(m->hm_jobs_dev), m->hm_stats, s);
@@ -230,6 +237,17 @@ int load_weights_device(gm_model* m, const float* const* T, hipStream_t s, int w
             j.dst = m->packed_h3 + (size_t)k * h3_image_floats();
         }
         rc = pack_h3(jobs.data(), m->d.edge_dim <= 16 ? M + 1 : M, s);
+        std::vector<PackH3Job> nj((size_t)M);
+        for (int k = 0; k < M; ++k) {   // node MLPs: the agg block of Linear 1 (its h block is Q), Linear 2, Linear 3
+            PackH3Job& j = nj[(size_t)k];
+            const int b = b_node(k);
+            j.W1 = T[b]; j.W1_col0 = m->ca * H; j.W1_ld = 2 * H; j.W2 = T[b + 2]; j.W3 = T[b + 4];
+            j.b1 = T[b + 1]; j.b2 = T[b + 3]; j.b3 = T[b + 5];
+            j.gamma = T[b + 6]; j.beta = T[b + 7];
+            j.enc_k1 = 0;
+            j.dst = m->packed_h3 + (size_t)(M + 1 + k) * h3_image_floats();
+        }
+        if (rc == GM_OK) rc = pack_h3(nj.data(), M, s);
     }
     return rc;
 }
@@ -374,8 +392,10 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             m->hm_node[k] = o; o += hm_lin_floats(H, 2 * H) + NL * hh;
             m->hm_node_tail[k] = o; o += k + 1 < M ? pj : NL * hh + hm_lin_floats(32, H);
         }
+        m->hm_node_q.resize(M);
+        for (int k = 0; k < M; ++k) { m->hm_node_q[k] = o; o += hh; }
         m->hm_floats = o;
-        m->hm_jobs_cap = (size_t)(2 + 2 * M) * (NL + 1) + M + NL + 1 + 4;
+        m->hm_jobs_cap = (size_t)(2 + 2 * M) * (NL + 1) + 2 * M + NL + 1 + 4;
         if (hipMalloc(&m->packed_hm, m->hm_floats * sizeof(float)) != hipSuccess ||
             hipMalloc(&m->hm_jobs_dev, m->hm_jobs_cap * sizeof(PackHmJob)) != hipSuccess ||
             hipMalloc(&m->hm_stats, m->hm_jobs_cap * 4 * sizeof(float)) != hipSuccess) {
@@ -384,7 +404,7 @@ int gm_model_create(const gm_model_desc* desc, const float* const* tensors, int 
             return GM_ERR_HIP;
         }
     }
-    if (m->H == 128 && NL == 2 && hipMalloc(&m->packed_h3, (size_t)(M + 1) * h3_image_floats() * sizeof(float)) != hipSuccess) {
+    if (m->H == 128 && NL == 2 && hipMalloc(&m->packed_h3, (size_t)(2 * M + 1) * h3_image_floats() * sizeof(float)) != hipSuccess) {
         gm::set_error("gm_model_create: hipMalloc failed");
         gm_model_destroy(m);
         return GM_ERR_HIP;
@@ -517,8 +537,23 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     na.bias = v; na.ln_g = v + (size_t)(NL + 1) * H; na.ln_b = v + (size_t)(NL + 2) * H; na.eps = m->d.ln_eps;
     // which kernel the processor edge launches of this forward take (the same for every step: it depends on sizes and the handle's choice)
     const bool sys_edge = cap > 0 && edge_launch_is_sys(H, NL, proc_edge_args(m, 0, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, f.side, 1), cap);
-    set_tail(m, na, 0, f.P, out, sys_edge);
+    // The systolic node path (hedge.h): graphs with enough 32-row blocks per workgroup to pipeline (or the handle's choice 7).  Its
+    // node MLP takes the h half of its first Linear as Q, written with P by the projection kernel behind every step.
+    const bool sys_node = sys_edge && m->packed_h3 && (m->edge_kernel == 7 || n >= kSysNodeMinNodes);
+    const size_t h3f = h3_image_floats();
+    auto project = [&](int k) {   // h -> P of edge step k, Q of node step k
+        ProjSysArgs pa{};
+        pa.h = f.h; pa.P = f.P; pa.Q = f.Q; pa.n = (int)n; pa.flags = &c.hdr->error_flags; pa.prof = m->prof;
+        pa.img_p = m->packed_hm + (k == 0 ? m->hm_enc_node_tail : m->hm_node_tail[k - 1]);
+        pa.img_q = m->packed_hm + m->hm_node_q[k];
+        pa.scale_p = edge_sys_p_scale(m->packed_h3 + (size_t)k * h3f);
+        pa.scale_q = edge_sys_p_scale(m->packed_h3 + (size_t)(M + 1 + k) * h3f);
+        return launch_proj_sys(pa, s);
+    };
+    if (sys_node) na.tail = 0;
+    else set_tail(m, na, 0, f.P, out, sys_edge);
     rc = launch_node(H, NL, 0, na, s);
+    if (rc == GM_OK && sys_node) rc = project(0);
     if (rc != GM_OK) return rc;
     // agg is zeroed once (nodes without in-edges read zeros; rows with in-edges are stored whole by every edge launch)
     GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
@@ -528,6 +563,24 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
         ea.P_prescaled = sys_edge;
         rc = launch_edge(H, NL, false, ea, cap, s);
         if (rc != GM_OK) return rc;
+        if (sys_node) {
+            // head partials of the scatter-add into agg, the node MLP (h in place), then the next step's projections -- or the decoder
+            rc = launch_agg_stitch(f.agg, f.side, carve_edge_blocks(c.blocks, n, cap), n, m->prof, s);
+            NodeSysArgs ns{};
+            ns.h = f.h; ns.agg = f.agg; ns.Q = f.Q; ns.h_out = f.h; ns.image = m->packed_h3 + (size_t)(M + 1 + k) * h3f;
+            ns.n = (int)n; ns.flags = &c.hdr->error_flags; ns.eps = m->d.ln_eps; ns.prof = m->prof;
+            if (rc == GM_OK) rc = launch_node_sys(ns, s);
+            if (rc == GM_OK && k + 1 < M) rc = project(k + 1);
+            if (rc == GM_OK && k + 1 == M) {
+                NodeArgs d{};
+                d.h_valid = m->H; d.n_nodes = (int)n; d.x_in = f.h; d.err_flags = &c.hdr->error_flags;
+                d.kernel_choice = m->edge_kernel; d.prof = m->prof;
+                set_tail(m, d, M, f.P, out);
+                rc = launch_node(H, NL, 3, d, s);
+            }
+            if (rc != GM_OK) return rc;
+            continue;
+        }
         NodeArgs a{};
         a.h_valid = m->H;
         a.n_nodes = (int)n; a.x_in = f.h; a.agg = f.agg; a.h_out = f.h; a.residual = 1;
@@ -660,10 +713,10 @@ extern "C" {
 
 int gm_model_set_edge_kernel(gm_model* m, int choice) {
     GM_REQUIRE(m, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: null model");
-    GM_REQUIRE(choice >= 0 && choice <= 6, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: choice %d out of range", choice);
+    GM_REQUIRE(choice >= 0 && choice <= 7, GM_ERR_INVALID_ARGUMENT, "gm_model_set_edge_kernel: choice %d out of range", choice);
     GM_REQUIRE(choice == 0 || choice >= 5, GM_ERR_UNSUPPORTED,
                "gm_model_set_edge_kernel: choices 1..4 (the round-1 fp32 / bf16 x 6 kernels) were removed from the library (round 5)");
-    GM_REQUIRE(choice != 5 || m->packed_h3, GM_ERR_UNSUPPORTED, "gm_model_set_edge_kernel: the systolic kernel is for hidden_size 128, num_layers 2");
+    GM_REQUIRE((choice != 5 && choice != 7) || m->packed_h3, GM_ERR_UNSUPPORTED, "gm_model_set_edge_kernel: the systolic kernel is for hidden_size 128, num_layers 2");
     m->edge_kernel = choice;
     return GM_OK;
 }

@@ -568,7 +568,7 @@ class EncProcDecGNN(nn.Module):
 
     auto_status = True   # check the previous inference forward's device-side error flags at the start of the next one
 
-    EDGE_KERNELS = {"auto": 0, "sys": 5, "hm": 6}   # 1 .. 4 were the round-1 fp32 / bf16 x 6 kernels (removed in round 5)
+    EDGE_KERNELS = {"auto": 0, "sys": 5, "hm": 6, "sys_all": 7}   # 1 .. 4 were the round-1 fp32 / bf16 x 6 kernels (removed in round 5)
 
     def profile(self, kind_mask):
         """HIP-event timing of this model's launches (gm_model_profile; bit 0 processor edge kernel, 1 processor node
@@ -586,7 +586,8 @@ class EncProcDecGNN(nn.Module):
 
     def set_edge_kernel(self, choice):
         """Processor edge kernel of this model (diagnostics / A-B measurements; no reference counterpart): 'auto', 'sys'
-        (systolic fp16 x 3, hidden 128 / num_layers 2), 'hm' (streamed fp16 x 3).  See include/gnn_manip_hip.h."""
+        (systolic fp16 x 3, hidden 128 / num_layers 2), 'hm' (streamed fp16 x 3), 'sys_all' (as 'sys', and the systolic node /
+        projection kernels whatever the graph's size: 'auto' takes them from 49152 nodes up).  See include/gnn_manip_hip.h."""
         self._handle.set_edge_kernel(self.EDGE_KERNELS.get(choice, choice))
 
     def forward(self, nodes, edge_attr, edge_index):

@@ -529,7 +529,7 @@ def test_candidate_batched_rollout_matches_independent_rollouts(dev):
     np.testing.assert_allclose(two[:, :, 2:5], ref[:, :, 2:5], rtol=0, atol=5e-6)
 
 
-@pytest.mark.parametrize("choice,name", [(5, "systolic fp16 x 3"), (6, "streamed fp16 x 3")])
+@pytest.mark.parametrize("choice,name", [(5, "systolic fp16 x 3"), (6, "streamed fp16 x 3"), (7, "systolic edge, node and projection kernels")])
 def test_every_processor_edge_kernel_form_vs_oracle(dev, choice, name):
     """Each selectable form of the processor edge kernel (EncProcDecGNN.set_edge_kernel, a per-model option) on a
     multi-tile graph, a ragged small one and a single node: same 1e-5 bar against the oracle."""
@@ -548,7 +548,7 @@ def test_every_processor_edge_kernel_form_vs_oracle(dev, choice, name):
 
 
 @pytest.mark.parametrize("seed", [71, 72, 73, 74, 75])
-@pytest.mark.parametrize("choice", [5, 6])
+@pytest.mark.parametrize("choice", [5, 6, 7])
 def test_split_operand_kernels_are_as_accurate_as_float32(dev, choice, seed):
     """The matrix-pipe forms compute fp32 results (three exact partial products of two-way fp16 operand splits with pre-scaled
     weights, fp32 accumulation): against a float64 evaluation of the same model their error must be of the order of a plain
