@@ -186,6 +186,10 @@ def test_results_do_not_depend_on_what_the_workspaces_held(dev, pattern):
                 if hid == 128:
                     eng = RolloutEngine(m, ga, obs.shape[1], device=dev)
                     out["rollout"] = eng.rollout(torch.from_numpy(obs).to(dev), traj, horizon=2).clone()
+                    m.set_edge_kernel("sys_all")   # the systolic node + projection kernels (large graphs take them by themselves)
+                    out["forward128_sys_all"] = m.forward(nodes, ea, ei).clone()
+                    out["rollout_sys_all"] = eng.rollout(torch.from_numpy(obs).to(dev), traj, horizon=2).clone()
+                    m.set_edge_kernel("auto")
             if hid not in (128, 64):      # (the training entry points take the instantiated widths)
                 continue
             m.zero_grad()

@@ -514,7 +514,7 @@ def test_candidate_batched_rollout_matches_independent_rollouts(dev):
     trajs = np.stack([scene.rigid_drift_trajectory(obs, steps, seed=100 + c, step_size=3e-4) for c in range(b)])
     params = orc.init_params(25, 4, 3, 128, 2, 10, 96)
     m = _model(params, (25, 4, 3, 128, 2, 10), dev)
-    for kernel in ("auto", "hm"):
+    for kernel in ("auto", "hm", "sys_all"):
         m.set_edge_kernel(kernel)
         with torch.no_grad():
             eng_b = RolloutEngine(m, _ga(), n, device=dev, candidates=b)
