@@ -110,7 +110,12 @@ def cpu_baseline(obs, model, stats, scene, hidden):
             fwd = t_encdec + 10.0 * max(t_one - t_encdec, 0.0)
             if best is None or fwd < best[0]:
                 best = (fwd, t_encdec, t_one, th, out)
-    t_forward, t_encdec, t_one, threads, out = best
+    _, t_encdec, t_one, threads, _ = best
+    # ... and the whole forward (all ten message-passing steps) TIMED once with that thread count: the baseline is a measured full
+    # step, the two short passes above only choose the thread count
+    with torch.no_grad():
+        torch.set_num_threads(threads)
+        t_forward, out = timed_forward(10)
     t0 = time.perf_counter()
     orc.get_position_from_prediction(stats, scene.CART, out.numpy(), obs)
     t_int = time.perf_counter() - t0
@@ -119,10 +124,10 @@ def cpu_baseline(obs, model, stats, scene, hidden):
                 graph_build_ms_single_thread=t_graph * 1e3, features_ms=t_feat * 1e3, forward_ms=t_forward * 1e3,
                 integrate_ms=t_int * 1e3,
                 forward_encoder_decoder_ms=t_encdec * 1e3, forward_one_mp_step_ms=max(t_one - t_encdec, 0.0) * 1e3,
-                sample=f"one rollout step of the same scene and weights (N={obs.shape[1]}, E={len(s)}, hidden={hidden}): oracle graph "
-                       f"build + features (numpy, single thread) once; oracle/torch_epd.py forward with torch.set_num_threads({threads}): "
-                       f"encoder + decoder and ONE of the 10 identical message-passing steps timed, forward = enc/dec + 10 x one MP step; "
-                       f"the faster of 32 and {cores} threads is reported")
+                sample=f"ONE whole rollout step of the same scene and weights, timed end to end (N={obs.shape[1]}, E={len(s)}, hidden={hidden}): "
+                       f"oracle graph build + features (numpy, single thread), the full oracle/torch_epd.py forward -- encoder, all 10 "
+                       f"message-passing steps, decoder -- with torch.set_num_threads({threads}) (the faster of 32 and {cores} threads, chosen on a "
+                       f"short pass: encoder + decoder + one step), integration")
 
 
 def build_engine(wl, dev, rank, candidates, edge_kernel, total_steps):
@@ -191,6 +196,14 @@ def roofline_record(model, ek, hidden, edges, n_nodes, workload_key):
            "fp32_equivalent_tflops": issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
            "alg_flops_per_launch": alg, "alg_tflops": alg / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
            "alg_bytes_per_launch": alg_bytes, "mfma": mfma, "hbm": hbmr}
+    if workload_key == "target":
+        # measured this round (not re-measured by this run): the target workload holds the board at its package power cap, the shader
+        # clock a third below its maximum; the chip's sustained fp16 matrix rate at that cap is what the micro-benchmark reaches
+        rec["power_limited"] = {"package_power_w": 1383, "cap_w": 1400, "sclk_mhz": 1674, "sclk_max_mhz": 2400,
+                                "source": "profiles/r05_power_watch.txt (rocm-smi during a 3000-step timed region, tools/micro/power_watch.sh)",
+                                "mfma_rate_at_the_cap_tflops": {"v_mfma_f32_32x32x16_f16": 1403, "v_mfma_f32_16x16x32_f16": 1625,
+                                                                "source": "profiles/r05_mfma_shape.txt (tools/micro/mfma_shape.hip: LDS-fed, random data, 3 waves per SIMD)"},
+                                "frac_of_that_rate": achieved / 1403.0}
     # HBM traffic of the same kernel from rocprofv3 PMC passes (collected separately with tools/profile_round.sh, committed
     # under profiles/).  Reported only when the newest file was collected from THIS tree's kernel sources (it records their
     # digest); otherwise null with the reason.

@@ -27,7 +27,9 @@ for wl in ("target", "c2", "c4"):
     cands = [r for r in stats if any(k in r["Name"] for k in EDGE_KERNELS)]
     top = max(cands, key=lambda r: float(r["TotalDurationNs"]))
     frag = next(k for k in EDGE_KERNELS if k in top["Name"])
-    d = {"kernel": EDGE_KERNELS[frag], "stats_avg_ns": float(top["AverageNs"]), "stats_calls": int(top["Calls"])}
+    same = [r for r in cands if frag in r["Name"]]   # every instantiation of the kernel (the last step's launch writes no e + e')
+    calls = sum(int(r["Calls"]) for r in same)
+    d = {"kernel": EDGE_KERNELS[frag], "stats_avg_ns": sum(float(r["TotalDurationNs"]) for r in same) / calls, "stats_calls": calls}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if not glob.glob(f"{src}/pmc_{c}_{wl}/*/*counter_collection.csv"):
             continue
@@ -47,7 +49,7 @@ for wl in ("target", "c2", "c4"):
         with open(f"{dst}/{tag}_{wl}_pmc_sq.csv", "w") as fo:
             fo.write("kernel,counter,dispatches,mean_per_dispatch\n")
             for k in agg:
-                if not any(s in k for s in ("sys_edge_kernel", "hm_edge_kernel", "hm_node_kernel")):
+                if not any(s in k for s in ("sys_edge_kernel", "sys_node_kernel", "sys_proj_kernel", "hm_edge_kernel", "hm_node_kernel")):
                     continue
                 for c, v in sorted(agg[k].items()):
                     fo.write(f"\"{k}\",{c},{len(v)},{sum(v)/len(v):.6g}\n")
