@@ -115,25 +115,11 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const int* __re
     if (threadIdx.x == 0) tmp[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_top_kernel(int64_t n_host, const int* __restrict__ n_dev,
-                                                               int* __restrict__ tmp) {
-    __shared__ int sm[4];
-    const int64_t n = n_dev ? (int64_t)(*n_dev) : n_host;
-    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    int carry = 0;
-    for (int64_t b0 = 0; b0 < nb; b0 += SCAN_BLOCK) {
-        int64_t i = b0 + threadIdx.x;
-        int v = i < nb ? tmp[i] : 0;
-        int tot;
-        int ex = block_excl_scan(v, sm, &tot);
-        if (i < nb) tmp[i] = carry + ex;
-        carry += tot;
-    }
-}
-
+// second pass: every block adds up the tile sums in front of its tile itself (a few hundred values at most: cheaper than a
+// launch of its own for a one-block scan of them), scans its tile and -- the block that holds the last item -- writes the total
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const int* in, int64_t n_host,
                                                                  const int* __restrict__ n_dev,
-                                                                 const int* __restrict__ tmp, int* out) {
+                                                                 const int* __restrict__ tmp, int* out, int* total_out) {
     __shared__ int sm[4];
     const int64_t n = n_dev ? (int64_t)(*n_dev) : n_host;
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
@@ -146,12 +132,17 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const int* in, i
         item[k] = i < n ? in[i] : 0;
         v += item[k];
     }
+    int before = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_BLOCK) before += tmp[i];
+    int prefix;
+    (void)block_excl_scan(before, sm, &prefix);   // prefix = sum of the tile sums of the blocks in front
     int tot;
-    int ex = block_excl_scan(v, sm, &tot) + tmp[blockIdx.x];
+    int ex = block_excl_scan(v, sm, &tot) + prefix;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         int64_t i = base + (int64_t)threadIdx.x * SCAN_ITEMS + k;
         if (i < n) out[i] = ex;
+        if (total_out && i == n - 1) *total_out = ex;   // callers that ask for the total append a zero item: the last output is the sum
         ex += item[k];
     }
 }
@@ -194,10 +185,6 @@ __global__ void __launch_bounds__(SCAN1_THREADS) scan_single_kernel(const int* i
     if (threadIdx.x == 0 && total_out) *total_out = carry_s;
 }
 
-__global__ void scan_total_kernel(const int* __restrict__ out, int64_t n, int* total_out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *total_out = out[n - 1];
-}
-
 // out may alias in.  Scans n items (n = *n_dev when n_dev != nullptr, bounded by n_max).  total_out (optional)
 // receives the sum; callers that ask for it append a zero item, so the sum is also the last output.
 int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s, int* total_out) {
@@ -208,13 +195,9 @@ int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev,
         return GM_OK;
     }
     const int nb = (int)cdiv(n_max, SCAN_TILE);
+    GM_REQUIRE(!total_out || !n_dev, GM_ERR_INVALID_ARGUMENT, "exclusive_scan_i32: total_out needs a host-side length");
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n_max, n_dev, tmp);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, n_max, n_dev, tmp);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n_max, n_dev, tmp, out);
-    if (total_out) {
-        GM_REQUIRE(!n_dev, GM_ERR_INVALID_ARGUMENT, "exclusive_scan_i32: total_out needs a host-side length");
-        hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, s, out, n_max, total_out);
-    }
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n_max, n_dev, tmp, out, total_out);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
