@@ -164,6 +164,102 @@ __device__ __forceinline__ void store_feat(const floatx16 (&v)[NKB], float* __re
             *reinterpret_cast<floatx4*>(row + 32 * kb + 8 * g + 4 * hi) = x;
         }
 }
+
+// The wave's 32 rows x 32 NKB features (accumulator layout) to 32 CONSECUTIVE rows of a row-major array as whole 128-byte lines:
+// each 32-feature block takes a turn through a wave-private LDS tile (32 rows of TURN_LD floats; no barrier: one wave's LDS
+// instructions execute in order), after which a store instruction covers 8 rows x 128 bytes instead of 32 rows x 32 bytes.
+// dst = row 0 of the wave's rows, ld = row stride (floats), rows_left = rows of the array from dst on (any value: rows past
+// the end are dropped by the buffer bound, and the instruction count -- 4 NKB, what run_layer's PEND expects -- does not vary).
+constexpr int TURN_LD = 36;
+constexpr int TURN_FLOATS = 32 * TURN_LD;
+typedef unsigned int uintx4_t __attribute__((ext_vector_type(4)));
+template <int NKB>
+__device__ __forceinline__ void store_feat_lines(const floatx16 (&v)[NKB], float* dst, int ld, int rows_left, float* turn, int lane) {
+    const int n = lane & 31, hi = lane >> 5, rr = lane >> 3, cq = lane & 7;
+    const int cnt = rows_left < 0 ? 0 : rows_left > 32 ? 32 : rows_left;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (unsigned)cnt * (unsigned)ld * 4u, 0x00020000);
+    float* wr = turn + n * TURN_LD + 4 * hi;
+    const float* rd = turn + rr * TURN_LD + 4 * cq;
+    const unsigned voff = ((unsigned)rr * (unsigned)ld + 4u * cq) * 4u;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            floatx4 x;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = v[kb][4 * g + t];
+            *reinterpret_cast<floatx4*>(wr + 8 * g) = x;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const floatx4 o = *reinterpret_cast<const floatx4*>(rd + 8 * j * TURN_LD);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, o), srd, voff + (unsigned)(8 * j * ld + 32 * kb) * 4u, 0, 0);
+        }
+    }
+}
+
+// The reverse turn: 32 CONSECUTIVE rows of a row-major array into the accumulator layout, fetched as whole lines (a load
+// instruction covers 8 rows x 128 bytes).  Rows past the end read as zero.  MODE 0: v = rows, 1: v += rows, 2: v = rows > 0 ? v : 0.
+template <int MODE>
+__device__ __forceinline__ void turn_in(floatx16& v, const floatx4 (&x)[4], float* turn, int lane) {
+    const int n = lane & 31, hi = lane >> 5, rr = lane >> 3, cq = lane & 7;
+    float* wr = turn + rr * TURN_LD + 4 * cq;
+    const float* rd = turn + n * TURN_LD + 4 * hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<floatx4*>(wr + 8 * j * TURN_LD) = x[j];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const floatx4 y = *reinterpret_cast<const floatx4*>(rd + 8 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (MODE == 0) v[4 * g + t] = y[t];
+            else if (MODE == 1) v[4 * g + t] += y[t];
+            else v[4 * g + t] = y[t] > 0.f ? v[4 * g + t] : 0.f;
+        }
+    }
+}
+template <int MODE, int NKB>
+__device__ __forceinline__ void load_feat_lines(floatx16 (&v)[NKB], const float* src, int ld, int rows_left, float* turn, int lane) {
+    const int rr = lane >> 3, cq = lane & 7;
+    const int cnt = rows_left < 0 ? 0 : rows_left > 32 ? 32 : rows_left;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (unsigned)cnt * (unsigned)ld * 4u, 0x00020000);
+    const unsigned voff = ((unsigned)rr * (unsigned)ld + 4u * cq) * 4u;
+    if (MODE == 0) {
+        // every line of the tile in flight at once, into the registers they end up in; then one block after the other takes its turn
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const floatx4 x = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(srd, voff + (unsigned)(8 * j * ld + 32 * kb) * 4u, 0, 0));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[kb][4 * j + t] = x[t];
+            }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            floatx4 x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x[j][t] = v[kb][4 * j + t];
+            turn_in<0>(v[kb], x, turn, lane);
+        }
+    } else {
+        // one block ahead (16 registers of lines in flight next to the 16 being turned)
+        floatx4 cur[4], nxt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(srd, voff + (unsigned)(8 * j * ld) * 4u, 0, 0));
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb + 1 < NKB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nxt[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(srd, voff + (unsigned)(8 * j * ld + 32 * (kb + 1)) * 4u, 0, 0));
+            }
+            turn_in<MODE>(v[kb], cur, turn, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        }
+    }
+}
 template <int NKB>
 __device__ __forceinline__ void relu_to(floatx16 (&dst)[NKB], const floatx16 (&src)[NKB]) {
 #pragma unroll

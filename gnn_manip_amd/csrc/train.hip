@@ -267,6 +267,13 @@ __device__ __forceinline__ void ln_param_sums(const floatx16 (&g)[NJB], const fl
     }
 }
 
+// Which of the chains' row-major arrays move as whole 128-byte lines through a wave-private LDS turn (store_feat_lines /
+// load_feat_lines) instead of accumulator-layout pieces (32 rows x 32 bytes per instruction).  Forward: 1 tape stores, 2 output
+// stores.  Backward: 8 dz stores, 16 input-gradient stores, 32 dY / G / xhat loads, 64 the ReLU-mask loads of the tape.
+#ifndef TRAIN_LINES
+#define TRAIN_LINES 127
+#endif
+
 // ------------------------------------------------------------------------------------------
 // forward with tape
 // ------------------------------------------------------------------------------------------
@@ -296,12 +303,15 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
     ws.parity = 0;
     ws.lane = lane;
     ws.wave = wave;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float* turn = ring + 2 * B3_STAGE_FLOATS + wave_u * TURN_FLOATS;   // store_feat_lines
     if ((int)blockIdx.x < ntiles) issue_stage3(ws, 0, 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < ntiles;
         const int p = tile * TILE + wave * 32 + n;
         const bool valid = p < R;
         const int64_t pc = valid ? p : R - 1;
+        const int row0 = tile * TILE + wave_u * 32;   // the wave's rows: row0 .. row0 + 31
         floatx16 acc[NJB], act[NJB];
         if (KIND == TK_ENC_EDGE || KIND == TK_ENC_NODE) {
             const int64_t rin = A.rowidx ? A.rowidx[pc] : pc;
@@ -319,10 +329,12 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
             load_feat(act, A.x_in + pc * H, hi);
             load_feat(acc, A.bias, hi);
             run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
-            if (valid) store_feat(acc, A.out + pc * (2 * H), hi);
+            if (TRAIN_LINES & 2) store_feat_lines(acc, A.out + (size_t)row0 * (2 * H), 2 * H, R - row0, turn, lane);
+            else store_feat(acc, A.out + pc * (2 * H), hi);
             zero_feat(acc);
             run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
-            if (valid) store_feat(acc, A.out + pc * (2 * H) + H, hi);
+            if (TRAIN_LINES & 2) store_feat_lines(acc, A.out + (size_t)row0 * (2 * H) + H, 2 * H, R - row0, turn, lane);
+            else store_feat(acc, A.out + pc * (2 * H) + H, hi);
             continue;
         } else if (KIND == TK_PROC_NODE) {
             load_feat(act, A.x_in + pc * H, hi);
@@ -344,12 +356,14 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
         for (int l = 1; l < NL; ++l) {   // Linear l + 1 (hidden)
             relu_to(act, acc);
             load_feat(acc, A.bias_tail + (size_t)(l - 1) * H, hi);
-            store_feat(act, A.tape.a + (size_t)(l - 1) * tstride + pc * H, hi);
+            if (TRAIN_LINES & 1) store_feat_lines(act, A.tape.a + (size_t)(l - 1) * tstride + (size_t)row0 * H, H, R - row0, turn, lane);
+            else store_feat(act, A.tape.a + (size_t)(l - 1) * tstride + pc * H, hi);
             run_layer_b3<H / 16, NJB, NJB, NST>(acc, act, ws, more);
         }
         relu_to(act, acc);
         if (KIND != TK_DEC) load_feat(acc, A.bias_tail + (size_t)(NL - 1) * H, hi);
-        store_feat(act, A.tape.a + (size_t)(NL - 1) * tstride + pc * H, hi);
+        if (TRAIN_LINES & 1) store_feat_lines(act, A.tape.a + (size_t)(NL - 1) * tstride + (size_t)row0 * H, H, R - row0, turn, lane);
+        else store_feat(act, A.tape.a + (size_t)(NL - 1) * tstride + pc * H, hi);
         if (KIND == TK_DEC) {
             floatx16 o[1];
             load_feat(o, A.bias_tail + (size_t)(NL - 1) * H, hi);  // out bias, zero-padded to 32
@@ -362,13 +376,18 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
         } else {
             run_layer_b3<H / 16, NJB, NJB, NST>(acc, act, ws, more);
             const float rstd = layer_norm_tape(acc, act, A.ln_g, A.ln_b, A.eps, hi);
-            if (valid) {
-                store_feat(act, A.tape.xhat + pc * H, hi);
-                if (hi == 0) A.tape.rstd[pc] = rstd;
+            if (TRAIN_LINES & 1) store_feat_lines(act, A.tape.xhat + (size_t)row0 * H, H, R - row0, turn, lane);
+            else store_feat(act, A.tape.xhat + pc * H, hi);
+            if (valid && hi == 0) A.tape.rstd[pc] = rstd;
+            if (KIND == TK_PROC_EDGE && A.rowidx) {   // the single-block entry point: e rows in the caller's order
+                const int64_t orow = A.rowidx[pc];
+                if (A.residual) add_feat(acc, A.x_in + orow * H, hi);
+                if (valid) store_feat(acc, A.out + orow * H, hi);
+            } else {
+                if ((KIND == TK_PROC_EDGE || KIND == TK_PROC_NODE) && A.residual) add_feat(acc, A.x_in + pc * H, hi);
+                if (TRAIN_LINES & 2) store_feat_lines(acc, A.out + (size_t)row0 * H, H, R - row0, turn, lane);
+                else store_feat(acc, A.out + pc * H, hi);
             }
-            const int64_t orow = KIND == TK_PROC_EDGE && A.rowidx ? (int64_t)A.rowidx[pc] : pc;
-            if ((KIND == TK_PROC_EDGE || KIND == TK_PROC_NODE) && A.residual) add_feat(acc, A.x_in + orow * H, hi);
-            if (valid) store_feat(acc, A.out + orow * H, hi);
             if ((KIND == TK_ENC_NODE || KIND == TK_PROC_NODE) && proj_tail) {
                 // the next edge step's factorised layer 1 on the rows still in registers: P = [h W_i^T + b1 | h W_j^T]
                 // (what the inference node kernels' tail does; it was a launch of its own that re-read h)
@@ -376,10 +395,12 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
                 for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
                 load_feat(acc, A.proj_bias, hi);
                 run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
-                if (valid) store_feat(acc, A.P_out + pc * (2 * H), hi);
+                if (TRAIN_LINES & 2) store_feat_lines(acc, A.P_out + (size_t)row0 * (2 * H), 2 * H, R - row0, turn, lane);
+                else store_feat(acc, A.P_out + pc * (2 * H), hi);
                 zero_feat(acc);
                 run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
-                if (valid) store_feat(acc, A.P_out + pc * (2 * H) + H, hi);
+                if (TRAIN_LINES & 2) store_feat_lines(acc, A.P_out + (size_t)row0 * (2 * H) + H, 2 * H, R - row0, turn, lane);
+                else store_feat(acc, A.P_out + pc * (2 * H) + H, hi);
             }
         }
     }
@@ -419,12 +440,15 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
     ws.parity = 0;
     ws.lane = lane;
     ws.wave = wave;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float* turn = lnacc + 4 * 2 * H + wave_u * TURN_FLOATS;   // store_feat_lines
     if ((int)blockIdx.x < ntiles) issue_stage3(ws, 0, 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < ntiles;
         const int p = tile * TILE + wave * 32 + n;
         const bool valid = p < R;
         const int64_t pc = valid ? p : R - 1;
+        const int row0 = tile * TILE + wave_u * 32;
         floatx16 acc[NJB], act[NJB];
         if (KIND == TB_DEC) {
             // dz3 = dY [rows][out_dim]; first product has K = out_dim (one k-octet)
@@ -434,42 +458,51 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
         } else {
             // total upstream gradient of the MLP output row
             if (A.dY) {
-                const int64_t rin = A.dyidx ? A.dyidx[pc] : pc;
-                load_feat(acc, A.dY + rin * H, hi);
+                if (A.dyidx || !(TRAIN_LINES & 32)) load_feat(acc, A.dY + (A.dyidx ? (int64_t)A.dyidx[pc] : pc) * H, hi);
+                else load_feat_lines<0>(acc, A.dY + (size_t)row0 * H, H, R - row0, turn, lane);
             } else {
                 zero_feat(acc);
             }
             if (KIND == TB_EDGE && A.dagg) add_feat(acc, A.dagg + (int64_t)A.dst[pc] * H, hi);
             if (has_g) {  // + W_i^T G_i + W_j^T G_j : input gradient of the NEXT edge step's factorised layer 1
-                load_feat(act, A.Gi + pc * H, hi);
+                if (TRAIN_LINES & 32) load_feat_lines<0>(act, A.Gi + (size_t)row0 * H, H, R - row0, turn, lane);
+                else load_feat(act, A.Gi + pc * H, hi);
                 run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
-                load_feat(act, A.Gj + pc * H, hi);
+                if (TRAIN_LINES & 32) load_feat_lines<0>(act, A.Gj + (size_t)row0 * H, H, R - row0, turn, lane);
+                else load_feat(act, A.Gj + pc * H, hi);
                 run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);
             }
             if (KIND == TB_PROJ) {
-                if (valid) store_feat(acc, A.dx + pc * H, hi);
+                if (TRAIN_LINES & 16) store_feat_lines(acc, A.dx + (size_t)row0 * H, H, R - row0, turn, lane);
+                else store_feat(acc, A.dx + pc * H, hi);
                 continue;
             }
             if (valid && KIND == TB_NODE && A.dx_resid) store_feat(acc, A.dx_resid + pc * H, hi);  // residual path: dh_in starts as dY
-            load_feat(act, A.tape.xhat + pc * H, hi);
+            if (TRAIN_LINES & 32) load_feat_lines<0>(act, A.tape.xhat + (size_t)row0 * H, H, R - row0, turn, lane);
+            else load_feat(act, A.tape.xhat + pc * H, hi);
             if (NORMED && A.ln_part) ln_param_sums(acc, act, valid, lnacc + wave * 2 * H, n, hi);
             layer_norm_bwd(acc, act, A.ln_g, A.tape.rstd[pc], hi);
             // dz stores: every lane (duplicates of the last row past the end), counted by run_layer<.., PEND>
-            store_feat(act, A.dz + (size_t)NL * A.dz_stride + pc * H, hi);
+            if (TRAIN_LINES & 8) store_feat_lines(act, A.dz + (size_t)NL * A.dz_stride + (size_t)row0 * H, H, R - row0, turn, lane);
+            else store_feat(act, A.dz + (size_t)NL * A.dz_stride + pc * H, hi);
             zero_feat(acc);
             run_layer_b3<H / 16, NJB, NJB, H / 8>(acc, act, ws, more);  // W_(NL+1)^T dz_(NL+1)
         }
 #pragma unroll 1
         for (int l = NL; l >= 2; --l) {   // dz_l = (W_(l+1)^T dz_(l+1)) [a_l > 0], then on through W_l^T
-            mask_feat(acc, A.tape.a + (size_t)(l - 1) * tstride + pc * H, hi);
-            store_feat(acc, A.dz + (size_t)(l - 1) * A.dz_stride + pc * H, hi);
+            if (TRAIN_LINES & 64) load_feat_lines<2>(acc, A.tape.a + (size_t)(l - 1) * tstride + (size_t)row0 * H, H, R - row0, turn, lane);
+            else mask_feat(acc, A.tape.a + (size_t)(l - 1) * tstride + pc * H, hi);
+            if (TRAIN_LINES & 8) store_feat_lines(acc, A.dz + (size_t)(l - 1) * A.dz_stride + (size_t)row0 * H, H, R - row0, turn, lane);
+            else store_feat(acc, A.dz + (size_t)(l - 1) * A.dz_stride + pc * H, hi);
 #pragma unroll
             for (int jb = 0; jb < NJB; ++jb) act[jb] = acc[jb];
             zero_feat(acc);
             run_layer_b3<H / 16, NJB, NJB, H / 8>(acc, act, ws, more);
         }
-        mask_feat(acc, A.tape.a + pc * H, hi);
-        store_feat(acc, A.dz + pc * H, hi);
+        if (TRAIN_LINES & 64) load_feat_lines<2>(acc, A.tape.a + (size_t)row0 * H, H, R - row0, turn, lane);
+        else mask_feat(acc, A.tape.a + pc * H, hi);
+        if (TRAIN_LINES & 8) store_feat_lines(acc, A.dz + (size_t)row0 * H, H, R - row0, turn, lane);
+        else store_feat(acc, A.dz + pc * H, hi);
         if (KIND == TB_ENC) {
             if (A.dx_in) {  // gradient w.r.t. the raw input features: dX = dz1 . W1  (k1 <= 32 columns)
 #pragma unroll
@@ -494,18 +527,26 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
         if (KIND == TB_EDGE) {
             // de_in = W_e^T dz1 (+ de_out through the residual), written over the row it came from
             if (A.residual && A.dY) {
-                const int64_t rin = A.dyidx ? A.dyidx[pc] : pc;
-                add_feat(acc, A.dY + rin * H, hi);
+                if (A.dyidx || !(TRAIN_LINES & 32)) add_feat(acc, A.dY + (A.dyidx ? (int64_t)A.dyidx[pc] : pc) * H, hi);
+                else load_feat_lines<1>(acc, A.dY + (size_t)row0 * H, H, R - row0, turn, lane);
             }
-            if (valid) store_feat(acc, A.dx + (A.dxidx ? (int64_t)A.dxidx[pc] : pc) * H, hi);
+            if (A.dxidx) {
+                if (valid) store_feat(acc, A.dx + (int64_t)A.dxidx[pc] * H, hi);
+            } else {
+                if (TRAIN_LINES & 16) store_feat_lines(acc, A.dx + (size_t)row0 * H, H, R - row0, turn, lane);
+                else store_feat(acc, A.dx + pc * H, hi);
+            }
         } else if (KIND == TB_NODE) {
             if (A.dx_resid) add_feat(acc, A.dx_resid + pc * H, hi);  // same thread wrote this row above
-            if (valid) store_feat(acc, A.dx + pc * H, hi);
+            if (TRAIN_LINES & 16) store_feat_lines(acc, A.dx + (size_t)row0 * H, H, R - row0, turn, lane);
+            else store_feat(acc, A.dx + pc * H, hi);
             zero_feat(acc);
             run_layer_b3<H / 16, NJB, NJB>(acc, act, ws, more);  // W_agg^T dz1
-            if (valid) store_feat(acc, A.dagg_out + pc * H, hi);
+            if (TRAIN_LINES & 16) store_feat_lines(acc, A.dagg_out + (size_t)row0 * H, H, R - row0, turn, lane);
+            else store_feat(acc, A.dagg_out + pc * H, hi);
         } else {
-            if (valid) store_feat(acc, A.dx + pc * H, hi);
+            if (TRAIN_LINES & 16) store_feat_lines(acc, A.dx + (size_t)row0 * H, H, R - row0, turn, lane);
+            else store_feat(acc, A.dx + pc * H, hi);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -845,7 +886,7 @@ static int set_dyn_lds(Kern k, size_t bytes) {
 
 template <int H>
 static int launch_train_fwd_h(int kind, const TrainFwdArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4;
+    const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4 + (size_t)4 * TURN_FLOATS * 4;
     const int grid = grid_tiles(a.rows);
     switch (kind) {
         case TK_ENC_EDGE: hipLaunchKernelGGL((train_fwd_kernel<H, TK_ENC_EDGE>), dim3(grid), dim3(THREADS), lds, s, a); break;
@@ -872,7 +913,7 @@ size_t train_bwd_ln_part_floats(int H) { return (size_t)2 * 1024 * 2 * H; }   //
 
 template <int H>
 static int launch_train_bwd_h(int kind, const TrainBwdArgs& a_in, hipStream_t s, WgradBatch* wb) {
-    const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4 + (size_t)4 * 2 * H * 4;
+    const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4 + (size_t)4 * 2 * H * 4 + (size_t)4 * TURN_FLOATS * 4;
     int grid = grid_tiles(a_in.rows);
     TrainBwdArgs a = a_in;
     const bool batched = wb && a.ln_part && a.dgamma && a.dbeta;
@@ -1023,7 +1064,7 @@ int launch_swap_index(const int* src_sorted, int64_t e, int64_t* ei2, hipStream_
 int train_kernels_init() {
     static PerDeviceOnce done_dev;
     return done_dev.run([]() -> int {
-    const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4 + (size_t)4 * 2 * 256 * 4;   // weight ring + the backward kernels' LayerNorm sums
+    const size_t lds = (size_t)2 * B3_STAGE_FLOATS * 4 + (size_t)4 * 2 * 256 * 4 + (size_t)4 * TURN_FLOATS * 4;   // weight ring + the backward kernels' LayerNorm sums + the line stores' turn tiles
     int rc = GM_OK;
 #define GM_SET(k) if (rc == GM_OK) rc = set_dyn_lds(k, lds)
     GM_SET((train_fwd_kernel<64, TK_ENC_EDGE>)); GM_SET((train_fwd_kernel<64, TK_ENC_NODE>)); GM_SET((train_fwd_kernel<64, TK_PROC_EDGE>));
