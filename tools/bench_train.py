@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--adam", choices=["foreach", "fused"], default="foreach", help="torch.optim.Adam implementation (the reference's train_dyn.py takes the default: foreach)")
     args = ap.parse_args()
     from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, scene
     dev = torch.device("cuda:0")
@@ -34,7 +35,7 @@ def main():
     H, M = args.hidden, 10
     torch.manual_seed(0)
     model = EncProcDecGNN(25, 4, 3, H, 2, M).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, **({"fused": True} if args.adam == "fused" else {}))
     crit = torch.nn.L1Loss(reduction="sum")
 
     def step():
