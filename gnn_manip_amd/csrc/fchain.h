@@ -170,6 +170,14 @@ __device__ __forceinline__ void store_feat(const floatx16 (&v)[NKB], float* __re
 // instructions execute in order), after which a store instruction covers 8 rows x 128 bytes instead of 32 rows x 32 bytes.
 // dst = row 0 of the wave's rows, ld = row stride (floats), rows_left = rows of the array from dst on (any value: rows past
 // the end are dropped by the buffer bound, and the instruction count -- 4 NKB, what run_layer's PEND expects -- does not vary).
+// a wave-uniform pointer the compiler cannot prove uniform (it would wrap every buffer instruction that uses a resource built from it
+// in a waterfall loop): both halves through v_readfirstlane
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
 constexpr int TURN_LD = 36;
 constexpr int TURN_FLOATS = 32 * TURN_LD;
 typedef unsigned int uintx4_t __attribute__((ext_vector_type(4)));
@@ -177,7 +185,7 @@ template <int NKB>
 __device__ __forceinline__ void store_feat_lines(const floatx16 (&v)[NKB], float* dst, int ld, int rows_left, float* turn, int lane) {
     const int n = lane & 31, hi = lane >> 5, rr = lane >> 3, cq = lane & 7;
     const int cnt = rows_left < 0 ? 0 : rows_left > 32 ? 32 : rows_left;
-    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (unsigned)cnt * (unsigned)ld * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(dst), 0, (unsigned)__builtin_amdgcn_readfirstlane(cnt * ld * 4), 0x00020000);
     float* wr = turn + n * TURN_LD + 4 * hi;
     const float* rd = turn + rr * TURN_LD + 4 * cq;
     const unsigned voff = ((unsigned)rr * (unsigned)ld + 4u * cq) * 4u;
@@ -222,7 +230,7 @@ template <int MODE, int NKB>
 __device__ __forceinline__ void load_feat_lines(floatx16 (&v)[NKB], const float* src, int ld, int rows_left, float* turn, int lane) {
     const int rr = lane >> 3, cq = lane & 7;
     const int cnt = rows_left < 0 ? 0 : rows_left > 32 ? 32 : rows_left;
-    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (unsigned)cnt * (unsigned)ld * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float*>(src)), 0, (unsigned)__builtin_amdgcn_readfirstlane(cnt * ld * 4), 0x00020000);
     const unsigned voff = ((unsigned)rr * (unsigned)ld + 4u * cq) * 4u;
     if (MODE == 0) {
         // every line of the tile in flight at once, into the registers they end up in; then one block after the other takes its turn

@@ -9,6 +9,8 @@ struct TapePtr {
     float* a;     // [num_layers][rows][H] post-ReLU outputs of Linear 1 .. num_layers (a_l = a + (l - 1) rows H)
     float* xhat;  // [rows][H] normalised, pre-affine LayerNorm output (normed MLPs)
     float* rstd;  // [rows]    1 / sqrt(var + eps)
+    uint32_t* mask;  // [num_layers][rows][H / 32] one bit per element: a_l > 0 (what the backward chain needs of a_l; its values are
+                     // read by the weight-gradient jobs only), in the chain kernels' register order (train.hip: relu_mask_store)
 };
 
 struct TrainFwdArgs {

@@ -149,19 +149,58 @@ __device__ __forceinline__ void zero_feat(floatx16 (&v)[NKB]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[kb][r] = 0.f;
 }
-// v = a > 0 ? v : 0   (ReLU backward; a = saved post-ReLU activation row)
+// The ReLU mask of a chain's activations as bits: lane (n, hi) packs its 16 NKB values (value 16 kb + r = feature
+// 32 kb + 8 (r >> 2) + 4 hi + (r & 3) of row n) into NKB / 2 words, stored at m[row][hi][NKB / 2] -- one store instruction per
+// lane, 512 contiguous bytes per wave at hidden 128.  The backward chain reads these H / 8 bytes per row instead of the
+// 4 H bytes of a_l (whose values only the weight-gradient jobs need).
 template <int NKB>
-__device__ __forceinline__ void mask_feat(floatx16 (&v)[NKB], const float* __restrict__ a_row, int hi) {
+__device__ __forceinline__ void relu_mask_store(const floatx16 (&act)[NKB], uint32_t* __restrict__ m) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // value q of a word is shifted in from the right (and the word reversed at the end).  The activations are post-ReLU (>= +0): the
+    // integer negation of the bit pattern has its sign bit set exactly when the value is > 0, and v_alignbit shifts that bit in:
+    // two vector instructions per value
+    uint32_t w[NKB / 2];
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
+    for (int q = 0; q < NKB / 2; ++q) w[q] = 0u;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const floatx4 x = *reinterpret_cast<const floatx4*>(a_row + 32 * kb + 8 * g + 4 * hi);
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[kb][4 * g + t] = x[t] > 0.f ? v[kb][4 * g + t] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const float x = act[kb][r];   // (a scalar copy: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+            w[kb >> 1] = __builtin_amdgcn_alignbit(w[kb >> 1], 0u - __float_as_uint(x), 31);
         }
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NKB / 2; ++q) w[q] = __builtin_bitreverse32(w[q]);   // value q at bit q
+    if (NKB == 2) *m = w[0];
+    else if (NKB == 4) *reinterpret_cast<u32x2*>(m) = u32x2{w[0], w[1 % (NKB / 2)]};
+    else *reinterpret_cast<u32x4*>(m) = u32x4{w[0], w[1 % (NKB / 2)], w[2 % (NKB / 2)], w[3 % (NKB / 2)]};
+}
+template <int NKB>
+__device__ __forceinline__ void mask_bits(floatx16 (&v)[NKB], const uint32_t* __restrict__ m) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t w[NKB / 2];
+    if (NKB == 2) {
+        w[0] = *m;
+    } else if (NKB == 4) {
+        const u32x2 x = *reinterpret_cast<const u32x2*>(m);
+        w[0] = x[0];
+        w[1 % (NKB / 2)] = x[1];
+    } else {
+        const u32x4 x = *reinterpret_cast<const u32x4*>(m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q % (NKB / 2)] = x[q];
     }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // a sign-extended one-bit field (0 / all ones) and an AND
+            const float x = v[kb][r];
+            const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)w[kb >> 1], (kb & 1) * 16 + r, 1);
+            v[kb][r] = __uint_as_float(__float_as_uint(x) & keep);
+        }
 }
 
 // LayerNorm forward that also leaves xhat in `xh` (registers) and returns 1/std; acc <- xhat*gamma + beta
@@ -269,9 +308,9 @@ __device__ __forceinline__ void ln_param_sums(const floatx16 (&g)[NJB], const fl
 
 // Which of the chains' row-major arrays move as whole 128-byte lines through a wave-private LDS turn (store_feat_lines /
 // load_feat_lines) instead of accumulator-layout pieces (32 rows x 32 bytes per instruction).  Forward: 1 tape stores, 2 output
-// stores.  Backward: 8 dz stores, 16 input-gradient stores, 32 dY / G / xhat loads, 64 the ReLU-mask loads of the tape.
+// stores.  Backward: 8 dz stores, 16 input-gradient stores, 32 dY / G / xhat loads.
 #ifndef TRAIN_LINES
-#define TRAIN_LINES 127
+#define TRAIN_LINES 63
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -358,12 +397,14 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
             load_feat(acc, A.bias_tail + (size_t)(l - 1) * H, hi);
             if (TRAIN_LINES & 1) store_feat_lines(act, A.tape.a + (size_t)(l - 1) * tstride + (size_t)row0 * H, H, R - row0, turn, lane);
             else store_feat(act, A.tape.a + (size_t)(l - 1) * tstride + pc * H, hi);
-            run_layer_b3<H / 16, NJB, NJB, NST>(acc, act, ws, more);
+            relu_mask_store(act, A.tape.mask + ((size_t)(l - 1) * R + pc) * NJB + hi * (NJB / 2));
+            run_layer_b3<H / 16, NJB, NJB, NST + 1>(acc, act, ws, more);
         }
         relu_to(act, acc);
         if (KIND != TK_DEC) load_feat(acc, A.bias_tail + (size_t)(NL - 1) * H, hi);
         if (TRAIN_LINES & 1) store_feat_lines(act, A.tape.a + (size_t)(NL - 1) * tstride + (size_t)row0 * H, H, R - row0, turn, lane);
         else store_feat(act, A.tape.a + (size_t)(NL - 1) * tstride + pc * H, hi);
+        relu_mask_store(act, A.tape.mask + ((size_t)(NL - 1) * R + pc) * NJB + hi * (NJB / 2));
         if (KIND == TK_DEC) {
             floatx16 o[1];
             load_feat(o, A.bias_tail + (size_t)(NL - 1) * H, hi);  // out bias, zero-padded to 32
@@ -374,7 +415,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_fwd_kernel(Tr
                     if (c < A.out_dim) A.out[pc * A.out_dim + c] = o[0][c];
             }
         } else {
-            run_layer_b3<H / 16, NJB, NJB, NST>(acc, act, ws, more);
+            run_layer_b3<H / 16, NJB, NJB, NST + 1>(acc, act, ws, more);
             const float rstd = layer_norm_tape(acc, act, A.ln_g, A.ln_b, A.eps, hi);
             if (TRAIN_LINES & 1) store_feat_lines(act, A.tape.xhat + (size_t)row0 * H, H, R - row0, turn, lane);
             else store_feat(act, A.tape.xhat + pc * H, hi);
@@ -490,8 +531,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
         }
 #pragma unroll 1
         for (int l = NL; l >= 2; --l) {   // dz_l = (W_(l+1)^T dz_(l+1)) [a_l > 0], then on through W_l^T
-            if (TRAIN_LINES & 64) load_feat_lines<2>(acc, A.tape.a + (size_t)(l - 1) * tstride + (size_t)row0 * H, H, R - row0, turn, lane);
-            else mask_feat(acc, A.tape.a + (size_t)(l - 1) * tstride + pc * H, hi);
+            mask_bits(acc, A.tape.mask + ((size_t)(l - 1) * R + pc) * NJB + hi * (NJB / 2));
             if (TRAIN_LINES & 8) store_feat_lines(acc, A.dz + (size_t)(l - 1) * A.dz_stride + (size_t)row0 * H, H, R - row0, turn, lane);
             else store_feat(acc, A.dz + (size_t)(l - 1) * A.dz_stride + pc * H, hi);
 #pragma unroll
@@ -499,8 +539,7 @@ __global__ void __launch_bounds__(THREADS, H <= 128 ? 2 : 1) train_bwd_kernel(Tr
             zero_feat(acc);
             run_layer_b3<H / 16, NJB, NJB, H / 8>(acc, act, ws, more);
         }
-        if (TRAIN_LINES & 64) load_feat_lines<2>(acc, A.tape.a + (size_t)row0 * H, H, R - row0, turn, lane);
-        else mask_feat(acc, A.tape.a + pc * H, hi);
+        mask_bits(acc, A.tape.mask + (size_t)pc * NJB + hi * (NJB / 2));
         if (TRAIN_LINES & 8) store_feat_lines(acc, A.dz + (size_t)row0 * H, H, R - row0, turn, lane);
         else store_feat(acc, A.dz + pc * H, hi);
         if (KIND == TB_ENC) {

@@ -26,6 +26,7 @@ struct Tape {
 TapePtr take_tape(Carver& c, int64_t rows, int H, int NL, bool normed) {
     TapePtr t{};
     t.a = c.take<float>((size_t)NL * rows * H);   // post-ReLU outputs of Linear 1 .. NL, one [rows][H] array each
+    t.mask = c.take<uint32_t>((size_t)NL * rows * (H / 32));
     if (normed) {
         t.xhat = c.take<float>((size_t)rows * H);
         t.rstd = c.take<float>((size_t)rows);
