@@ -55,6 +55,14 @@ __device__ unsigned long long g_hm_stamps[4 * 4 * 16];
 #else
 #define HM_STAMP_E(tile_i, slot) do { } while (0)
 #endif
+// HM_LINES: the edge kernel's e + e' rows (and the residual rows they are added to) move as whole 128-byte lines: a wave's
+// 32 rows x 32 features take a turn through a wave-private tile in the (then idle) image region, after which an instruction
+// covers 8 rows x 128 bytes instead of 32 rows x 32 bytes.  Rows in the caller's order (eid_out) keep the piece form.
+#ifndef HM_LINES
+#define HM_LINES 1
+#endif
+constexpr int HM_TURN_LD = 36;                       // floats per row of the turn tile
+constexpr int HM_TURN_FLOATS = 32 * HM_TURN_LD;
 constexpr int HM_THREADS = 512;
 constexpr int HM_WAVES = 8;
 constexpr int BE = 32;
@@ -524,6 +532,12 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) carry[r] = 0.f;
         int prev_last = -3, head = -1;
+        // the image is idle from here to the next tile's barrier: wave-private turn tiles at its start
+        const bool lines = HM_LINES && !ENC && !A.eid_out && !A.discard_e_out;
+        float* turn = reinterpret_cast<float*>(smem) + wave * HM_TURN_FLOATS;
+        float* t_acc = turn + n * HM_TURN_LD + 4 * hi;                       // this lane's pieces of row n: + 8 g
+        float* t_row = turn + (lane >> 3) * HM_TURN_LD + 4 * (lane & 7);      // row-major: row (lane >> 3) + 8 j: + 8 j HM_TURN_LD
+        const unsigned v_line = (unsigned)((lane >> 3) * H + 4 * (lane & 7)) * 4u;
         const int grp = t * C::NRG + rg;   // this wave's group of 4 blocks
         if (!ENC && A.agg && grp < A.tab->n_groups) head = A.head[grp];
 #pragma unroll
@@ -569,6 +583,18 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                 }
                 const bool lastblk = rb == 3;
                 const bool is_last = valid && (nxv != dnv || (lastblk && n == cnt - 1));
+                __amdgpu_buffer_rsrc_t srd_o;
+                if (lines) {
+                    const int p0 = __builtin_amdgcn_readfirstlane(sb[rbg].x), cu = __builtin_amdgcn_readfirstlane(cnt);
+                    srd_o = __builtin_amdgcn_make_buffer_rsrc(A.e_out + (size_t)(p0 < 0 ? 0 : p0) * H + 32 * jb, 0, (unsigned)cu * (unsigned)H * 4u, 0x00020000);
+                    if (A.residual) {
+                        floatx4 x[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(srd_o, v_line + (unsigned)(8 * j * H) * 4u, 0, 0));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<floatx4*>(t_row + 8 * j * HM_TURN_LD) = x[j];
+                    }
+                }
                 // stored exactly once: to its agg row, or -- the piece of a segment that began in an earlier group -- to this
                 // group's row of the side buffer
                 float* arow = (dnv == head ? A.side + (size_t)grp * H : A.agg + (size_t)(dnv < 0 ? 0 : dnv) * H) + 32 * jb + 4 * hi;
@@ -578,7 +604,15 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                     const floatx4 gm4 = *reinterpret_cast<const floatx4*>(gamp + 8 * g), bt4 = *reinterpret_cast<const floatx4*>(betp + 8 * g);
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) y[tt] = fmaf(fmaf(acc[rb][4 * g + tt], k, m), gm4[tt], bt4[tt]);
-                    if (valid && !A.discard_e_out) {   // (the last step of a forward: nobody reads its e + e')
+                    if (lines) {
+                        floatx4 eo = floatx4{y[0], y[1], y[2], y[3]};
+                        if (A.residual) {
+                            const floatx4 e0 = *reinterpret_cast<const floatx4*>(t_acc + 8 * g);
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) eo[tt] += e0[tt];
+                        }
+                        *reinterpret_cast<floatx4*>(t_acc + 8 * g) = eo;
+                    } else if (valid && !A.discard_e_out) {   // (the last step of a forward: nobody reads its e + e')
                         floatx4 eo = floatx4{y[0], y[1], y[2], y[3]};
                         if (A.residual) {
                             const floatx4 e0 = *reinterpret_cast<const floatx4*>(outp + 8 * g);
@@ -603,6 +637,13 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                     for (int tt = 0; tt < 4; ++tt)
                         carry[4 * g + tt] = __uint_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) | 31) * 4, __float_as_uint(y[tt])));
                     if (is_last) *reinterpret_cast<floatx4*>(arow + 8 * g) = floatx4{y[0], y[1], y[2], y[3]};
+                }
+                if (lines) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const floatx4 o = *reinterpret_cast<const floatx4*>(t_row + 8 * j * HM_TURN_LD);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, o), srd_o, v_line + (unsigned)(8 * j * H) * 4u, 0, 0);
+                    }
                 }
                 prev_last = cnt == BE ? __builtin_amdgcn_readlane(dnv, 31) : -3;
             }
