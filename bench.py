@@ -169,6 +169,8 @@ def resolve_kernel(edge_kernel, hidden):
 
 def roofline_record(model, ek, hidden, edges, n_nodes, workload_key):
     n_launch, total_ms = model.profile_query(0)
+    if n_launch < 0:   # more launches than the kind records (4096): the total covers the recorded ones
+        n_launch = 4096
     k_ms = total_ms / max(n_launch, 1)
     alg = edge_kernel_alg_flops(edges, hidden)
     issued = edge_kernel_issued_flops(edges, hidden)
@@ -196,20 +198,22 @@ def roofline_record(model, ek, hidden, edges, n_nodes, workload_key):
            "fp32_equivalent_tflops": issued / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
            "alg_flops_per_launch": alg, "alg_tflops": alg / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
            "alg_bytes_per_launch": alg_bytes, "mfma": mfma, "hbm": hbmr}
-    if workload_key == "target":
-        # measured this round (not re-measured by this run): the target workload holds the board at its package power cap, the shader
-        # clock a third below its maximum; the chip's sustained fp16 matrix rate at that cap is what the micro-benchmark reaches
-        rec["power_limited"] = {"package_power_w": 1383, "cap_w": 1400, "sclk_mhz": 1674, "sclk_max_mhz": 2400,
-                                "source": "profiles/r05_power_watch.txt (rocm-smi during a 3000-step timed region, tools/micro/power_watch.sh)",
-                                "mfma_rate_at_the_cap_tflops": {"v_mfma_f32_32x32x16_f16": 1403, "v_mfma_f32_16x16x32_f16": 1625,
-                                                                "source": "profiles/r05_mfma_shape.txt (tools/micro/mfma_shape.hip: LDS-fed, random data, 3 waves per SIMD)"},
-                                "frac_of_that_rate": achieved / 1403.0}
-    # HBM traffic of the same kernel from rocprofv3 PMC passes (collected separately with tools/profile_round.sh, committed
-    # under profiles/).  Reported only when the newest file was collected from THIS tree's kernel sources (it records their
-    # digest); otherwise null with the reason.
+    # Two figures this run does not measure itself come from committed profile files and only while those files were collected from
+    # THIS tree's kernel sources (each records their digest): the kernel's HBM traffic (rocprofv3 PMC passes, tools/profile_round.sh)
+    # and the board power / shader clock under the workload (rocm-smi, tools/micro/power_watch.sh).  Otherwise: null / absent, with
+    # the reason.  No literal of another run is printed.
     try:
         import glob
         from gnn_manip_amd.build import source_digest
+        pfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_power.json")))
+        if pfiles:
+            pw = json.load(open(pfiles[-1]))
+            pname = "profiles/" + os.path.basename(pfiles[-1])
+            if pw.get("source_digest") != source_digest():
+                rec["power_source"] = f"absent: {pname} was collected from other kernel sources than this tree's (digest mismatch)"
+            elif pw.get(workload_key):
+                rec["power"] = dict(pw[workload_key], source=f"{pname} (rocm-smi once a second during a long timed region of this "
+                                                              "build, tools/micro/power_watch.sh; not re-measured by this run)")
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
         tr = json.load(open(files[-1]))
         name = "profiles/" + os.path.basename(files[-1])
@@ -273,17 +277,28 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
     if rank == 0:
         # Kernel timings: the same K steps once more, untimed, with HIP events (on the launch stream) around every model kernel
         # of this handle -- the dominant kernel's average launch duration for the roofline, the others for the breakdown.
-        model.profile(15)
+        # A kind records at most 4096 scopes (gm_model_profile): the pass is bounded so that none fills up (a step opens ~31 node-side
+        # scopes), and a kind that did fill up is reported as null instead of a figure that is too low.
+        psteps = min(steps, 64)
+        model.profile(31)
         with torch.no_grad():
-            eng.run(obs, timed_traj, steps)
+            eng.run(obs, timed_traj[:psteps].contiguous(), psteps)
         torch.cuda.synchronize()
         model.profile(0)
         roof, k_ms = roofline_record(model, ek, wl["hidden"], edges, wl["n"] * candidates, wl_key)
-        br = {"edge_kernel_ms_per_step": k_ms * 10}
-        for name, kind in {"node_kernel": 1, "graph_build": 2, "encoder_kernels": 3}.items():
+        br = {"edge_kernel_ms_per_step": k_ms * 10, "profiled_steps": psteps}
+        # node side; radius graph; encoders; and the rest of the step: state update + node features, destination sort + block
+        # tables + edge features, clears, integration + window shift
+        parts = [k_ms * 10]
+        for name, kind in {"node_kernel": 1, "graph_build": 2, "encoder_kernels": 3, "csr_and_features": 4}.items():
             n_k, ms_k = model.profile_query(kind)   # totals over the profiled steps (a step's node side is several launches)
-            br[name + "_ms_per_step"] = ms_k / max(steps, 1)
-            br[name + "_launches_per_step"] = n_k / max(steps, 1)
+            full = n_k < 0   # more scopes than the kind records
+            br[name + "_ms_per_step"] = None if full else ms_k / psteps
+            br[name + "_launches_per_step"] = abs(n_k) / psteps
+            parts.append(None if full else ms_k / psteps)
+        # the parts are kernel time (HIP events of a separate, instrumented pass); ms_per_step is the wall time of the uninstrumented
+        # timed region: their ratio says how much of the step is launch gaps / unattributed work
+        br["sum_of_parts_ms_per_step"] = None if any(p is None for p in parts) else sum(parts)
         rec = {"value": world * candidates * steps / el, "unit": "rollout steps/s", "steps": steps, "warmup": warmup,
                "ms_per_step": el / steps * 1e3,
                "config": {"workload": wl["name"], "n_particles": wl["n"], "hidden": wl["hidden"], "edges_last_step": edges, "k_steps": 6,
@@ -291,6 +306,8 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
                           "particle_ids": "random (scene.make_scene); the engine renumbers its working copy in grid-cell order per run() call, "
                                           "inside the timed region" if eng.renumber else "random (scene.make_scene), used as given"},
                "roofline": roof, "breakdown": br, "collective_ms": coll * 1e3}
+        if br["sum_of_parts_ms_per_step"] is not None:
+            br["sum_of_parts_over_step"] = br["sum_of_parts_ms_per_step"] / rec["ms_per_step"]
     return rec, (model, obs_np, stats, scene, ek)
 
 
@@ -308,13 +325,13 @@ def run_c5(dev, rank, world, dist, cdev, args):
     batch = max(1, min(args.batch, per_rank))
     ga = GraphBoundedMultimaterialControl(scn.CONN_R, stats, scn.CART, scn.MAT, scn.CTRL, scn.BOUNDS)
     eng = RolloutEngine(model, ga, wl["n"], device=dev, candidates=batch)
-    coffee = obs[-1, :, 1] != 1
-    target_cloud = (obs[-1, coffee, 2:5] + 0.01).contiguous()
+    coffee_rows = torch.nonzero(obs[-1, :, 1] != 1).reshape(-1)   # once: a boolean-mask index synchronises per use
+    target_cloud = (obs[-1].index_select(0, coffee_rows)[:, 2:5] + 0.01).contiguous()
     loss_fn = SamplesLoss("sinkhorn", p=2, blur=0.05)
 
     def objective(block):  # block: [b, dim] candidate parameters (here: an offset of the scripted cup drift per candidate)
         block = np.asarray(block, np.float64)
-        out = []
+        ends = []
         for lo in range(0, block.shape[0], batch):
             cand = block[lo:lo + batch]
             b = cand.shape[0]
@@ -324,10 +341,9 @@ def run_c5(dev, rank, world, dist, cdev, args):
             trajs = (traj.unsqueeze(0) + 1e-6 * offs.view(batch, 1, 1, 3)).contiguous()
             with torch.no_grad():
                 final = eng.rollout_candidates(obs, trajs, horizon)
-            for c in range(b):
-                cloud = final[c, -1][coffee][:, 2:5].contiguous()
-                out.append(float(loss_fn(cloud, target_cloud)))
-        return np.asarray(out, np.float64)
+            ends.append(final[:b, -1].index_select(1, coffee_rows)[:, :, 2:5])
+        # the Sinkhorn losses of the rank's whole block in one batched launch sequence, one transfer of the values
+        return loss_fn.batched(torch.cat(ends).contiguous(), target_cloud).double().cpu().numpy()
 
     ev = planner.CandidateEvaluator(None, result_dim=1, group=None, device=cdev)
     rng = np.random.Generator(np.random.PCG64(7))
@@ -360,21 +376,22 @@ def run_c5(dev, rank, world, dist, cdev, args):
             "data": "synthetic (seeded dense scene; random-init weights; a candidate = an offset of the scripted cup drift)",
             "config": {"workload": wl["name"], "n_particles": wl["n"], "candidates": popsize, "candidates_per_rank": per_rank,
                        "block_diagonal_batch": batch, "horizon": horizon, "generation_s": el, "loss_mean": float(np.mean(losses)),
-                       "parallelism": f"candidate-parallel x{world}"},
+                       "losses_finite": bool(np.isfinite(losses).all()), "parallelism": f"candidate-parallel x{world}"},
             # rank 0's wall time inside the generation's broadcast + all-gather calls (the all-gather includes the wait for the
             # slowest rank): what is not rollout or loss work when the 1 -> N curve falls short
             "collective_ms": ev.collective_s * 1e3, "collective_backend": dist.get_backend() if dist else None}
 
 
 def extra_c5_1gpu(dev, args):
-    """A reduced CMA-ES generation on this GPU (BASELINE C5's path at a size that takes a few seconds): 16 candidates x 50
-    rollout steps at N = 5k in block-diagonal batches of 8 + one device Sinkhorn loss per candidate (run_c5, one rank)."""
+    """BASELINE config C5 at its own size on this ONE GPU: a CMA-ES generation of 64 candidates x 200 rollout steps at N = 5k in
+    block-diagonal batches of 8 + the 64 device Sinkhorn losses in one batched launch sequence (run_c5 with one rank; what the
+    8-GPU run shards 8 ways)."""
     import copy
     a = copy.copy(args)
-    a.candidates_total, a.batch, a.steps = 16, 8, 50
+    a.candidates_total, a.batch, a.steps = 64, 8, 200
     r = run_c5(dev, 0, 1, None, dev, a)
     return {"value": r["value"], "unit": r["unit"], "ms": r["config"]["generation_s"] * 1e3, "config": r["config"],
-            "note": "the full C5 shape (64 x 200, one GPU) is `--workload c5`"}
+            "note": "the same record is `--workload c5` (add `--collectives always` for the RCCL exchange at one rank)"}
 
 
 def extra_train(dev, steps=5, warmup=2):
@@ -427,29 +444,49 @@ def extra_train(dev, steps=5, warmup=2):
                        "nodes": int(nodes.shape[0]), "edges": int(edge_attr.shape[0]), "steps": steps, "warmup": warmup}}
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, rank_timeout):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, the env
     rendezvous torch.distributed.run would have set up, 127.0.0.1), relay rank 0's JSON line, return non-zero if any
     rank failed.  The parent makes no GPU call and replaces no process (gpurun rules): children are ordinary
-    subprocesses, rank 0's stdout is piped, everything else is inherited."""
+    subprocesses.  Nothing hangs silently: every rank's stderr (and the stdout of ranks > 0) goes to a file of its own, a rank
+    that fails takes the others down, and after `rank_timeout` seconds the children still running -- exactly the PIDs started
+    here -- are terminated (killed 10 s later if they ignore it), the exit status is 124 and the tails of all the rank files
+    are printed with the failure."""
     import socket
     import subprocess
+    import tempfile
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="gm_bench_ranks_")
+    procs, files = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    import threading
+        ferr = open(os.path.join(logdir, f"rank{r}.err"), "wb")
+        fout = subprocess.PIPE if r == 0 else open(os.path.join(logdir, f"rank{r}.out"), "wb")
+        files += [ferr] + ([] if r == 0 else [fout])
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=fout, stderr=ferr))
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
-    rc = 0
+    rc, why = 0, ""
     live = list(procs)
+    deadline = time.monotonic() + rank_timeout
+
+    def stop(ps):   # exactly the PIDs started above
+        for q in ps:
+            q.terminate()
+        t_kill = time.monotonic() + 10.0
+        for q in ps:
+            try:
+                q.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
+
     while live:   # a rank that fails takes the others down with it (they would wait in the rendezvous / a collective)
         time.sleep(0.2)
         for p in list(live):
@@ -458,19 +495,35 @@ def spawn_ranks(n):
                 continue
             live.remove(p)
             if code != 0 and rc == 0:
-                rc = code
-                for q in live:
-                    q.terminate()   # exactly the PIDs started above
+                rc, why = code, f"rank {procs.index(p)} exited with status {code}"
+                stop(live)
+        if live and rc == 0 and time.monotonic() > deadline:
+            stuck = [procs.index(p) for p in live]
+            rc, why = 124, f"rank(s) {stuck} still running after --rank-timeout {rank_timeout:g} s: terminated"
+            stop(live)
+            live = []
     reader.join(timeout=10.0)
+    for f in files:
+        f.close()
     out0 = b"".join(chunks).decode(errors="replace")
     lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
-    if lines:
+    if lines and rc == 0:
         print(lines[-1], flush=True)
     elif rc == 0:
-        rc = 1
+        rc, why = 1, "rank 0 printed no JSON line"
     if rc:
-        sys.stderr.write(f"bench.py: a rank failed (exit status {rc})\n")
-    return 1 if rc else 0
+        sys.stderr.write(f"bench.py: {why}\n")
+        for r in range(n):   # what every rank said last
+            for kind in ("out", "err"):
+                path = os.path.join(logdir, f"rank{r}.{kind}")
+                text = out0 if (r == 0 and kind == "out") else (open(path, errors="replace").read() if os.path.exists(path) else "")
+                tail = text.strip().splitlines()[-15:]
+                if tail:
+                    sys.stderr.write(f"---- rank {r} std{kind} (last lines; files under {logdir})\n" + "\n".join(tail) + "\n")
+        return 124 if rc == 124 else 1
+    import shutil
+    shutil.rmtree(logdir, ignore_errors=True)
+    return 0
 
 
 def main():
@@ -486,6 +539,10 @@ def main():
     ap.add_argument("--collectives", default="auto", choices=["auto", "always"],
                     help="always: initialise torch.distributed (nccl = RCCL) and run the per-generation broadcast / all-gather even "
                          "with ONE rank -- the multi-GPU code path, device-resident payloads included, on a one-GPU box")
+    ap.add_argument("--rank-timeout", type=float, default=540.0,
+                    help="seconds after which a multi-rank run that has not finished is ended with a non-zero exit (the launcher "
+                         "terminates the ranks it started; a rank started by torch.distributed.run gives up its rendezvous / "
+                         "collectives after the same time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C3 / C4 sub-records")
     ap.add_argument("--edge-kernel", default="auto", choices=["auto", "sys", "hm"],
@@ -494,7 +551,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU)
-        raise SystemExit(spawn_ranks(args.gpus))
+        raise SystemExit(spawn_ranks(args.gpus, args.rank_timeout))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -502,6 +559,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher's environment says WORLD_SIZE={world}")
     if os.environ.get("GM_BENCH_FAIL_RANK") == str(rank) and world > 1:   # tests: a rank that dies before the rendezvous
         raise SystemExit(3)
+    if os.environ.get("GM_BENCH_STUCK_RANK") == str(rank) and world > 1:   # tests: a rank that never reaches the rendezvous
+        sys.stderr.write(f"rank {rank}: GM_BENCH_STUCK_RANK set, sleeping\n")
+        sys.stderr.flush()
+        while True:
+            time.sleep(1.0)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
     # GM_BENCH_REHEARSE=1: all ranks on cuda:0 with gloo (multi-rank rehearsal on a one-GPU box; RCCL refuses two ranks per
     # device).  Never set by the driver.
@@ -520,10 +582,14 @@ def main():
                     os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        # a rendezvous / collective that never completes raises -- a minute after the launcher's own deadline, so that a run started
+        # by spawn_ranks ends with the launcher's report (which rank was stuck) and one started by torch.distributed.run still ends
+        tmo = datetime.timedelta(seconds=args.rank_timeout + 60.0)
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
     cdev = torch.device("cpu") if rehearse else dev  # where collective payloads live
 
     if args.workload == "c5":

@@ -86,6 +86,8 @@ PROTOTYPES = {
     "gm_interaction_network_backward": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "gm_sinkhorn_workspace_bytes": (_sz, [_i64, _i64]),
     "gm_sinkhorn_divergence": (_i32, [_vp, _i64, _vp, _i64, _f32, _f32, _vp, _vp, _sz, _vp]),
+    "gm_sinkhorn_batched_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gm_sinkhorn_divergence_batched": (_i32, [_vp, _i64, _i64, _vp, _i64, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp]),
     "gm_rollout_workspace_bytes": (_sz, [_MD, _i64, _i32]),
     "gm_rollout_step": (_i32, [_vp, _vp, _i64, _FD, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gm_rollout_renumber_workspace_bytes": (_sz, [_FD, _i64]),

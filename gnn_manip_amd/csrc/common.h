@@ -142,14 +142,29 @@ struct CsrWs {
 };
 CsrWs carve_csr(void* ws, int64_t n, int64_t cap);
 
+// Between the phases of a wave-private LDS transpose (lane a writes what lane b reads; no workgroup barrier, because one wave's LDS
+// instructions execute in order): this keeps the COMPILER from moving the reads above the writes, or the next turn's writes above
+// the reads -- its single-thread memory model allows either once it proves a lane's own two addresses distinct, and both are pure
+// functions of the lane id.  Generates no instruction.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wave_lds_turn() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
+
 // ---- optional per-kernel timing with HIP events on the launch stream, owned by a model handle (gm_model_profile)
-enum ProfKind : int { PROF_EDGE = 0, PROF_NODE = 1, PROF_GRAPH = 2, PROF_ENC = 3, PROF_KINDS = 4 };
+// PROF_REST: everything else of a rollout step -- state update + node features, destination sort + block tables + edge features,
+// the forward's clears, integration + window shift -- so that the kinds of a step add up to the step
+enum ProfKind : int { PROF_EDGE = 0, PROF_NODE = 1, PROF_GRAPH = 2, PROF_ENC = 3, PROF_REST = 4, PROF_KINDS = 5 };
 constexpr int PROF_MAX = 4096;
 struct ProfState {
     int mask = 0;  // bit k: record kind k
-    int count[PROF_KINDS] = {0, 0, 0, 0};
-    hipEvent_t* start[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t* stop[PROF_KINDS] = {nullptr, nullptr, nullptr, nullptr};
+    int count[PROF_KINDS] = {};
+    int dropped[PROF_KINDS] = {};   // scopes that found the kind's PROF_MAX event pairs used up (gm_model_profile_query reports them)
+    hipEvent_t* start[PROF_KINDS] = {};
+    hipEvent_t* stop[PROF_KINDS] = {};
     ~ProfState();
 };
 struct ProfScope {

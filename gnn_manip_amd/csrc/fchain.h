@@ -198,11 +198,13 @@ __device__ __forceinline__ void store_feat_lines(const floatx16 (&v)[NKB], float
             for (int t = 0; t < 4; ++t) x[t] = v[kb][4 * g + t];
             *reinterpret_cast<floatx4*>(wr + 8 * g) = x;
         }
+        wave_lds_turn();   // the tile is written: other lanes' pieces may be read
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const floatx4 o = *reinterpret_cast<const floatx4*>(rd + 8 * j * TURN_LD);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, o), srd, voff + (unsigned)(8 * j * ld + 32 * kb) * 4u, 0, 0);
         }
+        wave_lds_turn();   // the tile is read: the next block may overwrite it
     }
 }
 
@@ -215,6 +217,7 @@ __device__ __forceinline__ void turn_in(floatx16& v, const floatx4 (&x)[4], floa
     const float* rd = turn + n * TURN_LD + 4 * hi;
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<floatx4*>(wr + 8 * j * TURN_LD) = x[j];
+    wave_lds_turn();   // the tile is written: other lanes' pieces may be read
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const floatx4 y = *reinterpret_cast<const floatx4*>(rd + 8 * g);
@@ -225,6 +228,7 @@ __device__ __forceinline__ void turn_in(floatx16& v, const floatx4 (&x)[4], floa
             else v[4 * g + t] = y[t] > 0.f ? v[4 * g + t] : 0.f;
         }
     }
+    wave_lds_turn();   // the tile is read: the next turn may overwrite it
 }
 template <int MODE, int NKB>
 __device__ __forceinline__ void load_feat_lines(floatx16 (&v)[NKB], const float* src, int ld, int rows_left, float* turn, int lane) {

@@ -33,7 +33,8 @@ ProfState::~ProfState() {
 }
 
 ProfScope::ProfScope(ProfState* state, int k, hipStream_t st) : p(state), idx(-1), kind(k), s(st) {
-    if (!p || !((p->mask >> k) & 1) || p->count[k] >= PROF_MAX) return;
+    if (!p || !((p->mask >> k) & 1)) return;
+    if (p->count[k] >= PROF_MAX) { ++p->dropped[k]; return; }
     if (!p->start[k]) {
         hipEvent_t* a = new hipEvent_t[PROF_MAX];
         hipEvent_t* b = new hipEvent_t[PROF_MAX];
@@ -803,7 +804,7 @@ extern "C" {
 
 const char* gm_last_error(void) { return gm::last_error(); }
 
-int gm_abi_version(void) { return 6; }
+int gm_abi_version(void) { return 7; }
 
 size_t gm_graph_workspace_bytes(int64_t n_nodes, int max_neighbours) {
     if (n_nodes < 0 || max_neighbours < 1) return 0;

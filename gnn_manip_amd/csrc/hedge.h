@@ -57,7 +57,7 @@ struct PackH3Job {
 size_t h3_image_floats();
 int pack_h3(const PackH3Job* jobs, int n, hipStream_t s);
 
-int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s);
+int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, int64_t edge_capacity, hipStream_t s);
 // device address of the power of two the systolic kernel's accumulators carry through its first Linear (T1 of the step's weight
 // image): the node kernel that writes P for that step multiplies it in (NodeArgs::p_scale), the edge kernel then adds P_i + P_j as is
 inline const float* edge_sys_p_scale(const float* h3_image) { return h3_image; }

@@ -78,45 +78,18 @@ __device__ unsigned long long g_sys_stamps[3 * 32 * 8 + 32];   // + the 100 MHz 
 #ifndef EPI_SPLIT
 #define EPI_SPLIT 1   // row groups (of 8 rows) of a block's LayerNorm + e_out epilogue that role 1 keeps; role 2 takes the others
 #endif
-#ifndef HEDGE_VAR
-#define HEDGE_VAR 0   // development builds: structural variants under A/B test (bit meanings at their use)
-#endif
-#ifndef HEDGE_ROT0
-#define HEDGE_ROT0 1   // role 0 runs its MFMAs at the top of the tick and prepares the next block's accumulators behind them
-#endif
-#ifndef HEDGE_PSPREAD
-#define HEDGE_PSPREAD 0   // role 0 issues its P-row requests between its first MFMAs instead of before them
-#endif
 #ifndef HEDGE_XCD
 #define HEDGE_XCD 1
 #endif
-#ifndef HEDGE_NT
-#define HEDGE_NT 4     // non-temporal hint on: 1 the e rows role 0 reads, 2 the residual re-read, 4 the e_out stores (with sc1: written
-                       // through and kept out of L2 / the Infinity Cache, which then hold h, P and agg for the kernels that follow)
-#endif
-#ifndef HEDGE_ROT2
-#define HEDGE_ROT2 0   // role 2 runs the scatter-add of block x-3 before its MFMAs instead of between them
-#endif
-#ifndef HEDGE_ABL
-#define HEDGE_ABL 0   // development builds: timing ablations (1 no residual read, 2 P_j from the P_i row, 4 no e_out store, 8 no agg store, 16 no e read, 32 e_out rows folded onto 1024 rows)
-#endif
-#ifndef HEDGE_DEFER
-#define HEDGE_DEFER 0   // roles 0 / 1 run the ReLU + split -> image of a block in the MFMA gaps of the NEXT tick (two register sets per wave
-                        // change places: accumulators of the block in flight <-> previous results, then the next initial accumulators)
-#endif
-#ifndef HEDGE_EIMG1
-#define HEDGE_EIMG1 0   // 1: role 1 (not role 0) requests the e rows and writes the operand image E: four requests, 24 vector instructions,
-                        // eight LDS stores and 16 registers leave the role that is last at the barrier most often
-#endif
-#ifndef HEDGE_TAIL0
-#define HEDGE_TAIL0 11   // MFMA slots (of 24) in which the two halves of a deferred tail run
-#define HEDGE_TAIL1 15
-#endif
+// Cache policy of a launch's row stores (aux bits of the buffer instructions: 2 = nt, 16 = sc1).  STREAM launches write e + e' with
+// sc1 | nt -- written through and kept out of L2 / the Infinity Cache, which then hold h, P and agg for the kernels that follow -- and
+// agg with sc1: right when the rows a launch writes cannot stay resident until the next launch reads them (target: 1 GB per launch,
+// + 3 % on the step).  Small graphs keep the default policy: at N = 5k the 49 MB of e live in the 256 MB Infinity Cache from launch to
+// launch, and writing them through costs every launch an HBM round trip (round 5 shipped the streaming policy at every size: C2 - 8 %).
+// The launcher chooses (launch_edge_sys: kStreamStoreBytes).
+constexpr int ST_STREAM_E = 2 | 16, ST_STREAM_AGG = 16;
 #ifndef HENC_ST_AUX
 #define HENC_ST_AUX 0    // cache policy of the edge encoder's e stores (2 = nt, 16 = sc1)
-#endif
-#ifndef HEDGE_SC1
-#define HEDGE_SC1 12   // sc1 (write-through, the line is not kept in L2) on: 1 the e rows role 0 reads, 2 the residual re-read, 4 the e_out stores, 8 the agg stores; 16: sc0 on the e_out stores too
 #endif
 constexpr int HW_HEADER_FLOATS = 4;            // T1, 1/T3, cap of the per-row input scale (encoder image), pad
 constexpr int HW_VEC_FLOATS = 5 * H;           // b2*T2 | b3*T3 | gamma | beta | b1*T1 (the encoder's; a processor step has b1 in P)
@@ -160,7 +133,8 @@ template <int NT>
 __device__ __forceinline__ void bst4s(srd_t r, unsigned voff, unsigned soff, floatx4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), r, voff, soff, NT); }
 __device__ __forceinline__ intx4 bldi4(srd_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(intx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
 __device__ __forceinline__ void bst4(srd_t r, unsigned voff, unsigned soff, floatx4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), r, voff, soff, 0); }
-__device__ __forceinline__ void bst1(srd_t r, unsigned voff, unsigned soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, (HEDGE_SC1 & 8) ? 16 : 0); }
+template <int AUX>
+__device__ __forceinline__ void bst1s(srd_t r, unsigned voff, unsigned soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX); }
 // scalar clamp to [0, hi]: written as SALU so that the values that feed a resource stay in scalar registers
 // Workgroups are dealt to the 8 XCDs in turn (workgroup i runs on XCD i % 8), each XCD with its own L2.  The systolic kernels give
 // workgroup i the i-th contiguous range of the destination-sorted edge list; numbered this way, the 32 workgroups of an XCD hold one
@@ -200,40 +174,10 @@ __device__ __forceinline__ void acc_to_image(const floatx16& a, char* smem, unsi
     }
 }
 
-// the same, one fragment (registers 8q .. 8q+7) per call: for the MFMA gaps of the next tick (HEDGE_DEFER)
-__device__ __forceinline__ void tail_piece(const floatx16& a, char* smem, unsigned addr, int q) {
-    uintx2 h0, l0, h1, l1;
-    split4(relu(a[8 * q]), relu(a[8 * q + 1]), relu(a[8 * q + 2]), relu(a[8 * q + 3]), h0, l0);
-    split4(relu(a[8 * q + 4]), relu(a[8 * q + 5]), relu(a[8 * q + 6]), relu(a[8 * q + 7]), h1, l1);
-    LDS(uintx4, addr + (q * 2 + 0) * 1024) = uintx4{h0[0], h0[1], h1[0], h1[1]};
-    LDS(uintx4, addr + (q * 2 + 1) * 1024) = uintx4{l0[0], l0[1], l1[0], l1[1]};
-}
-
 // One Linear for this wave's 32 output features: 8 k-groups x 3 MFMAs (lo*hi, hi*lo, hi*hi).  side(slot), slot = 0..23, runs
 // after each MFMA with the instruction order pinned.  B fragments are fetched one k-group (hi part) / two MFMAs (lo part) ahead.  a0 / a1: byte address of this
 // lane's slot in fragment (0, hi part) for the even / odd k-groups (they differ in the swizzled image E only); c0: initial
 // accumulators (the first MFMA's C operand).
-#ifndef HEDGE_MFMA16
-#define HEDGE_MFMA16 0   // development builds, TIMING ONLY (results invalid): every 32x32x16 MFMA issued as two 16x16x32 on the same registers
-#endif
-typedef float floatx4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void mfma_step(floatx16& acc, const half8& a, const half8& b, const floatx16& c, int which) {
-#if HEDGE_MFMA16
-    // two quarter tiles per issue slot of the 32x32 form: the same operands, FLOPs and register traffic, not the same numbers
-    floatx4v q0, q1;
-    const int i0 = (2 * which) & 3, i1 = (2 * which + 1) & 3;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { q0[t] = c[4 * i0 + t]; q1[t] = c[4 * i1 + t]; }
-    q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);
-    q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q1, 0, 0, 0);
-    if (&acc != &c) acc = c;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { acc[4 * i0 + t] = q0[t]; acc[4 * i1 + t] = q1[t]; }
-#else
-    (void)which;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-#endif
-}
 template <class F>
 __device__ __forceinline__ void mlp_layer(floatx16& acc, const floatx16& c0, const half8 (&wh)[8], const half8 (&wl)[8], char* smem, unsigned a0, unsigned a1, F&& side) {
     half8 bh = LDS(half8, a0), bl = LDS(half8, a0 + 1024);
@@ -242,17 +186,17 @@ __device__ __forceinline__ void mlp_layer(floatx16& acc, const floatx16& c0, con
         half8 nh = bh;
         const unsigned an = (((ks + 1) & 1) ? a1 : a0) + (ks + 1) * 2048;
         GM_SB;
-        if (ks == 0) mfma_step(acc, wl[ks], bh, c0, 3 * ks); else mfma_step(acc, wl[ks], bh, acc, 3 * ks);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], bh, ks == 0 ? c0 : acc, 0, 0, 0);
         GM_SB;
         if (ks + 1 < 8) nh = LDS(half8, an);
         side(3 * ks);
         GM_SB;
-        mfma_step(acc, wh[ks], bl, acc, 3 * ks + 1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bl, acc, 0, 0, 0);
         GM_SB;
         if (ks + 1 < 8) bl = LDS(half8, an + 1024);   // the low part is read by the middle MFMA only: its registers are free again
         side(3 * ks + 1);
         GM_SB;
-        mfma_step(acc, wh[ks], bh, acc, 3 * ks + 2);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bh, acc, 0, 0, 0);
         GM_SB;
         side(3 * ks + 2);
         bh = nh;
@@ -312,7 +256,8 @@ __device__ __forceinline__ void scan3(float& ya, float& yb, float& yc, float ypr
 // WRITE_E = false: the launch whose e_out nobody reads (the last message-passing step of a forward: the decoder takes h only,
 // epd_gnn.py:96) -- LayerNorm statistics and the scatter-add run as always, the row-major epilogue (residual read, e + e', store)
 // does not exist: 1 GB less written and 1 GB less re-read at the target.
-template <bool WRITE_E>
+// STREAM: the cache policy of the row stores (ST_STREAM_* above).
+template <bool WRITE_E, bool STREAM>
 __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeader* a_hdr, const int* __restrict__ a_dst, const int* __restrict__ a_src, const float* __restrict__ a_P,
                                                                        const float* a_e_in, float* a_e_out, float* __restrict__ a_agg, const float* __restrict__ a_hw,
                                                                        const int2* __restrict__ a_blk, const int2* __restrict__ a_seg, const int* __restrict__ a_head,
@@ -389,20 +334,16 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         int rng = 0;            // range check of the fp16 split: set once an accumulator row turns NaN
         floatx4 eq[4];          // e rows of block x+1 on their way into the operand image E (the first block's: requested here)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) eq[j] = HEDGE_EIMG1 ? floatx4{0.f, 0.f, 0.f, 0.f} : bld4(srd_ein, v_eoff, j * 4096);
-        // Two register sets.  Plain form: `acc` = the block's accumulators, c0v = (P_i + P_j) T1 of the next block (the first MFMA's C
-        // operand).  HEDGE_DEFER: the sets change places every tick -- `cur` arrives holding the block's initial accumulators and is
-        // accumulated in place, `prv` holds the previous block's results until their ReLU + split has run in this tick's MFMA gaps and
-        // then receives the next block's initial accumulators.
+        for (int j = 0; j < 4; ++j) eq[j] = bld4(srd_ein, v_eoff, j * 4096);
+        // Two register sets: `acc` = the block's accumulators, c0v = (P_i + P_j) T1 of the next block (the first MFMA's C operand).
         floatx16 acc, c0v;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { c0v[r] = 0.f; acc[r] = 0.f; }
         intx4 di = bldi4(srd_dst, v_ioff, 0), si = bldi4(srd_src, v_ioff, 0);   // indices of the rows of block b0 ( = "x+1" of the first tick's requests)
         int2 be = a_blk[clampb(b0 + 1)];   // table entry of block x+2 (its .x = first edge): the rows and indices requested this tick
-        auto tick = [&](auto par_c, int t, floatx16& cur, floatx16& prv) {
+        auto tick = [&](auto par_c, int t) {
             constexpr int PAR = decltype(par_c)::value;   // parity of x: the images' double buffers are compile-time offsets
             const int x = b0 + t;
-            floatx16& c0v = HEDGE_DEFER ? prv : cur;      // where prepare() leaves the next block's initial accumulators
             SYS_STAMP(t, 0);
             auto prepare = [&]() {   // accumulator = (P_i[dst] + P_j[src]) * T1: row-major sum -> tile -> accumulator layout
 #pragma unroll
@@ -414,7 +355,6 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     for (int tt = 0; tt < 4; ++tt) c0v[4 * g + tt] = v[tt];
                 }
             };
-            if (!HEDGE_ROT0) prepare();   // P rows of this block (requested a tick ago)
             SYS_STAMP(t, 1);
             // Requests, all at the top of the tick so that they have a whole tick to arrive (loads and stores complete in issue
             // order on one counter).  P rows of block x+1 (whole 128-byte lines: 8 lanes per row); its destinations also go to
@@ -423,92 +363,73 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             const unsigned rel = (unsigned)(be.x - e0);
             auto p_loads = [&](int j) {
                 pi[j] = bld4(srd_P, (unsigned)(di[j] << 10) + v_poff, 0);
-                pj[j] = bld4(srd_P, (unsigned)(((HEDGE_ABL & 2) ? di[j] : si[j]) << 10) + v_poff + H * 4, 0);   // P_j: second half of the row
+                pj[j] = bld4(srd_P, (unsigned)(si[j] << 10) + v_poff + H * 4, 0);   // P_j: second half of the row
             };
             auto idx_loads = [&]() {
                 di = bldi4(srd_dst, v_ioff + rel * 4, 0);     // indices of block x+2
                 si = bldi4(srd_src, v_ioff + rel * 4, 0);
             };
-            if (!HEDGE_PSPREAD) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) p_loads(j);
-                SYS_STAMP(t, 7);   // (development) the eight P requests issued
-                idx_loads();
-            }
+            for (int j = 0; j < 4; ++j) p_loads(j);
+            SYS_STAMP(t, 7);   // (development) the eight P requests issued
+            idx_loads();
             const int2 be_next = a_blk[clampb(x + 3)];
             // e of block x+1 -> operand image E (this role reads it next tick), one row group per call, between the MFMAs;
             // then the rows of block x+2 are requested into the same registers
             auto side = [&](int slot) {
-                if (!HEDGE_EIMG1 && slot < 8 && !(slot & 1)) {
+                if (slot < 8 && !(slot & 1)) {
                     const int j = slot >> 1;
                     uintx2 h, l;
                     split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
                     LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128) = h;
                     LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128 + 1024) = l;
-                } else if (HEDGE_PSPREAD && slot < 8) {
-                    // the tick's requests one pair per MFMA slot instead of a burst at its top: the CU's one address pipe takes a
-                    // kilobyte-wide request every ~16+ cycles, and a burst of 10 from each of the four role-0 waves holds their MFMAs back
-                    p_loads(slot >> 1);
-                    if (slot == 7) idx_loads();
                 } else if (slot == 8) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (!(HEDGE_ABL & 16) && !HEDGE_EIMG1) eq[j] = bld4s<((HEDGE_NT & 1) ? 2 : 0) | ((HEDGE_SC1 & 1) ? 16 : 0)>(srd_ein, v_eoff, rel * 512 + j * 4096);
+                    for (int j = 0; j < 4; ++j) eq[j] = bld4(srd_ein, v_eoff, rel * 512 + j * 4096);
                     be = be_next;
-                } else if (HEDGE_DEFER && slot == 9) {
-                    rng |= __any(prv[0] != prv[0]) ? 1 : 0;   // range check of block x-1 (see below), ahead of the asm readers
-                } else if (HEDGE_DEFER && (slot == HEDGE_TAIL0 || slot == HEDGE_TAIL1)) {
-                    tail_piece(prv, smem, x1_w + (1 - PAR) * IMG_B, slot == HEDGE_TAIL1);   // image X1 of block x-1
                 }
             };
             SYS_STAMP(t, 2);
-            if (HEDGE_DEFER) mlp_layer(cur, cur, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
-            else mlp_layer(prv, cur, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
+            mlp_layer(acc, c0v, wh, wl, smem, e_r0 + PAR * IMG_B, e_r1 + PAR * IMG_B, side);
             SYS_STAMP(t, 3);
             // range check of the fp16 split: a value that does not fit an operand image is (inf, -inf) as a pair and turns every
             // accumulator of its row into NaN (hmlp.hip: check_rows) -- one comparison per tick, wave-uniform verdict
-            if (!HEDGE_DEFER) {
-                rng |= __any(prv[0] != prv[0]) ? 1 : 0;
-                GM_SB;
-                acc_to_image(prv, smem, x1_w + PAR * IMG_B);
-            }
+            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
+            GM_SB;
+            acc_to_image(acc, smem, x1_w + PAR * IMG_B);
             SYS_STAMP(t, 4);
-            // Rotated tick (HEDGE_ROT0): this wave's MFMAs open the tick -- while roles 1 and 2 merge statistics -- and the
-            // accumulators of block x+1 (rows requested at the top of this tick) are prepared here, behind them, and cross the
-            // barrier in registers: the three roles' matrix phases spread over the tick instead of piling up in its middle.
-            if (HEDGE_ROT0) prepare();
+            // Rotated tick: this wave's MFMAs open the tick -- while roles 1 and 2 merge statistics -- and the accumulators of
+            // block x+1 (rows requested at the top of this tick) are prepared here, behind them, and cross the barrier in
+            // registers: the three roles' matrix phases spread over the tick instead of piling up in its middle.
+            prepare();
             SYS_STAMP(t, 5);
             lds_barrier();
             SYS_STAMP(t, 6);
         };
         // Ticks -1 .. nb + 2: one tick of fill (the e rows and indices of the first block come from the prologue), nb ticks in
         // which blocks enter, three that drain the pipeline: an even count (nb is a multiple of 4), taken as (odd, even) pairs --
-        // at N = 5k a workgroup has 12 blocks, and every fill / drain tick counts.  (HEDGE_DEFER: two more, the two hand-offs take a
-        // tick longer each.)  Plain form: (cur, prv) = (c0v, acc) every tick; deferred form: the two sets change places.
+        // at N = 5k a workgroup has 12 blocks, and every fill / drain tick counts.
 #pragma unroll 1
-        for (int t = -1; t <= nb + 1 + 2 * HEDGE_DEFER; t += 2) {
-            tick(odd, t, c0v, acc);
-            if (HEDGE_DEFER) tick(even, t + 1, acc, c0v);
-            else tick(even, t + 1, c0v, acc);
+        for (int t = -1; t <= nb + 1; t += 2) {
+            tick(odd, t);
+            tick(even, t + 1);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else if (role == 1) {
         // ------------------------------------------------------------------ role 1
-        // Plain form: this role runs Linear 2 of block x-1 and its share of the epilogue of block x-3.  HEDGE_DEFER: role 0's image
-        // arrives a tick later and this role's own goes out a tick later (ReLU + split in the next tick's MFMA gaps): Linear 2 of block
-        // x-2, image X2 of block x-3, epilogue of block x-5 (D = 2 ticks behind the plain schedule).
-        constexpr int D = 2 * HEDGE_DEFER;
-        floatx16 acc, acc2;
+        // This role runs Linear 2 of block x-1 and its share of the epilogue of block x-3.
+        floatx16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         int rng = 0;
-        floatx4 er[EPI_SPLIT + 1];          // e rows (row-major quads, rows 8 j + rr) of block x-3-D for the residual
-        int st_a = e0, cnt_a = 0, st_b = e0, cnt_b = 0;  // blocks x-3-D, x-2-D
-        int2 bi_c = a_blk[b0];                          // raw table entry of block x-1-D (decoded a tick after its load)
+        floatx4 er[EPI_SPLIT + 1];          // e rows (row-major quads, rows 8 j + rr) of block x-3 for the residual
+        int st_a = e0, cnt_a = 0, st_b = e0, cnt_b = 0;  // blocks x-3, x-2
+        int2 bi_c = a_blk[b0];                          // raw table entry of block x-1 (decoded a tick after its load)
         const float res_w = a_residual ? 1.f : 0.f;
         // LayerNorm gamma / beta of this lane's feature quad and the bias of Linear 2 in accumulator layout: constant over the launch
         const floatx4 gm = LDS(floatx4, L_VEC + (2 * H + 32 * jb + 4 * cq) * 4);
         const floatx4 bt = LDS(floatx4, L_VEC + (3 * H + 32 * jb + 4 * cq) * 4);
-        floatx16 b2v;   // b2 T2 in accumulator layout: constant over the launch (plain form: this role has the registers)
+        floatx16 b2v;   // b2 T2 in accumulator layout: constant over the launch (this role has the registers)
         auto init_acc = [&](floatx16& dstv) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -517,7 +438,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 for (int tt = 0; tt < 4; ++tt) dstv[4 * g + tt] = v[tt];
             }
         };
-        if (!HEDGE_DEFER) init_acc(b2v);
+        init_acc(b2v);
         const unsigned st_r = opaque(L_ST + n * 4);
         const unsigned km_w = opaque(L_KM + jb * 128 + n * 4), km_r = opaque(L_KM + jb * 128 + rr * 4);
         const unsigned z_r = opaque(L_Z + jb * TILE_B + rr * TILE_ROW_B + cq * 16);
@@ -525,44 +446,19 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         float* const e_out_wg = a_e_out + (size_t)e0 * H;
 #pragma unroll
         for (int j = 0; j < EPI_SPLIT; ++j) er[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        // HEDGE_EIMG1: the e rows of block x+1 on their way into the operand image E that role 0 multiplies next tick (row 8 j + rr,
-        // this wave's 128-byte slab; the first block's are requested here), written between this role's MFMAs
-        const int kg1 = cq & 1, ksb1 = cq >> 2, half1 = (cq >> 1) & 1;
-        const unsigned e_w = opaque(L_E + ((2 * jb + ksb1) * 2 * 64 + ((rr ^ (2 * (ksb1 + 2 * kg1))) + 32 * kg1)) * 16 + half1 * 8);   // + 128 j, + 1024: lo part
-        floatx4 eq[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) eq[j] = HEDGE_EIMG1 ? bld4(srd_ein, v_eoff, j * 4096) : floatx4{0.f, 0.f, 0.f, 0.f};
-        int2 be = a_blk[clampb(b0 + 1)];   // table entry of block x+2: the rows requested this tick
-        auto tick = [&](auto par_c, int t, floatx16& cur, floatx16& prv) {
-            constexpr int PAR = decltype(par_c)::value, P1 = HEDGE_DEFER ? PAR : 1 - PAR, P3 = 1 - PAR;   // parities of blocks x, this Linear's (x-1 / x-2), x-3-D
+        auto tick = [&](auto par_c, int t) {
+            constexpr int PAR = decltype(par_c)::value, P1 = 1 - PAR, P3 = 1 - PAR;   // parities of blocks x, x-1 (this Linear's), x-3
             const int x = b0 + t;
             SYS_STAMP(t, 0);
-            // 1 / (T sigma) of the rows of block x-3-D: lane n (both halves) -> this wave's table
+            // 1 / (T sigma) of the rows of block x-3: lane n (both halves) -> this wave's table
             if (WRITE_E) LDS(float, km_w) = ln_k(smem, st_r + P3 * 512, inv_T, a_eps);
-            const int cnt_st = ok(x - 3 - D) ? cnt_a : 0;   // rows of block x-3-D that exist (none in the fill / drain ticks)
-            const int2 bi_n = a_blk[clampb(x - D)];     // requested now, used at the end of the tick: the barrier's wait for the
+            const int cnt_st = ok(x - 3) ? cnt_a : 0;   // rows of block x-3 that exist (none in the fill / drain ticks)
+            const int2 bi_n = a_blk[clampb(x)];         // requested now, used at the end of the tick: the barrier's wait for the
                                                         // scalar-memory counter then finds it done
-            if (HEDGE_DEFER) init_acc(cur);   // b2 T2 -> the first MFMA's C operand (from LDS: both register sets are in use), accumulated in place
             const unsigned rel_a = (unsigned)(st_a - e0), rel_b = (unsigned)(st_b - e0);
             float kr;
             floatx4 zq;
-            const int2 be_next = a_blk[clampb(x + 3)];
-            const unsigned rel_e = (unsigned)(be.x - e0);
-            auto side = [&](int slot) {   // LayerNorm + e_out of block x-3-D, row group slot / SIDE_STRIDE
-                if (HEDGE_EIMG1 && slot >= 3 && slot <= 9 && (slot & 1)) {   // e of block x+1 -> image E, one row group per call
-                    const int j = (slot - 3) >> 1;
-                    uintx2 h, l;
-                    split4(eq[j][0], eq[j][1], eq[j][2], eq[j][3], h, l);
-                    LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128) = h;
-                    LDS(uintx2, e_w + (1 - PAR) * IMG_B + j * 128 + 1024) = l;
-                }
-                if (HEDGE_EIMG1 && slot == 10) {   // ... then the rows of block x+2 are requested into the same registers
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) eq[j] = bld4(srd_ein, v_eoff, rel_e * 512 + j * 4096);
-                    be = be_next;
-                }
-                if (HEDGE_DEFER && slot == 9) rng |= __any(prv[0] != prv[0]) ? 1 : 0;   // range check of block x-3, ahead of the asm readers
-                if (HEDGE_DEFER && (slot == HEDGE_TAIL0 || slot == HEDGE_TAIL1)) tail_piece(prv, smem, x_out + (1 - PAR) * IMG_B, slot == HEDGE_TAIL1);
+            auto side = [&](int slot) {   // LayerNorm + e_out of block x-3, row group slot / SIDE_STRIDE
                 if (!WRITE_E || slot >= EPI_SPLIT * SIDE_STRIDE) return;   // the other row groups are role 2's (balance of the roles' ticks)
                 const int j = slot / SIDE_STRIDE;
                 if (slot % SIDE_STRIDE == 0) {
@@ -574,20 +470,16 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(er[j][tt], res_w, fmaf(zq[tt] * kr, gm[tt], bt[tt]));
                     // rows past the block's end (and every row of a fill / drain tick) lie beyond the resource's byte count: dropped
                     // (the block's position is in the resource's base: gfx9 subtracts a scalar offset from the byte count)
-                    if (!(HEDGE_ABL & 4)) bst4s<((HEDGE_NT & 4) ? 2 : 0) | ((HEDGE_SC1 & 4) ? 16 : 0) | ((HEDGE_SC1 & 16) ? 1 : 0)>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
-                    if (!(HEDGE_ABL & 1)) er[j] = bld4s<((HEDGE_NT & 2) ? 2 : 0) | ((HEDGE_SC1 & 2) ? 16 : 0)>(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
+                    bst4s<STREAM ? ST_STREAM_E : 0>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
+                    er[j] = bld4(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
                 }
             };
             SYS_STAMP(t, 1);
             SYS_STAMP(t, 2);
-            if (HEDGE_DEFER) {
-                mlp_layer(cur, cur, wh, wl, smem, x_in + P1 * IMG_B, x_in + P1 * IMG_B, side);
-            } else {
-                mlp_layer(cur, b2v, wh, wl, smem, x_in + P1 * IMG_B, x_in + P1 * IMG_B, side);
-                rng |= __any(cur[0] != cur[0]) ? 1 : 0;
-                GM_SB;
-                acc_to_image(cur, smem, x_out + P1 * IMG_B);
-            }
+            mlp_layer(acc, b2v, wh, wl, smem, x_in + P1 * IMG_B, x_in + P1 * IMG_B, side);
+            rng |= __any(acc[0] != acc[0]) ? 1 : 0;
+            GM_SB;
+            acc_to_image(acc, smem, x_out + P1 * IMG_B);
             SYS_STAMP(t, 3);
             SYS_STAMP(t, 4);
             st_a = st_b; cnt_a = cnt_b;
@@ -598,10 +490,9 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 6);
         };
 #pragma unroll 1
-        for (int t = -1; t <= nb + 1 + 2 * HEDGE_DEFER; t += 2) {
-            tick(odd, t, acc, acc2);
-            if (HEDGE_DEFER) tick(even, t + 1, acc2, acc);
-            else tick(even, t + 1, acc, acc2);
+        for (int t = -1; t <= nb + 1; t += 2) {
+            tick(odd, t);
+            tick(even, t + 1);
         }
         if (rng && lane0 == 0) atomicOr(a_flags, ERRF_SPLIT_RANGE);
     } else {
@@ -659,7 +550,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
         };
         auto tick = [&](auto par_c, int t) {
             constexpr int PAR = decltype(par_c)::value, P2 = PAR, P3 = 1 - PAR;   // parities of blocks x-2, x-3
-            const int x = b0 + t - 2 * HEDGE_DEFER;   // HEDGE_DEFER: the images reach this role two ticks later (same parities)
+            const int x = b0 + t;
             // table entries of block x (decoded next tick): requested at the top, so that the barrier's scalar-memory wait finds them done
             const int2 bn_n = a_blk[clampb(x)], sn_n = a_seg[clampb(x)];
             const int hd_n = a_head[clampb(x - 1) >> 2];   // head of block x-1's group (used if that block opens its group)
@@ -717,8 +608,8 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                             floatx4 o;
 #pragma unroll
                             for (int tt = 0; tt < 4; ++tt) o[tt] = fmaf(er[j - EPI_SPLIT][tt], res_w, fmaf(ezq[tt] * ek, gmq[tt], btq[tt]));
-                            if (!(HEDGE_ABL & 4)) bst4s<((HEDGE_NT & 4) ? 2 : 0) | ((HEDGE_SC1 & 4) ? 16 : 0) | ((HEDGE_SC1 & 16) ? 1 : 0)>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
-                            if (!(HEDGE_ABL & 1)) er[j - EPI_SPLIT] = bld4s<((HEDGE_NT & 2) ? 2 : 0) | ((HEDGE_SC1 & 2) ? 16 : 0)>(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
+                            bst4s<STREAM ? ST_STREAM_E : 0>(make_srd(e_out_wg + (size_t)(rel_a + 8 * j) * H, (unsigned)s_clamp0(cnt_st - 8 * j, 8) * 512u), v_eoff, 0, o);
+                            er[j - EPI_SPLIT] = bld4(srd_ein, v_eoff, rel_b * 512 + j * 4096);   // residual rows of block x-2: a whole tick to arrive
                         }
                     }
                 }
@@ -739,7 +630,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                     if (__builtin_amdgcn_inverse_ballot_w64(mk)) {
                         const int d = LDS(int, drp + 4 * r);
                         const unsigned off = (d == head_a ? side_row : (unsigned)d * (H * 4u)) + v_aoff;
-                        if (!(HEDGE_ABL & 8)) bst1(srd_agg, off, 0, y[r] + cpend);
+                        bst1s<STREAM ? ST_STREAM_AGG : 0>(srd_agg, off, 0, y[r] + cpend);
                         cpend = 0.f;
                     }
                 }
@@ -747,17 +638,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 const float nc = upper_half_to_both(y[15] + cpend);
                 carry = (((last >> 31) & 1u) || !agg_on || cnt_a < BE) ? 0.f : nc;
             };
-            if (HEDGE_ROT2) {
-                // Late matrix phase: the scatter-add of block x-3 runs first, as plain code, and this wave's MFMAs start when the
-                // other roles' are under way (the three roles' matrix phases spread over the tick); only the e_out epilogue stays
-                // between the MFMAs.
-#pragma unroll
-                for (int sl = 0; sl < 14; ++sl) side(sl);
-                stores();
-                mlp_layer(acc, b3v, wh, wl, smem, x_in + P2 * IMG_B, x_in + P2 * IMG_B, [&](int slot) { if (slot >= 14) side(slot); });
-            } else {
-                mlp_layer(acc, b3v, wh, wl, smem, x_in + P2 * IMG_B, x_in + P2 * IMG_B, side);
-            }
+            mlp_layer(acc, b3v, wh, wl, smem, x_in + P2 * IMG_B, x_in + P2 * IMG_B, side);
             SYS_STAMP(t, 3);   // 24 MFMAs with the scatter-add between them
             rng |= __any(acc[0] != acc[0]) ? 1 : 0;
             {
@@ -777,7 +658,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
                 }
             }
             SYS_STAMP(t, 4);   // statistics + Z written
-            if (!HEDGE_ROT2) stores();
+            stores();
             cnt_a = cnt_b; fl_a = fl_b; cont_a = cont_b; last_a = last_b;
             if (fl_b & 1) head_a = head_b;
             st_a = st_b;
@@ -789,7 +670,7 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_edge_kernel(const CsrHeade
             SYS_STAMP(t, 6);   // every wave of the workgroup has finished the tick
         };
 #pragma unroll 1
-        for (int t = -1; t <= nb + 1 + 2 * HEDGE_DEFER; t += 2) {
+        for (int t = -1; t <= nb + 1; t += 2) {
             tick(odd, t);
             tick(even, t + 1);
         }
@@ -1619,7 +1500,11 @@ bool edge_sys_fits(int64_t n_nodes, int64_t edge_capacity) {
     return (uint64_t)n_nodes * 2 * H * 4 < (1ull << 32) && agg_rows * H * 4 < (1ull << 32);
 }
 
-int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
+#ifndef HEDGE_STREAM_MB
+#define HEDGE_STREAM_MB 128   // A/B builds move it; 0 = always stream (round 5's policy), a huge value = never
+#endif
+constexpr uint64_t kStreamStoreBytes = (uint64_t)HEDGE_STREAM_MB << 20;
+int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, int64_t edge_capacity, hipStream_t s) {
     GM_REQUIRE(a.hdr && a.wstream_h3 && a.agg && a.side && !a.eid && !a.eid_out, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: unsupported argument combination");
     GM_REQUIRE(a.P_prescaled, GM_ERR_INVALID_ARGUMENT, "launch_edge_sys: P must carry the weight scale of this step (NodeArgs::p_scale = edge_sys_p_scale(image))");
     // the scatter-add addresses agg rows and side rows with 32-bit byte offsets from agg (carve_fwd puts them in one workspace)
@@ -1628,8 +1513,10 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
                "launch_edge_sys: P and agg + side buffer must each stay below 4 GiB (edge_sys_fits)");
     static PerDeviceOnce attr_done;
     const int rc_attr = attr_done.run([]() -> int {
-        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
-        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
+        GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sys_edge_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYS_LDS_BYTES));
         return GM_OK;
     });
     if (rc_attr != GM_OK) return rc_attr;
@@ -1637,14 +1524,16 @@ int launch_edge_sys(const EdgeArgs& a, const EdgeBlocks& t, hipStream_t s) {
         ProfScope prof(a.prof, PROF_EDGE, s);
         // pointers as separate __restrict__ parameters (e_in / e_out may be the same array): the table reads are then provably
         // unclobbered and become scalar loads
-        if (a.discard_e_out)
-            hipLaunchKernelGGL(sys_edge_kernel<false>, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
+        // Store policy by size (ST_STREAM_*): the edge rows of the launch's capacity against what the 256 MB Infinity Cache can keep from
+        // one launch to the next beside h, P and agg.  The capacity, not the device-side edge count: no host synchronisation.
+        const bool stream = (uint64_t)edge_capacity * H * 4 > kStreamStoreBytes;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
                                a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, (unsigned)(a.side - a.agg), (unsigned)agg_bytes,
                                (unsigned)((uint64_t)a.n_nodes_tab * 2 * H * 4), const_cast<int*>(&a.hdr->error_flags), a.eps, a.residual);
-        else
-            hipLaunchKernelGGL(sys_edge_kernel<true>, dim3(device_cus()), dim3(SYS_THREADS), SYS_LDS_BYTES, s, a.hdr, a.dst, a.src, a.P, a.e_in, a.e_out,
-                               a.agg, a.wstream_h3, t.blk, t.seg, t.head, t.hdr, (unsigned)(a.side - a.agg), (unsigned)agg_bytes,
-                               (unsigned)((uint64_t)a.n_nodes_tab * 2 * H * 4), const_cast<int*>(&a.hdr->error_flags), a.eps, a.residual);
+        };
+        if (a.discard_e_out) { if (stream) go(sys_edge_kernel<false, true>); else go(sys_edge_kernel<false, false>); }
+        else { if (stream) go(sys_edge_kernel<true, true>); else go(sys_edge_kernel<true, false>); }
     }
     GM_LAUNCH_CHECK();
     return GM_OK;

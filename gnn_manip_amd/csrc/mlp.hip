@@ -48,7 +48,7 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     const EdgeArgs& a = a_in;
     const int choice = a.kernel_choice;
     if (!enc && edge_launch_is_sys(H, NL, a, edge_capacity))
-        return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), s);
+        return launch_edge_sys(a, carve_edge_blocks(const_cast<int*>(a.edge_blocks), a.n_nodes_tab, edge_capacity), edge_capacity, s);
     GM_REQUIRE(enc || !a.P_prescaled, GM_ERR_INVALID_ARGUMENT, "edge kernel: P carries the systolic kernel's scale, but the launch is not its");
     // the encoder phi_e in the same weight-stationary form: 4 raw features per edge, rows in sorted order (the rollout path)
     if (enc && H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && a.wstream_h3 && a.hdr && !a.eid && a.k1 == 4 &&

@@ -525,6 +525,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     rc = launch_edge(H, NL, true, enc_edge_args(m, edge_attr, attr_is_csr_order ? nullptr : c.eid, c.hdr, 0, f.e), cap, s);
     if (rc != GM_OK) return rc;
     if (cap > 0) {
+        ProfScope prof(m->prof, PROF_REST, s);
         rc = zero_edge_pad_rows(c.hdr, f.e, H, s);
         if (rc != GM_OK) return rc;
     }
@@ -556,7 +557,10 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     if (rc == GM_OK && sys_node) rc = project(0);
     if (rc != GM_OK) return rc;
     // agg is zeroed once (nodes without in-edges read zeros; rows with in-edges are stored whole by every edge launch)
-    GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
+    {
+        ProfScope prof(m->prof, PROF_REST, s);
+        GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
+    }
     for (int k = 0; k < M; ++k) {
         EdgeArgs ea = proc_edge_args(m, k, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, f.side, 1);
         ea.discard_e_out = k + 1 == M;   // the decoder reads h only (epd_gnn.py:96): the last step's e + e' is never looked at
@@ -728,7 +732,7 @@ int gm_model_profile(gm_model* m, int kind_mask) {
         m->prof = new ProfState();
     }
     for (int k = 0; k < PROF_KINDS; ++k)
-        if (((kind_mask & ~m->prof->mask) >> k) & 1) m->prof->count[k] = 0;  // newly enabled kinds start from zero
+        if (((kind_mask & ~m->prof->mask) >> k) & 1) m->prof->count[k] = m->prof->dropped[k] = 0;  // newly enabled kinds start from zero
     m->prof->mask = kind_mask;
     return GM_OK;
 }
@@ -739,7 +743,9 @@ int gm_model_profile_query(const gm_model* m, int kind, int64_t* launches, doubl
     *total_ms = 0.0;
     const ProfState* p = m->prof;
     if (!p) return GM_OK;
-    *launches = p->count[kind];
+    // scopes beyond the kind's PROF_MAX event pairs were not timed: the count comes back NEGATIVE (minus the scopes opened) and the
+    // total covers the first PROF_MAX only -- a caller that divides by steps must not use it
+    *launches = p->dropped[kind] ? -(int64_t)(p->count[kind] + p->dropped[kind]) : p->count[kind];
     for (int i = 0; i < p->count[kind]; ++i) {
         GM_HIP_CHECK(hipEventSynchronize(p->stop[kind][i]));
         float ms = 0.f;
@@ -769,7 +775,10 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
     int rc;
     hipStream_t hs = (hipStream_t)stream;
     // state_pre + node features in one launch
-    rc = gm::rollout_pre_features(obs, n, fd, rigid_rank, rigid_target, r.x, hs);
+    {
+        ProfScope prof(m->prof, PROF_REST, hs);
+        rc = gm::rollout_pre_features(obs, n, fd, rigid_rank, rigid_target, r.x, hs);
+    }
     if (rc != GM_OK) return rc;
     const float* last_pos = obs + (size_t)(fd->k_steps - 1) * n * fd->data_dim + fd->cart_col;
     {
@@ -779,12 +788,16 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
     }
     if (rc != GM_OK) return rc;
     // destination sort; the edge features are written by the same pass that fixes each segment's order
-    rc = gm::csr_from_graph_with_features(r.graph, n, K, r.csr, r.csr_bytes, last_pos, fd->data_dim, (float)fd->conn_r,
-                                          r.edge_attr, m->d.flow, hs);
+    {
+        ProfScope prof(m->prof, PROF_REST, hs);
+        rc = gm::csr_from_graph_with_features(r.graph, n, K, r.csr, r.csr_bytes, last_pos, fd->data_dim, (float)fd->conn_r,
+                                              r.edge_attr, m->d.flow, hs);
+    }
     if (rc != GM_OK) return rc;
     rc = gm_epd_forward(m, r.x, n, r.edge_attr, 1, r.csr, cap, r.pred, r.fwd, r.fwd_bytes, stream);
     if (rc != GM_OK) return rc;
     // integrator + window shift + write-back (+ copy of the prediction) in one launch
+    ProfScope prof(m->prof, PROF_REST, hs);
     return gm::rollout_integrate_post(obs, n, fd, r.pred, rigid_rank, rigid_target, pred_acc_out, hs);
 }
 

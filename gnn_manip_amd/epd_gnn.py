@@ -75,8 +75,11 @@ class _Handle:
         self.edge_kernel = 0
         self.prof_mask = 0
 
-    def get(self, desc_tuple, params, device):
-        key = (desc_tuple, str(device), tuple((p.data_ptr(), p._version) for p in params))
+    def get(self, desc_tuple, params, device, key_params=None):
+        """key_params: the tensors whose (address, version) decide whether `params` changed -- `params` themselves, unless those are
+        DERIVED tensors (EncProcDecGNN._padded_training builds fresh padded copies every step: version 0 always, and the caching
+        allocator hands out the same addresses step after step), in which case the caller names the parameters they derive from."""
+        key = (desc_tuple, str(device), tuple((p.data_ptr(), p._version) for p in (params if key_params is None else key_params)))
         if self.h is not None and key == self.key:
             return self.h
         L = lib()
@@ -418,14 +421,15 @@ class _EpdTrainFunction(torch.autograd.Function):
     """``EncProcDecGNN.forward`` under autograd (examples/train_dyn.py:45-72): the forward records the
     activation tape in one device buffer, the backward is gm_epd_backward.  Gradients are produced for the
     parameters only; nodes / edge_attr / edge_index are data.  `spec` = (model descriptor tuple, _Handle): the module's own, or
-    -- for a hidden size between the training kernels' widths -- the zero-padded model's (EncProcDecGNN._padded_training)."""
+    -- for a hidden size between the training kernels' widths -- the zero-padded model's (EncProcDecGNN._padded_training), with
+    the module's own parameters as the third element: the tensors whose versions say when the padded copies are stale."""
 
     @staticmethod
     def forward(ctx, module, spec, nodes, edge_attr, edge_index, *params):
         L = lib()
         n, e = int(nodes.shape[0]), int(edge_attr.shape[0])
-        desc_tuple, handle = spec
-        h = handle.get(desc_tuple, list(params), nodes.device)
+        desc_tuple, handle, key_params = spec
+        h = handle.get(desc_tuple, list(params), nodes.device, key_params)
         d = ModelDesc(*desc_tuple)
         tape = _ws(L.gm_train_tape_bytes(C.byref(d), n, e), nodes.device)
         out = torch.empty((n, module.dims[2]), dtype=torch.float32, device=nodes.device)
@@ -583,6 +587,8 @@ class EncProcDecGNN(nn.Module):
         """Re-pack the device weight images on next use (after writes through ``.data`` / raw pointers, which the
         version counters do not see)."""
         self._handle.invalidate()
+        if "_pad_handle" in self.__dict__:   # the zero-padded training model of a hidden size between the kernels' widths
+            self._pad_handle.invalidate()
 
     def set_edge_kernel(self, choice):
         """Processor edge kernel of this model (diagnostics / A-B measurements; no reference counterpart): 'auto', 'sys'
@@ -609,17 +615,21 @@ class EncProcDecGNN(nn.Module):
             # edge_index entries outside [0, n) are flagged on the device by the forward's destination sort (and left out; the
             # kernels stay inside their arrays): no blocking range check here -- a training loop queues its steps ahead of the GPU.
             # The flag surfaces as GMError at a later forward (auto_status) or at status(), like the inference path's.  Until it
-            # does, the flagged step is harmless by construction: its prediction is NaN and its backward returns zero gradients
-            # (csrc/train_model.hip: poison_if_flagged_kernel / gate_grad_out_kernel), so the optimiser steps that run before the
-            # error is raised leave the weights where a raise at the forward (the reference's behaviour) would have left them.
+            # does, the flagged step cannot inject garbage: its prediction is NaN (so its loss is, visibly) and its backward returns
+            # exactly zero gradients (csrc/train_model.hip: poison_if_flagged_kernel / gate_grad_out_kernel).  That is NOT the same
+            # as the reference's raise at the forward for every optimiser: plain SGD leaves the weights alone on a zero gradient,
+            # but Adam (train_dyn.py:58) still advances its step count, decays its moment estimates and moves the weights along its
+            # first-moment history, and weight decay applies as always -- for the one to eight steps until the error is raised.
             _check_edge_index(edge_index, n, e, ranges=False)
             if self.auto_status:
                 self._reap_watched(block=False)
             hidden = self.dims[3]
             if hidden in TRAIN_WIDTHS:
-                return _EpdTrainFunction.apply(self, (self.model_desc(), self._handle), nodes, edge_attr, edge_index, *params)
+                return _EpdTrainFunction.apply(self, (self.model_desc(), self._handle, None), nodes, edge_attr, edge_index, *params)
             spec, padded = self._padded_training(params)
-            return _EpdTrainFunction.apply(self, spec, nodes, edge_attr, edge_index, *padded)
+            # the padded tensors are rebuilt every step (version 0, recycled addresses): the handle is keyed on the parameters they
+            # come from, so an optimiser step on ANY of them -- whatever is frozen -- re-packs the padded model's weight streams
+            return _EpdTrainFunction.apply(self, spec + (tuple(params),), nodes, edge_attr, edge_index, *padded)
         if self.auto_status:
             # EARLIER inference forwards of this model: a device-side error (edge_index entry out of range, fp16 split range
             # exceeded) of one that has FINISHED surfaces here -- a reference-style caller never calls status() itself.
@@ -648,8 +658,12 @@ class EncProcDecGNN(nn.Module):
         w = self.__dict__.setdefault("_watched", [])
         if "_watch_pin" not in self.__dict__ or self._watch_pin.device != torch.device("cpu"):
             self._watch_pin, self._watch_next = torch.zeros((self._WATCH_SLOTS, 4), dtype=torch.int32).pin_memory(), 0
-        if len(w) >= self._WATCH_SLOTS:   # every pinned row in use: the oldest forward is waited for (a loop 8 forwards ahead of the GPU)
-            self._reap_watched(block=True, at_most=1)
+        if len(w) >= self._WATCH_SLOTS:   # every pinned row in use (a loop 8 forwards ahead of the GPU)
+            if self.auto_status:
+                self._reap_watched(block=True, at_most=1)   # the oldest forward is waited for, its error raised here
+            else:
+                w.pop(0)   # the caller opted out of unasked checks: the oldest watch is dropped unread, nothing blocks or raises (its
+                           # row is reused: the new copy is queued behind the old one on the same stream)
         is_csr = isinstance(csr, DstCsr)   # else: a training tape (it begins with the forward's csr workspace); not kept alive here
         w.append((_HeaderWatch(csr.ws if is_csr else csr, self._watch_pin[self._watch_next]), csr if is_csr else None))
         self._watch_next = (self._watch_next + 1) % self._WATCH_SLOTS

@@ -178,6 +178,7 @@ class TrajectoryCMAsolver:
         c0 = graph_attr.cartesian_idx[0]
         self.rigid_particles_idx = obs[-1, :, mat] == 1
         self.coffee_particles_idx = obs[-1, :, mat] == 0
+        self._coffee_rows = torch.nonzero(self.coffee_particles_idx).reshape(-1)   # taken once: a boolean-mask index synchronises per use
         self.rigid_particles = obs[-1, self.rigid_particles_idx, c0:c0 + 3].contiguous()
         self.loss = SamplesLoss(loss="sinkhorn", p=2, blur=.05)
         self.cma_options = cmaes.CMAOptions()
@@ -229,7 +230,11 @@ class TrajectoryCMAsolver:
         return 0.0
 
     def compute_loss(self, end_position, actions, cup_states=None, coffee_states=None, x=None):
-        wasserstein_loss = float(self.loss(end_position, self.desired_pos).item())
+        """traj_utils.py:275-285 for one candidate (one device loss, one transfer)."""
+        return self._assemble_loss(float(self.loss(end_position, self.desired_pos).item()), actions, x)
+
+    def _assemble_loss(self, wasserstein_loss, actions, x=None):
+        """Everything of compute_loss but the Wasserstein term itself: host float64 like the reference."""
         vel, acc = self.compute_vel_acc(actions)
         vel_loss, acc_loss = self.compute_vel_loss(vel), self.compute_acc_loss(acc)
         bound_penalty = self.compute_boundaries_penalty(actions)
@@ -243,19 +248,21 @@ class TrajectoryCMAsolver:
         return self._engines[b]
 
     def _end_positions(self, final_states):
+        """final_states [B, k, N, D] -> the coffee particles' end positions [B, Nc, 3] (traj_utils.py:154-155)."""
         c0 = self.graph_attr.cartesian_idx[0]
-        return [fs[-1, self.coffee_particles_idx, c0:c0 + 3].contiguous() for fs in final_states]
+        return final_states[:, -1].index_select(1, self._coffee_rows)[:, :, c0:c0 + 3].contiguous()
 
     def cma_objective(self, x):
         """traj_utils.py:114-159 for one candidate."""
-        return self._block_losses([np.asarray(x, dtype=np.float64)])[0]
+        return self._local_losses([np.asarray(x, dtype=np.float64)])[0]
 
-    def _block_losses(self, xs):
+    def _block_ends(self, xs):
+        """Block-diagonal batched rollout of the candidates xs: their end clouds [B, Nc, 3] (device) and action arrays."""
         trajs, acts = zip(*[self.get_rigid_body_trajectory_from_diff(x) for x in xs])
         eng = self._engine(len(xs))
         with torch.no_grad():
             finals = eng.rollout_candidates(self.initial_state[0].contiguous(), torch.stack(trajs), horizon=self.horizon)
-        return [self.compute_loss(end, a)[0] for end, a in zip(self._end_positions(finals), acts)]
+        return self._end_positions(finals), list(acts)
 
     def population_losses(self, X):
         """Losses of a whole generation.  Under torch.distributed rank 0's X is broadcast and every rank evaluates
@@ -268,11 +275,20 @@ class TrajectoryCMAsolver:
             return ev.evaluate_blocks(X, self._local_losses).reshape(-1).tolist()
         return self._local_losses(X)
 
+    _loss_takes_x = False   # InterpolatedCMAsolver.compute_loss reads the search variables too
+
     def _local_losses(self, X):
-        out = []
+        """This rank's candidates: rollouts in blocks of `candidates_per_gpu`, then the Wasserstein terms of ALL of them in one
+        batched launch sequence (SamplesLoss.batched) and ONE transfer of the values; the penalty terms on the host."""
+        if not len(X):
+            return []
+        ends, acts = [], []
         for b in range(0, len(X), self.candidates_per_gpu):
-            out += self._block_losses(X[b:b + self.candidates_per_gpu])
-        return out
+            e, a = self._block_ends(X[b:b + self.candidates_per_gpu])
+            ends.append(e)
+            acts += a
+        w = self.loss.batched(torch.cat(ends), self.desired_pos).double().cpu().numpy()
+        return [self._assemble_loss(float(w[i]), acts[i], X[i] if self._loss_takes_x else None)[0] for i in range(len(X))]
 
     def _start_point(self):
         """The search starts at the sample trajectory: all rotation variables, then all translation variables."""
@@ -336,20 +352,14 @@ class InterpolatedCMAsolver(TrajectoryCMAsolver):
         upper = np.abs(vel) - np.array([self.max_rot * self.nr_traj_points, self.max_ty * self.nr_traj_points])
         return np.concatenate((upper[:, 0] / self.scale_rot, upper[:, 1] / self.scale_ty))
 
-    def compute_loss(self, end_position, actions, cup_states=None, coffee_states=None, x=None):
-        wasserstein_loss = float(self.loss(end_position, self.desired_pos).item())
+    _loss_takes_x = True
+
+    def _assemble_loss(self, wasserstein_loss, actions, x=None):
         vel, acc = self.compute_vel_acc(actions)
         vel_loss, acc_loss = self.compute_vel_loss(vel), self.compute_acc_loss(acc)
         interp_loss = self.compute_vel_noninterp(x) if x is not None else 0.0
         loss = self.beta * wasserstein_loss + self.alpha * vel_loss + self.gamma * acc_loss + self.rho * interp_loss
         return loss, wasserstein_loss, vel_loss, acc_loss, interp_loss, 0.0
-
-    def _block_losses(self, xs):
-        trajs, acts = zip(*[self.get_rigid_body_trajectory_from_diff(x) for x in xs])
-        eng = self._engine(len(xs))
-        with torch.no_grad():
-            finals = eng.rollout_candidates(self.initial_state[0].contiguous(), torch.stack(trajs), horizon=self.horizon)
-        return [self.compute_loss(end, a, x=x)[0] for end, a, x in zip(self._end_positions(finals), acts, xs)]
 
     def optimize_trajectory(self, desired_position):
         """traj_utils.py:324-337."""

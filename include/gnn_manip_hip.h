@@ -296,6 +296,17 @@ int gm_interaction_network_backward(const gm_model* m, int block, const float* c
 size_t gm_sinkhorn_workspace_bytes(int64_t n, int64_t m);
 int gm_sinkhorn_divergence(const float* x, int64_t n, const float* y, int64_t m, float blur, float scaling,
                            float* loss_device, void* ws, size_t ws_bytes, void* stream);
+/* The losses of a whole block of candidates in one launch sequence (ABI 7) -- the loop of traj_utils.py:279 over the
+ * candidates of a CMA-ES generation (traj_utils.py:247-259), `batch` clouds x [batch, N, 3] against y [M, 3]
+ * (y_shared != 0: the desired cloud of the planner) or [batch, M, 3].  Pair b gets the epsilon schedule a call of
+ * gm_sinkhorn_divergence on it alone would have used (its own bounding-box diameter), and loss_device[b] equals
+ * that call's result bit for bit; pairs with shorter schedules idle through the tail of the longest one.
+ * diameter > 0: geomloss's `diameter=` keyword -- every pair takes it and NO host synchronisation happens;
+ * diameter <= 0 (geomloss default): one host synchronisation per call (the longest schedule = the launch count). */
+size_t gm_sinkhorn_batched_workspace_bytes(int64_t batch, int64_t n, int64_t m);
+int gm_sinkhorn_divergence_batched(const float* x, int64_t batch, int64_t n, const float* y, int64_t m, int y_shared,
+                                   float blur, float scaling, float diameter, float* loss_device /*[batch]*/, void* ws,
+                                   size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * One device-resident rollout step = compute_rollout's loop body, rollout_utils.py:38-61 ==
@@ -338,8 +349,11 @@ int gm_rollout_status(const void* rollout_ws, const gm_model_desc* desc, int64_t
  * time.time(), examples/optimise_traj.py:99-103).  Per model handle: when enabled, launches made on behalf of THIS
  * model are bracketed with HIP events on their launch stream; other handles and streams are unaffected.
  * kind: 0 processor edge kernel, 1 processor node kernel, 2 radius-graph build of gm_rollout_step (all its kernels),
- * 3 encoder kernels; kind_mask has bit `kind` set for every kind to record (0 disables; a newly enabled kind
- * restarts its counters).  gm_model_profile_query synchronises on the recorded events.
+ * 3 encoder kernels, 4 the rest of gm_rollout_step (state update + node features, destination sort + block tables + edge
+ * features, clears, integration + window shift: kinds 0 .. 4 add up to the step); kind_mask has bit `kind` set for every kind
+ * to record (0 disables; a newly enabled kind restarts its counters).  gm_model_profile_query synchronises on the recorded
+ * events.  A kind records at most 4096 scopes: once more were opened, *launches comes back NEGATIVE (minus the number opened) and
+ * *total_ms covers the first 4096 only.
  * ------------------------------------------------------------------------------------------ */
 int gm_model_profile(gm_model* model, int kind_mask);
 int gm_model_profile_query(const gm_model* model, int kind, int64_t* launches, double* total_ms);

@@ -513,7 +513,7 @@ def rollout(params, obs0, trajectory, horizon, stats, bounds, conn_r, cartesian_
 # --------------------------------------------------------------------------------------
 # planner loss (gnn_manip/utils/traj_utils.py:69,161-165,230-285)
 # --------------------------------------------------------------------------------------
-def sinkhorn_divergence(x, y, blur=0.05, scaling=0.5, dtype=np.float64):
+def sinkhorn_divergence(x, y, blur=0.05, scaling=0.5, dtype=np.float64, diameter=None):
     """geomloss.SamplesLoss(loss="sinkhorn", p=2, blur=blur) between two uniform clouds (call sites
     traj_utils.py:69,279).  geomloss is an un-vendored, un-pinned pip dependency (environment.yml:25): this is a
     restatement of its published algorithm (Feydy et al. 2019; geomloss sinkhorn_divergence.py `sinkhorn_loop` /
@@ -524,7 +524,9 @@ def sinkhorn_divergence(x, y, blur=0.05, scaling=0.5, dtype=np.float64):
     y = np.asarray(y, dtype)
     n, m = x.shape[0], y.shape[0]
     both = np.concatenate((x, y)).astype(np.float32)
-    diameter = float(np.sqrt(((both.max(0) - both.min(0)).astype(np.float32) ** 2).sum(dtype=np.float32)))
+    if diameter is None:   # geomloss: max_diameter of the two clouds unless the caller names one (`diameter=` keyword)
+        diameter = float(np.sqrt(((both.max(0) - both.min(0)).astype(np.float32) ** 2).sum(dtype=np.float32)))
+    diameter = float(np.float32(diameter))
     if diameter == 0.0:
         return 0.0
     eps_s = [diameter ** 2] + [float(np.exp(e)) for e in np.arange(2 * np.log(diameter), 2 * np.log(blur), 2 * np.log(scaling))] + [blur ** 2]

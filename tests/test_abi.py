@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     handle = _lib.lib()
     for name in declared:
         assert hasattr(handle, name), name
-    assert handle.gm_abi_version() == 6
+    assert handle.gm_abi_version() == 7
 
 
 def test_workspace_queries_and_host_side_errors():

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import BOUNDS, CART, CTRL, G1_CASES, MAT, STATS
+from conftest import BOUNDS, CART, CTRL, G1_CASES, MAT, STATS, assert_forward_close
 from oracle import epd_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -240,7 +240,7 @@ def test_epd_forward_golden(golden, dev):
     with torch.no_grad():
         out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
     ref = g7["h128.out"]
-    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()  # north_star: 1e-5 relative fp32
+    assert_forward_close(out, ref)  # north_star: 1e-5 relative fp32, per element
 
 
 @pytest.mark.parametrize("n,side,seed", [(3000, 0.11, 61), (130, 0.3, 62), (1, 0.1, 63)])
@@ -255,7 +255,7 @@ def test_epd_forward_vs_oracle(dev, n, side, seed):
     with torch.no_grad():
         out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
     ref = orc.epd_forward(params, nodes, ea, ei, 2, 10)
-    assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
+    assert_forward_close(out, ref, floor=1e-3)
 
 
 @pytest.mark.parametrize("n,side,seed", [(700, 0.075, 65), (129, 0.2, 66)])
@@ -278,7 +278,7 @@ def test_epd_forward_hidden_256_vs_oracle(dev, n, side, seed):
     np.testing.assert_allclose(e1.cpu().numpy(), e1o, rtol=1e-5, atol=5e-6)
     np.testing.assert_allclose(h1.cpu().numpy(), h1o, rtol=1e-5, atol=5e-6)
     ref = orc.epd_forward(params, nodes, ea, ei, 2, 10)
-    assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
+    assert_forward_close(out, ref, floor=1e-3)
 
 
 def test_unsupported_sizes_fail_loudly(dev):
@@ -544,7 +544,7 @@ def test_every_processor_edge_kernel_form_vs_oracle(dev, choice, name):
         with torch.no_grad():
             out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
         ref = orc.epd_forward(params, nodes, ea, ei, 2, 10)
-        assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3), (name, n)
+        assert_forward_close(out, ref, floor=1e-3, what=(name, n))
 
 
 @pytest.mark.parametrize("seed", [71, 72, 73, 74, 75])
@@ -599,7 +599,7 @@ def test_block_convention_switch_forward_block_and_rollout(dev, conv):
         out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
     ref = orc.epd_forward(params, nodes, ea, ei, 2, 3, **conv)
     dflt = orc.epd_forward(params, nodes, ea, ei, 2, 3)
-    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert_forward_close(out, ref)
     assert np.abs(ref - dflt).max() > 1e-3 * np.abs(ref).max()   # the conventions really differ on this (asymmetric) graph
     # standalone block
     h0, e0 = orc.graph_independent(params, "encoder", nodes, ea, 2)
@@ -674,7 +674,7 @@ def test_epd_h64_l3_golden(golden, dev):
     np.testing.assert_allclose(h1.cpu().numpy(), g7["h64_l3_m2.h1"], rtol=1e-5, atol=5e-6)
     np.testing.assert_allclose(e1.cpu().numpy()[:64], g7["h64_l3_m2.e1_head"], rtol=1e-5, atol=5e-6)
     ref = g7["h64_l3_m2.out"]
-    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert_forward_close(out, ref)
 
 
 @pytest.mark.parametrize("hid,nl,ms", [(64, 2, 3), (64, 5, 2), (128, 3, 3), (128, 2, 3), (256, 2, 3), (256, 4, 2)])
@@ -692,7 +692,7 @@ def test_epd_any_size_vs_oracle(dev, hid, nl, ms):
         with torch.no_grad():
             out = m.forward(_t(nodes, dev), _t(ea, dev), _t(ei, dev)).cpu().numpy()
         ref = orc.epd_forward(params, nodes, ea, ei, nl, ms)
-        assert np.abs(out - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3), (n, np.abs(out - ref).max(), np.abs(ref).max())
+        assert_forward_close(out, ref, floor=1e-3, what=n)
     # blocks on the last (517-node) graph
     with torch.no_grad():
         h0, e0, _ = m.encoder(_t(nodes, dev), _t(ea, dev), _t(ei, dev))
@@ -789,7 +789,7 @@ def test_scatter_add_is_deterministic_with_hub_nodes(dev, kernel):
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
     ref = orc.epd_forward(params, nodes, ea, ei, 2, 3)
-    assert np.abs(outs[0] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
+    assert_forward_close(outs[0], ref, floor=1e-3)
     # the standalone block (edges in the caller's order, eid indirection) goes through the same lists
     h0, e0 = orc.graph_independent(params, "encoder", nodes, ea, 2)
     with torch.no_grad():
@@ -837,7 +837,7 @@ def test_hidden_sizes_between_the_instantiated_widths(dev, hidden, nl, ms):
         h1, e1, _ = m.processor[0](h0, e0, _t(ei, dev))
     assert m.status() == ei.shape[1]
     ref = orc.epd_forward(params, nodes, ea, ei, nl, ms)
-    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert_forward_close(out, ref)
     ho, eo = orc.graph_independent(params, "encoder", nodes, ea, nl)
     assert tuple(h0.shape) == (nodes.shape[0], hidden) and tuple(e0.shape) == (ea.shape[0], hidden)
     np.testing.assert_allclose(h0.cpu().numpy(), ho, rtol=1e-5, atol=5e-6)

@@ -59,6 +59,54 @@ def test_sinkhorn_kernel_known_answers(dev):
         SamplesLoss(loss="energy")
 
 
+def test_sinkhorn_batched_equals_one_call_per_pair(dev):
+    """gm_sinkhorn_divergence_batched (the losses of a block of candidates in one launch sequence): pair b gets the epsilon
+    schedule of a call on it alone -- the clouds below have diameters from 0.1 to 3, i.e. schedules of different lengths, one
+    pair is a single repeated point (diameter 0: loss 0) -- and its loss equals that call's bit for bit, with the desired cloud
+    shared by the batch (the planner's case) and with one per pair; every value also against the float64 oracle."""
+    from gnn_manip_amd.losses import SamplesLoss
+    rng = np.random.default_rng(21)
+    n, m, B = 700, 620, 6
+    spreads = [0.02, 0.3, 0.05, 1.0, 0.1, 0.0]
+    X = np.stack([(0.5 + sp * rng.standard_normal((n, 3))).astype(np.float32) for sp in spreads])
+    y = (0.52 + 0.04 * rng.standard_normal((m, 3))).astype(np.float32)
+    Y = np.stack([(0.5 + (sp + 0.01) * rng.standard_normal((m, 3))).astype(np.float32) for sp in spreads])
+    Y[5] = X[5][:m]   # pair 5 (per-pair case): every point of both clouds is the same point
+    loss = SamplesLoss(loss="sinkhorn", p=2, blur=.05)
+    got_shared = loss.batched(_t(X, dev), _t(y, dev)).cpu().numpy()
+    got_own = loss.batched(_t(X, dev), _t(Y, dev)).cpu().numpy()
+    assert got_shared.shape == (B,) and got_shared.dtype == np.float32
+    for b in range(B):
+        one_s = loss(_t(X[b], dev), _t(y, dev)).cpu().numpy()
+        one_o = loss(_t(X[b], dev), _t(Y[b], dev)).cpu().numpy()
+        assert got_shared[b].tobytes() == one_s.tobytes(), (b, got_shared[b], one_s)
+        assert got_own[b].tobytes() == one_o.tobytes(), (b, got_own[b], one_o)
+        ref = orc.sinkhorn_divergence(X[b], y, blur=0.05)
+        assert abs(got_shared[b] - ref) <= 2e-5 * abs(ref) + 1e-9, (b, got_shared[b], ref)
+    assert got_own[5] == 0.0
+    # a different batch around the same pair changes nothing for that pair
+    sub = loss.batched(_t(X[[3, 0]], dev), _t(y, dev)).cpu().numpy()
+    assert sub[0].tobytes() == got_shared[3].tobytes() and sub[1].tobytes() == got_shared[0].tobytes()
+
+
+def test_sinkhorn_diameter_keyword_and_bad_input(dev):
+    """geomloss's `diameter=` keyword: the schedule starts from the caller's diameter (no host synchronisation in the library);
+    against the oracle restated with the same keyword.  A non-finite coordinate is reported, not propagated."""
+    from gnn_manip_amd._lib import GMError
+    from gnn_manip_amd.losses import SamplesLoss
+    rng = np.random.default_rng(22)
+    x = (0.5 + 0.05 * rng.standard_normal((500, 3))).astype(np.float32)
+    y = (0.53 + 0.06 * rng.standard_normal((450, 3))).astype(np.float32)
+    for d in (0.8, 0.2):
+        got = float(SamplesLoss(loss="sinkhorn", p=2, blur=.05, diameter=d)(_t(x, dev), _t(y, dev)).item())
+        ref = orc.sinkhorn_divergence(x, y, blur=0.05, diameter=d)
+        assert abs(got - ref) <= 2e-5 * abs(ref), (d, got, ref)
+    xb = x.copy()
+    xb[17, 1] = np.nan
+    with pytest.raises(GMError):
+        SamplesLoss(loss="sinkhorn", p=2, blur=.05).batched(_t(np.stack((x, xb)), dev), _t(y, dev))
+
+
 def _solver(dev, n=400, horizon=5, cands=4):
     from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, scene
     from gnn_manip_amd.planner import TrajectoryCMAsolver
@@ -295,3 +343,131 @@ def test_bench_launcher_reports_a_failed_rank(dev):
                        env=env, capture_output=True, timeout=300)
     assert r.returncode != 0
     assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+
+
+def test_c5_full_size_generation_through_rccl(dev):
+    """BASELINE config C5 at its OWN size on the one card: `bench.py --workload c5 --collectives always`, unreduced -- a CMA-ES
+    generation of 64 candidates x 200 rollout steps at N = 5k (hidden 128, 10 message-passing steps) in block-diagonal batches of
+    8, the 64 Sinkhorn losses in one batched launch sequence, the population broadcast and the losses all-gathered through the
+    `nccl` backend (RCCL; one rank) -- as a fresh child process.  What the 8-GPU run shards eight ways
+    (traj_utils.py:114-159,247-259)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GM_BENCH_REHEARSE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c5", "--collectives", "always"], env=env,
+                       capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace")
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert cfg["candidates"] == 64 and cfg["horizon"] == 200 and cfg["n_particles"] == 5000
+    assert cfg["candidates_per_rank"] == 64 and cfg["block_diagonal_batch"] == 8
+    assert rec["collective_backend"] == "nccl" and rec["n_gpus"] == 1 and rec["scaling"] == "strong"
+    assert cfg["losses_finite"] and np.isfinite(cfg["loss_mean"]) and cfg["loss_mean"] > 0
+    assert rec["value"] > 0 and rec["unit"] == "rollout steps/s" and rec["steps"] == 200
+    assert 0.0 <= rec["collective_ms"] < cfg["generation_s"] * 1e3
+    print(f"C5 64 x 200 on one GPU: {rec['value']:.0f} rollout steps/s, generation {cfg['generation_s']:.2f} s, "
+          f"collectives {rec['collective_ms']:.1f} ms")
+
+
+def _c5_scene(dev, m_steps=10, seed=83):
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, scene
+    n = 5000
+    obs = scene.make_scene(n, seed=41, vel_scale=1e-6)
+    params = orc.init_params(25, 4, 3, 128, 2, m_steps, seed)
+    params["decoder.4.weight"] = params["decoder.4.weight"] * 1e-3   # the pile stays dense over 200 steps
+    params["decoder.4.bias"] = params["decoder.4.bias"] * 1e-3
+    model = EncProcDecGNN(25, 4, 3, 128, 2, m_steps)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model = model.to(dev)
+    stats = dict(STATS, acceleration_mean=[0.0, 0.0, 0.0])
+    ga = GraphBoundedMultimaterialControl(0.015, stats, CART, MAT, CTRL, BOUNDS)
+    return n, obs, params, model, ga, stats
+
+
+def test_c5_candidates_of_a_full_batch_equal_their_standalone_rollouts(dev):
+    """C5's unit of work at its own size: 8 candidates x 200 steps at N = 5k as ONE block-diagonal batch.  Candidates 2 and 5 of
+    the batch equal their standalone 200-step rollouts bit for bit (per-graph block tables: what shares a launch never changes a
+    sum), and so do their Sinkhorn losses taken in the batch of 8 against the losses taken one by one."""
+    from gnn_manip_amd import RolloutEngine, scene
+    from gnn_manip_amd.losses import SamplesLoss
+    n, obs, params, model, ga, _ = _c5_scene(dev)
+    horizon, B = 200, 8
+    base = scene.rigid_drift_trajectory(obs, horizon, seed=42, step_size=2e-5)
+    offs = np.linspace(-1.0, 1.0, B).astype(np.float32)
+    trajs = np.stack([base + np.float32(3e-5) * o * np.arange(1, horizon + 1, dtype=np.float32)[:, None, None] for o in offs])
+    obs_d = _t(obs, dev)
+    eng8 = RolloutEngine(model, ga, n, device=dev, candidates=B)
+    with torch.no_grad():
+        finals = eng8.rollout_candidates(obs_d, _t(trajs, dev), horizon)
+    assert finals.shape == (B, 6, n, 8) and bool(torch.isfinite(finals).all())
+    assert eng8.status() > 8 * 85000   # the 8 piles are still dense after 200 steps
+    rows = torch.nonzero(obs_d[-1, :, 1] != 1).reshape(-1)
+    clouds = finals[:, -1].index_select(1, rows)[:, :, 2:5].contiguous()
+    target = (obs_d[-1].index_select(0, rows)[:, 2:5] + 0.01).contiguous()
+    loss = SamplesLoss(loss="sinkhorn", p=2, blur=.05)
+    w8 = loss.batched(clouds, target).cpu().numpy()
+    assert np.isfinite(w8).all() and (w8 > 0).all() and len(set(w8.tolist())) == B   # eight different candidates
+    eng1 = RolloutEngine(model, ga, n, device=dev)
+    for c in (2, 5):
+        with torch.no_grad():
+            alone = eng1.rollout(obs_d, _t(trajs[c], dev), horizon=horizon)
+        assert torch.equal(alone, finals[c]), (c, float((alone - finals[c]).abs().max()))
+        w1 = loss(alone[-1].index_select(0, rows)[:, 2:5].contiguous(), target).cpu().numpy()
+        assert w1.tobytes() == w8[c].tobytes()
+
+
+def test_c5_short_horizon_candidate_against_the_oracle(dev):
+    """One candidate of the C5 scene over a short horizon against the CPU restatement end to end: oracle.rollout (the reference's
+    cma_objective loop, pinned by fixture G8) and oracle.sinkhorn_divergence (float64, dense) on its end cloud."""
+    from gnn_manip_amd import RolloutEngine, scene
+    from gnn_manip_amd.losses import SamplesLoss
+    n, obs, params, model, ga, stats = _c5_scene(dev)
+    horizon = 3
+    traj = scene.rigid_drift_trajectory(obs, horizon, seed=43, step_size=2e-5)
+    B = 8
+    trajs = np.stack([traj + np.float32(1e-5 * c) for c in range(B)])
+    eng = RolloutEngine(model, ga, n, device=dev, candidates=B)
+    with torch.no_grad():
+        finals = eng.rollout_candidates(_t(obs, dev), _t(trajs, dev), horizon)
+    c = 3
+    ref = orc.rollout(params, obs, trajs[c], horizon, stats, BOUNDS, 0.015, CART, MAT, CTRL, 2, 10)
+    got = finals[c].cpu().numpy()
+    d = np.abs(got[:, :, 2:8] - ref[:, :, 2:8])
+    assert d.max() <= 5e-5 and (d > 5e-6).mean() <= 2e-4, (d.max(), (d > 5e-6).sum())
+    coffee = obs[-1, :, 1] != 1
+    target = obs[-1, coffee, 2:5] + np.float32(0.01)
+    rows = torch.nonzero(_t(obs, dev)[-1, :, 1] != 1).reshape(-1)
+    w = SamplesLoss(loss="sinkhorn", p=2, blur=.05).batched(finals[:, -1].index_select(1, rows)[:, :, 2:5].contiguous(), _t(target, dev))
+    w_ref = orc.sinkhorn_divergence(ref[-1, coffee, 2:5], target, blur=0.05)
+    assert abs(float(w[c]) - w_ref) <= 1e-4 * abs(w_ref), (float(w[c]), w_ref)
+
+
+def test_bench_launcher_ends_a_stuck_rank(dev):
+    """A rank that never arrives (stuck before the rendezvous -- what a wedged RCCL init looks like from outside) must not hang
+    `bench.py --gpus N` until somebody else's timeout: after --rank-timeout the launcher terminates the ranks it started, exits
+    non-zero, prints no JSON line, and says which rank was stuck together with the tails of the per-rank output files."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GM_BENCH_REHEARSE="1", GM_BENCH_STUCK_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "2", "--warmup", "0",
+                        "--rank-timeout", "45"], env=env, capture_output=True, timeout=300)
+    took = time.monotonic() - t0
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 124, (r.returncode, err)
+    assert took < 120, took
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert "rank(s) [0, 1] still running after --rank-timeout 45 s" in err, err   # rank 0 waits in the rendezvous, rank 1 never came
+    assert "GM_BENCH_STUCK_RANK set" in err   # the stuck rank's own stderr tail is part of the message
