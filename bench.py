@@ -164,7 +164,7 @@ def resolve_kernel(edge_kernel, hidden):
     ek = edge_kernel
     if ek == "auto":
         ek = "sys" if hidden == 128 else "hm"
-    return ek
+    return "sys" if ek == "sys_all" else ek   # sys_all: the systolic edge kernel, and the systolic node path at every size
 
 
 def roofline_record(model, ek, hidden, edges, n_nodes, workload_key):
@@ -545,7 +545,7 @@ def main():
                          "collectives after the same time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C3 / C4 sub-records")
-    ap.add_argument("--edge-kernel", default="auto", choices=["auto", "sys", "hm"],
+    ap.add_argument("--edge-kernel", default="auto", choices=["auto", "sys", "sys_all", "hm"],
                     help="processor edge kernel (per-model option): auto = systolic fp16 x 3 kernel for hidden 128 (DESIGN.md 5.1)")
     args = ap.parse_args()
 

@@ -113,7 +113,8 @@ struct GraphWs {
     int* cnt;          // [N + 1] neighbours kept per query (cnt[N] = 0)
     int* out_ptr;      // [N + 1] exclusive scan of cnt; out_ptr[N] = E
     int* nbr;          // [N * max_nb] neighbour lists, distance-sorted
-    int* scan_tmp;     // block sums for the scans
+    int* scan_cells;   // state of the single-pass scan over the cell counts (scan_state_ints)
+    int* scan_cnt;     // ... over cnt
     int max_cells;
     size_t bytes;
 };
@@ -134,7 +135,8 @@ struct CsrWs {
     int* dst;      // [cap] aggregation node of sorted position p
     int* src;      // [cap]
     int* eid;      // [cap] original edge id (row in the caller's edge order)
-    int* scan_tmp;
+    int* scan_tmp;  // block sums of the three-kernel scan (csr_from_edge_index)
+    int* scan_in;   // state of the single-pass scan over the in-degrees (scan_state_ints)
     int* sort_tmp;  // [2 * cap] copies of long segments during the destination sort
     int64_t cap;
     int* blocks;   // block / chunk tables for the systolic edge kernel (hedge.h: carve_edge_blocks)
@@ -176,9 +178,10 @@ struct ProfScope {
     ~ProfScope();
 };
 
+struct StepClear;
 // fused kernels of the rollout step (features.hip)
 int rollout_pre_features(float* obs, int64_t n, const gm_feature_desc* d, const int* rank, const float* target, float* out,
-                         hipStream_t s);
+                         hipStream_t s, const StepClear* clear);   // clear (or nullptr): the step's resets, done by the same launch
 int rollout_integrate_post(float* obs, int64_t n, const gm_feature_desc* d, const float* pred, const int* rank,
                            const float* target, float* pred_out, hipStream_t s);
 // renumbered rollout (features.hip): out[t][j] = in[t][src(j)] over the k frames, src = perm (or the identity when the order was
@@ -200,5 +203,91 @@ int cell_order(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, d
                int* perm, hipStream_t s);
 int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev, int* tmp, hipStream_t s, int* total_out);
 size_t scan_tmp_ints(int64_t n_max);
+
+// Single-pass exclusive scan (decoupled look-back: a tile publishes its sum, then its inclusive prefix, in one 64-bit status word;
+// tiles are handed out by a ticket so that a tile only ever waits for tiles that are already running): ONE launch per scan, and two
+// independent scans can share it.  `state` (scan_state_ints(n) ints, 8-byte aligned) must be ZERO when the launch starts: the
+// callers' clear pass (StepClear) does that.  out may alias in; total_out (optional) receives the sum of all n items.
+size_t scan_state_ints(int64_t n_max);
+struct ScanJob {
+    const int* in;
+    int* out;
+    long long n;
+    int* total_out;
+    int* state;
+};
+int scan_lookback(const ScanJob* jobs, int n_jobs, hipStream_t s);
+
+// Everything a build has to reset before its first kernel, as ONE pass that can ride in another launch (the rollout step's first
+// kernel) or be a launch of its own (the stand-alone entry points): value fills + the two workspace headers.
+struct ClearJob {
+    int* p;
+    long long n;
+    int v;
+};
+constexpr int kClearJobsMax = 12;
+struct GraphHeader;
+struct StepClear {
+    int n_jobs = 0;
+    ClearJob job[kClearJobsMax] = {};
+    GraphHeader* gh = nullptr;   // reset for a build
+    CsrHeader* ch = nullptr;     // reset for a destination sort (flow = `flow`)
+    int flow = 0;
+    void add(int* p, long long n, int v) { if (p && n > 0 && n_jobs < kClearJobsMax) job[n_jobs++] = ClearJob{p, n, v}; }
+};
+int launch_step_clear(const StepClear& c, hipStream_t s);
+#if defined(__HIPCC__)
+// thread t of nt: its share of every job (16-byte stores where the array allows), thread 0 the headers
+__device__ inline void step_clear_run(const StepClear& c, long long t, long long nt) {
+    for (int q = 0; q < c.n_jobs; ++q) {
+        int* p = c.job[q].p;
+        const long long n = c.job[q].n;
+        const int v = c.job[q].v;
+        if ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && n >= 4) {
+            const long long n4 = n >> 2;
+            int4* p4 = reinterpret_cast<int4*>(p);
+            for (long long i = t; i < n4; i += nt) p4[i] = make_int4(v, v, v, v);
+            for (long long i = (n4 << 2) + t; i < n; i += nt) p[i] = v;
+        } else {
+            for (long long i = t; i < n; i += nt) p[i] = v;
+        }
+    }
+    if (t == 0) {
+        if (GraphHeader* hdr = c.gh) {
+            hdr->n_edges = 0;
+            hdr->error_flags = 0;
+            hdr->ncells = 1;
+            for (int a = 0; a < 3; ++a) {
+                hdr->bbox_min[a] = 0xffffffffu;
+                hdr->bbox_max[a] = 0u;
+                hdr->dims[a] = 1;
+                hdr->origin[a] = 0.0;
+            }
+            hdr->inv_h = 1.0;
+            hdr->n_per_graph = 1;
+            hdr->ncells_local = 1;
+            hdr->ticket = 0;
+            hdr->order_skip = 0;
+        }
+        if (CsrHeader* ch = c.ch) {
+            ch->n_edges = 0;
+            ch->error_flags = 0;
+            ch->flow = c.flow;
+            ch->pad = 0;
+        }
+    }
+}
+#endif
+struct GraphWs;
+struct CsrWs;
+void graph_clear_jobs(StepClear& c, const GraphWs& g, int64_t n);             // what gm_radius_graph_build resets
+void csr_clear_jobs(StepClear& c, const CsrWs& w, int64_t n, int flow);        // what the destination sort of a radius graph resets
+
+// The rollout step's graph path with its resets already done (StepClear in the step's first launch) and the in-degree count
+// riding in the neighbour search: radius graph -> destination sort + edge features + block tables in 9 launches.
+int radius_graph_build_fused(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K, void* graph_ws,
+                             size_t graph_ws_bytes, void* csr_ws, size_t csr_ws_bytes, int flow, hipStream_t s);
+int csr_from_graph_fused(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, const float* pos, int64_t pos_stride,
+                         float conn_r, float* edge_attr, int flow, hipStream_t s);
 
 }  // namespace gm

@@ -116,11 +116,13 @@ __global__ void __launch_bounds__(256) integrate_kernel(const float* __restrict_
     }
 }
 
-// rollout step, fused: state_pre + node features (one thread owns row i of every frame)
+// rollout step, fused: state_pre + node features (one thread owns row i of every frame) -- and, as the step's first launch, the
+// resets of everything the step's later launches build on (StepClear: graph / destination-sort workspaces, scan states, agg)
 __global__ void __launch_bounds__(256) pre_features_kernel(float* __restrict__ obs, int64_t n, FeatParams P,
                                                             const int* __restrict__ rank, const float* __restrict__ target,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, StepClear clr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    step_clear_run(clr, i, (long long)gridDim.x * blockDim.x);
     if (i >= n) return;
     const int64_t fs = n * P.D;
     float* row = obs + i * P.D;
@@ -323,11 +325,11 @@ int renumber_scatter(const float* in, float* out, int frames, int64_t n, int D, 
 }
 
 int rollout_pre_features(float* obs, int64_t n, const gm_feature_desc* d, const int* rank, const float* target, float* out,
-                         hipStream_t s) {
+                         hipStream_t s, const StepClear* clear) {
     FeatParams P;
     int rc = to_params(d, &P, "gm_rollout_step");
     if (rc != GM_OK) return rc;
-    hipLaunchKernelGGL(pre_features_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, obs, n, P, rank, target, out);
+    hipLaunchKernelGGL(pre_features_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, obs, n, P, rank, target, out, clear ? *clear : StepClear{});
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include "common.h"
 #include "hedge.h"
+#include "blocks_dev.h"
 
 namespace gm {
 
@@ -204,6 +205,125 @@ int exclusive_scan_i32(const int* in, int* out, int64_t n_max, const int* n_dev,
 }
 
 // ------------------------------------------------------------------------------------------
+// single-pass scan (decoupled look-back), up to two independent scans per launch
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN2_ITEMS = 8;
+constexpr int SCAN2_TILE = SCAN_BLOCK * SCAN2_ITEMS;
+constexpr int SCAN2_JOBS = 2;
+size_t scan_state_ints(int64_t n_max) { return 2 * (size_t)cdiv(n_max > 0 ? n_max : 1, SCAN2_TILE) + 4; }   // [ticket, pad | status u64 per tile]
+struct ScanJobs {
+    ScanJob j[SCAN2_JOBS];
+};
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 status_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void status_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(ScanJobs J) {
+    __shared__ int sm[4];
+    __shared__ int s_tile, s_prefix;
+    const ScanJob& job = J.j[blockIdx.y];
+    const long long n = job.n;
+    const int tiles = (int)((n + SCAN2_TILE - 1) / SCAN2_TILE);
+    if ((int)blockIdx.x >= tiles) return;   // exactly `tiles` workgroups take a ticket
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // tiles in ticket order: a tile only waits for tiles with a smaller ticket, and those have started
+    if (tid == 0) s_tile = atomicAdd(&job.state[0], 1);
+    __syncthreads();
+    const int tile = s_tile;
+    const long long base = (long long)tile * SCAN2_TILE + (long long)tid * SCAN2_ITEMS;
+    int item[SCAN2_ITEMS];
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN2_ITEMS; ++k) {
+        item[k] = base + k < n ? job.in[base + k] : 0;
+        v += item[k];
+    }
+    int tot;
+    int ex = block_excl_scan(v, sm, &tot);
+    if (wave == 0) {
+        u64* st = reinterpret_cast<u64*>(job.state + 2);
+        int prefix = 0;
+        if (tile == 0) {
+            if (lane == 0) status_store(st, (2ull << 32) | (unsigned)tot);
+        } else {
+            if (lane == 0) status_store(st + tile, (1ull << 32) | (unsigned)tot);    // this tile's sum
+            int back = tile - 1;
+            while (true) {   // 64 predecessors per look: sums up to the nearest tile that already knows its inclusive prefix
+                const int p = back - lane;
+                u64 sv = 2ull << 32;   // in front of tile 0: inclusive prefix 0
+                if (p >= 0) {
+                    do { sv = status_load(st + p); } while ((sv >> 32) == 0);
+                }
+                const u64 inc = __ballot((sv >> 32) == 2);
+                int val = (int)(unsigned)sv;
+                if (inc) val = lane <= (int)__builtin_ctzll(inc) ? val : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+                prefix += val;
+                if (inc) break;
+                back -= 64;
+            }
+            if (lane == 0) status_store(st + tile, (2ull << 32) | (unsigned)(prefix + tot));
+        }
+        if (lane == 0) s_prefix = prefix;
+    }
+    __syncthreads();
+    ex += s_prefix;
+#pragma unroll
+    for (int k = 0; k < SCAN2_ITEMS; ++k) {
+        if (base + k < n) job.out[base + k] = ex;
+        ex += item[k];
+    }
+    if (job.total_out && tile == tiles - 1 && tid == 0) *job.total_out = s_prefix + tot;
+}
+
+int scan_lookback(const ScanJob* jobs, int n_jobs, hipStream_t s) {
+    GM_REQUIRE(n_jobs >= 1 && n_jobs <= SCAN2_JOBS, GM_ERR_INVALID_ARGUMENT, "scan_lookback: 1 or 2 scans per launch");
+    ScanJobs J{};
+    long long nmax = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        J.j[i] = jobs[i];
+        GM_REQUIRE(jobs[i].in && jobs[i].out && jobs[i].state && jobs[i].n >= 0, GM_ERR_INVALID_ARGUMENT, "scan_lookback: bad job");
+        nmax = jobs[i].n > nmax ? jobs[i].n : nmax;
+    }
+    if (nmax <= 0) return GM_OK;
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)cdiv(nmax, SCAN2_TILE), (unsigned)n_jobs), dim3(SCAN_BLOCK), 0, s, J);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// resets of a build (StepClear, common.h)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) step_clear_kernel(StepClear c) {
+    step_clear_run(c, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+int launch_step_clear(const StepClear& c, hipStream_t s) {
+    long long work = 1;
+    for (int q = 0; q < c.n_jobs; ++q) work = c.job[q].n > work ? c.job[q].n : work;
+    long long nb = cdiv(work, 256 * 4);
+    nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    hipLaunchKernelGGL(step_clear_kernel, dim3((unsigned)nb), dim3(256), 0, s, c);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+void graph_clear_jobs(StepClear& c, const GraphWs& g, int64_t n) {
+    c.gh = g.hdr;
+    c.add(g.cell_start, (long long)g.max_cells + 1, 0);   // counts -> offsets
+    c.add(g.cell_cursor, g.max_cells, 0);
+    c.add(g.cnt + n, 1, 0);                                // cnt[0 .. n) is written by the neighbour search; cnt[n] closes the scan
+    c.add(g.scan_cells, (long long)scan_state_ints((int64_t)g.max_cells + 1), 0);
+    c.add(g.scan_cnt, (long long)scan_state_ints(n + 1), 0);
+}
+void csr_clear_jobs(StepClear& c, const CsrWs& w, int64_t n, int flow) {
+    c.ch = w.hdr;
+    c.flow = flow;
+    c.add(w.in_ptr, n + 1, 0);
+    c.add(w.scan_in, (long long)scan_state_ints(n + 1), 0);
+    c.add(carve_edge_blocks(w.blocks, n, w.cap).stitch, n, -1);
+}
+
+// ------------------------------------------------------------------------------------------
 // workspace carving
 // ------------------------------------------------------------------------------------------
 int max_cells_for(int64_t n) {
@@ -225,9 +345,8 @@ GraphWs carve_graph(void* ws, int64_t n, int max_nb) {
     g.cnt = c.take<int>(n + 1);
     g.out_ptr = c.take<int>(n + 1);
     g.nbr = c.take<int>((size_t)n * max_nb);
-    size_t st = scan_tmp_ints((int64_t)g.max_cells + 1);
-    size_t st2 = scan_tmp_ints(n + 1);
-    g.scan_tmp = c.take<int>(st > st2 ? st : st2);
+    g.scan_cells = c.take<int>(scan_state_ints((int64_t)g.max_cells + 1));
+    g.scan_cnt = c.take<int>(scan_state_ints(n + 1));
     g.bytes = c.used();
     return g;
 }
@@ -242,6 +361,7 @@ CsrWs carve_csr(void* ws, int64_t n, int64_t cap) {
     w.src = c.take<int>(cap);
     w.eid = c.take<int>(cap);
     w.scan_tmp = c.take<int>(scan_tmp_ints(n + 1));
+    w.scan_in = c.take<int>(scan_state_ints(n + 1));
     w.sort_tmp = c.take<int>(2 * (size_t)cap);   // copies of long segments (in-degree > 96) while they are rank-sorted
     w.cap = cap;
     w.blocks = c.take<int>(edge_blocks_ints(n, cap));
@@ -258,32 +378,6 @@ __device__ __forceinline__ unsigned f2ord(float f) {
 }
 __device__ __forceinline__ float ord2f(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-
-// one launch: header reset + the three zero-fills of a graph build
-__global__ void __launch_bounds__(256) graph_clear_kernel(GraphHeader* hdr, int* __restrict__ cell_start, int64_t n_cs,
-                                                           int* __restrict__ cell_cursor, int64_t n_cc,
-                                                           int* __restrict__ cnt, int64_t n_cnt) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cs; i += stride) cell_start[i] = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cc; i += stride) cell_cursor[i] = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cnt; i += stride) cnt[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        hdr->n_edges = 0;
-        hdr->error_flags = 0;
-        hdr->ncells = 1;
-        for (int a = 0; a < 3; ++a) {
-            hdr->bbox_min[a] = 0xffffffffu;
-            hdr->bbox_max[a] = 0u;
-            hdr->dims[a] = 1;
-            hdr->origin[a] = 0.0;
-        }
-        hdr->inv_h = 1.0;
-        hdr->n_per_graph = 1;
-        hdr->ncells_local = 1;
-        hdr->ticket = 0;
-        hdr->order_skip = 0;
-    }
 }
 
 __device__ void grid_params(GraphHeader* hdr, double r, int max_cells, int64_t n, int64_t n_per);
@@ -454,10 +548,14 @@ constexpr int NB_CAP = 96;
 constexpr int NB_STRIDE = NB_CAP + 1;  // doubles per list: odd stride keeps the 8 groups of a wave on distinct banks
 constexpr int NB_QPB = 32;             // queries per 256-thread block
 
+// indeg / arrival (optional: the rollout step's fused path): the counting pass of the destination sort rides along -- every kept
+// neighbour takes its arrival number within its aggregation node's segment (flow 0: the neighbour, 1: the query) from an atomic on
+// indeg[], so that the fill pass places the edge with plain stores (see indeg_graph_kernel, the stand-alone form of the same count).
 __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __restrict__ sorted,
                                                              const int* __restrict__ cell_start,
                                                              const GraphHeader* __restrict__ hdr, int64_t n, double r2,
-                                                             int K, int* __restrict__ cnt, int* __restrict__ nbr) {
+                                                             int K, int* __restrict__ cnt, int* __restrict__ nbr,
+                                                             int* __restrict__ indeg, int* __restrict__ arrival, int flow) {
     __shared__ double sd2[NB_QPB * NB_STRIDE];
     __shared__ int sj[NB_QPB * NB_STRIDE];
     const int tid = threadIdx.x, sub = tid & 7, ql = tid >> 3, lane = tid & 63;
@@ -535,7 +633,10 @@ __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __rest
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (a0 + 8 * u < count && rank[u] < K) nbr[(int64_t)qi * K + rank[u]] = ja[u];
+            if (a0 + 8 * u < count && rank[u] < K) {
+                nbr[(int64_t)qi * K + rank[u]] = ja[u];
+                if (indeg) arrival[(int64_t)qi * K + rank[u]] = atomicAdd(&indeg[flow ? qi : ja[u]], 1);
+            }
     }
     if (sub == 0) cnt[qi] = count < K ? count : K;
 }
@@ -548,7 +649,8 @@ template <int BS>
 __global__ void __launch_bounds__(BS) neighbor_kernel(const float4* __restrict__ sorted,
                                                        const int* __restrict__ cell_start,
                                                        const GraphHeader* __restrict__ hdr, int64_t n, double r2,
-                                                       int K, int* __restrict__ cnt, int* __restrict__ nbr) {
+                                                       int K, int* __restrict__ cnt, int* __restrict__ nbr,
+                                                       int* __restrict__ indeg, int* __restrict__ arrival, int flow) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* kd = reinterpret_cast<double*>(smem);                   // [K][BS]
     int* ki = reinterpret_cast<int*>(smem + (size_t)K * BS * 8);    // [K][BS]
@@ -606,7 +708,11 @@ __global__ void __launch_bounds__(BS) neighbor_kernel(const float4* __restrict__
         }
     }
     cnt[qi] = kept;
-    for (int s = 0; s < kept; ++s) nbr[(int64_t)qi * K + s] = ki[s * BS + t];
+    for (int s = 0; s < kept; ++s) {
+        const int j = ki[s * BS + t];
+        nbr[(int64_t)qi * K + s] = j;
+        if (indeg) arrival[(int64_t)qi * K + s] = atomicAdd(&indeg[flow ? qi : j], 1);
+    }
 }
 
 __global__ void __launch_bounds__(256) emit_edges_kernel(const int* __restrict__ cnt, const int* __restrict__ out_ptr,
@@ -627,21 +733,6 @@ __global__ void __launch_bounds__(256) emit_edges_kernel(const int* __restrict__
 // ------------------------------------------------------------------------------------------
 // destination-sorted structure
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) csr_clear_kernel(CsrHeader* hdr, int* __restrict__ in_ptr, int* __restrict__ cursor,
-                                                         int64_t n1, int flow) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) {
-        in_ptr[i] = 0;
-        cursor[i] = 0;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        hdr->n_edges = 0;
-        hdr->error_flags = 0;
-        hdr->flow = flow;
-        hdr->pad = 0;
-    }
-}
-
 // mode 0: slots of the radius graph (source = query i, destination = neighbour)
 // flow 0: the aggregation node of edge (query i -> neighbour) is the neighbour (edge_index[1]); 1: the query (edge_index[0])
 // The counting pass hands every edge its arrival number within its destination's segment (`slot`), so the fill pass places the
@@ -655,12 +746,16 @@ __global__ void __launch_bounds__(256) indeg_graph_kernel(const int* __restrict_
     slot[id] = atomicAdd(&indeg[flow ? (int)i : nbr[id]], 1);
 }
 
+// One thread of the launch also lays out the 32-edge block tables' plan (per-graph block counts: it needs in_ptr only, which the scan
+// in front has finished) -- the tables themselves are filled by the launch that follows (segment_sort_kernel).
 __global__ void __launch_bounds__(256) fill_graph_kernel(const int* __restrict__ cnt, const int* __restrict__ out_ptr,
                                                           const int* __restrict__ nbr, int64_t n, int K,
                                                           const int* __restrict__ in_ptr, const int* __restrict__ slot,
                                                           int64_t cap, int flow, int* __restrict__ dst, int* __restrict__ src,
-                                                          int* __restrict__ eid, CsrHeader* hdr) {
+                                                          int* __restrict__ eid, CsrHeader* hdr, const int* n_per_dev,
+                                                          EdgeBlockHeader* tab, int* gblk) {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id == 0 && tab) edge_blocks_plan(in_ptr, (int)n, n_per_dev, 0, tab, gblk, (int)n + 1);
     if (id >= n * K) return;
     int64_t i = id / K;
     int s = (int)(id - i * K);
@@ -712,14 +807,32 @@ __global__ void __launch_bounds__(256) fill_ei_kernel(const int64_t* __restrict_
 // whole workgroup through a copy in the workspace.
 constexpr int SEG_CAP = 96;
 constexpr int SEG_STRIDE = SEG_CAP + 1;
+// Workgroups beyond the cdiv(n, 32) that sort fill the 32-edge block tables of the same structure (they read in_ptr and dst, which
+// the sort does not touch; the plan was laid out by the launch in front): bt.hdr == nullptr when the grid has none.
+struct BlockTabArgs {
+    const int* dst;
+    EdgeBlockHeader* hdr;
+    const int* gblk;
+    int2* blk;
+    int2* seg;
+    int* head;
+    int* stitch;
+    int* stitch_list;
+};
 __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict__ in_ptr, int64_t n,
                                                             int* __restrict__ src, int* __restrict__ eid,
                                                             CsrHeader* hdr, const float* __restrict__ pos,
                                                             int64_t pos_stride, float conn_r, float* __restrict__ edge_attr, int flow,
-                                                            int* __restrict__ tmp_eid, int* __restrict__ tmp_src) {
+                                                            int* __restrict__ tmp_eid, int* __restrict__ tmp_src, BlockTabArgs bt) {
     __shared__ int se[32 * SEG_STRIDE];
     __shared__ int ss[32 * SEG_STRIDE];
     __shared__ int s_long[32];
+    const int n_sort = (int)((n + 31) / 32);
+    if ((int)blockIdx.x >= n_sort) {
+        edge_blocks_fill(in_ptr, bt.dst, (int)n, bt.hdr, bt.gblk, bt.blk, bt.seg, bt.head, bt.stitch, bt.stitch_list,
+                         ((int)blockIdx.x - n_sort) * 256 + (int)threadIdx.x, ((int)gridDim.x - n_sort) * 256);
+        return;
+    }
     const int tid = threadIdx.x, sub = tid & 7, sl = tid >> 3;
     const int64_t i = (int64_t)blockIdx.x * 32 + sl;
     if (i == 0 && sub == 0) hdr->n_edges = in_ptr[n];
@@ -782,13 +895,15 @@ int cell_order(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, d
     GM_REQUIRE(pos && graph_ws && perm && n > 0 && pos_stride >= 3 && conn_r > 0.0, GM_ERR_INVALID_ARGUMENT, "cell_order: bad argument");
     GraphWs g = carve_graph(graph_ws, n, K);
     GM_REQUIRE(graph_ws_bytes >= g.bytes, GM_ERR_WORKSPACE, "cell_order: workspace %zu < %zu", graph_ws_bytes, g.bytes);
-    const int64_t work = (int64_t)g.max_cells + 1;
-    const int cb = (int)cdiv(work, 256), nb = (int)cdiv(n, 256);
-    hipLaunchKernelGGL(graph_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, g.hdr, g.cell_start, (int64_t)g.max_cells + 1,
-                       g.cell_cursor, (int64_t)g.max_cells, g.cnt, (int64_t)0);
+    const int nb = (int)cdiv(n, 256);
+    StepClear clr;
+    graph_clear_jobs(clr, g, n);
+    int rc = launch_step_clear(clr, s);
+    if (rc != GM_OK) return rc;
     hipLaunchKernelGGL(bbox_kernel, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, pos, pos_stride, n, g.hdr, conn_r, g.max_cells, n_per);
     hipLaunchKernelGGL(cell_assign_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.hdr, g.cell_of, g.cell_start);
-    const int rc = exclusive_scan_i32(g.cell_start, g.cell_start, (int64_t)g.max_cells + 1, nullptr, g.scan_tmp, s, nullptr);
+    const ScanJob sj{g.cell_start, g.cell_start, (long long)g.max_cells + 1, nullptr, g.scan_cells};
+    rc = scan_lookback(&sj, 1, s);
     if (rc != GM_OK) return rc;
     hipLaunchKernelGGL(cell_fill_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.cell_of, g.cell_start, g.cell_cursor, g.sorted);
     hipLaunchKernelGGL(cell_order_kernel, dim3(nb), dim3(256), 0, s, g.sorted, g.cell_of, g.cell_start, g.hdr, n, perm);
@@ -816,9 +931,10 @@ int gm_radius_graph_build(const float* pos, int64_t pos_stride, int64_t n, doubl
     return gm_radius_graph_build_batched(pos, pos_stride, n, n, conn_r, K, ws, ws_bytes, stream);
 }
 
-int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K,
-                                  void* ws, size_t ws_bytes, void* stream) {
-    gm::DevGuard dev_guard(pos);
+}  // extern "C"
+
+namespace {
+int check_build_args(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K, const void* ws) {
     GM_REQUIRE(n_per >= 0 && (n_per == 0 || n % n_per == 0 || n_per >= n), GM_ERR_INVALID_ARGUMENT,
                "gm_radius_graph_build_batched: n_nodes=%lld is not a multiple of nodes_per_graph=%lld", (long long)n, (long long)n_per);
     GM_REQUIRE(n >= 0 && n < (int64_t)1 << 30, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: n_nodes=%lld out of range", (long long)n);
@@ -827,61 +943,78 @@ int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t 
     GM_REQUIRE(conn_r > 0.0 && conn_r == conn_r, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: conn_r must be > 0");
     GM_REQUIRE(pos_stride >= 3, GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: pos_stride < 3");
     GM_REQUIRE(ws != nullptr && (pos != nullptr || n == 0), GM_ERR_INVALID_ARGUMENT, "gm_radius_graph_build: null pointer");
+    return GM_OK;
+}
+
+// The build behind its resets (StepClear: a launch of its own in the stand-alone entry point, part of the step's first launch in the
+// rollout): bounding box + grid, cell assignment, ONE-launch scan of the cell counts, cell fill, the two neighbour kernels.  The scan
+// of cnt (-> out_ptr, E) is the caller's: the rollout path runs it together with the in-degree scan of the destination sort.
+// indeg / slot: the destination sort's counting pass rides in the neighbour kernels (nullptr: it does not).
+int radius_graph_build_core(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K, const GraphWs& g,
+                            int* indeg, int* slot, int flow, hipStream_t s) {
+    if (n <= 0) return GM_OK;
+    int nb = (int)cdiv(n, 256);
+    hipLaunchKernelGGL(bbox_kernel, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, pos, pos_stride, n, g.hdr, conn_r,
+                       g.max_cells, n_per);
+    hipLaunchKernelGGL(cell_assign_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.hdr, g.cell_of, g.cell_start);
+    const ScanJob sj{g.cell_start, g.cell_start, (long long)g.max_cells + 1, nullptr, g.scan_cells};
+    int rc = scan_lookback(&sj, 1, s);
+    if (rc != GM_OK) return rc;
+    hipLaunchKernelGGL(cell_fill_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.cell_of, g.cell_start,
+                       g.cell_cursor, g.sorted);
+    const double r2 = conn_r * conn_r;  // KDTree compares rdist with r*r in float64
+    hipLaunchKernelGGL(neighbor_fast_kernel, dim3((unsigned)cdiv(n, NB_QPB)), dim3(256), 0, s, g.sorted, g.cell_start,
+                       g.hdr, n, r2, K, g.cnt, g.nbr, indeg, slot, flow);
+    if (K <= 64) {
+        constexpr int BS = 128;
+        size_t lds = (size_t)K * BS * 12;
+        if (lds > 64 * 1024) {
+            static PerDeviceOnce big_lds;
+            const int rc_attr = big_lds.run([]() -> int {
+                GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbor_kernel<BS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                return GM_OK;
+            });
+            if (rc_attr != GM_OK) return rc_attr;
+        }
+        hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
+                           g.hdr, n, r2, K, g.cnt, g.nbr, indeg, slot, flow);
+    } else {
+        constexpr int BS = 64;
+        size_t lds = (size_t)K * BS * 12;
+        GM_REQUIRE(lds <= 160 * 1024, GM_ERR_UNSUPPORTED, "gm_radius_graph_build: max_neighbours=%d needs %zu bytes of LDS", K, lds);
+        if (lds > 64 * 1024) {
+            static PerDeviceOnce big_lds64;
+            const int rc_attr = big_lds64.run([]() -> int {
+                GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbor_kernel<BS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                return GM_OK;
+            });
+            if (rc_attr != GM_OK) return rc_attr;
+        }
+        hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
+                           g.hdr, n, r2, K, g.cnt, g.nbr, indeg, slot, flow);
+    }
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int gm_radius_graph_build_batched(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    gm::DevGuard dev_guard(pos);
+    int rc = check_build_args(pos, pos_stride, n, n_per, conn_r, K, ws);
+    if (rc != GM_OK) return rc;
     GraphWs g = carve_graph(ws, n, K);
     GM_REQUIRE(ws_bytes >= g.bytes, GM_ERR_WORKSPACE, "gm_radius_graph_build: workspace %zu < %zu", ws_bytes, g.bytes);
     hipStream_t s = (hipStream_t)stream;
-    {
-        const int64_t work = (int64_t)g.max_cells + 1;
-        int cb = (int)cdiv(work, 256);
-        hipLaunchKernelGGL(graph_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, g.hdr, g.cell_start,
-                           (int64_t)g.max_cells + 1, g.cell_cursor, (int64_t)g.max_cells, g.cnt, n + 1);
-    }
-    if (n > 0) {
-        int nb = (int)cdiv(n, 256);
-        hipLaunchKernelGGL(bbox_kernel, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, pos, pos_stride, n, g.hdr, conn_r,
-                           g.max_cells, n_per);
-        hipLaunchKernelGGL(cell_assign_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.hdr, g.cell_of, g.cell_start);
-        int rc = exclusive_scan_i32(g.cell_start, g.cell_start, (int64_t)g.max_cells + 1, nullptr, g.scan_tmp, s, nullptr);
-        if (rc != GM_OK) return rc;
-        hipLaunchKernelGGL(cell_fill_kernel, dim3(nb), dim3(256), 0, s, pos, pos_stride, n, g.cell_of, g.cell_start,
-                           g.cell_cursor, g.sorted);
-        const double r2 = conn_r * conn_r;  // KDTree compares rdist with r*r in float64
-        hipLaunchKernelGGL(neighbor_fast_kernel, dim3((unsigned)cdiv(n, NB_QPB)), dim3(256), 0, s, g.sorted, g.cell_start,
-                           g.hdr, n, r2, K, g.cnt, g.nbr);
-        if (K <= 64) {
-            constexpr int BS = 128;
-            size_t lds = (size_t)K * BS * 12;
-            if (lds > 64 * 1024) {
-                static PerDeviceOnce big_lds;
-                const int rc_attr = big_lds.run([]() -> int {
-                    GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbor_kernel<BS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    return GM_OK;
-                });
-                if (rc_attr != GM_OK) return rc_attr;
-            }
-            hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
-                               g.hdr, n, r2, K, g.cnt, g.nbr);
-        } else {
-            constexpr int BS = 64;
-            size_t lds = (size_t)K * BS * 12;
-            GM_REQUIRE(lds <= 160 * 1024, GM_ERR_UNSUPPORTED, "gm_radius_graph_build: max_neighbours=%d needs %zu bytes of LDS", K, lds);
-            if (lds > 64 * 1024) {
-                static PerDeviceOnce big_lds64;
-                const int rc_attr = big_lds64.run([]() -> int {
-                    GM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbor_kernel<BS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    return GM_OK;
-                });
-                if (rc_attr != GM_OK) return rc_attr;
-            }
-            hipLaunchKernelGGL(neighbor_kernel<BS>, dim3((int)cdiv(n, BS)), dim3(BS), lds, s, g.sorted, g.cell_start,
-                               g.hdr, n, r2, K, g.cnt, g.nbr);
-        }
-        GM_LAUNCH_CHECK();
-    }
-    int rc = exclusive_scan_i32(g.cnt, g.out_ptr, n + 1, nullptr, g.scan_tmp, s, &g.hdr->n_edges);
+    StepClear clr;
+    graph_clear_jobs(clr, g, n);
+    rc = launch_step_clear(clr, s);
+    if (rc == GM_OK) rc = radius_graph_build_core(pos, pos_stride, n, n_per, conn_r, K, g, nullptr, nullptr, 0, s);
     if (rc != GM_OK) return rc;
-    GM_LAUNCH_CHECK();
-    return GM_OK;
+    const ScanJob sj{g.cnt, g.out_ptr, (long long)n + 1, &g.hdr->n_edges, g.scan_cnt};
+    return scan_lookback(&sj, 1, s);
 }
 
 int gm_radius_graph_num_edges(const void* ws, int64_t* n_edges_host, void* stream) {
@@ -924,6 +1057,32 @@ int gm_csr_from_graph_flow(const void* graph_ws, int64_t n, int K, int flow, voi
 }  // extern "C"
 
 namespace gm {
+namespace {
+// scan(s) -> fill (+ block-table plan) -> segment sort + edge features + block tables.  with_cnt_scan: the radius graph's own scan
+// of cnt (-> out_ptr, E) shares the scan launch (the fused rollout path; the stand-alone build has already run it).
+int csr_tail(const GraphWs& g, int64_t n, int K, const CsrWs& c, const float* pos, int64_t pos_stride, float conn_r, float* edge_attr,
+             int flow, bool with_cnt_scan, hipStream_t s) {
+    const int64_t cap = n * K;
+    const unsigned nb = (unsigned)cdiv(cap, 256);
+    int* slot = c.sort_tmp;   // [cap]: free until segment_sort_kernel (which runs after the fill) needs it for long segments
+    ScanJob sj[2] = {{c.in_ptr, c.in_ptr, (long long)n + 1, nullptr, c.scan_in},
+                     {g.cnt, g.out_ptr, (long long)n + 1, &g.hdr->n_edges, g.scan_cnt}};
+    int rc = scan_lookback(sj, with_cnt_scan ? 2 : 1, s);
+    if (rc != GM_OK) return rc;
+    const EdgeBlocks t = carve_edge_blocks(c.blocks, n, cap);
+    hipLaunchKernelGGL(fill_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.out_ptr, g.nbr, n, K, c.in_ptr,
+                       slot, cap, flow, c.dst, c.src, c.eid, c.hdr, &g.hdr->n_per_graph, t.hdr, t.gblk);
+    // 32-edge blocks aligned to every graph's first edge (the systolic processor edge kernel walks them): extra workgroups of the sort
+    int gb = (int)cdiv(t.max_blocks, 256);
+    gb = gb < 1 ? 1 : (gb > 1024 ? 1024 : gb);
+    const BlockTabArgs bt{c.dst, t.hdr, t.gblk, t.blk, t.seg, t.head, t.stitch, t.stitch_list};
+    hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32) + (unsigned)gb), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr,
+                       pos, pos_stride, conn_r, edge_attr, flow, c.sort_tmp, c.sort_tmp + c.cap, bt);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+}  // namespace
+
 int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, const float* pos,
                                  int64_t pos_stride, float conn_r, float* edge_attr, int flow, hipStream_t stream) {
     GM_REQUIRE(graph_ws && csr_ws, GM_ERR_INVALID_ARGUMENT, "gm_csr_from_graph: null pointer");
@@ -933,23 +1092,33 @@ int csr_from_graph_with_features(const void* graph_ws, int64_t n, int K, void* c
     CsrWs c = carve_csr(csr_ws, n, cap);
     GM_REQUIRE(csr_ws_bytes >= c.bytes, GM_ERR_WORKSPACE, "gm_csr_from_graph: workspace %zu < %zu", csr_ws_bytes, c.bytes);
     hipStream_t s = (hipStream_t)stream;
-    {
-        int cb = (int)cdiv(n + 1, 256);
-        hipLaunchKernelGGL(csr_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, c.hdr, c.in_ptr, c.cursor, n + 1, flow);
-    }
-    if (n > 0) {
-        unsigned nb = (unsigned)cdiv(cap, 256);
-        int* slot = c.sort_tmp;   // [cap]: free until segment_sort_kernel (which runs after the fill) needs it for long segments
-        hipLaunchKernelGGL(indeg_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.nbr, n, K, flow, c.in_ptr, slot);
-        int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s, nullptr);
-        if (rc != GM_OK) return rc;
-        hipLaunchKernelGGL(fill_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.out_ptr, g.nbr, n, K, c.in_ptr,
-                           slot, cap, flow, c.dst, c.src, c.eid, c.hdr);
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, pos, pos_stride, conn_r, edge_attr, flow, c.sort_tmp, c.sort_tmp + c.cap);
-        GM_LAUNCH_CHECK();
-    }
-    // 32-edge blocks aligned to every graph's first edge (the systolic processor edge kernel walks them)
-    return build_edge_blocks(c.in_ptr, c.dst, n, cap, &g.hdr->n_per_graph, 0, carve_edge_blocks(c.blocks, n, cap), s);
+    StepClear clr;
+    csr_clear_jobs(clr, c, n, flow);
+    int rc = launch_step_clear(clr, s);
+    if (rc != GM_OK || n <= 0) return rc;
+    hipLaunchKernelGGL(indeg_graph_kernel, dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, s, g.cnt, g.nbr, n, K, flow, c.in_ptr, c.sort_tmp);
+    return csr_tail(g, n, K, c, pos, pos_stride, conn_r, edge_attr, flow, false, s);
+}
+
+// The rollout step's graph path (resets done by the caller's StepClear, see graph_clear_jobs / csr_clear_jobs): 9 launches from
+// positions to the destination-sorted structure with edge features and block tables.
+int radius_graph_build_fused(const float* pos, int64_t pos_stride, int64_t n, int64_t n_per, double conn_r, int K, void* graph_ws,
+                             size_t graph_ws_bytes, void* csr_ws, size_t csr_ws_bytes, int flow, hipStream_t s) {
+    int rc = check_build_args(pos, pos_stride, n, n_per, conn_r, K, graph_ws);
+    if (rc != GM_OK) return rc;
+    GM_REQUIRE(csr_ws && (flow == 0 || flow == 1), GM_ERR_INVALID_ARGUMENT, "radius_graph_build_fused: bad csr workspace / flow");
+    GraphWs g = carve_graph(graph_ws, n, K);
+    CsrWs c = carve_csr(csr_ws, n, n * K);
+    GM_REQUIRE(graph_ws_bytes >= g.bytes && csr_ws_bytes >= c.bytes, GM_ERR_WORKSPACE, "radius_graph_build_fused: workspace too small");
+    return radius_graph_build_core(pos, pos_stride, n, n_per, conn_r, K, g, c.in_ptr, c.sort_tmp, flow, s);
+}
+int csr_from_graph_fused(const void* graph_ws, int64_t n, int K, void* csr_ws, size_t csr_ws_bytes, const float* pos, int64_t pos_stride,
+                         float conn_r, float* edge_attr, int flow, hipStream_t s) {
+    if (n <= 0) return GM_OK;
+    GraphWs g = carve_graph(const_cast<void*>(graph_ws), n, K);
+    CsrWs c = carve_csr(csr_ws, n, n * K);
+    GM_REQUIRE(csr_ws_bytes >= c.bytes, GM_ERR_WORKSPACE, "csr_from_graph_fused: workspace %zu < %zu", csr_ws_bytes, c.bytes);
+    return csr_tail(g, n, K, c, pos, pos_stride, conn_r, edge_attr, flow, true, s);
 }
 }  // namespace gm
 
@@ -978,18 +1147,22 @@ int csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, int flow, void*
     GM_REQUIRE(csr_ws_bytes >= c.bytes, GM_ERR_WORKSPACE, "gm_csr_from_edge_index: workspace %zu < %zu", csr_ws_bytes, c.bytes);
     hipStream_t s = (hipStream_t)stream;
     {
-        int cb = (int)cdiv(n + 1, 256);
-        hipLaunchKernelGGL(csr_clear_kernel, dim3(cb < 512 ? cb : 512), dim3(256), 0, s, c.hdr, c.in_ptr, c.cursor, n + 1, flow);
+        StepClear clr;
+        csr_clear_jobs(clr, c, n, flow);
+        clr.add(c.cursor, n + 1, 0);
+        const int rc = launch_step_clear(clr, s);
+        if (rc != GM_OK) return rc;
     }
     if (e > 0) {
         unsigned nb = (unsigned)cdiv(e, 256);
         hipLaunchKernelGGL(indeg_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, flow, c.in_ptr, c.hdr);
-        int rc = exclusive_scan_i32(c.in_ptr, c.in_ptr, n + 1, nullptr, c.scan_tmp, s, nullptr);
+        const ScanJob sj{c.in_ptr, c.in_ptr, (long long)n + 1, nullptr, c.scan_in};
+        int rc = scan_lookback(&sj, 1, s);
         if (rc != GM_OK) return rc;
         hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, flow, c.in_ptr, c.cursor, c.dst, c.src, c.eid, c.hdr);
     }
     if (n > 0)
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0, c.sort_tmp, c.sort_tmp + c.cap);
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0, c.sort_tmp, c.sort_tmp + c.cap, BlockTabArgs{});
     GM_LAUNCH_CHECK();
     if (!with_blocks) return GM_OK;
     return build_edge_blocks(c.in_ptr, c.dst, n, e, nullptr, (int)n, carve_edge_blocks(c.blocks, n, e), s);

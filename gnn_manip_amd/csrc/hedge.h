@@ -14,7 +14,8 @@ struct EdgeBlockHeader {
     int n_groups;       // n_blocks / 4
     int n_graphs;
     int n_per_graph;
-    int pad[4];
+    int n_stitch;       // entries of stitch_list
+    int pad[3];
 };
 struct EdgeBlocks {
     EdgeBlockHeader* hdr;
@@ -25,6 +26,8 @@ struct EdgeBlocks {
                         // row, inside a group); bit n of .y: row n is the last one of its segment's piece in this group
     int* head;          // [n_groups] destination whose segment continues from the previous group into this one, or -1
     int* stitch;        // [n_nodes] first group of the run of head partials of a destination, or -1
+    int* stitch_list;   // [n_nodes] the destinations with stitch[v] >= 0, in no particular order (n_stitch of them): what the systolic
+                        // node path's agg_stitch_kernel walks, once per message-passing step, instead of every node
     int64_t max_blocks;
 };
 size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity);

@@ -45,6 +45,7 @@
 #include "hedge.h"
 #include "hmlp.h"
 #include "hmma_dev.h"
+#include "blocks_dev.h"
 
 namespace gm {
 
@@ -53,6 +54,7 @@ namespace {
 constexpr int H = 128;
 constexpr int BE = 32;             // edges per block
 constexpr int SYS_THREADS = 768;
+static_assert(BE == kBlockEdges, "block tables and the systolic kernels agree on the block size");
 #ifndef SIDE_STRIDE
 #define SIDE_STRIDE 6   // MFMA slots per row group of role 1's e_out epilogue (24 slots per tick, 4 row groups)
 #endif
@@ -698,7 +700,7 @@ constexpr int LE_VEC = LE_ZERO_END;                // 5 x 128 floats
 constexpr size_t ENC_LDS_BYTES = LE_VEC + 5 * H * 4;
 
 __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader* a_hdr, const float* __restrict__ a_x, float* __restrict__ a_e_out,
-                                                                      const float* __restrict__ a_hw, int* a_flags, float a_eps) {
+                                                                      const float* __restrict__ a_hw, int* a_flags, float a_eps, int a_pad_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -708,6 +710,10 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_enc_kernel(const CsrHeader
     const int wg = xcd_major_wg();
     const int b0 = (int)((long long)wg * nblk / gridDim.x), b1 = (int)((long long)(wg + 1) * nblk / gridDim.x);
     const int nb = b1 - b0;
+    // The processor edge kernel reads whole 32-row blocks: the kEdgePadRows rows behind row E hold zeros (zero_edge_pad_rows does that
+    // for the other encoders).  Nobody else writes them: stores past a block's last row are dropped by their buffer bound.
+    if (a_pad_rows && blockIdx.x == 0)
+        for (int i = tid; i < kEdgePadRows * H / 4; i += SYS_THREADS) reinterpret_cast<floatx4*>(a_e_out + (size_t)E * H)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     if (nb <= 0) return;
     const float inv_T = a_hw[1], cap = a_hw[2];
     const float* hvec = a_hw + HW_HEADER_FLOATS;
@@ -1191,25 +1197,30 @@ __global__ void __launch_bounds__(SYS_THREADS, 1) sys_proj_kernel(const float* _
 
 // agg rows of the nodes whose in-edge segment crosses groups of the scatter-add: + the head partials the later groups hold, in
 // group order (hedge.h: stitch / head lists) -- what hm_node_kernel does while it reads agg; the systolic node kernel reads plain rows.
+// Walks the list of those nodes (EdgeBlocks::stitch_list, written with the tables once per structure: about one node in seven of a
+// dense scene), eight threads per entry, instead of asking every node.
 __global__ void __launch_bounds__(256) agg_stitch_kernel(float* __restrict__ agg, const float* __restrict__ side, const int* __restrict__ stitch,
-                                                          const int* __restrict__ head, const EdgeBlockHeader* __restrict__ tab, int n) {
-    const int id = blockIdx.x * 256 + threadIdx.x;
-    const int v = id >> 3, c = id & 7;   // eight threads per node: most nodes have nothing to add and leave at once
-    if (v >= n) return;
-    const int ng = tab->n_groups;
-    const int g0 = stitch[v];
-    if (g0 < 0 || g0 >= ng || head[g0] != v) return;
-    floatx4 a[4];
+                                                          const int* __restrict__ stitch_list, const int* __restrict__ head,
+                                                          const EdgeBlockHeader* __restrict__ tab, int n) {
+    const int ng = tab->n_groups, ns = tab->n_stitch;
+    const int c = threadIdx.x & 7;
+    for (int k = (blockIdx.x * 256 + threadIdx.x) >> 3; k < ns; k += (gridDim.x * 256) >> 3) {
+        const int v = stitch_list[k];
+        if (v < 0 || v >= n) continue;
+        const int g0 = stitch[v];
+        if (g0 < 0 || g0 >= ng || head[g0] != v) continue;
+        floatx4 a[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<floatx4*>(agg + (size_t)v * H + 16 * c + 4 * q);
-    int g = g0;
-    do {
+        for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<floatx4*>(agg + (size_t)v * H + 16 * c + 4 * q);
+        int g = g0;
+        do {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] += *reinterpret_cast<const floatx4*>(side + (size_t)g * H + 16 * c + 4 * q);
-        ++g;
-    } while (g < ng && head[g] == v);
+            for (int q = 0; q < 4; ++q) a[q] += *reinterpret_cast<const floatx4*>(side + (size_t)g * H + 16 * c + 4 * q);
+            ++g;
+        } while (g < ng && head[g] == v);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<floatx4*>(agg + (size_t)v * H + 16 * c + 4 * q) = a[q];
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<floatx4*>(agg + (size_t)v * H + 16 * c + 4 * q) = a[q];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1352,78 +1363,16 @@ __global__ void __launch_bounds__(H3_PACK_THREADS) pack_h3_kernel(PackH3Jobs J) 
 // ------------------------------------------------------------------------------------------
 // block / chunk tables of a destination-sorted edge list that holds one or more equal-sized graphs back to back
 // ------------------------------------------------------------------------------------------
-__host__ __device__ inline int edge_blocks_padded(int n_edges) { return ((n_edges + BE - 1) / BE + 3) & ~3; }
-
 __global__ void __launch_bounds__(256) edge_blocks_plan_kernel(const int* __restrict__ in_ptr, int n_nodes, const int* n_per_dev, int n_per_host,
                                                                EdgeBlockHeader* tab, int* gblk, int max_graphs) {
-    // one thread: per-graph block counts and their prefix.  Every graph is padded to a multiple of 4 blocks = one group
-    // (the unit over which the scatter-add carries a running sum: a wave's rows in hmlp.hip, 4 ticks in the systolic kernel),
-    // so groups never straddle graphs and the partial sums of a graph do not depend on what else shares the launch.
-    if (threadIdx.x != 0) return;
-    int n_per = n_per_dev ? *n_per_dev : n_per_host;
-    if (n_per <= 0) n_per = n_nodes > 0 ? n_nodes : 1;
-    int G = (n_nodes + n_per - 1) / n_per;
-    if (G > max_graphs) G = max_graphs;   // capacity of the prefix array (never hit: it holds n_nodes + 2 entries)
-    int pb = 0;
-    for (int g = 0; g < G; ++g) {
-        const int lo = g * n_per, hi = min(n_nodes, (g + 1) * n_per);
-        gblk[g] = pb;
-        pb += edge_blocks_padded(in_ptr[hi] - in_ptr[lo]);
-    }
-    gblk[G] = pb;
-    tab->n_blocks = pb;
-    tab->n_groups = pb / 4;
-    tab->n_graphs = G;
-    tab->n_per_graph = n_per;
+    if (threadIdx.x == 0) edge_blocks_plan(in_ptr, n_nodes, n_per_dev, n_per_host, tab, gblk, max_graphs);
 }
 
-// blk[b] = (first edge, count | flags << 8) with flags 1 = first block of its group, 2 = last;
-// head[g] = the destination whose segment continues from group g - 1 into group g (its sum over group g is a "head
-// partial", stored to the side buffer), or -1;  stitch[v] = first group of the run of head partials of destination v.
 __global__ void __launch_bounds__(256) edge_blocks_fill_kernel(const int* __restrict__ in_ptr, const int* __restrict__ dst, int n_nodes,
-                                                               const EdgeBlockHeader* tab, const int* __restrict__ gblk, int2* blk, int2* seg,
-                                                               int* __restrict__ head, int* __restrict__ stitch) {
-    const int nblk = tab->n_blocks, G = tab->n_graphs, n_per = tab->n_per_graph;
-    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
-        int lo = 0, hi = G;   // graph g with gblk[g] <= b < gblk[g + 1]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (gblk[mid] <= b) lo = mid; else hi = mid;
-        }
-        const int g = lo, j = b - gblk[g];
-        const int e0 = in_ptr[g * n_per], e1 = in_ptr[min(n_nodes, (g + 1) * n_per)];
-        const int start = min(e0 + j * BE, e1);          // padding blocks: (end of the graph, 0 edges)
-        const int cnt = min(BE, e1 - start);
-        const int fl = ((j & 3) == 0 ? 1 : 0) | ((j & 3) == 3 ? 2 : 0);
-        blk[b] = make_int2(start, cnt | (fl << 8));
-        {
-            // Segment structure of the block's rows (destination-sorted): same reasoning as the kernels' scans.  A block shorter
-            // than 32 rows ends its graph; the group's last block ends every open piece.
-            unsigned cont = 0, last = 0;
-            int prev = (cnt > 0 && (j & 3) != 0 && start > e0) ? dst[start - 1] : -1;   // a full block precedes it in the group
-            for (int n = 0; n < cnt; ++n) {
-                const int d = dst[start + n];
-                if (d == prev) cont |= 1u << n;
-                prev = d;
-                bool is_last;
-                if (n + 1 < cnt) is_last = dst[start + n + 1] != d;
-                else is_last = (j & 3) == 3 || cnt < BE || start + cnt >= e1 || dst[start + cnt] != d;
-                if (is_last) last |= 1u << n;
-            }
-            seg[b] = make_int2((int)cont, (int)last);
-        }
-        if ((j & 3) == 0) {
-            int h = -1;
-            if (cnt > 0 && start > e0 && dst[start - 1] == dst[start]) h = dst[start];
-            head[b >> 2] = h;
-            if (h >= 0) {
-                // the run of head partials of h starts here unless the previous group (then entirely h's) is one too
-                const int ps = start - 4 * BE;
-                const bool prev_is_head = j >= 4 && dst[ps] == h && ps > e0 && dst[ps - 1] == h;
-                if (!prev_is_head) stitch[h] = b >> 2;
-            }
-        }
-    }
+                                                               EdgeBlockHeader* tab, const int* __restrict__ gblk, int2* blk, int2* seg,
+                                                               int* __restrict__ head, int* __restrict__ stitch, int* __restrict__ stitch_list) {
+    edge_blocks_fill(in_ptr, dst, n_nodes, tab, gblk, blk, seg, head, stitch, stitch_list, blockIdx.x * blockDim.x + threadIdx.x,
+                     gridDim.x * blockDim.x);
 }
 
 }  // namespace
@@ -1456,8 +1405,8 @@ size_t edge_groups_max(int64_t n_nodes, int64_t edge_capacity) { return max_bloc
 
 size_t edge_blocks_ints(int64_t n_nodes, int64_t edge_capacity) {
     const size_t nblk = max_blocks_of(n_nodes, edge_capacity);
-    // header | gblk[n+2] | blk[nblk] (int2) | seg[nblk] (int2) | head[nblk/4 + 2] | stitch[n]
-    return 8 + ((size_t)n_nodes + 2) + 1 + 4 * nblk + (nblk / 4 + 2) + (size_t)n_nodes;
+    // header | gblk[n+2] | blk[nblk] (int2) | seg[nblk] (int2) | head[nblk/4 + 2] | stitch[n] | stitch_list[n]
+    return 8 + ((size_t)n_nodes + 2) + 1 + 4 * nblk + (nblk / 4 + 2) + 2 * (size_t)n_nodes;
 }
 
 EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity) {
@@ -1471,6 +1420,7 @@ EdgeBlocks carve_edge_blocks(int* base, int64_t n_nodes, int64_t edge_capacity) 
     t.seg = reinterpret_cast<int2*>(p + 2 * nblk);
     t.head = p + 4 * nblk;
     t.stitch = t.head + nblk / 4 + 2;
+    t.stitch_list = t.stitch + n_nodes;
     t.max_blocks = (int64_t)nblk;
     return t;
 }
@@ -1483,12 +1433,13 @@ static int device_cus() {
 
 int build_edge_blocks(const int* in_ptr, const int* dst, int64_t n_nodes, int64_t edge_capacity, const int* n_per_graph_dev,
                       int n_per_graph_host, const EdgeBlocks& t, hipStream_t s) {
-    GM_HIP_CHECK(hipMemsetAsync(t.stitch, 0xff, (size_t)n_nodes * sizeof(int), s));
+    // t.stitch is -1 everywhere: the destination sort's clear pass set it (csr_clear_jobs)
     hipLaunchKernelGGL(edge_blocks_plan_kernel, dim3(1), dim3(64), 0, s, in_ptr, (int)n_nodes, n_per_graph_dev, n_per_graph_host,
                        t.hdr, t.gblk, (int)n_nodes + 1);
     int gb = (int)cdiv(t.max_blocks, 256);
     gb = gb < 1 ? 1 : (gb > 1024 ? 1024 : gb);
-    hipLaunchKernelGGL(edge_blocks_fill_kernel, dim3(gb), dim3(256), 0, s, in_ptr, dst, (int)n_nodes, t.hdr, t.gblk, t.blk, t.seg, t.head, t.stitch);
+    hipLaunchKernelGGL(edge_blocks_fill_kernel, dim3(gb), dim3(256), 0, s, in_ptr, dst, (int)n_nodes, t.hdr, t.gblk, t.blk, t.seg, t.head, t.stitch,
+                       t.stitch_list);
     GM_LAUNCH_CHECK();
     (void)edge_capacity;
     return GM_OK;
@@ -1551,7 +1502,7 @@ int launch_edge_sys_enc(const EdgeArgs& a, hipStream_t s) {
     {
         ProfScope prof(a.prof, PROF_ENC, s);
         hipLaunchKernelGGL(sys_enc_kernel, dim3(device_cus()), dim3(SYS_THREADS), ENC_LDS_BYTES, s, a.hdr, a.e_in, a.e_out, a.wstream_h3,
-                           const_cast<int*>(&a.hdr->error_flags), a.eps);
+                           const_cast<int*>(&a.hdr->error_flags), a.eps, a.zero_pad_rows ? 1 : 0);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;
@@ -1593,7 +1544,10 @@ int launch_agg_stitch(float* agg, const float* side, const EdgeBlocks& t, int64_
     if (n <= 0) return GM_OK;
     {
         ProfScope prof(prof_state, PROF_NODE, s);
-        hipLaunchKernelGGL(agg_stitch_kernel, dim3((unsigned)cdiv(n * 8, 256)), dim3(256), 0, s, agg, side, t.stitch, t.head, t.hdr, (int)n);
+        // sized for the list's worst case (every node) up to two rounds of the chip's workgroup slots; a dense scene's list is n / 7
+        int64_t gb = cdiv(n * 8, 256 * 4);
+        gb = gb < 1 ? 1 : (gb > 2048 ? 2048 : gb);
+        hipLaunchKernelGGL(agg_stitch_kernel, dim3((unsigned)gb), dim3(256), 0, s, agg, side, t.stitch, t.stitch_list, t.head, t.hdr, (int)n);
     }
     GM_LAUNCH_CHECK();
     return GM_OK;

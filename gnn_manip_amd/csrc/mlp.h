@@ -31,6 +31,8 @@ struct EdgeArgs {
     int P_prescaled;       // P was written times the systolic kernel's weight scale T1 (NodeArgs::p_scale): only that kernel may take the launch
     int k1;                // encoder: edge_dim
     int h_valid;           // the model's hidden_size (<= the width H the kernel runs at; LayerNorm statistics are over these features)
+    int zero_pad_rows;     // encoder: e_out is a forward's latent array -- keep kEdgePadRows zero rows behind row n_edges (hedge.h)
+    int* pad_rows_done;    // encoder: set to 1 when the launch has taken care of zero_pad_rows itself (else the caller launches zero_edge_pad_rows)
 };
 
 struct NodeArgs {

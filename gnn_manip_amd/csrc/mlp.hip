@@ -53,7 +53,10 @@ int launch_edge(int H, int NL, bool enc, const EdgeArgs& a_in, int64_t edge_capa
     // the encoder phi_e in the same weight-stationary form: 4 raw features per edge, rows in sorted order (the rollout path)
     if (enc && H == 128 && (a.h_valid == 0 || a.h_valid == 128) && NL == 2 && a.wstream_h3 && a.hdr && !a.eid && a.k1 == 4 &&
         (choice == EK_AUTO || choice == EK_SYS || choice == EK_SYS_ALL))
+    {
+        if (a.zero_pad_rows && a.pad_rows_done) *a.pad_rows_done = 1;   // the systolic encoder zeroes them in the same launch
         return launch_edge_sys_enc(a, s);
+    }
     // the streamed fp16 x 3 kernels (hmlp.hip): every other case
     if (a.wstream_hm && hm_supported(H) && (enc || (a.edge_blocks && (a.side || !a.agg)))) {
         HmEdgeArgs h{};

@@ -508,8 +508,26 @@ void set_tail(const gm_model* m, NodeArgs& a, int next_edge_step /* -1: none, M:
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+// agg_cleared: the caller's first launch has zeroed agg (the rollout step's StepClear)
+int epd_forward_impl(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, int attr_is_csr_order,
+                     const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream, bool agg_cleared);
+}
+
+extern "C" {
+
 int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, int attr_is_csr_order,
                    const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream) {
+    return epd_forward_impl(m, nodes, n, edge_attr, attr_is_csr_order, csr_ws, cap, out, fwd_ws, fwd_ws_bytes, stream, false);
+}
+
+}  // extern "C"
+
+namespace {
+int epd_forward_impl(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, int attr_is_csr_order,
+                     const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream, bool agg_cleared) {
     gm::DevGuard dev_guard(out);
     GM_REQUIRE(m && csr_ws && fwd_ws, GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: null pointer");
     GM_REQUIRE(n >= 0 && cap >= 0 && n < ((int64_t)1 << 31) && cap < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: sizes out of range");
@@ -522,9 +540,15 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_inference_images(m, s);
     if (rc != GM_OK) return rc;
-    rc = launch_edge(H, NL, true, enc_edge_args(m, edge_attr, attr_is_csr_order ? nullptr : c.eid, c.hdr, 0, f.e), cap, s);
+    int pad_done = 0;
+    {
+        EdgeArgs ee = enc_edge_args(m, edge_attr, attr_is_csr_order ? nullptr : c.eid, c.hdr, 0, f.e);
+        ee.zero_pad_rows = 1;
+        ee.pad_rows_done = &pad_done;
+        rc = launch_edge(H, NL, true, ee, cap, s);
+    }
     if (rc != GM_OK) return rc;
-    if (cap > 0) {
+    if (cap > 0 && !pad_done) {
         ProfScope prof(m->prof, PROF_REST, s);
         rc = zero_edge_pad_rows(c.hdr, f.e, H, s);
         if (rc != GM_OK) return rc;
@@ -557,7 +581,7 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     if (rc == GM_OK && sys_node) rc = project(0);
     if (rc != GM_OK) return rc;
     // agg is zeroed once (nodes without in-edges read zeros; rows with in-edges are stored whole by every edge launch)
-    {
+    if (!agg_cleared) {
         ProfScope prof(m->prof, PROF_REST, s);
         GM_HIP_CHECK(hipMemsetAsync(f.agg, 0, (size_t)n * H * sizeof(float), s));
     }
@@ -599,6 +623,9 @@ int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float
     }
     return GM_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int gm_graph_independent_forward(const gm_model* m, const float* x, int64_t n, const float* edge_attr, int64_t e,
                                  float* h_out, float* e_out, void* stream) {
@@ -774,27 +801,33 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
     const int64_t cap = n * K;
     int rc;
     hipStream_t hs = (hipStream_t)stream;
-    // state_pre + node features in one launch
+    // state_pre + node features in one launch -- which also resets what the step's later launches build on: the graph and
+    // destination-sort workspaces (headers, cell counts, in-degrees, scan states, stitch table) and the forward's agg rows
     {
+        StepClear clr;
+        graph_clear_jobs(clr, carve_graph(r.graph, n, K), n);
+        csr_clear_jobs(clr, carve_csr(r.csr, n, cap), n, m->d.flow);
+        FwdWs f = carve_fwd(r.fwd, m->Hp, n, cap, cap);
+        clr.add(reinterpret_cast<int*>(f.agg), (long long)n * m->Hp, 0);
         ProfScope prof(m->prof, PROF_REST, hs);
-        rc = gm::rollout_pre_features(obs, n, fd, rigid_rank, rigid_target, r.x, hs);
+        rc = gm::rollout_pre_features(obs, n, fd, rigid_rank, rigid_target, r.x, hs, &clr);
     }
     if (rc != GM_OK) return rc;
     const float* last_pos = obs + (size_t)(fd->k_steps - 1) * n * fd->data_dim + fd->cart_col;
-    {
+    {   // the in-degree count of the destination sort rides in the neighbour search
         ProfScope prof(m->prof, PROF_GRAPH, hs);
-        rc = gm_radius_graph_build_batched(last_pos, fd->data_dim, n, fd->nodes_per_graph > 0 ? fd->nodes_per_graph : n, fd->conn_r, K,
-                                       r.graph, r.graph_bytes, stream);
+        rc = gm::radius_graph_build_fused(last_pos, fd->data_dim, n, fd->nodes_per_graph > 0 ? fd->nodes_per_graph : n, fd->conn_r, K,
+                                          r.graph, r.graph_bytes, r.csr, r.csr_bytes, m->d.flow, hs);
     }
     if (rc != GM_OK) return rc;
-    // destination sort; the edge features are written by the same pass that fixes each segment's order
+    // destination sort; the edge features and the block tables are written by the same pass that fixes each segment's order
     {
         ProfScope prof(m->prof, PROF_REST, hs);
-        rc = gm::csr_from_graph_with_features(r.graph, n, K, r.csr, r.csr_bytes, last_pos, fd->data_dim, (float)fd->conn_r,
-                                              r.edge_attr, m->d.flow, hs);
+        rc = gm::csr_from_graph_fused(r.graph, n, K, r.csr, r.csr_bytes, last_pos, fd->data_dim, (float)fd->conn_r, r.edge_attr,
+                                      m->d.flow, hs);
     }
     if (rc != GM_OK) return rc;
-    rc = gm_epd_forward(m, r.x, n, r.edge_attr, 1, r.csr, cap, r.pred, r.fwd, r.fwd_bytes, stream);
+    rc = epd_forward_impl(m, r.x, n, r.edge_attr, 1, r.csr, cap, r.pred, r.fwd, r.fwd_bytes, stream, true);
     if (rc != GM_OK) return rc;
     // integrator + window shift + write-back (+ copy of the prediction) in one launch
     ProfScope prof(m->prof, PROF_REST, hs);

@@ -71,6 +71,7 @@ class _Handle:
     def __init__(self):
         self.h = None
         self.key = None
+        self.built_for = None
         self.desc = None
         self.edge_kernel = 0
         self.prof_mask = 0
@@ -86,7 +87,7 @@ class _Handle:
         tensors = [p.detach().to(device=device, dtype=torch.float32).contiguous() for p in params]
         arr = (C.c_void_p * len(tensors))(*[ptr(t).value for t in tensors])
         d = ModelDesc(*desc_tuple)
-        if self.h is not None and self.key[0] == desc_tuple and self.key[1] == str(device):
+        if self.h is not None and self.built_for == (desc_tuple, str(device)):   # (not self.key: invalidate() clears that)
             check(L.gm_model_update(self.h, arr, len(tensors), 1, current_stream()))
         else:
             self.close()
@@ -100,6 +101,7 @@ class _Handle:
         # no synchronisation: the pack kernels are queued on torch's current stream, and the caching allocator hands the
         # temporaries' memory out again only in that stream's order
         self.key = key
+        self.built_for = (desc_tuple, str(device))
         self.desc = d
         return self.h
 

@@ -179,7 +179,10 @@ def test_optimizer_steps_at_a_padded_hidden_size_with_a_frozen_decoder(dev):
     o_ref = torch_epd.epd_forward(p64, n64, e64, i64, dims[4], dims[5]).detach().numpy()
     out_t = m.forward(x, a, idx).detach().cpu().numpy()                         # training forward on the copied weights
     assert np.abs(out_t - o_ref).max() <= 1e-5 * max(np.abs(o_ref).max(), 1e-3)
-    assert np.isfinite(out_inf.cpu().numpy()).all()
+    with torch.no_grad():
+        out_i2 = m.forward(x, a, idx).cpu().numpy()                             # ... and the fused inference path (the module's own handle)
+    assert np.abs(out_i2 - o_ref).max() <= 1e-5 * max(np.abs(o_ref).max(), 1e-3)
+    assert np.isfinite(out_inf.cpu().numpy()).all() and np.abs(out_inf.cpu().numpy() - out_i2).max() > 0   # the copy did change the weights
 
 
 def test_backward_over_many_seeds(dev):
