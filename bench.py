@@ -247,6 +247,13 @@ def measure(wl_key, dev, rank, world, dist, cdev, args, steps, warmup, candidate
             eng.run(obs, traj[:warmup].contiguous(), warmup)
         eng.status()
         timed_traj = traj[warmup:].contiguous()
+        if dist:
+            # untimed warm-up of the exchange itself, same shapes as the timed one: the first broadcast / all-gather of a process
+            # group sets up its channels (tens of milliseconds with RCCL -- a tenth of this timed region)
+            w0 = timed_traj[0].to(cdev).clone()
+            dist.broadcast(w0, src=0)
+            w1 = obs[-1, :, 2:5].mean(dim=0).to(cdev)
+            dist.all_gather([torch.empty_like(w1) for _ in range(world)], w1)
         barrier()
         coll = 0.0   # the timed region below carries no instrumentation: kernel timings come from a separate pass after it
         t0 = time.perf_counter()

@@ -144,18 +144,6 @@ struct CsrWs {
 };
 CsrWs carve_csr(void* ws, int64_t n, int64_t cap);
 
-// Between the phases of a wave-private LDS transpose (lane a writes what lane b reads; no workgroup barrier, because one wave's LDS
-// instructions execute in order): this keeps the COMPILER from moving the reads above the writes, or the next turn's writes above
-// the reads -- its single-thread memory model allows either once it proves a lane's own two addresses distinct, and both are pure
-// functions of the lane id.  Generates no instruction.
-#if defined(__HIPCC__)
-__device__ __forceinline__ void wave_lds_turn() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-#endif
-
 // ---- optional per-kernel timing with HIP events on the launch stream, owned by a model handle (gm_model_profile)
 // PROF_REST: everything else of a rollout step -- state update + node features, destination sort + block tables + edge features,
 // the forward's clears, integration + window shift -- so that the kinds of a step add up to the step

@@ -178,6 +178,14 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
     return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
 }
+// No barrier or fence separates a turn's writes from its reads, and none is needed -- neither in hardware (one wave's LDS
+// instructions execute in order) nor against the compiler: every read instruction of a turn has a lane that reads a piece THAT LANE
+// wrote (the transposition's diagonal: lanes 0 / 45 / 18 / 63 for row groups 0 .. 3), and every write of the next turn has a lane
+// that overwrites a piece it has just read.  A lane's own read and write addresses therefore do alias, no proof to the contrary
+// exists, and the single-thread memory model itself keeps each such pair in program order -- for the whole wave, since all lanes
+// execute one instruction stream.  tests/test_turn_tiles.py checks that property of the index maps (here and in hmlp.hip's
+// HM_LINES turn).  Explicit fences were measured instead (round 6, tools/ab_train.sh): any form -- all address spaces, LDS-only
+// at wavefront scope, volatile tile accesses -- costs the training step 2.8 % (the chains' global prefetches no longer cross a turn).
 constexpr int TURN_LD = 36;
 constexpr int TURN_FLOATS = 32 * TURN_LD;
 typedef unsigned int uintx4_t __attribute__((ext_vector_type(4)));
@@ -198,13 +206,11 @@ __device__ __forceinline__ void store_feat_lines(const floatx16 (&v)[NKB], float
             for (int t = 0; t < 4; ++t) x[t] = v[kb][4 * g + t];
             *reinterpret_cast<floatx4*>(wr + 8 * g) = x;
         }
-        wave_lds_turn();   // the tile is written: other lanes' pieces may be read
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const floatx4 o = *reinterpret_cast<const floatx4*>(rd + 8 * j * TURN_LD);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, o), srd, voff + (unsigned)(8 * j * ld + 32 * kb) * 4u, 0, 0);
         }
-        wave_lds_turn();   // the tile is read: the next block may overwrite it
     }
 }
 
@@ -217,7 +223,6 @@ __device__ __forceinline__ void turn_in(floatx16& v, const floatx4 (&x)[4], floa
     const float* rd = turn + n * TURN_LD + 4 * hi;
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<floatx4*>(wr + 8 * j * TURN_LD) = x[j];
-    wave_lds_turn();   // the tile is written: other lanes' pieces may be read
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const floatx4 y = *reinterpret_cast<const floatx4*>(rd + 8 * g);
@@ -228,7 +233,6 @@ __device__ __forceinline__ void turn_in(floatx16& v, const floatx4 (&x)[4], floa
             else v[4 * g + t] = y[t] > 0.f ? v[4 * g + t] : 0.f;
         }
     }
-    wave_lds_turn();   // the tile is read: the next turn may overwrite it
 }
 template <int MODE, int NKB>
 __device__ __forceinline__ void load_feat_lines(floatx16 (&v)[NKB], const float* src, int ld, int rows_left, float* turn, int lane) {

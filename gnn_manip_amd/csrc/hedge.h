@@ -93,9 +93,11 @@ struct ProjSysArgs {
 int launch_proj_sys(const ProjSysArgs& a, hipStream_t s);
 int launch_agg_stitch(float* agg, const float* side, const EdgeBlocks& t, int64_t n, ProfState* prof, hipStream_t s);
 #ifndef GM_SYS_NODE_MIN_NODES
-#define GM_SYS_NODE_MIN_NODES (32 * 256 * 6)
+#define GM_SYS_NODE_MIN_NODES (32 * 256 * 4)
 #endif
-constexpr int64_t kSysNodeMinNodes = GM_SYS_NODE_MIN_NODES;   // graphs from this size take the systolic node path (a workgroup needs blocks to pipeline)
+// graphs from this size take the systolic node path (a workgroup needs blocks to pipeline: four per workgroup.  Round 6: measured + 1 % on
+// a C5 batch -- 8 scenes x 5k = 40k nodes, 4.9 blocks per workgroup -- against the streamed node kernel; six blocks was round 5's guess)
+constexpr int64_t kSysNodeMinNodes = GM_SYS_NODE_MIN_NODES;
 // encoder phi_e in the same weight-stationary form: raw rows [E][4] in sorted order -> e [E][128] (LayerNorm output)
 int launch_edge_sys_enc(const EdgeArgs& a, hipStream_t s);
 // whether the kernel's 32-bit byte offsets cover a graph of this size (P < 4 GiB, agg + side buffer < 4 GiB: about 4M nodes at

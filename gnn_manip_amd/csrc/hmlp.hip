@@ -593,7 +593,6 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                         for (int j = 0; j < 4; ++j) x[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(srd_o, v_line + (unsigned)(8 * j * H) * 4u, 0, 0));
 #pragma unroll
                         for (int j = 0; j < 4; ++j) *reinterpret_cast<floatx4*>(t_row + 8 * j * HM_TURN_LD) = x[j];
-                        wave_lds_turn();   // residual rows in the tile: other lanes' pieces may be read (accumulator layout, below)
                     }
                 }
                 // stored exactly once: to its agg row, or -- the piece of a segment that began in an earlier group -- to this
@@ -640,13 +639,11 @@ __global__ void __launch_bounds__(HM_THREADS, 1) hm_edge_kernel(HmEdgeArgs A) {
                     if (is_last) *reinterpret_cast<floatx4*>(arow + 8 * g) = floatx4{y[0], y[1], y[2], y[3]};
                 }
                 if (lines) {
-                    wave_lds_turn();   // e + e' in the tile (accumulator layout): read back row-major
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const floatx4 o = *reinterpret_cast<const floatx4*>(t_row + 8 * j * HM_TURN_LD);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, o), srd_o, v_line + (unsigned)(8 * j * H) * 4u, 0, 0);
                     }
-                    wave_lds_turn();   // the tile is read: the next row block may overwrite it
                 }
                 prev_last = cnt == BE ? __builtin_amdgcn_readlane(dnv, 31) : -3;
             }
