@@ -624,15 +624,19 @@ def main():
                 out["collective_backend"] = dist.get_backend()
             if world == 1 and not args.no_extra and args.workload == "target" and args.candidates == 1:
                 extra = {}
+
+                def sub(key, fn):   # a sub-record that fails is reported as such; the headline above stands on its own
+                    try:
+                        extra[key] = fn()
+                    except Exception as e:   # noqa: BLE001
+                        extra[key] = {"error": f"{type(e).__name__}: {e}"}
+                    torch.cuda.empty_cache()
+
                 for key in ("c2", "c3", "c4"):
                     w2 = WORKLOADS[key]
-                    r2, _ = measure(key, dev, rank, world, None, cdev, args, w2["steps"], w2["warmup"], 1)
-                    extra[key] = r2
-                    torch.cuda.empty_cache()
-                extra["c5_1gpu"] = extra_c5_1gpu(dev, args)
-                torch.cuda.empty_cache()
-                extra["train"] = extra_train(dev)
-                torch.cuda.empty_cache()
+                    sub(key, lambda: measure(key, dev, rank, world, None, cdev, args, w2["steps"], w2["warmup"], 1)[0])
+                sub("c5_1gpu", lambda: extra_c5_1gpu(dev, args))
+                sub("train", lambda: extra_train(dev))
                 out["extra"] = extra
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(obs_np, model, stats, scene, hidden)

@@ -93,10 +93,13 @@ struct ProjSysArgs {
 int launch_proj_sys(const ProjSysArgs& a, hipStream_t s);
 int launch_agg_stitch(float* agg, const float* side, const EdgeBlocks& t, int64_t n, ProfState* prof, hipStream_t s);
 #ifndef GM_SYS_NODE_MIN_NODES
-#define GM_SYS_NODE_MIN_NODES (32 * 256 * 4)
+#define GM_SYS_NODE_MIN_NODES (32 * 256 * 6)
 #endif
-// graphs from this size take the systolic node path (a workgroup needs blocks to pipeline: four per workgroup.  Round 6: measured + 1 % on
-// a C5 batch -- 8 scenes x 5k = 40k nodes, 4.9 blocks per workgroup -- against the streamed node kernel; six blocks was round 5's guess)
+// Graphs from this size take the systolic node path (a workgroup needs blocks to pipeline).  The size that counts is ONE GRAPH's
+// (the rollout step passes nodes_per_graph of a block-diagonal batch): the systolic and the streamed node kernels add a row's terms in
+// different orders, so a choice by the batch's total would make candidate c of a batch of 10 differ in the last bits from candidate c
+// of a batch of 8 -- or alone.  (Round 6 measured the systolic path at + 1 % on a C5 batch, 8 scenes x 5k = 40k nodes; the batch
+// invariance is worth more than that.)
 constexpr int64_t kSysNodeMinNodes = GM_SYS_NODE_MIN_NODES;
 // encoder phi_e in the same weight-stationary form: raw rows [E][4] in sorted order -> e [E][128] (LayerNorm output)
 int launch_edge_sys_enc(const EdgeArgs& a, hipStream_t s);

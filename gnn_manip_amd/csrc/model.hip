@@ -511,23 +511,26 @@ extern "C" {
 }  // extern "C"
 
 namespace {
-// agg_cleared: the caller's first launch has zeroed agg (the rollout step's StepClear)
+// agg_cleared: the caller's first launch has zeroed agg (the rollout step's StepClear); n_per_graph: nodes of ONE graph of a
+// block-diagonal batch of equal-sized graphs (the kernel choice must not depend on how many graphs share the call), or n
 int epd_forward_impl(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, int attr_is_csr_order,
-                     const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream, bool agg_cleared);
+                     const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream, bool agg_cleared,
+                     int64_t n_per_graph);
 }
 
 extern "C" {
 
 int gm_epd_forward(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, int attr_is_csr_order,
                    const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream) {
-    return epd_forward_impl(m, nodes, n, edge_attr, attr_is_csr_order, csr_ws, cap, out, fwd_ws, fwd_ws_bytes, stream, false);
+    return epd_forward_impl(m, nodes, n, edge_attr, attr_is_csr_order, csr_ws, cap, out, fwd_ws, fwd_ws_bytes, stream, false, n);
 }
 
 }  // extern "C"
 
 namespace {
 int epd_forward_impl(const gm_model* m, const float* nodes, int64_t n, const float* edge_attr, int attr_is_csr_order,
-                     const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream, bool agg_cleared) {
+                     const void* csr_ws, int64_t cap, float* out, void* fwd_ws, size_t fwd_ws_bytes, void* stream, bool agg_cleared,
+                     int64_t n_per_graph) {
     gm::DevGuard dev_guard(out);
     GM_REQUIRE(m && csr_ws && fwd_ws, GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: null pointer");
     GM_REQUIRE(n >= 0 && cap >= 0 && n < ((int64_t)1 << 31) && cap < ((int64_t)1 << 31), GM_ERR_INVALID_ARGUMENT, "gm_epd_forward: sizes out of range");
@@ -564,7 +567,7 @@ int epd_forward_impl(const gm_model* m, const float* nodes, int64_t n, const flo
     const bool sys_edge = cap > 0 && edge_launch_is_sys(H, NL, proc_edge_args(m, 0, c, n, c.hdr, 0, nullptr, f.P, f.e, f.e, f.agg, f.side, 1), cap);
     // The systolic node path (hedge.h): graphs with enough 32-row blocks per workgroup to pipeline (or the handle's choice 7).  Its
     // node MLP takes the h half of its first Linear as Q, written with P by the projection kernel behind every step.
-    const bool sys_node = sys_edge && m->packed_h3 && (m->edge_kernel == 7 || n >= kSysNodeMinNodes);
+    const bool sys_node = sys_edge && m->packed_h3 && (m->edge_kernel == 7 || (n_per_graph > 0 ? n_per_graph : n) >= kSysNodeMinNodes);
     const size_t h3f = h3_image_floats();
     auto project = [&](int k) {   // h -> P of edge step k, Q of node step k
         ProjSysArgs pa{};
@@ -827,7 +830,8 @@ int gm_rollout_step(const gm_model* m, float* obs, int64_t n, const gm_feature_d
                                       m->d.flow, hs);
     }
     if (rc != GM_OK) return rc;
-    rc = epd_forward_impl(m, r.x, n, r.edge_attr, 1, r.csr, cap, r.pred, r.fwd, r.fwd_bytes, stream, true);
+    rc = epd_forward_impl(m, r.x, n, r.edge_attr, 1, r.csr, cap, r.pred, r.fwd, r.fwd_bytes, stream, true,
+                          fd->nodes_per_graph > 0 ? fd->nodes_per_graph : n);
     if (rc != GM_OK) return rc;
     // integrator + window shift + write-back (+ copy of the prediction) in one launch
     ProfScope prof(m->prof, PROF_REST, hs);

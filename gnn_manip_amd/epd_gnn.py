@@ -595,7 +595,7 @@ class EncProcDecGNN(nn.Module):
     def set_edge_kernel(self, choice):
         """Processor edge kernel of this model (diagnostics / A-B measurements; no reference counterpart): 'auto', 'sys'
         (systolic fp16 x 3, hidden 128 / num_layers 2), 'hm' (streamed fp16 x 3), 'sys_all' (as 'sys', and the systolic node /
-        projection kernels whatever the graph's size: 'auto' takes them from 32768 nodes up).  See include/gnn_manip_hip.h."""
+        projection kernels whatever the graph's size: 'auto' takes them for graphs of 49152 nodes or more).  See include/gnn_manip_hip.h."""
         self._handle.set_edge_kernel(self.EDGE_KERNELS.get(choice, choice))
 
     def forward(self, nodes, edge_attr, edge_index):

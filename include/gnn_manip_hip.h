@@ -209,7 +209,7 @@ void gm_model_destroy(gm_model* m);
  * (the systolic fp16 x 3 kernel for hidden 128 / num_layers 2 in the fused forward, else the
  * streamed one); 5 = systolic fp16 x 3 where it applies, else 6; 6 = streamed fp16 x 3 (hmlp.hip; every MLP of the
  * model, any supported size); 7 = as 5, and the processor NODE MLPs in the systolic form too (node kernel + projection kernel,
- * hedge.hip) whatever the graph's size -- 0 takes those from 32768 nodes up, where a workgroup has blocks enough to pipeline.  1..4 were round 1's fp32 / bf16 x 6 kernels: removed from the library in round 5
+ * hedge.hip) whatever the graph's size -- 0 takes those for graphs of 49152 nodes or more (one graph of a batch counts, not the batch), where a workgroup has blocks enough to pipeline.  1..4 were round 1's fp32 / bf16 x 6 kernels: removed from the library in round 5
  * (GM_ERR_UNSUPPORTED).  No environment variable is read: the choice belongs to the handle. */
 int gm_model_set_edge_kernel(gm_model* m, int choice);
 

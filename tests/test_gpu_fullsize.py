@@ -313,3 +313,25 @@ def test_rollout_full_size_is_invariant_under_particle_numbering(dev, scene100k)
     assert torch.equal(recs[-1, :, 2:5], f1[-2, :, 2:5])          # the record of the last step is the frame before the final one
     d = (f1[:, :, 2:8] - f0[:, :, 2:8]).abs()
     assert float(d.max()) <= 2e-6, float(d.max())
+
+
+def test_batch_invariance_does_not_depend_on_the_batch_size(dev):
+    """A block-diagonal batch large enough to cross the node kernels' size threshold by its TOTAL (10 scenes x 5000 = 50 000 nodes
+    against 49 152): the kernels are chosen by the size of one graph, so candidate c of the batch still equals candidate c rolled
+    out alone bit for bit (round 5 chose by the total: the systolic and the streamed node kernels add a row's terms in different
+    orders, and a batch of 10 differed from a batch of 8 in the last bits)."""
+    from gnn_manip_amd import EncProcDecGNN, GraphBoundedMultimaterialControl, RolloutEngine, scene
+    n, steps, b = 5000, 2, 10
+    obs = scene.make_scene(n, seed=17)
+    trajs = np.stack([scene.rigid_drift_trajectory(obs, steps, seed=300 + c, step_size=2e-4) for c in range(b)])
+    params = orc.init_params(25, 4, 3, 128, 2, 10, 85)
+    m = EncProcDecGNN(25, 4, 3, 128, 2, 10)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev)
+    ga = GraphBoundedMultimaterialControl(0.015, STATS, CART, MAT, CTRL, BOUNDS)
+    with torch.no_grad():
+        out = RolloutEngine(m, ga, n, device=dev, candidates=b).rollout_candidates(_t(obs, dev), _t(trajs, dev))
+        eng1 = RolloutEngine(m, ga, n, device=dev)
+        for c in (0, 7, 9):
+            one = eng1.rollout(_t(obs, dev), _t(trajs[c], dev), horizon=steps)
+            assert torch.equal(out[c], one), (c, float((out[c] - one).abs().max()))
