@@ -21,7 +21,7 @@ def source_digest():
     import hashlib
     h = hashlib.sha256()
     # the processor edge kernels whose traffic is recorded, and what they include (host-side files do not change a kernel)
-    for f in ("common.h", "hedge.h", "hedge.hip", "hmlp.h", "hmlp.hip", "hmma_dev.h", "mlp.h"):
+    for f in ("common.h", "hedge.h", "hedge.hip", "hmlp.h", "hmlp.hip", "hmma_dev.h", "mlp.h", "blocks_dev.h"):
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]

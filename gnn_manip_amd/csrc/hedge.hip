@@ -18,15 +18,15 @@
 //           clamped); P_i[dst] + P_j[src] of block x -> accumulators; e of block x+1 -> operand image E (between the
 //           MFMAs); Linear 1 on E, ReLU, image X1; destinations of the block into a small LDS ring for role 2;
 //   role 1: Linear 2 of block x-1 (X1 -> X2); LayerNorm + e_out = e + e' of the first EPI_SPLIT row groups of block x-3
-//           (row-major, 8 lanes per row; unconditional stores, rows that do not exist go to the workgroup's sink rows);
+//           (row-major, 8 lanes per row; unconditional stores: rows that do not exist lie beyond the store's buffer bound);
 //   role 2: Linear 3 of block x-2 (X2 -> Z + LayerNorm partial statistics); the other row groups of that epilogue;
 //           aggregation of block x-3 on a TRANSPOSED view (lane = feature, 16 rows of a half block in registers): the
 //           segment structure of the destination-sorted rows is the same for every feature, so it lives in scalar
 //           registers (continuation / last-row bit masks from the block tables) and the segmented scan is 15 masked adds
 //           down the registers; one 128-byte store per finished segment and half wave -- to its agg row, or, for the piece
 //           of a segment that began in an earlier group of 4 blocks, to that group's row of the side buffer, which the
-//           node kernel adds in group order: no atomics.  Role 2 issues no vector loads; roles run at different s_setprio
-//           levels (role 2 first).
+//           node kernel adds in group order: no atomics.  Roles run at different s_setprio levels (role 2 first).
+// The cache policy of the row stores is chosen per launch by size (STREAM, below).
 // hipcc's counted vmcnt waits assume the path with the fewest younger operations and share one in-order counter between
 // loads and stores: every global access of the tick loops is therefore branch-free, the weights are waited for before the
 // loops, and the block tables come through scalar loads (separate __restrict__ kernel parameters).
