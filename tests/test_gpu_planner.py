@@ -154,7 +154,10 @@ def test_objective_matches_oracle_rollout_and_loss(dev):
     actions = np.stack((rot[:s.horizon], ty[:s.horizon]), axis=1)
     v, a, b = orc.planner_penalties(actions, s.rx_init, s.rotation_limit, [s.max_rot, s.max_ty], [s.max_rot, s.max_ty])
     ref = s.beta * w + s.penalty * b + s.alpha * v + s.gamma * a
-    assert abs(got - ref) <= 1e-3 * abs(ref)
+    # the Wasserstein term alone: device loss of the DEVICE rollout's end cloud against the float64 oracle loss of the ORACLE rollout's
+    # (the two rollouts agree to a few 1e-6 in position; the loss is quadratic in displacements of ~2e-3)
+    print(f"objective: device {got:.9g}, oracle {ref:.9g}, relative difference {abs(got - ref) / abs(ref):.2e}")
+    assert abs(got - ref) <= 3e-4 * abs(ref)
 
 
 def test_optimize_trajectory_improves_the_objective(dev):
