@@ -807,8 +807,9 @@ __global__ void __launch_bounds__(256) fill_ei_kernel(const int64_t* __restrict_
 // whole workgroup through a copy in the workspace.
 constexpr int SEG_CAP = 96;
 constexpr int SEG_STRIDE = SEG_CAP + 1;
-// Workgroups beyond the cdiv(n, 32) that sort fill the 32-edge block tables of the same structure (they read in_ptr and dst, which
-// the sort does not touch; the plan was laid out by the launch in front): bt.hdr == nullptr when the grid has none.
+// The first n_tab workgroups of the grid fill the 32-edge block tables of the same structure (they read in_ptr and dst, which the
+// sort does not touch; the plan was laid out by the launch in front; a thread walks a block's 32 destinations serially, so these
+// workgroups go FIRST and the sort's run beside them), the other cdiv(n, 32) sort.  n_tab == 0: no tables (csr_from_edge_index).
 struct BlockTabArgs {
     const int* dst;
     EdgeBlockHeader* hdr;
@@ -818,6 +819,7 @@ struct BlockTabArgs {
     int* head;
     int* stitch;
     int* stitch_list;
+    int n_tab;   // workgroups of the launch that fill the tables
 };
 __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict__ in_ptr, int64_t n,
                                                             int* __restrict__ src, int* __restrict__ eid,
@@ -827,14 +829,14 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
     __shared__ int se[32 * SEG_STRIDE];
     __shared__ int ss[32 * SEG_STRIDE];
     __shared__ int s_long[32];
-    const int n_sort = (int)((n + 31) / 32);
-    if ((int)blockIdx.x >= n_sort) {
+    if ((int)blockIdx.x < bt.n_tab) {
         edge_blocks_fill(in_ptr, bt.dst, (int)n, bt.hdr, bt.gblk, bt.blk, bt.seg, bt.head, bt.stitch, bt.stitch_list,
-                         ((int)blockIdx.x - n_sort) * 256 + (int)threadIdx.x, ((int)gridDim.x - n_sort) * 256);
+                         (int)blockIdx.x * 256 + (int)threadIdx.x, bt.n_tab * 256);
         return;
     }
+    const int wg = (int)blockIdx.x - bt.n_tab;   // this workgroup's 32 segments
     const int tid = threadIdx.x, sub = tid & 7, sl = tid >> 3;
-    const int64_t i = (int64_t)blockIdx.x * 32 + sl;
+    const int64_t i = (int64_t)wg * 32 + sl;
     if (i == 0 && sub == 0) hdr->n_edges = in_ptr[n];
     const bool active = i < n;
     const int b = active ? in_ptr[i] : 0, e = active ? in_ptr[i + 1] : 0;
@@ -874,7 +876,7 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
     // the workspace, len^2 / 256 comparisons per thread instead of a single lane's insertion sort
     for (int q = 0; q < 32; ++q) {
         if (!s_long[q]) continue;   // uniform
-        const int64_t node = (int64_t)blockIdx.x * 32 + q;
+        const int64_t node = (int64_t)wg * 32 + q;
         const int lb = in_ptr[node], ll = in_ptr[node + 1] - lb;
         for (int a = tid; a < ll; a += 256) { tmp_eid[lb + a] = eid[lb + a]; tmp_src[lb + a] = src[lb + a]; }
         __syncthreads();   // the copy is complete (this workgroup is the only writer of the segment)
@@ -1073,9 +1075,10 @@ int csr_tail(const GraphWs& g, int64_t n, int K, const CsrWs& c, const float* po
     hipLaunchKernelGGL(fill_graph_kernel, dim3(nb), dim3(256), 0, s, g.cnt, g.out_ptr, g.nbr, n, K, c.in_ptr,
                        slot, cap, flow, c.dst, c.src, c.eid, c.hdr, &g.hdr->n_per_graph, t.hdr, t.gblk);
     // 32-edge blocks aligned to every graph's first edge (the systolic processor edge kernel walks them): extra workgroups of the sort
-    int gb = (int)cdiv(t.max_blocks, 256);
-    gb = gb < 1 ? 1 : (gb > 1024 ? 1024 : gb);
-    const BlockTabArgs bt{c.dst, t.hdr, t.gblk, t.blk, t.seg, t.head, t.stitch, t.stitch_list};
+    // a thread per block of the list's capacity (cap / 32 + the per-graph padding blocks), at most 512 workgroups: they loop
+    int gb = (int)cdiv(cdiv(cap, kBlockEdges) + 8, 256);
+    gb = gb < 1 ? 1 : (gb > 512 ? 512 : gb);
+    const BlockTabArgs bt{c.dst, t.hdr, t.gblk, t.blk, t.seg, t.head, t.stitch, t.stitch_list, gb};
     hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32) + (unsigned)gb), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr,
                        pos, pos_stride, conn_r, edge_attr, flow, c.sort_tmp, c.sort_tmp + c.cap, bt);
     GM_LAUNCH_CHECK();
