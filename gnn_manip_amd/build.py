@@ -11,7 +11,7 @@ LIB = os.path.join(HERE, "libgnnmanip_hip.so")
 SOURCES = ["graph.hip", "features.hip", "mlp.hip", "hedge.hip", "hmlp.hip", "model.hip", "train.hip", "train_model.hip", "sinkhorn.hip"]
 # hedge.hip: packed fp32 VALU (SLP-vectorised v_pk_fma_f32) returned wrong low lanes next to its LDS / MFMA traffic on gfx950
 EXTRA_FLAGS = {"hedge.hip": ["-fno-slp-vectorize"] + os.environ.get("GM_HEDGE_FLAGS", "").split(), "hmlp.hip": ["-fno-slp-vectorize"] + os.environ.get("GM_HM_FLAGS", "").split(),
-               "train.hip": os.environ.get("GM_TRAIN_FLAGS", "").split()}
+               "train.hip": os.environ.get("GM_TRAIN_FLAGS", "").split(), "graph.hip": os.environ.get("GM_GRAPH_FLAGS", "").split()}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 
 

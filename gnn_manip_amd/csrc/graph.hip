@@ -538,15 +538,19 @@ __global__ void __launch_bounds__(256) cell_order_kernel(const float4* __restric
 }
 
 // ------------------------------------------------------------------------------------------
-// neighbour search, fast path: 8 lanes per query.  The lanes scan the 27-cell candidate ranges
+// neighbour search, fast path: NB_LPQ (16) lanes per query.  The lanes scan the 27-cell candidate ranges
 // together, append in-radius candidates (d2, index) to the query's list in LDS through a ballot
 // prefix, then rank the list (rank = number of smaller (d2, index) keys: no dependent chains, the
 // order (d2, index) is total so the result is order-independent) and emit the first K.  Queries
 // with more than NB_CAP in-radius candidates are marked (cnt = -1) for the general kernel below.
 // ------------------------------------------------------------------------------------------
+#ifndef NB_LPQ
+#define NB_LPQ 16                      // lanes per query.  Round 6, same box: 4 lanes graph scope 77 us at C2 / 238 us at the target, 8 lanes
+#endif                                 // (rounds 2 - 5) 55 / 170, 16 lanes 40 / 133: an x-run of three cells holds ~14 candidates, one step of 16 lanes
+static_assert(NB_LPQ == 4 || NB_LPQ == 8 || NB_LPQ == 16, "lanes per query: a power of two that divides a wave, below 32 (the ballot mask)");
 constexpr int NB_CAP = 96;
-constexpr int NB_STRIDE = NB_CAP + 1;  // doubles per list: odd stride keeps the 8 groups of a wave on distinct banks
-constexpr int NB_QPB = 32;             // queries per 256-thread block
+constexpr int NB_STRIDE = NB_CAP + 1;  // doubles per list: odd stride keeps the groups of a wave on distinct banks
+constexpr int NB_QPB = 256 / NB_LPQ;   // queries per 256-thread block
 
 // indeg / arrival (optional: the rollout step's fused path): the counting pass of the destination sort rides along -- every kept
 // neighbour takes its arrival number within its aggregation node's segment (flow 0: the neighbour, 1: the query) from an atomic on
@@ -558,8 +562,8 @@ __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __rest
                                                              int* __restrict__ indeg, int* __restrict__ arrival, int flow) {
     __shared__ double sd2[NB_QPB * NB_STRIDE];
     __shared__ int sj[NB_QPB * NB_STRIDE];
-    const int tid = threadIdx.x, sub = tid & 7, ql = tid >> 3, lane = tid & 63;
-    const int grp_shift = (lane >> 3) * 8;  // position of this group's 8 bits in the wave ballot
+    const int tid = threadIdx.x, sub = tid & (NB_LPQ - 1), ql = tid / NB_LPQ, lane = tid & 63;
+    const int grp_shift = (lane / NB_LPQ) * NB_LPQ;  // position of this group's bits in the wave ballot
     const int64_t slot = (int64_t)blockIdx.x * NB_QPB + ql;
     const bool active = slot < n;
     const float4 q = sorted[active ? slot : 0];
@@ -580,7 +584,7 @@ __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __rest
             for (int y = max(cy - 1, 0); y <= min(cy + 1, dy - 1); ++y) {
                 const int row = cbase + (z * dy + y) * dx;
                 const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
-                for (int c0 = b; c0 < e; c0 += 8) {
+                for (int c0 = b; c0 < e; c0 += NB_LPQ) {
                     const int c = c0 + sub;
                     bool in = false;
                     double d2 = 0.0;
@@ -596,7 +600,7 @@ __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __rest
                         in = d2 <= r2;
                         j = __float_as_int(p.w);
                     }
-                    const unsigned m = (unsigned)(__ballot(in) >> grp_shift) & 0xffu;
+                    const unsigned m = (unsigned)(__ballot(in) >> grp_shift) & ((1u << NB_LPQ) - 1u);
                     const int pos = count + __popc(m & ((1u << sub) - 1u));
                     if (in && pos < NB_CAP) {
                         ld[pos] = d2;
@@ -615,12 +619,12 @@ __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __rest
     }
     // rank = number of smaller (d2, index) keys.  A lane keeps four of its elements in registers and walks the list once for all
     // of them (the list reads are the same address for the 8 lanes of the group: one broadcast per element)
-    for (int a0 = sub; a0 < count; a0 += 32) {
+    for (int a0 = sub; a0 < count; a0 += 4 * NB_LPQ) {
         double da[4];
         int ja[4], rank[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int a = a0 + 8 * u;
+            const int a = a0 + NB_LPQ * u;
             da[u] = a < count ? ld[a] : -1.0;   // d2 >= 0: nothing ranks below a filler, its rank is never used
             ja[u] = a < count ? lj[a] : 0;
             rank[u] = 0;
@@ -633,7 +637,7 @@ __global__ void __launch_bounds__(256) neighbor_fast_kernel(const float4* __rest
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (a0 + 8 * u < count && rank[u] < K) {
+            if (a0 + NB_LPQ * u < count && rank[u] < K) {
                 nbr[(int64_t)qi * K + rank[u]] = ja[u];
                 if (indeg) arrival[(int64_t)qi * K + rank[u]] = atomicAdd(&indeg[flow ? qi : ja[u]], 1);
             }
@@ -805,6 +809,10 @@ __global__ void __launch_bounds__(256) fill_ei_kernel(const int64_t* __restrict_
 // 8 lanes per segment: the segment is staged in LDS, every element is ranked against the others
 // (ids are unique) and written back in place.  Segments longer than SEG_CAP (in-degree > 96) are rank-sorted by the
 // whole workgroup through a copy in the workspace.
+#ifndef SEG_LPS
+#define SEG_LPS 8                  // lanes per segment (A/B builds)
+#endif
+constexpr int SEG_PER_WG = 256 / SEG_LPS;   // segments per workgroup
 constexpr int SEG_CAP = 96;
 constexpr int SEG_STRIDE = SEG_CAP + 1;
 // The first n_tab workgroups of the grid fill the 32-edge block tables of the same structure (they read in_ptr and dst, which the
@@ -826,17 +834,17 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
                                                             CsrHeader* hdr, const float* __restrict__ pos,
                                                             int64_t pos_stride, float conn_r, float* __restrict__ edge_attr, int flow,
                                                             int* __restrict__ tmp_eid, int* __restrict__ tmp_src, BlockTabArgs bt) {
-    __shared__ int se[32 * SEG_STRIDE];
-    __shared__ int ss[32 * SEG_STRIDE];
-    __shared__ int s_long[32];
+    __shared__ int se[SEG_PER_WG * SEG_STRIDE];
+    __shared__ int ss[SEG_PER_WG * SEG_STRIDE];
+    __shared__ int s_long[SEG_PER_WG];
     if ((int)blockIdx.x < bt.n_tab) {
         edge_blocks_fill(in_ptr, bt.dst, (int)n, bt.hdr, bt.gblk, bt.blk, bt.seg, bt.head, bt.stitch, bt.stitch_list,
                          (int)blockIdx.x * 256 + (int)threadIdx.x, bt.n_tab * 256);
         return;
     }
-    const int wg = (int)blockIdx.x - bt.n_tab;   // this workgroup's 32 segments
-    const int tid = threadIdx.x, sub = tid & 7, sl = tid >> 3;
-    const int64_t i = (int64_t)wg * 32 + sl;
+    const int wg = (int)blockIdx.x - bt.n_tab;   // this workgroup's SEG_PER_WG segments
+    const int tid = threadIdx.x, sub = tid & (SEG_LPS - 1), sl = tid / SEG_LPS;
+    const int64_t i = (int64_t)wg * SEG_PER_WG + sl;
     if (i == 0 && sub == 0) hdr->n_edges = in_ptr[n];
     const bool active = i < n;
     const int b = active ? in_ptr[i] : 0, e = active ? in_ptr[i + 1] : 0;
@@ -845,7 +853,7 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
     int* ls = ss + sl * SEG_STRIDE;
     const bool small = len <= SEG_CAP;
     if (small)
-        for (int a = sub; a < len; a += 8) {
+        for (int a = sub; a < len; a += SEG_LPS) {
             le[a] = eid[b + a];
             ls[a] = src[b + a];
         }
@@ -863,7 +871,7 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
         *reinterpret_cast<float4*>(edge_attr + at * 4) = make_float4(d[0], d[1], d[2], __fsqrt_rn(q));
     };
     if (active && small) {
-        for (int a = sub; a < len; a += 8) {
+        for (int a = sub; a < len; a += SEG_LPS) {
             const int ka = le[a];
             int rank = 0;
             for (int f = 0; f < len; ++f) rank += le[f] < ka ? 1 : 0;
@@ -874,9 +882,9 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(const int* __restrict
     }
     // long segments (hub nodes of a caller's edge_index): the whole workgroup rank-sorts one at a time through a copy in
     // the workspace, len^2 / 256 comparisons per thread instead of a single lane's insertion sort
-    for (int q = 0; q < 32; ++q) {
+    for (int q = 0; q < SEG_PER_WG; ++q) {
         if (!s_long[q]) continue;   // uniform
-        const int64_t node = (int64_t)wg * 32 + q;
+        const int64_t node = (int64_t)wg * SEG_PER_WG + q;
         const int lb = in_ptr[node], ll = in_ptr[node + 1] - lb;
         for (int a = tid; a < ll; a += 256) { tmp_eid[lb + a] = eid[lb + a]; tmp_src[lb + a] = src[lb + a]; }
         __syncthreads();   // the copy is complete (this workgroup is the only writer of the segment)
@@ -1079,7 +1087,7 @@ int csr_tail(const GraphWs& g, int64_t n, int K, const CsrWs& c, const float* po
     int gb = (int)cdiv(cdiv(cap, kBlockEdges) + 8, 256);
     gb = gb < 1 ? 1 : (gb > 512 ? 512 : gb);
     const BlockTabArgs bt{c.dst, t.hdr, t.gblk, t.blk, t.seg, t.head, t.stitch, t.stitch_list, gb};
-    hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32) + (unsigned)gb), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr,
+    hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, SEG_PER_WG) + (unsigned)gb), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr,
                        pos, pos_stride, conn_r, edge_attr, flow, c.sort_tmp, c.sort_tmp + c.cap, bt);
     GM_LAUNCH_CHECK();
     return GM_OK;
@@ -1165,7 +1173,7 @@ int csr_from_edge_index(const int64_t* ei, int64_t n, int64_t e, int flow, void*
         hipLaunchKernelGGL(fill_ei_kernel, dim3(nb), dim3(256), 0, s, ei, n, e, flow, c.in_ptr, c.cursor, c.dst, c.src, c.eid, c.hdr);
     }
     if (n > 0)
-        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0, c.sort_tmp, c.sort_tmp + c.cap, BlockTabArgs{});
+        hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)cdiv(n, SEG_PER_WG)), dim3(256), 0, s, c.in_ptr, n, c.src, c.eid, c.hdr, nullptr, 3, 1.f, nullptr, 0, c.sort_tmp, c.sort_tmp + c.cap, BlockTabArgs{});
     GM_LAUNCH_CHECK();
     if (!with_blocks) return GM_OK;
     return build_edge_blocks(c.in_ptr, c.dst, n, e, nullptr, (int)n, carve_edge_blocks(c.blocks, n, e), s);
