@@ -566,7 +566,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher's environment says WORLD_SIZE={world}")
     if os.environ.get("GM_BENCH_FAIL_RANK") == str(rank) and world > 1:   # tests: a rank that dies before the rendezvous
         raise SystemExit(3)
-    if os.environ.get("GM_BENCH_STUCK_RANK") == str(rank) and world > 1:   # tests: a rank that never reaches the rendezvous
+    if os.environ.get("GM_BENCH_STUCK_RANK") in (str(rank), "all") and world > 1:   # tests: a rank that never reaches the rendezvous
         sys.stderr.write(f"rank {rank}: GM_BENCH_STUCK_RANK set, sleeping\n")
         sys.stderr.flush()
         while True:

@@ -133,3 +133,39 @@ def test_cma_generation_loop_sharded_over_gloo_world2():
     assert f0 == f1 and np.array_equal(x0, x1)          # identical optimiser state on both ranks
     assert f0 < 1e-3 and np.abs(x0 - 0.3).max() < 0.05  # and it optimises
     assert set(b0) == {5} and set(b1) == {4}            # 9 candidates -> blocks of 5 and 4, one batched call each
+
+
+def _bench(extra, env_extra, timeout=120):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + extra, env=env, capture_output=True, timeout=timeout)
+
+
+def test_bench_launcher_deadline_without_a_gpu():
+    """The launcher of `bench.py --gpus N` (spawn_ranks) makes no GPU call itself, so its failure handling runs here: ranks that
+    never finish (stuck before anything touches the GPU) are terminated after --rank-timeout, the exit status is 124, no JSON line is
+    printed, and the report names the ranks and quotes the tails of their output files."""
+    import time
+    t0 = time.monotonic()
+    r = _bench(["--workload", "c2", "--rank-timeout", "4"], {"GM_BENCH_STUCK_RANK": "all"})
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 124, (r.returncode, err)
+    assert time.monotonic() - t0 < 60
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert "rank(s) [0, 1] still running after --rank-timeout 4 s" in err, err
+    assert err.count("GM_BENCH_STUCK_RANK set, sleeping") == 2   # both ranks' stderr tails
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box WITHOUT a GPU: the ranks must fail on their own")
+def test_bench_launcher_reports_failing_ranks_without_a_gpu():
+    """Without a GPU every rank stops at bench.py's own check (the product path has no CPU fallback): the launcher turns that into a
+    non-zero exit with the rank's message, not a hang and not a JSON line."""
+    r = _bench(["--workload", "c2", "--rank-timeout", "60"], {})
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 1, (r.returncode, err)
+    assert "exited with status" in err and "bench.py needs a GPU" in err, err
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
