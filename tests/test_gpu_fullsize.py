@@ -335,3 +335,29 @@ def test_batch_invariance_does_not_depend_on_the_batch_size(dev):
         for c in (0, 7, 9):
             one = eng1.rollout(_t(obs, dev), _t(trajs[c], dev), horizon=steps)
             assert torch.equal(out[c], one), (c, float((out[c] - one).abs().max()))
+
+
+def test_single_pass_scans_over_thousands_of_tiles(dev):
+    """The destination sort's in-degree scan (scan_lookback_kernel: decoupled look-back, one launch) far beyond the sizes of the
+    benchmark: 3 M nodes = 1465 tiles of 2048, i.e. a look-back that spans many 64-tile looks -- in_ptr read back from the csr
+    workspace against cumsum(bincount) -- and the radius graph of 600 k particles (586 tiles of cell counts, 293 of neighbour
+    counts) against the oracle's lists, bit for bit."""
+    from gnn_manip_amd import get_connectivity
+    from gnn_manip_amd.epd_gnn import DstCsr
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n, e = 3_000_000, 4_000_000
+    ei = torch.randint(0, n, (2, e), generator=g, dtype=torch.int64)
+    ei[1, : e // 4] = ei[1, : e // 4] % 1000          # a crowd of hubs: long segments, and long runs of empty ones behind them
+    csr = DstCsr(ei.to(dev), n)
+    assert csr.validate() == e
+    in_ptr = csr.ws[256:256 + 4 * (n + 1)].view(torch.int32).cpu().numpy()   # carve_csr: header (one 256-byte slot), then in_ptr[n + 1]
+    ref = np.concatenate(([0], np.cumsum(np.bincount(ei[1].numpy(), minlength=n))))
+    assert np.array_equal(in_ptr, ref)
+    del csr
+    rng = np.random.default_rng(6)
+    m = 600_000
+    pos = rng.uniform(0.1, 0.1 + 0.015 * (m / 5.0) ** (1.0 / 3.0) * 1.6, size=(m, 3)).astype(np.float32)   # mean in-radius count ~5
+    s_d, r_d = get_connectivity(_t(pos, dev), 0.015, 20)
+    s_o, r_o = orc.get_connectivity(pos, 0.015, 20)
+    assert len(s_o) > 2 * m
+    assert np.array_equal(s_d.cpu().numpy(), s_o) and np.array_equal(r_d.cpu().numpy(), r_o)
