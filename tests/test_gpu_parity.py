@@ -769,6 +769,34 @@ def test_profile_is_per_model(dev):
     assert a.profile_query(0)[0] == 2
 
 
+def test_profile_kinds_cover_a_rollout_step_and_report_when_they_run_out(dev):
+    """The five profiling kinds of gm_model_profile bracket every launch of a rollout step (0 processor edge kernels, 1 node side,
+    2 radius graph, 3 encoders, 4 the rest: state update + features + resets, destination sort + edge features + block tables,
+    integration) -- bench.py's breakdown adds them up against the step.  A kind records 4096 scopes; once more were opened its
+    count comes back NEGATIVE (minus the number opened) instead of a silently truncated total."""
+    from gnn_manip_amd import RolloutEngine, scene
+    n = 400
+    obs = scene.make_scene(n, seed=71, side=0.06)
+    m = _model(orc.init_params(25, 4, 3, 128, 2, 10, 72), (25, 4, 3, 128, 2, 10), dev)
+    eng = RolloutEngine(m, _ga(), n, device=dev)
+    state = _t(obs, dev)
+    eng.set_scene(state)
+    traj = _t(scene.rigid_drift_trajectory(obs, 8, seed=73, step_size=1e-5), dev)
+    with torch.no_grad():
+        eng.run(state, traj[:2].contiguous(), 2)     # packs the weight images
+        m.profile(31)
+        eng.run(state, traj[2:5].contiguous(), 3)
+    counts = [m.profile_query(k) for k in range(5)]
+    assert [c[0] for c in counts] == [30, 30, 3, 6, 9], counts     # per step: 10 edge, 10 node (streamed path), 1 graph scope, 2 encoders, 3 rest scopes
+    assert all(c[1] > 0.0 for c in counts)
+    with torch.no_grad():
+        eng.run(state, traj[5:].contiguous().repeat(140, 1, 1), 420)        # 4200 more edge scopes: beyond the 4096 of a kind
+    full, ms_full = m.profile_query(0)
+    assert full == -(30 + 4200) and ms_full > counts[0][1]
+    assert m.profile_query(2)[0] == 3 + 420           # the kinds with room left keep counting
+    m.profile(0)
+
+
 @pytest.mark.parametrize("kernel", ["auto", "hm"])
 def test_scatter_add_is_deterministic_with_hub_nodes(dev, kernel):
     """Destinations whose segments span many 4-block groups (in-degree 700 and 300, i.e. > 5 and > 2 groups of 128 edges):
