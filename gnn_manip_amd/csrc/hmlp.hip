@@ -1085,6 +1085,10 @@ int launch_node_hr(int mode, const HmNodeArgs& a, hipStream_t s) {
 // once its tiles fill the CUs that many times over.  1 is the measured choice: at N = 100k / hidden 128 (391 tiles of 256
 // rows on 256 CUs, a half-empty second round) the small form is still 16 % slower (1.80 vs 1.55 ms of node kernels per
 // step, A/B on one box) -- it streams the weights four times as often.
+// Round 6, hidden 128: the kernel deals 32-row BLOCKS evenly to the workgroups whatever the form, so what counts is blocks per
+// workgroup, not whole tiles -- measured on one box (bench.py, -DHM_NODE_SMALL_BLOCKS): 1.2 blocks per workgroup (2 x 5k nodes)
+// one-block form 1924 vs four-block form 1503 steps/s; 2.4 (4 x 5k) 2091 vs 2021; 4.9 (a C5 batch, 8 x 5k) 2304 vs 2355 - 2360.
+// The four-block form takes over from 4 blocks per workgroup (round 5: from 8).  Results do not depend on the form.
 #ifndef HM_NODE_SMALL_ROUNDS
 #define HM_NODE_SMALL_ROUNDS 1
 #endif
@@ -1093,7 +1097,10 @@ int launch_node_hr(int mode, const HmNodeArgs& a, hipStream_t s) {
 #endif
 template <int H>
 int launch_node_h(int mode, const HmNodeArgs& a, hipStream_t s) {
-    if (cdiv(a.n_nodes, Cfg<H, 4>::M) < (int64_t)HM_NODE_SMALL_ROUNDS * device_cus()) return launch_node_hr<H, 1>(mode, a, s);
+#ifndef HM_NODE_SMALL_BLOCKS
+#define HM_NODE_SMALL_BLOCKS (H == 128 ? 4 : HM_NODE_SMALL_ROUNDS * Cfg<H, 4>::NRB)   // 32-row blocks per workgroup below which the one-block form runs
+#endif
+    if (cdiv(a.n_nodes, 32) < (int64_t)(HM_NODE_SMALL_BLOCKS) * device_cus()) return launch_node_hr<H, 1>(mode, a, s);
     return launch_node_hr<H, HM_NODE_RBW>(mode, a, s);
 }
 
