@@ -27,6 +27,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Test hooks of the launcher's failure handling (tests/test_planner_dist.py, tests/test_gpu_planner.py): a rank that dies / never
+# arrives.  Handled before the heavy imports, so that what the launcher sees does not depend on how long `import torch` takes.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ:
+    if os.environ.get("GM_BENCH_FAIL_RANK") == os.environ["RANK"]:     # a rank that dies before the rendezvous
+        raise SystemExit(3)
+    if os.environ.get("GM_BENCH_STUCK_RANK") in (os.environ["RANK"], "all"):   # a rank that never reaches the rendezvous
+        sys.stderr.write(f"rank {os.environ['RANK']}: GM_BENCH_STUCK_RANK set, sleeping\n")
+        sys.stderr.flush()
+        while True:
+            time.sleep(1.0)
+
 import numpy as np
 import torch
 
@@ -564,13 +575,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher's environment says WORLD_SIZE={world}")
-    if os.environ.get("GM_BENCH_FAIL_RANK") == str(rank) and world > 1:   # tests: a rank that dies before the rendezvous
-        raise SystemExit(3)
-    if os.environ.get("GM_BENCH_STUCK_RANK") in (str(rank), "all") and world > 1:   # tests: a rank that never reaches the rendezvous
-        sys.stderr.write(f"rank {rank}: GM_BENCH_STUCK_RANK set, sleeping\n")
-        sys.stderr.flush()
-        while True:
-            time.sleep(1.0)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
     # GM_BENCH_REHEARSE=1: all ranks on cuda:0 with gloo (multi-rank rehearsal on a one-GPU box; RCCL refuses two ranks per
     # device).  Never set by the driver.
